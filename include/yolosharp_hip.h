@@ -1,0 +1,163 @@
+/* yolosharp_hip.h -- C ABI of libyolosharp_hip.so: an MI355X (gfx950) native engine for the
+ * YOLO forward / loss / backward / AdamW / NMS hot path of IntptrMax/YoloSharp.
+ *
+ * The reference has no FFI of its own (it is 100 % managed C# on TorchSharp); the "operator API"
+ * it exposes is the TorchSharp module surface.  Each entry point below names the reference
+ * interface (file:line under /root/reference/YoloSharp) whose arithmetic it replaces.  A C# host
+ * binds these with P/Invoke; tests bind them with ctypes.
+ *
+ * Conventions: extern "C", blittable arguments only, opaque handles, int32 status return
+ * (YS_OK == 0), thread-local error text via ys_last_error(), no callbacks, no exceptions across
+ * the boundary.  Tensors crossing the edge are plain fp32 in the reference's own layouts
+ * (images NCHW, weights OIHW, predictions [B,C,A]); internal layouts (NHWC bf16/f32) never leak.
+ * Pointers flagged `on_device` are HIP device pointers that are already resident in HBM;
+ * otherwise they are host pointers and the call copies (and, for outputs, synchronises).
+ * One HIP stream per ys_ctx; calls on one ctx must be serialised by the caller.
+ */
+#ifndef YOLOSHARP_HIP_H
+#define YOLOSHARP_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YS_API __attribute__((visibility("default")))
+
+typedef struct ys_ctx ys_ctx;
+typedef struct ys_model ys_model;
+
+enum ys_status {
+  YS_OK = 0,
+  YS_ERR_INVALID_ARG = 1, /* mirrors the reference's ArgumentException (e.g. Ops.cs:248-255) */
+  YS_ERR_HIP = 2,
+  YS_ERR_OOM = 3,
+  YS_ERR_UNSUPPORTED = 4,
+  YS_ERR_STATE = 5
+};
+enum ys_dtype { YS_F32 = 0, YS_BF16 = 1 };          /* compute/storage type of activations+weights */
+enum ys_family { YS_YOLOV8 = 8, YS_YOLOV11 = 11 };   /* Models/Yolo.cs:10-135, :200-258 */
+enum ys_size { YS_N = 0, YS_S = 1, YS_M = 2, YS_L = 3, YS_X = 4 }; /* Types/YoloTypes.cs YoloSize; Yolo.cs:43-51 */
+enum ys_task { YS_DETECT = 0, YS_SEGMENT = 1 };
+
+YS_API const char* ys_last_error(void);
+YS_API int ys_version(void);
+/* 1 when built by hipcc for gfx950, 0 for the test-only CPU interpreter build (never shipped). */
+YS_API int ys_is_device_build(void);
+
+/* ---- context: one device + one stream ------------------------------------------------------ */
+YS_API int ys_ctx_create(int device, ys_ctx** out);
+/* Same, but run on a caller-owned hipStream_t (e.g. torch's current stream) so that RCCL
+ * collectives issued by the host order correctly against the engine's kernels. */
+YS_API int ys_ctx_create_on_stream(int device, void* hip_stream, ys_ctx** out);
+YS_API int ys_ctx_destroy(ys_ctx* ctx);
+YS_API int ys_ctx_synchronize(ys_ctx* ctx);
+YS_API void* ys_ctx_stream(ys_ctx* ctx);
+
+/* ---- model: replaces Models/Yolo.cs Yolov8 (:10-135) built from Modules/Convs.cs Conv (:36-62),
+ *      Modules/Block.cs C2f (:371-399) / Bottleneck (:572-608) / SPPF (:236-285),
+ *      Modules/Head.cs Detect (:8-236) ---------------------------------------------------------- */
+typedef struct ys_model_desc {
+  int32_t family;     /* ys_family */
+  int32_t size;       /* ys_size */
+  int32_t task;       /* ys_task */
+  int32_t nc;         /* number of classes (Config.NumberClass) */
+  int32_t reg_max;    /* DFL bins (16) */
+  int32_t height;     /* input H (multiple of 32) */
+  int32_t width;      /* input W (multiple of 32) */
+  int32_t max_batch;  /* capacity; forward may use any B <= max_batch */
+  int32_t dtype;      /* ys_dtype: YS_F32 = parity path, YS_BF16 = performance path */
+  int32_t max_labels; /* capacity of ground-truth rows per batch for the loss (0 = default 64*max_batch) */
+} ys_model_desc;
+
+YS_API int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out);
+YS_API int ys_model_destroy(ys_model* m);
+
+/* state_dict surface (names and order as TorchSharp's named_parameters()+buffers, e.g.
+ * "model.0.conv.weight" [16,3,3,3]; Yolo.cs:10-39, YoloBaseTaskModel.cs:31-32,470-490). */
+YS_API int ys_model_num_tensors(ys_model* m);
+YS_API int ys_model_tensor_info(ys_model* m, int index, char* name, int name_cap,
+                                int32_t* ndim, int64_t shape[4], int32_t* is_param);
+/* OIHW / [C] fp32 host arrays at the edge. */
+YS_API int ys_model_set_tensor(ys_model* m, const char* name, const float* host, size_t count);
+YS_API int ys_model_get_tensor(ys_model* m, const char* name, float* host, size_t count);
+YS_API int ys_model_get_grad(ys_model* m, const char* name, float* host, size_t count);
+/* PyTorch-default initialisation of every tensor (kaiming-uniform(a=sqrt 5) conv weights and
+ * biases, BN gamma=1 beta=0, running stats 0/1) from a 64-bit seed (deterministic, host-side). */
+YS_API int ys_model_init_weights(ys_model* m, uint64_t seed);
+YS_API int ys_model_set_training(ys_model* m, int training);   /* Module.train()/eval() */
+YS_API int ys_model_num_anchors(ys_model* m);                  /* A = sum_l (H/s_l)(W/s_l) */
+YS_API int64_t ys_model_num_params(ys_model* m);
+
+/* Yolov8.forward (Yolo.cs:92-134).  images: fp32 NCHW [B,3,H,W] in [0,1].
+ * training: Detect returns preds only (Head.cs:89-106): "boxes" [B,4*reg_max,A], "scores" [B,nc,A].
+ * eval: additionally Detect._inference (Head.cs:204-223): "pred" [B,4+nc,A] (xywh*stride, sigmoid). */
+YS_API int ys_model_forward(ys_model* m, const float* images, int on_device, int batch);
+/* Copy an output to a host fp32 array in the reference layout: key = "boxes" | "scores" | "pred". */
+YS_API int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count);
+/* Device pointer of the eval prediction [B,4+nc,A] fp32 (input of ys_nms_batched). */
+YS_API int ys_model_pred_device(ys_model* m, float** dptr);
+
+/* v8DetectionLoss.forward (Utils/Loss.cs:411-484) + TaskAlignedAssigner (Utils/Tal.cs:13-258)
+ * + BboxLoss/DFLoss (Loss.cs:94-167) + bbox_iou CIoU (Utils/Metrics.cs:36-111), and d(sum(loss*B))/d(preds).
+ * Labels use the collate contract (Data/YoloDataLoader.cs:18-44): batch_idx[n], cls[n], bboxes[n,4]
+ * normalised cxcywh, all fp32.  Asynchronous: results stay on the device until ys_loss_read. */
+YS_API int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
+                          int n_labels, int on_device);
+/* loss_items[3] = (box, cls, dfl) un-multiplied (the reference's loss_detach), *loss_sum = sum(items)*B
+ * (the scalar the reference calls backward() on, Amp.cs:340).  Synchronises the stream. */
+YS_API int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum);
+
+/* autograd backward of sum(loss*B) through the whole graph (Amp.cs:348,370). Gradients accumulate
+ * into the flat fp32 gradient buffer like torch's .grad (call ys_model_zero_grad between steps). */
+YS_API int ys_model_backward(ys_model* m);
+/* Backward in `nseg` consecutive segments (0 = head ... nseg-1 = stem) so the host can launch the
+ * RCCL all-reduce of a finished gradient bucket while later segments still run. */
+YS_API int ys_model_backward_segments(ys_model* m);
+YS_API int ys_model_backward_segment(ys_model* m, int seg);
+/* [offset,count) (in floats) of the flat gradient buffer completed by segment `seg`. */
+YS_API int ys_model_segment_grad_range(ys_model* m, int seg, int64_t* offset, int64_t* count);
+YS_API int ys_model_zero_grad(ys_model* m);
+/* flat fp32 device buffers (all parameters / all gradients, same order) for collectives. */
+YS_API int ys_model_grad_buffer(ys_model* m, float** dptr, int64_t* count);
+YS_API int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count);
+
+/* torch.optim.AdamW.step (built YoloBaseTaskModel.cs:144-153, stepped Amp.cs:355-356,371-372):
+ * decoupled weight decay, bias-corrected.  Parameter groups follow the reference's name rule:
+ * group 0 = names containing "bias", 1 = "weight" (non-BN), 2 = "bn" weights.  lr comes from the host
+ * (warm-up / LambdaLR stay in C#, YoloBaseTaskModel.cs:306-319). */
+YS_API int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups,
+                               float beta1, float beta2, float eps, float weight_decay);
+
+/* Ops.non_max_suppression (Utils/Ops.cs:239-371) incl. torchvision.ops.nms (:357).
+ * pred: [B, C=4+nc+extra, A] fp32 xywh + class probabilities; boxes are converted to xyxy IN PLACE
+ * like the reference (:288-291).  out_rows [B,max_det,6+extra] = (x1,y1,x2,y2,conf,cls,extra...),
+ * out_keep [B,max_det] = original anchor index, out_count [B].  `on_device` applies to all four
+ * pointers.  conf/iou outside [0,1] -> YS_ERR_INVALID_ARG (ArgumentException in the reference). */
+YS_API int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int batch, int channels, int anchors,
+                          float conf_thres, float iou_thres, int max_det, int nc, int max_nms, int max_wh,
+                          float* out_rows, int64_t* out_keep, int32_t* out_count);
+
+/* ---- per-operator entry points (unit parity; a TorchSharp-free C# Conv wrapper) ---------------
+ * Convs.Conv.forward (Convs.cs:36-62): y = act(BN(conv2d(x))) on device buffers in NCHW fp32 at the
+ * edge.  training != 0 uses batch statistics and updates running stats (momentum 0.03, eps 1e-3). */
+YS_API int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, int Cin, int H, int W,
+                              const float* w_oihw, int Cout, int k, int stride,
+                              const float* bn_gamma, const float* bn_beta, float* bn_mean, float* bn_var,
+                              const float* bias, int act_silu, int training, float* y_nchw);
+
+/* device memory helpers for hosts without a HIP binding of their own */
+YS_API int ys_device_malloc(ys_ctx* ctx, size_t bytes, void** dptr);
+YS_API int ys_device_free(ys_ctx* ctx, void* dptr);
+YS_API int ys_memcpy_h2d(ys_ctx* ctx, void* dst, const void* src, size_t bytes);
+YS_API int ys_memcpy_d2h(ys_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* timing of the most recent calls on this ctx's stream, measured with HIP events on that stream:
+ * name = "forward" | "loss" | "backward" | "optim" | "nms"; returns ms of the last completed call. */
+YS_API int ys_ctx_profile_enable(ys_ctx* ctx, int enable);
+YS_API int ys_ctx_last_ms(ys_ctx* ctx, const char* name, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOSHARP_HIP_H */

@@ -1,0 +1,115 @@
+"""Build the native pieces in-tree.
+
+  build_device(): hipcc --offload-arch=gfx950 -> yolosharp_amd/libyolosharp_hip.so   (THE product)
+  build_emu():    g++ + tools/hipemu          -> tools/hipemu/libyolosharp_emu.so   (test-only SIMT interpreter
+                                                build of the same kernel sources; never loaded by the package)
+  build_oracle(): gcc                         -> oracle/libys_oracle.so              (test-only checker)
+
+hipcc cross-compiles for gfx950 without a GPU, so all three run in the CPU-only dev container.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "yolosharp_amd", "csrc")
+EMU = os.path.join(ROOT, "tools", "hipemu")
+BUILD = os.path.join(ROOT, "build")
+
+SOURCES = ["core.hip", "nms.hip", "conv.hip", "elementwise.hip", "loss.hip", "model.hip"]
+# bit-exact fp32 sections (NMS IoU arithmetic) must not be contracted into FMAs
+NO_CONTRACT = {"nms.hip"}
+
+LIB_DEVICE = os.path.join(ROOT, "yolosharp_amd", "libyolosharp_hip.so")
+LIB_EMU = os.path.join(EMU, "libyolosharp_emu.so")
+LIB_ORACLE = os.path.join(ROOT, "oracle", "libys_oracle.so")
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(ROOT, "include", "yolosharp_hip.h")]
+    hs += [os.path.join(EMU, f) for f in os.listdir(EMU) if f.endswith(".h")]
+    return hs
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
+        raise RuntimeError("build failed: " + " ".join(cmd[:3]))
+    return r.stdout
+
+
+def build_device(verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.join(BUILD, "dev"), exist_ok=True)
+    hdrs = _headers()
+    objs, jobs = [], []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(BUILD, "dev", s + ".o")
+        objs.append(obj)
+        if _newer(obj, [src] + hdrs):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                   "-Wno-unused-result", "-I", CSRC, "-c", src, "-o", obj]
+            if s in NO_CONTRACT:
+                cmd.insert(4, "-ffp-contract=off")
+            jobs.append(cmd)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(_run, jobs))
+    if jobs or _newer(LIB_DEVICE, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_DEVICE] + objs)
+    if verbose:
+        print("built", LIB_DEVICE, "(%d TU recompiled)" % len(jobs))
+    return LIB_DEVICE
+
+
+def build_emu(verbose=False):
+    os.makedirs(os.path.join(BUILD, "emu"), exist_ok=True)
+    hdrs = _headers()
+    objs, jobs = [], []
+    srcs = [(os.path.join(CSRC, s), s) for s in _sources()] + [(os.path.join(EMU, "hip_emu.cpp"), "hip_emu.cpp")]
+    for src, name in srcs:
+        obj = os.path.join(BUILD, "emu", name + ".o")
+        objs.append(obj)
+        if _newer(obj, [src] + hdrs):
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-fvisibility=hidden", "-DYS_EMU_BUILD",
+                         "-Wno-unused-result", "-I", CSRC, "-I", EMU, "-x", "c++", "-c", src, "-o", obj])
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(_run, jobs))
+    if jobs or _newer(LIB_EMU, objs):
+        _run(["g++", "-shared", "-fPIC", "-fopenmp", "-o", LIB_EMU] + objs)
+    if verbose:
+        print("built", LIB_EMU, "(%d TU recompiled)" % len(jobs))
+    return LIB_EMU
+
+
+def build_oracle(verbose=False):
+    src = os.path.join(ROOT, "oracle", "nms_ref.c")
+    if _newer(LIB_ORACLE, [src]):
+        _run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB_ORACLE, src])
+    if verbose:
+        print("built", LIB_ORACLE)
+    return LIB_ORACLE
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["device", "emu", "oracle"]
+    if "device" in what:
+        build_device(True)
+    if "emu" in what:
+        build_emu(True)
+    if "oracle" in what:
+        build_oracle(True)

@@ -1,0 +1,150 @@
+// core.hip -- context, error reporting, memory helpers and the NMS entry point of the C ABI.
+#include "ys_internal.h"
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+
+void ys_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* ys_last_error(void) { return g_err; }
+int ys_version(void) { return 100; }
+int ys_is_device_build(void) {
+#ifdef YS_EMU_BUILD
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+static int ctx_create_common(int device, void* stream, bool own, ys_ctx** out) {
+  YS_REQUIRE(out != nullptr, "ys_ctx_create: out is null");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    ys_set_error("ys_ctx_create: no HIP device available (hipGetDeviceCount -> %d, n=%d): the engine has no CPU path", (int)e, ndev);
+    return YS_ERR_HIP;
+  }
+  YS_REQUIRE(device >= 0 && device < ndev, "ys_ctx_create: device %d out of range [0,%d)", device, ndev);
+  YS_CHECK_HIP(hipSetDevice(device));
+  ys_ctx* c = new ys_ctx();
+  c->device = device;
+  if (own) {
+    YS_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  } else {
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+  }
+  YS_CHECK_HIP(hipEventCreate(&c->ev0));
+  YS_CHECK_HIP(hipEventCreate(&c->ev1));
+  *out = c;
+  return YS_OK;
+}
+
+int ys_ctx_create(int device, ys_ctx** out) { return ctx_create_common(device, nullptr, true, out); }
+int ys_ctx_create_on_stream(int device, void* hip_stream, ys_ctx** out) {
+  return ctx_create_common(device, hip_stream, false, out);
+}
+
+int ys_ctx_destroy(ys_ctx* ctx) {
+  if (!ctx) return YS_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->nms_ws) hipFree(ctx->nms_ws);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return YS_OK;
+}
+
+int ys_ctx_synchronize(ys_ctx* ctx) {
+  YS_REQUIRE(ctx, "ys_ctx_synchronize: null ctx");
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return YS_OK;
+}
+
+void* ys_ctx_stream(ys_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ys_ctx_profile_enable(ys_ctx* ctx, int enable) {
+  YS_REQUIRE(ctx, "null ctx");
+  ctx->profile = enable != 0;
+  return YS_OK;
+}
+
+int ys_ctx_last_ms(ys_ctx* ctx, const char* name, float* ms) {
+  YS_REQUIRE(ctx && name && ms, "ys_ctx_last_ms: null argument");
+  auto it = ctx->last_ms.find(name);
+  YS_REQUIRE(it != ctx->last_ms.end(), "ys_ctx_last_ms: no timing recorded for '%s'", name);
+  *ms = it->second;
+  return YS_OK;
+}
+
+int ys_device_malloc(ys_ctx* ctx, size_t bytes, void** dptr) {
+  YS_REQUIRE(ctx && dptr, "ys_device_malloc: null argument");
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  YS_CHECK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+  return YS_OK;
+}
+int ys_device_free(ys_ctx* ctx, void* dptr) {
+  YS_REQUIRE(ctx, "null ctx");
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (dptr) YS_CHECK_HIP(hipFree(dptr));
+  return YS_OK;
+}
+int ys_memcpy_h2d(ys_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  YS_REQUIRE(ctx && dst && src, "ys_memcpy_h2d: null argument");
+  YS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return YS_OK;
+}
+int ys_memcpy_d2h(ys_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  YS_REQUIRE(ctx && dst && src, "ys_memcpy_d2h: null argument");
+  YS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return YS_OK;
+}
+
+int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A, float conf_thres,
+                   float iou_thres, int max_det, int nc, int max_nms, int max_wh, float* out_rows,
+                   int64_t* out_keep, int32_t* out_count) {
+  YS_REQUIRE(ctx && pred && out_rows && out_keep && out_count, "ys_nms_batched: null argument");
+  // Ops.cs:248-255: ArgumentException for thresholds outside [0,1]
+  YS_REQUIRE(conf_thres >= 0.f && conf_thres <= 1.f, "Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", conf_thres);
+  YS_REQUIRE(iou_thres >= 0.f && iou_thres <= 1.f, "Invalid IoU %g, valid values are between 0.0 and 1.0", iou_thres);
+  YS_REQUIRE(B > 0 && A > 0 && C > 4 && max_det > 0 && max_nms > 0, "ys_nms_batched: bad shape B=%d C=%d A=%d", B, C, A);
+  if (nc == 0) nc = C - 4;  // Ops.cs:269
+  YS_REQUIRE(nc > 0 && nc <= C - 4, "ys_nms_batched: nc=%d incompatible with C=%d", nc, C);
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  const int extra = C - 4 - nc;
+  const size_t n_pred = (size_t)B * C * A, n_rows = (size_t)B * max_det * (6 + extra), n_keep = (size_t)B * max_det;
+  YsTimer timer(ctx, "nms");
+  if (on_device) return ys_nms_launch(ctx, pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, out_rows, out_keep, out_count);
+  float* d_pred = nullptr; float* d_rows = nullptr; int64_t* d_keep = nullptr; int32_t* d_cnt = nullptr;
+  YS_CHECK_HIP(hipMalloc(&d_pred, n_pred * 4));
+  YS_CHECK_HIP(hipMalloc(&d_rows, n_rows * 4));
+  YS_CHECK_HIP(hipMalloc(&d_keep, n_keep * 8));
+  YS_CHECK_HIP(hipMalloc(&d_cnt, (size_t)B * 4));
+  YS_CHECK_HIP(hipMemcpyAsync(d_pred, pred, n_pred * 4, hipMemcpyHostToDevice, ctx->stream));
+  int st = ys_nms_launch(ctx, d_pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, d_rows, d_keep, d_cnt);
+  if (st == YS_OK) {
+    hipMemcpyAsync(pred, d_pred, n_pred * 4, hipMemcpyDeviceToHost, ctx->stream);  // in-place xyxy visible to the caller
+    hipMemcpyAsync(out_rows, d_rows, n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(out_keep, d_keep, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(out_count, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_pred); hipFree(d_rows); hipFree(d_keep); hipFree(d_cnt);
+  if (st != YS_OK) return st;
+  if (e != hipSuccess) { ys_set_error("ys_nms_batched: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
+  return YS_OK;
+}
+
+}  // extern "C"

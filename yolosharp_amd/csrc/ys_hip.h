@@ -1,0 +1,182 @@
+// ys_hip.h -- common device/host definitions for the yolosharp_hip kernels (gfx950 / CDNA4).
+// Built by hipcc for the product library.  When YS_EMU_BUILD is defined the same sources are
+// compiled by g++ against tools/hipemu (a TEST-ONLY SIMT interpreter; never shipped, never a
+// fallback -- see tools/hipemu/hip_emu.h).
+#pragma once
+#ifdef YS_EMU_BUILD
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include <stddef.h>
+
+#define YS_WAVE 64
+
+// ---------------------------------------------------------------- launch helper
+#ifdef YS_EMU_BUILD
+#define YS_LAUNCH(KERNEL, GRID, BLOCK, STREAM, ...) \
+  emu::launch(dim3(GRID), dim3(BLOCK), [=]() { KERNEL(__VA_ARGS__); })
+#else
+#define YS_LAUNCH(KERNEL, GRID, BLOCK, STREAM, ...) \
+  hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__)
+#endif
+
+// ---------------------------------------------------------------- bf16 storage type
+struct bf16_t { unsigned short v; };
+
+__host__ __device__ inline float ys_u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+__host__ __device__ inline unsigned ys_f2u(float f) { return __builtin_bit_cast(unsigned, f); }
+
+__host__ __device__ inline float bf16_bits_to_f32(unsigned short h) { return ys_u2f(((unsigned)h) << 16); }
+// round-to-nearest-even, NaN preserved (quiet)
+__host__ __device__ inline unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = ys_f2u(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <class T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPL = 4;  // elements per 16-byte lane load
+  __host__ __device__ static inline float to_f(float x) { return x; }
+  __host__ __device__ static inline float from_f(float x) { return x; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int EPL = 8;
+  __host__ __device__ static inline float to_f(bf16_t x) { return bf16_bits_to_f32(x.v); }
+  __host__ __device__ static inline bf16_t from_f(float x) { bf16_t r; r.v = f32_to_bf16_bits(x); return r; }
+};
+
+// unpack / pack one 16-byte vector of T to floats
+template <class T> __device__ inline void ys_unpack(const uint4& v, float* f);
+template <> __device__ inline void ys_unpack<float>(const uint4& v, float* f) {
+  f[0] = ys_u2f(v.x); f[1] = ys_u2f(v.y); f[2] = ys_u2f(v.z); f[3] = ys_u2f(v.w);
+}
+template <> __device__ inline void ys_unpack<bf16_t>(const uint4& v, float* f) {
+  f[0] = ys_u2f(v.x << 16); f[1] = ys_u2f(v.x & 0xffff0000u);
+  f[2] = ys_u2f(v.y << 16); f[3] = ys_u2f(v.y & 0xffff0000u);
+  f[4] = ys_u2f(v.z << 16); f[5] = ys_u2f(v.z & 0xffff0000u);
+  f[6] = ys_u2f(v.w << 16); f[7] = ys_u2f(v.w & 0xffff0000u);
+}
+template <class T> __device__ inline uint4 ys_pack(const float* f);
+template <> __device__ inline uint4 ys_pack<float>(const float* f) {
+  return make_uint4(ys_f2u(f[0]), ys_f2u(f[1]), ys_f2u(f[2]), ys_f2u(f[3]));
+}
+__device__ inline unsigned ys_pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+}
+template <> __device__ inline uint4 ys_pack<bf16_t>(const float* f) {
+  return make_uint4(ys_pack_bf16x2(f[0], f[1]), ys_pack_bf16x2(f[2], f[3]),
+                    ys_pack_bf16x2(f[4], f[5]), ys_pack_bf16x2(f[6], f[7]));
+}
+
+// ---------------------------------------------------------------- accumulator vector
+#ifdef YS_EMU_BUILD
+struct f32x4 {
+  float d[4];
+  float& operator[](int i) { return d[i]; }
+  const float& operator[](int i) const { return d[i]; }
+};
+#else
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
+__device__ inline f32x4 f32x4_zero() { f32x4 z; z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f; return z; }
+
+// ---------------------------------------------------------------- MFMA wrappers
+// v_mfma_f32_16x16x32_bf16: D[16x16] = A[16x32] * B[32x16] + C.
+//   lane l supplies A[i = l&15][k = 8*(l>>4) .. +8) and B[k = 8*(l>>4) .. +8)[j = l&15];
+//   it receives D[i = 4*(l>>4) + r][j = l&15], r = 0..3.
+__device__ inline f32x4 mfma_16x16x32_bf16(const uint4& a, const uint4& b, const f32x4& c) {
+#ifdef YS_EMU_BUILD
+  struct Dep { uint4 a, b; } dep{a, b};
+  f32x4 d = c;
+  const int l = emu::lane();
+  emu::wave_collective(&dep, sizeof(dep), [&](unsigned char (*slot)[128]) {
+    const int j = l & 15;
+    for (int r = 0; r < 4; r++) {
+      const int i = 4 * (l >> 4) + r;
+      float acc = d[r];
+      for (int k = 0; k < 32; k++) {
+        Dep da, db;
+        memcpy(&da, slot[i + 16 * (k >> 3)], sizeof(Dep));
+        memcpy(&db, slot[j + 16 * (k >> 3)], sizeof(Dep));
+        const unsigned short* pa = (const unsigned short*)&da.a;
+        const unsigned short* pb = (const unsigned short*)&db.b;
+        acc += bf16_bits_to_f32(pa[k & 7]) * bf16_bits_to_f32(pb[k & 7]);
+      }
+      d[r] = acc;
+    }
+  });
+  return d;
+#else
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
+}
+
+// v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain): lane l supplies A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15]; receives D[4*(l>>4)+r][l&15].
+__device__ inline f32x4 mfma_16x16x4_f32(float a, float b, const f32x4& c) {
+#ifdef YS_EMU_BUILD
+  struct Dep { float a, b; } dep{a, b};
+  f32x4 d = c;
+  const int l = emu::lane();
+  emu::wave_collective(&dep, sizeof(dep), [&](unsigned char (*slot)[128]) {
+    const int j = l & 15;
+    for (int r = 0; r < 4; r++) {
+      const int i = 4 * (l >> 4) + r;
+      float acc = d[r];
+      for (int k = 0; k < 4; k++) {
+        Dep da, db;
+        memcpy(&da, slot[i + 16 * k], sizeof(Dep));
+        memcpy(&db, slot[j + 16 * k], sizeof(Dep));
+        acc = fmaf(da.a, db.b, acc);
+      }
+      d[r] = acc;
+    }
+  });
+  return d;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+// One "k-step" of the tile product for storage type T: each lane holds 16 bytes of the
+// row operand (a) and 16 bytes of the column operand (b), both K-contiguous.
+//   bf16: one 16x16x32 MFMA (lane's 8 elements = k 8q..8q+7).
+//   f32 : four 16x16x4 MFMAs (element t of every lane forms k-slot q of MFMA t) -- any
+//         consistent permutation of k between a and b is a valid dot product.
+template <class T> __device__ inline f32x4 ys_mma(const uint4& a, const uint4& b, f32x4 c);
+template <> __device__ inline f32x4 ys_mma<bf16_t>(const uint4& a, const uint4& b, f32x4 c) {
+  return mfma_16x16x32_bf16(a, b, c);
+}
+template <> __device__ inline f32x4 ys_mma<float>(const uint4& a, const uint4& b, f32x4 c) {
+  c = mfma_16x16x4_f32(ys_u2f(a.x), ys_u2f(b.x), c);
+  c = mfma_16x16x4_f32(ys_u2f(a.y), ys_u2f(b.y), c);
+  c = mfma_16x16x4_f32(ys_u2f(a.z), ys_u2f(b.z), c);
+  c = mfma_16x16x4_f32(ys_u2f(a.w), ys_u2f(b.w), c);
+  return c;
+}
+
+__device__ inline float ys_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ inline float ys_silu(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))
+__device__ inline float ys_silu_grad(float x) { float s = ys_sigmoid(x); return s * (1.0f + x * (1.0f - s)); }
+
+__device__ inline uint4 ys_ld16(const void* p) { return *(const uint4*)p; }
+__device__ inline void ys_st16(void* p, const uint4& v) { *(uint4*)p = v; }
+__device__ inline uint4 ys_zero16() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// wave reductions (64 lanes)
+__device__ inline float ys_wave_sum(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ inline float ys_wave_max(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,68 @@
+// ys_internal.h -- host-side internals shared by the translation units of libyolosharp_hip.
+#pragma once
+#include "ys_hip.h"
+#include "../../include/yolosharp_hip.h"
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdio>
+#include <cstdarg>
+
+void ys_set_error(const char* fmt, ...);
+
+#define YS_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      ys_set_error("HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+      return YS_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define YS_REQUIRE(cond, ...)                \
+  do {                                       \
+    if (!(cond)) {                           \
+      ys_set_error(__VA_ARGS__);             \
+      return YS_ERR_INVALID_ARG;             \
+    }                                        \
+  } while (0)
+
+#define YS_TRY(expr)                 \
+  do {                               \
+    int _s = (expr);                 \
+    if (_s != YS_OK) return _s;      \
+  } while (0)
+
+struct ys_ctx {
+  int device = 0;
+  hipStream_t stream = 0;
+  bool own_stream = true;
+  bool profile = false;
+  // NMS workspace (grown on demand)
+  void* nms_ws = nullptr;
+  size_t nms_ws_bytes = 0;
+  // scratch for per-operator entry points
+  std::map<std::string, float> last_ms;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// simple RAII-free timing helper: records events on the ctx stream when profiling is on
+struct YsTimer {
+  ys_ctx* c; const char* name; bool on;
+  YsTimer(ys_ctx* ctx, const char* n) : c(ctx), name(n), on(ctx->profile) {
+    if (on) hipEventRecord(c->ev0, c->stream);
+  }
+  ~YsTimer() {
+    if (on) {
+      hipEventRecord(c->ev1, c->stream);
+      hipEventSynchronize(c->ev1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      c->last_ms[name] = ms;
+    }
+  }
+};
+
+// ---- kernels' host launchers (defined in the .hip files) ----
+int ys_nms_launch(ys_ctx* ctx, float* pred_dev, int B, int C, int A, float conf, float iou, int max_det,
+                  int nc, int max_nms, int max_wh, float* out_rows, int64_t* out_keep, int32_t* out_count);
