@@ -43,7 +43,7 @@ static void run_block(Block& b) {
   b.waves.resize(nw);
   for (int w = 0; w < nw; w++) {
     Wave& wv = b.waves[w];
-    wv.arrived[0] = wv.arrived[1] = wv.left[0] = wv.left[1] = 0;
+    wv.arrived[0] = wv.arrived[1] = 0; wv.gen[0] = wv.gen[1] = 0;
     wv.alive = std::min(64, n - w * 64);
   }
   b.alive = n;

@@ -60,7 +60,7 @@ struct Thread {
 struct Wave {
   alignas(16) unsigned char slot[2][64][128];  // per-lane deposit area (two generations)
   int arrived[2];
-  int left[2];
+  int gen[2];
   int alive;
 };
 
@@ -96,11 +96,16 @@ inline void wave_collective(const void* dep, int nbytes, F reader) {
   int p = t.par;
   t.par ^= 1;
   memcpy(w.slot[p][t.lin & 63], dep, nbytes);
+  const int my_gen = w.gen[p];
   w.arrived[p]++;
-  while (w.arrived[p] < w.alive) yield();
+  for (;;) {
+    if (w.gen[p] != my_gen) break;                       // completed by another lane
+    if (w.arrived[p] >= w.alive) { w.arrived[p] = 0; w.gen[p]++; break; }  // I complete it
+    yield();
+  }
+  // slots of generation p stay valid until parity p is reused, which needs every alive lane to
+  // have completed the next (p^1) collective, i.e. to have finished this read.
   reader(w.slot[p]);
-  w.left[p]++;
-  if (w.left[p] >= w.alive) { w.arrived[p] = 0; w.left[p] = 0; }
 }
 
 void barrier();

@@ -1,0 +1,475 @@
+// conv.hip -- NHWC implicit-GEMM convolution for gfx950 (CDNA4), forward / dgrad / wgrad.
+//
+// Replaces the arithmetic of torch.nn.Conv2d inside Modules/Convs.cs:36-62 (Conv = conv2d, bias=False,
+// p = k/2) and the plain biased Conv2d heads of Modules/Head.cs:47-50, plus their autograd
+// (Amp.cs:348,370).  k in {1,3}, stride in {1,2}, groups = 1.
+//
+// Layout: activations NHWC (channel stride `ldc`, channel offset `coff` so producers write straight
+// into concat buffers and chunk() is a view); weights [Cout][kh][kw][Cin] (K-contiguous per cout).
+// GEMM view per launch:  D[cout][pixel] = sum_k W[cout][k] * X[pixel][k],  k = (kh,kw,ci).
+// MFMA orientation is "weights as the row operand": a lane ends up with 4 consecutive output
+// channels of ONE pixel -> 8-byte (bf16) / 16-byte (f32) NHWC stores, and BN batch statistics
+// reduce across lanes with 4 xor-shuffles.
+//   T = bf16_t : v_mfma_f32_16x16x32_bf16, one 16-byte fragment load feeds one MFMA (K = 32)
+//   T = float  : v_mfma_f32_16x16x4_f32 x4 (exact f32 fma chain) -- the parity path
+// Activations stream HBM -> VGPR fragments directly (no reuse across waves: waves split pixels);
+// the weight tile of the current tap is staged in LDS once per workgroup and shared by 4 waves.
+//
+// The same kernel computes dgrad:  ih*DIV = oh*SA + kh - PAD  describes both the forward gather
+// (SA = stride, DIV = 1, PAD = k/2) and the input-gradient gather of a strided conv
+// (SA = 1, DIV = stride, PAD = k-1-k/2, spatially flipped + transposed weights).
+#include "ys_internal.h"
+#include "ys_kernels.h"
+
+template <class T, int MR, int NR>
+__global__ void __launch_bounds__(256)
+conv_igemm_kernel(ConvArgs a) {
+  constexpr int EPL = Elem<T>::EPL;
+  constexpr int BN = NR * 16;
+  constexpr int CK = 32 * EPL;  // channels per LDS weight chunk (32 x 16-byte units per row)
+  __shared__ uint4 sW[BN][33];
+  __shared__ float sStat[4][BN][2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 15;
+  const int q = lane >> 4;
+  const int m0 = blockIdx.x * (4 * MR * 16) + wave * (MR * 16);
+  const int n0 = blockIdx.y * BN;
+  const int HWo = a.Hout * a.Wout;
+  const char* xb = (const char*)a.x;
+  const char* wb = (const char*)a.w;
+  const int Ktot = a.KH * a.KW * a.Cin;
+
+  // per m-fragment pixel coordinates of this lane's column (pixel j = li)
+  int pb[MR], poh[MR], pow_[MR];
+  bool pv[MR];
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++) {
+    const int m = m0 + mf * 16 + li;
+    pv[mf] = m < a.M;
+    const int mm = pv[mf] ? m : 0;
+    const int b = mm / HWo;
+    const int r = mm - b * HWo;
+    pb[mf] = b;
+    poh[mf] = r / a.Wout;
+    pow_[mf] = r - poh[mf] * a.Wout;
+  }
+
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+
+  for (int kh = 0; kh < a.KH; kh++) {
+    for (int kw = 0; kw < a.KW; kw++) {
+      const int tap = kh * a.KW + kw;
+      // gather base pointer of each m-fragment's pixel for this tap
+      const char* px[MR];
+      bool pvt[MR];
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++) {
+        const int ihn = poh[mf] * a.SA + kh - a.PAD;
+        const int iwn = pow_[mf] * a.SA + kw - a.PAD;
+        const int ih = ihn >> a.DIVS, iw = iwn >> a.DIVS;
+        const bool ok = pv[mf] && ihn >= 0 && iwn >= 0 && ((ihn | iwn) & a.DIVM) == 0 && ih < a.Hin && iw < a.Win;
+        pvt[mf] = ok;
+        const long pix = ok ? ((long)pb[mf] * a.in_bstride + (long)ih * a.Win + iw) : 0;
+        px[mf] = xb + (pix * a.in_ldc + a.in_coff) * (long)sizeof(T);
+      }
+      for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();
+        // stage W[n0..n0+BN)[tap][c0..c0+CK) into LDS, zero-filled outside [Cout) x [Cin)
+        for (int idx = tid; idx < BN * 32; idx += 256) {
+          const int n = idx >> 5, u = idx & 31;
+          const int c = c0 + u * EPL;
+          uint4 v = ys_zero16();
+          if (n0 + n < a.Cout && c < a.Cin)
+            v = ys_ld16(wb + ((long)(n0 + n) * Ktot + (long)tap * a.Cin + c) * (long)sizeof(T));
+          sW[n][u] = v;
+        }
+        __syncthreads();
+        const int cend = (a.Cin - c0) < CK ? (a.Cin - c0) : CK;
+        const int nsteps = (cend + 4 * EPL - 1) / (4 * EPL);
+        for (int s = 0; s < nsteps; s++) {
+          const int u = 4 * s + q;
+          const int c = c0 + u * EPL;
+          uint4 xf[MR];
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++) {
+            xf[mf] = ys_zero16();
+            if (pvt[mf] && c < a.Cin) xf[mf] = ys_ld16(px[mf] + (long)c * (long)sizeof(T));
+          }
+#pragma unroll
+          for (int nf = 0; nf < NR; nf++) {
+            const uint4 wf = sW[nf * 16 + li][u];
+#pragma unroll
+            for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf, xf[mf], acc[mf][nf]);
+          }
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const bool do_stats = a.stats != nullptr;
+  float s1[NR][4], s2[NR][4];
+#pragma unroll
+  for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
+
+  char* yb = (char*)a.y;
+  const char* rb = (const char*)a.res;
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++) {
+    const int m = m0 + mf * 16 + li;
+    const bool mv = m < a.M;
+    const int mm = mv ? m : 0;
+    const int b = mm / HWo;
+    const int pix = mm - b * HWo;
+    const long orow = (long)b * a.out_bstride + pix;
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++) {
+      const int c = n0 + nf * 16 + 4 * q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
+      if (a.scale || a.shift) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int cc = (c + r) < a.Cout ? (c + r) : 0;
+          const float sc = a.scale ? a.scale[cc] : 1.0f;
+          const float sh = a.shift ? a.shift[cc] : 0.0f;
+          v[r] = v[r] * sc + sh;
+          if (a.act) v[r] = ys_silu(v[r]);
+        }
+      }
+      if (rb && mv) {
+        const T* rp = (const T*)(rb + (orow * a.res_ldc + a.res_coff + c) * (long)sizeof(T));
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (c + r < a.Cout) v[r] += Elem<T>::to_f(rp[r]);
+      }
+      T* yp = (T*)(yb + (orow * a.out_ldc + a.out_coff + c) * (long)sizeof(T));
+      if (a.accumulate && mv) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (c + r < a.Cout) v[r] += Elem<T>::to_f(yp[r]);
+      }
+      alignas(16) T o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r] = Elem<T>::from_f(v[r]);
+      if (do_stats) {
+        // statistics of the values actually stored (what BN will normalise)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float f = Elem<T>::to_f(o[r]);
+          s1[nf][r] += f;
+          s2[nf][r] += f * f;
+        }
+      }
+      if (mv) {
+        if (a.vec_ok && c + 3 < a.Cout) {
+          if (sizeof(T) == 2) {
+            uint2 pk;
+            pk.x = (unsigned)((const unsigned short*)o)[0] | ((unsigned)((const unsigned short*)o)[1] << 16);
+            pk.y = (unsigned)((const unsigned short*)o)[2] | ((unsigned)((const unsigned short*)o)[3] << 16);
+            *(uint2*)yp = pk;
+          } else {
+            *(uint4*)yp = *(const uint4*)o;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (c + r < a.Cout) yp[r] = o[r];
+        }
+      }
+    }
+  }
+
+  if (do_stats) {
+    // reduce over the 16 pixels held by lanes with equal q (xor 1,2,4,8), then over waves via LDS
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float x1 = s1[nf][r], x2 = s2[nf][r];
+        for (int msk = 1; msk <= 8; msk <<= 1) {
+          x1 += __shfl_xor(x1, msk);
+          x2 += __shfl_xor(x2, msk);
+        }
+        if (li == 0) {
+          sStat[wave][nf * 16 + 4 * q + r][0] = x1;
+          sStat[wave][nf * 16 + 4 * q + r][1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Cout) {
+      const float t1 = sStat[0][tid][0] + sStat[1][tid][0] + sStat[2][tid][0] + sStat[3][tid][0];
+      const float t2 = sStat[0][tid][1] + sStat[1][tid][1] + sStat[2][tid][1] + sStat[3][tid][1];
+      a.stats[((long)blockIdx.x * 2 + 0) * a.Cout + n0 + tid] = t1;
+      a.stats[((long)blockIdx.x * 2 + 1) * a.Cout + n0 + tid] = t2;
+    }
+  }
+}
+
+template <class T, int MR, int NR>
+static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
+  dim3 grid(ys_cdiv(a.M, 4 * MR * 16), ys_cdiv(a.Cout, NR * 16));
+  YS_LAUNCH((conv_igemm_kernel<T, MR, NR>), grid, 256, st, a);
+}
+
+int ys_conv_grid_m(const ConvArgs& a) { return ys_cdiv(a.M, 4 * 2 * 16); }
+
+template <class T>
+static int conv_launch_dtype(hipStream_t st, const ConvArgs& a) {
+  const int nfr = (a.Cout + 15) / 16;
+  // MR is fixed at 2 (128 pixels per workgroup) so that the BN partial-statistics grid is known
+  if (nfr <= 1) conv_launch_t<T, 2, 1>(st, a);
+  else if (nfr == 2) conv_launch_t<T, 2, 2>(st, a);
+  else if (nfr == 3) conv_launch_t<T, 2, 3>(st, a);
+  else if (nfr == 4) conv_launch_t<T, 2, 4>(st, a);
+  else if (nfr == 5) conv_launch_t<T, 2, 5>(st, a);
+  else if (nfr == 6) conv_launch_t<T, 2, 6>(st, a);
+  else if (nfr % 8 == 0 || nfr > 10) conv_launch_t<T, 2, 8>(st, a);
+  else if (nfr % 5 == 0) conv_launch_t<T, 2, 5>(st, a);
+  else conv_launch_t<T, 2, 4>(st, a);
+  return YS_OK;
+}
+
+int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (a.Cin % epl || a.in_ldc % epl || a.in_coff % epl) {
+    ys_set_error("conv: Cin/ldc/coff (%d,%d,%d) must be multiples of %d", a.Cin, a.in_ldc, a.in_coff, epl);
+    return YS_ERR_INVALID_ARG;
+  }
+  if (dtype == YS_BF16) return conv_launch_dtype<bf16_t>(st, a);
+  return conv_launch_dtype<float>(st, a);
+}
+
+// ===================================================================================== wgrad
+// dW[co][tap][ci] = sum_p dy[p][co] * x[pix(p,tap)][ci].  Both operands have the reduction dim
+// (pixels) as the slow axis in NHWC, so tiles are staged pixel-major in LDS and read transposed.
+// Grid: (pixel splits, co-tile x ci-tile, taps).  Each wave owns a quarter of the workgroup's pixel
+// range; waves are combined through LDS and the workgroup writes ONE fp32 partial tile, which
+// wgrad_reduce_kernel sums over splits in a fixed order (deterministic, no atomics).
+template <class T, int MRA, int NRB>
+__global__ void __launch_bounds__(256)
+conv_wgrad_kernel(WgradArgs a) {
+  constexpr int EPL = Elem<T>::EPL;
+  constexpr int KS = 4 * EPL;  // pixels per wave-step
+  constexpr int COT = MRA * 16, CIT = NRB * 16;
+  constexpr int PD = COT + 16 / (int)sizeof(T);  // LDS pitches in elements (rows stay 16-byte aligned)
+  constexpr int PX = CIT + 16 / (int)sizeof(T);
+  constexpr int STAGE_BYTES = 4 * KS * (PD + PX) * (int)sizeof(T);
+  constexpr int RED_BYTES = 4 * COT * CIT * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  __shared__ uint4 smem[LDS_BYTES / 16];
+  T* sD = (T*)smem;                       // [4][KS][PD]
+  T* sX = sD + 4 * KS * PD;               // [4][KS][PX]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int ci_tiles = (a.Cin + CIT - 1) / CIT;
+  const int co0 = (blockIdx.y / ci_tiles) * COT;
+  const int ci0 = (blockIdx.y % ci_tiles) * CIT;
+  const int tap = blockIdx.z;
+  const int kh = tap / a.KW, kw = tap % a.KW;
+  const int HWo = a.Hout * a.Wout;
+  // pixel range of this workgroup, in wave-steps
+  const long steps_total = ((long)a.M + KS - 1) / KS;
+  const long steps_per_blk = (steps_total + gridDim.x - 1) / gridDim.x;
+  const long sb = (long)blockIdx.x * steps_per_blk;
+  long se = sb + steps_per_blk;
+  if (se > steps_total) se = steps_total;
+  const long iters = (steps_per_blk + 3) / 4;  // uniform trip count for all waves/blocks
+
+  f32x4 acc[MRA][NRB];
+#pragma unroll
+  for (int i = 0; i < MRA; i++)
+#pragma unroll
+    for (int j = 0; j < NRB; j++) acc[i][j] = f32x4_zero();
+
+  T* myD = sD + wave * KS * PD;
+  T* myX = sX + wave * KS * PX;
+  const char* dyb = (const char*)a.dy;
+  const char* xb = (const char*)a.x;
+  constexpr int DV = COT / EPL;  // 16-byte vectors per pixel row of the dy tile
+  constexpr int XV = CIT / EPL;
+
+  for (long it = 0; it < iters; it++) {
+    const long step = sb + it * 4 + wave;
+    const bool active = step < se;
+    const long p0 = step * KS;
+    // ---- stage dy tile [KS][COT] and gathered x tile [KS][CIT]
+    for (int v = lane; v < KS * DV; v += 64) {
+      const int pr = v / DV, cv = v % DV;
+      const long p = p0 + pr;
+      const int c = co0 + cv * EPL;
+      uint4 val = ys_zero16();
+      if (active && p < a.M && c < a.Cout)
+        val = ys_ld16(dyb + ((p * a.dy_ldc) + a.dy_coff + c) * (long)sizeof(T));
+      *(uint4*)(myD + pr * PD + cv * EPL) = val;
+    }
+    for (int v = lane; v < KS * XV; v += 64) {
+      const int pr = v / XV, cv = v % XV;
+      const long p = p0 + pr;
+      const int c = ci0 + cv * EPL;
+      uint4 val = ys_zero16();
+      if (active && p < a.M && c < a.Cin) {
+        const int b = (int)(p / HWo);
+        const int r = (int)(p - (long)b * HWo);
+        const int oh = r / a.Wout, ow = r - oh * a.Wout;
+        const int ih = oh * a.stride + kh - a.pad, iw = ow * a.stride + kw - a.pad;
+        if (ih >= 0 && ih < a.Hin && iw >= 0 && iw < a.Win)
+          val = ys_ld16(xb + ((((long)b * a.in_bstride + (long)ih * a.Win + iw) * a.in_ldc) + a.in_coff + c) * (long)sizeof(T));
+      }
+      *(uint4*)(myX + pr * PX + cv * EPL) = val;
+    }
+    __syncthreads();
+    // ---- transposed fragment reads + MFMA
+    uint4 fa[MRA], fb[NRB];
+#pragma unroll
+    for (int i = 0; i < MRA; i++) {
+      alignas(16) T tmp[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; e++) tmp[e] = myD[(q * EPL + e) * PD + i * 16 + li];
+      fa[i] = *(const uint4*)tmp;
+    }
+#pragma unroll
+    for (int j = 0; j < NRB; j++) {
+      alignas(16) T tmp[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; e++) tmp[e] = myX[(q * EPL + e) * PX + j * 16 + li];
+      fb[j] = *(const uint4*)tmp;
+    }
+#pragma unroll
+    for (int i = 0; i < MRA; i++)
+#pragma unroll
+      for (int j = 0; j < NRB; j++) acc[i][j] = ys_mma<T>(fa[i], fb[j], acc[i][j]);
+    __syncthreads();
+  }
+  // ---- combine the 4 waves, write the partial tile
+  float* sR = (float*)smem;  // [4][COT][CIT]
+#pragma unroll
+  for (int i = 0; i < MRA; i++)
+#pragma unroll
+    for (int j = 0; j < NRB; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        sR[(wave * COT + i * 16 + 4 * q + r) * CIT + j * 16 + li] = acc[i][j][r];
+  __syncthreads();
+  float* outp = a.partial + (long)blockIdx.x * a.Cout * a.KH * a.KW * a.Cin;
+  for (int e = tid; e < COT * CIT; e += 256) {
+    const int co = co0 + e / CIT, ci = ci0 + e % CIT;
+    if (co < a.Cout && ci < a.Cin) {
+      const float v = sR[e] + sR[COT * CIT + e] + sR[2 * COT * CIT + e] + sR[3 * COT * CIT + e];
+      outp[((long)co * a.KH * a.KW + tap) * a.Cin + ci] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int cin_pad, int cin_real,
+                    float* __restrict__ grad) {
+  // grad[(row)*cin_real + ci] += sum_s partial[s][row*cin_pad + ci]   (drops padded input channels)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long row = i / cin_pad;
+  const int ci = (int)(i - row * cin_pad);
+  if (ci >= cin_real) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; k++) s += partial[(long)k * n + i];
+  grad[row * cin_real + ci] += s;
+}
+
+template <class T, int MRA, int NRB>
+static void wgrad_launch_t(hipStream_t st, const WgradArgs& a, int splits) {
+  const int co_tiles = ys_cdiv(a.Cout, MRA * 16), ci_tiles = ys_cdiv(a.Cin, NRB * 16);
+  dim3 grid(splits, co_tiles * ci_tiles, a.KH * a.KW);
+  YS_LAUNCH((conv_wgrad_kernel<T, MRA, NRB>), grid, 256, st, a);
+}
+
+template <class T>
+static void wgrad_dispatch(hipStream_t st, const WgradArgs& a, int splits) {
+  const int cof = (a.Cout + 15) / 16, cif = (a.Cin + 15) / 16;
+  const int mra = cof >= 4 ? ((cof % 5 == 0) ? 5 : 4) : cof;  // 1,2,3,4,5
+  const int nrb = cif >= 4 ? 4 : cif;
+#define WG(M_, N_) if (mra == M_ && nrb == N_) { wgrad_launch_t<T, M_, N_>(st, a, splits); return; }
+  WG(1, 1) WG(1, 2) WG(1, 3) WG(1, 4)
+  WG(2, 1) WG(2, 2) WG(2, 3) WG(2, 4)
+  WG(3, 1) WG(3, 2) WG(3, 3) WG(3, 4)
+  WG(4, 1) WG(4, 2) WG(4, 3) WG(4, 4)
+  WG(5, 1) WG(5, 2) WG(5, 3) WG(5, 4)
+#undef WG
+}
+
+// number of pixel splits used for a layer (also sizes the partial workspace)
+int ys_wgrad_splits(const WgradArgs& a, int dtype) {
+  const int ks = dtype == YS_BF16 ? 32 : 16;
+  const int cof = (a.Cout + 15) / 16, cif = (a.Cin + 15) / 16;
+  const int mra = cof >= 4 ? ((cof % 5 == 0) ? 5 : 4) : cof;
+  const int nrb = cif >= 4 ? 4 : cif;
+  const long tiles = (long)ys_cdiv(a.Cout, mra * 16) * ys_cdiv(a.Cin, nrb * 16) * a.KH * a.KW;
+  const long steps = ((long)a.M + ks - 1) / ks;
+  long s = (2048 + tiles - 1) / tiles;          // aim for ~2k workgroups (256 CUs x 8)
+  const long smax = (steps + 15) / 16;          // at least 16 wave-steps (4 iterations) per workgroup
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (a.Cin % epl || a.in_ldc % epl || a.in_coff % epl || a.dy_ldc % epl || a.dy_coff % epl) {
+    ys_set_error("wgrad: channel counts/strides must be multiples of %d (Cin %d Cout %d)", epl, a.Cin, a.Cout);
+    return YS_ERR_INVALID_ARG;
+  }
+  if (dtype == YS_BF16) wgrad_dispatch<bf16_t>(st, a, splits);
+  else wgrad_dispatch<float>(st, a, splits);
+  const long n = (long)a.Cout * a.KH * a.KW * a.Cin;
+  YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 256), 256, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
+  return YS_OK;
+}
+
+// ===================================================================================== weight prep
+// master fp32 weights [Cout][taps][Cin_real] -> forward weights T [Cout][taps][Cin_pad]
+//                                            -> dgrad weights  T [Cin_real][taps flipped][Cout_pad]
+template <class T>
+__global__ void __launch_bounds__(256)
+weight_prep_kernel(const float* __restrict__ w, int Cout, int taps, int cin_real, int cin_pad, int cout_pad,
+                   T* __restrict__ wf, T* __restrict__ wd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nf = (long)Cout * taps * cin_pad;
+  if (i < nf) {
+    const int ci = (int)(i % cin_pad);
+    const long r = i / cin_pad;  // co*taps + tap
+    wf[i] = Elem<T>::from_f(ci < cin_real ? w[r * cin_real + ci] : 0.f);
+  }
+  if (wd) {
+    const long nd = (long)cin_real * taps * cout_pad;
+    if (i < nd) {
+      const int co = (int)(i % cout_pad);
+      const long r = i / cout_pad;
+      const int tapf = (int)(r % taps);
+      const int ci = (int)(r / taps);
+      const int tap = taps - 1 - tapf;  // spatial flip of a square kernel
+      wd[i] = Elem<T>::from_f(co < Cout ? w[((long)co * taps + tap) * cin_real + ci] : 0.f);
+    }
+  }
+}
+
+int ys_weight_prep_launch(hipStream_t st, int dtype, const float* w, int Cout, int taps, int cin_real, int cin_pad,
+                          int cout_pad, void* wf, void* wd) {
+  const long nf = (long)Cout * taps * cin_pad;
+  const long nd = wd ? (long)cin_real * taps * cout_pad : 0;
+  const long n = nf > nd ? nf : nd;
+  if (dtype == YS_BF16)
+    YS_LAUNCH((weight_prep_kernel<bf16_t>), ys_cdiv(n, 256), 256, st, w, Cout, taps, cin_real, cin_pad, cout_pad, (bf16_t*)wf, (bf16_t*)wd);
+  else
+    YS_LAUNCH((weight_prep_kernel<float>), ys_cdiv(n, 256), 256, st, w, Cout, taps, cin_real, cin_pad, cout_pad, (float*)wf, (float*)wd);
+  return YS_OK;
+}

@@ -1,0 +1,628 @@
+// elementwise.hip -- HBM-bound NHWC kernels around the convolutions (gfx950).
+//   BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU forward/backward  (Modules/Convs.cs:36-62)
+//   MaxPool2d(5,1,2) chain of SPPF                                  (Modules/Block.cs:236-285)
+//   Upsample(x2, nearest) + Concat as channel-slice writes           (Models/Yolo.cs:70-75, Convs.cs:435-448)
+//   Detect._inference decode                                         (Modules/Head.cs:204-223, Block.cs:40-45)
+//   AdamW step                                                       (YoloBaseTaskModel.cs:144-153, Amp.cs:355-372)
+// All tensors are [rows][ldc] views with a channel offset; one thread moves 16 bytes (8 bf16 / 4 f32).
+#include "ys_internal.h"
+#include "ys_kernels.h"
+
+#define EW_THREADS 256
+
+// ------------------------------------------------------------------ input pack / unpack
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+pack_input_kernel(const float* __restrict__ x, int B, int C, long HW, int cpad, T* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const long b = i / HW, p = i - b * HW;
+  for (int c = 0; c < cpad; c++) {
+    const float v = c < C ? x[(b * C + c) * HW + p] : 0.f;
+    y[i * cpad + c] = Elem<T>::from_f(v);
+  }
+}
+int ys_pack_input_launch(hipStream_t st, int dtype, const float* x, int B, int C, int H, int W, int cpad, void* y) {
+  const long n = (long)B * H * W;
+  if (dtype == YS_BF16) YS_LAUNCH((pack_input_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, (long)H * W, cpad, (bf16_t*)y);
+  else YS_LAUNCH((pack_input_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, (long)H * W, cpad, (float*)y);
+  return YS_OK;
+}
+
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+unpack_nchw_kernel(const T* __restrict__ x, int ldc, int coff, int B, int C, long rpb, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * C * rpb;
+  if (i >= n) return;
+  const long p = i % rpb;
+  const long bc = i / rpb;
+  const int c = (int)(bc % C);
+  const long b = bc / C;
+  y[i] = Elem<T>::to_f(x[(b * rpb + p) * ldc + coff + c]);
+}
+int ys_unpack_nchw_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, int B, int C, long rpb, float* y) {
+  const long n = (long)B * C * rpb;
+  if (dtype == YS_BF16) YS_LAUNCH((unpack_nchw_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)x, ldc, coff, B, C, rpb, y);
+  else YS_LAUNCH((unpack_nchw_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)x, ldc, coff, B, C, rpb, y);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ block reduction helper (double)
+__device__ inline double block_sum_d(double v, double* sbuf) {
+  const int tid = threadIdx.x;
+  sbuf[tid] = v;
+  __syncthreads();
+  for (int s = EW_THREADS / 2; s > 0; s >>= 1) {
+    if (tid < s) sbuf[tid] += sbuf[tid + s];
+    __syncthreads();
+  }
+  const double r = sbuf[0];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------ BN forward finalize
+// one workgroup per channel: deterministic sum of the conv epilogue's partials in double
+__global__ void __launch_bounds__(EW_THREADS)
+bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
+                   float* __restrict__ run_var, float* __restrict__ nbt, float* __restrict__ scale,
+                   float* __restrict__ shift, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  __shared__ double sbuf[EW_THREADS];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += EW_THREADS) {
+    s1 += (double)partial[((long)k * 2 + 0) * C + c];
+    s2 += (double)partial[((long)k * 2 + 1) * C + c];
+  }
+  s1 = block_sum_d(s1, sbuf);
+  s2 = block_sum_d(s2, sbuf);
+  if (threadIdx.x == 0) {
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;  // biased (torch BatchNorm2d training normalisation)
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma[c], bt = beta[c];
+    scale[c] = g * rstd;
+    shift[c] = bt - (float)mean * g * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    // running stats: momentum 0.03, unbiased variance (Convs.cs:41-42,48)
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+    if (c == 0 && nbt) nbt[0] += 1.0f;
+  }
+}
+int ys_bn_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, const float* gamma,
+                          const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* nbt,
+                          float* scale, float* shift, float* mean, float* rstd) {
+  YS_LAUNCH(bn_finalize_kernel, C, EW_THREADS, st, partial, nblk, C, (double)count, gamma, beta, eps, momentum,
+            run_mean, run_var, nbt, scale, shift, mean, rstd);
+  return YS_OK;
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.0f / sqrtf(rv[c] + eps);
+  scale[c] = gamma[c] * rstd;
+  shift[c] = beta[c] - rm[c] * gamma[c] * rstd;
+}
+int ys_bn_eval_coeffs_launch(hipStream_t st, int C, const float* gamma, const float* beta, const float* rm,
+                             const float* rv, float eps, float* scale, float* shift) {
+  YS_LAUNCH(bn_eval_coeffs_kernel, ys_cdiv(C, EW_THREADS), EW_THREADS, st, C, gamma, beta, rm, rv, eps, scale, shift);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ BN + act apply (training forward, pass 2)
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_apply_kernel(const T* __restrict__ y, long rows, int C, const float* __restrict__ scale,
+                    const float* __restrict__ shift, int act, const T* __restrict__ res, int res_ldc, int res_coff,
+                    T* __restrict__ z, int z_ldc, int z_coff) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * CG) return;
+  const long row = i / CG;
+  const int c = (int)(i - row * CG) * EPL;
+  float f[EPL], r[EPL];
+  ys_unpack<T>(ys_ld16(y + row * C + c), f);
+  if (res) ys_unpack<T>(ys_ld16(res + row * res_ldc + res_coff + c), r);
+#pragma unroll
+  for (int e = 0; e < EPL; e++) {
+    float u = f[e] * scale[c + e] + shift[c + e];
+    if (act) u = ys_silu(u);
+    if (res) u += r[e];
+    f[e] = u;
+  }
+  ys_st16(z + row * z_ldc + z_coff + c, ys_pack<T>(f));
+}
+int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const float* scale,
+                           const float* shift, int act, const void* res, int res_ldc, int res_coff, void* z,
+                           int z_ldc, int z_coff) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = rows * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((bn_act_apply_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)y, rows, C, scale, shift, act, (const bf16_t*)res, res_ldc, res_coff, (bf16_t*)z, z_ldc, z_coff);
+  else
+    YS_LAUNCH((bn_act_apply_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)y, rows, C, scale, shift, act, (const float*)res, res_ldc, res_coff, (float*)z, z_ldc, z_coff);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ per-channel reductions over rows
+// thread t owns channel vector cv = t % CG and row lane t / CG; workgroup blk owns a contiguous row range.
+// MODE 0: BN backward (sum du, sum du*xhat), optional res_grad += dz.   MODE 1: plain column sum.
+template <class T, int MODE>
+__global__ void __launch_bounds__(EW_THREADS)
+chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
+                   const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, int act, T* __restrict__ rg, int rg_ldc, int rg_coff,
+                   float* __restrict__ partial) {
+  constexpr int EPL = Elem<T>::EPL;
+  __shared__ float sAcc[EW_THREADS][EPL * 2];
+  const int CG = C / EPL;
+  const int RP = EW_THREADS / CG;  // rows per pass
+  const int tid = threadIdx.x;
+  const int cv = tid % CG, rl = tid / CG;
+  const int c = cv * EPL;
+  const long rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  long r1 = r0 + rows_per_blk;
+  if (r1 > rows) r1 = rows;
+  float a1[EPL], a2[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) { a1[e] = 0.f; a2[e] = 0.f; }
+  if (rl < RP) {
+    float sc[EPL], sh[EPL], mu[EPL], rs[EPL];
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < EPL; e++) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; rs[e] = rstd[c + e]; }
+    }
+    for (long row = r0 + rl; row < r1; row += RP) {
+      float g[EPL];
+      const uint4 gv = ys_ld16(dz + row * dz_ldc + dz_coff + c);
+      ys_unpack<T>(gv, g);
+      if (MODE == 0) {
+        float f[EPL];
+        ys_unpack<T>(ys_ld16(y + row * C + c), f);
+        if (rg) {
+          float o[EPL];
+          T* rp = rg + row * rg_ldc + rg_coff + c;
+          ys_unpack<T>(ys_ld16(rp), o);
+#pragma unroll
+          for (int e = 0; e < EPL; e++) o[e] += g[e];
+          ys_st16(rp, ys_pack<T>(o));
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+          const float u = f[e] * sc[e] + sh[e];
+          const float du = act ? g[e] * ys_silu_grad(u) : g[e];
+          const float xh = (f[e] - mu[e]) * rs[e];
+          a1[e] += du;
+          a2[e] += du * xh;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) a1[e] += g[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPL; e++) { sAcc[tid][e] = a1[e]; sAcc[tid][EPL + e] = a2[e]; }
+  __syncthreads();
+  if (tid < CG) {
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < RP; k++) { t1 += sAcc[k * CG + tid][e]; t2 += sAcc[k * CG + tid][EPL + e]; }
+      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = t1;
+      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = t2;
+    }
+  }
+}
+
+static int reduce_blocks(long rows, int C, int epl) {
+  const int cg = C / epl;
+  const int rp = EW_THREADS / cg;
+  long nb = (rows + (long)rp * 8 - 1) / ((long)rp * 8);  // >= 8 passes per workgroup
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+int ys_colsum_blocks(long rows, int C, int dtype) { return reduce_blocks(rows, C, dtype == YS_BF16 ? 8 : 4); }
+
+int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
+                            int C, const float* scale, const float* shift, const float* mean, const float* rstd,
+                            int act, void* res_grad, int rg_ldc, int rg_coff, float* partial, int* nblk_out) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (C % epl || C / epl > EW_THREADS) { ys_set_error("bn_bwd: unsupported channel count %d", C); return YS_ERR_UNSUPPORTED; }
+  const int nb = reduce_blocks(rows, C, epl);
+  *nblk_out = nb;
+  if (dtype == YS_BF16)
+    YS_LAUNCH((chan_reduce_kernel<bf16_t, 0>), nb, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, act, (bf16_t*)res_grad, rg_ldc, rg_coff, partial);
+  else
+    YS_LAUNCH((chan_reduce_kernel<float, 0>), nb, EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, act, (float*)res_grad, rg_ldc, rg_coff, partial);
+  return YS_OK;
+}
+
+// one workgroup per channel: sums partials; MODE 0 -> BN grads + coefficients, MODE 1 -> bias grad
+template <int MODE>
+__global__ void __launch_bounds__(EW_THREADS)
+chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count, float* __restrict__ g0,
+                     float* __restrict__ g1, float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double sbuf[EW_THREADS];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += EW_THREADS) {
+    s1 += (double)partial[((long)k * 2 + 0) * C + c];
+    if (MODE == 0) s2 += (double)partial[((long)k * 2 + 1) * C + c];
+  }
+  s1 = block_sum_d(s1, sbuf);
+  if (MODE == 0) s2 = block_sum_d(s2, sbuf);
+  if (threadIdx.x == 0) {
+    if (MODE == 0) {
+      g0[c] += (float)s2;  // dgamma = sum(du * xhat)
+      g1[c] += (float)s1;  // dbeta  = sum(du)
+      c1[c] = (float)(s1 / count);
+      c2[c] = (float)(s2 / count);
+    } else {
+      g0[c] += (float)s1;
+    }
+  }
+}
+int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, float* dgamma,
+                              float* dbeta, float* c1, float* c2) {
+  YS_LAUNCH((chan_finalize_kernel<0>), C, EW_THREADS, st, partial, nblk, C, (double)count, dgamma, dbeta, c1, c2);
+  return YS_OK;
+}
+
+int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, int C, float* partial, float* grad) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const int Cp = (C + epl - 1) / epl * epl;  // padded channels of the view are zero
+  if (Cp / epl > EW_THREADS) { ys_set_error("colsum: unsupported channel count %d", C); return YS_ERR_UNSUPPORTED; }
+  const int nb = reduce_blocks(rows, Cp, epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((chan_reduce_kernel<bf16_t, 1>), nb, EW_THREADS, st, (const bf16_t*)x, ldc, coff, (const bf16_t*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (bf16_t*)nullptr, 0, 0, partial);
+  else
+    YS_LAUNCH((chan_reduce_kernel<float, 1>), nb, EW_THREADS, st, (const float*)x, ldc, coff, (const float*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0, 0, partial);
+  // partial rows are Cp wide; finalize only the C real channels
+  YS_LAUNCH((chan_finalize_kernel<1>), C, EW_THREADS, st, (const float*)partial, nb, Cp, 1.0, grad, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  return YS_OK;
+}
+
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
+                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ c1,
+                    const float* __restrict__ c2, int act, T* __restrict__ dy) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * CG) return;
+  const long row = i / CG;
+  const int c = (int)(i - row * CG) * EPL;
+  float g[EPL], f[EPL];
+  ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
+  ys_unpack<T>(ys_ld16(y + row * C + c), f);
+#pragma unroll
+  for (int e = 0; e < EPL; e++) {
+    const float u = f[e] * scale[c + e] + shift[c + e];
+    const float du = act ? g[e] * ys_silu_grad(u) : g[e];
+    const float xh = (f[e] - mean[c + e]) * rstd[c + e];
+    f[e] = gamma[c + e] * rstd[c + e] * (du - c1[c + e] - xh * c2[c + e]);
+  }
+  ys_st16(dy + row * C + c, ys_pack<T>(f));
+}
+int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
+                           int C, const float* scale, const float* shift, const float* mean, const float* rstd,
+                           const float* gamma, const float* c1, const float* c2, int act, void* dy) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = rows * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((bn_bwd_apply_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, gamma, c1, c2, act, (bf16_t*)dy);
+  else
+    YS_LAUNCH((bn_bwd_apply_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, gamma, c1, c2, act, (float*)dy);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ max-pool 5x5 s1 p2
+// argmax = first maximum in (kh,kw) scan order with strict '>' (ATen max_pool2d CPU semantics)
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+maxpool5_fwd_kernel(const T* __restrict__ x, int x_ldc, int x_coff, int B, int H, int W, int C, T* __restrict__ y,
+                    int y_ldc, int y_coff, unsigned char* __restrict__ amax) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * H * W * CG;
+  if (i >= n) return;
+  const int c = (int)(i % CG) * EPL;
+  const long pix = i / CG;
+  const int w = (int)(pix % W);
+  const int h = (int)((pix / W) % H);
+  const long b = pix / ((long)W * H);
+  float best[EPL];
+  int bi[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) { best[e] = -INFINITY; bi[e] = 0; }
+  bool first = true;
+  for (int kh = 0; kh < 5; kh++) {
+    const int ih = h + kh - 2;
+    if (ih < 0 || ih >= H) continue;
+    for (int kw = 0; kw < 5; kw++) {
+      const int iw = w + kw - 2;
+      if (iw < 0 || iw >= W) continue;
+      float f[EPL];
+      ys_unpack<T>(ys_ld16(x + ((b * H + ih) * W + iw) * x_ldc + x_coff + c), f);
+#pragma unroll
+      for (int e = 0; e < EPL; e++)
+        if (first || f[e] > best[e]) { best[e] = f[e]; bi[e] = kh * 5 + kw; }
+      first = false;
+    }
+  }
+  ys_st16(y + pix * y_ldc + y_coff + c, ys_pack<T>(best));
+  if (amax) {
+#pragma unroll
+    for (int e = 0; e < EPL; e++) amax[pix * C + c + e] = (unsigned char)bi[e];
+  }
+}
+int ys_maxpool5_fwd_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
+                           void* y, int y_ldc, int y_coff, unsigned char* argmax) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = (long)B * H * W * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((maxpool5_fwd_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)x, x_ldc, x_coff, B, H, W, C, (bf16_t*)y, y_ldc, y_coff, argmax);
+  else
+    YS_LAUNCH((maxpool5_fwd_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)x, x_ldc, x_coff, B, H, W, C, (float*)y, y_ldc, y_coff, argmax);
+  return YS_OK;
+}
+
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+maxpool5_bwd_kernel(const T* __restrict__ dy, int dy_ldc, int dy_coff, int B, int H, int W, int C,
+                    const unsigned char* __restrict__ amax, T* __restrict__ dx, int dx_ldc, int dx_coff, int accumulate) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * H * W * CG;
+  if (i >= n) return;
+  const int c = (int)(i % CG) * EPL;
+  const long pix = i / CG;
+  const int w = (int)(pix % W);
+  const int h = (int)((pix / W) % H);
+  const long b = pix / ((long)W * H);
+  float acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) acc[e] = 0.f;
+  for (int kh = 0; kh < 5; kh++) {
+    const int oh = h - kh + 2;  // output whose window holds (h,w) at offset (kh,kw)
+    if (oh < 0 || oh >= H) continue;
+    for (int kw = 0; kw < 5; kw++) {
+      const int ow = w - kw + 2;
+      if (ow < 0 || ow >= W) continue;
+      const long op = (b * H + oh) * W + ow;
+      float g[EPL];
+      ys_unpack<T>(ys_ld16(dy + op * dy_ldc + dy_coff + c), g);
+      const int code = kh * 5 + kw;
+#pragma unroll
+      for (int e = 0; e < EPL; e++)
+        if (amax[op * C + c + e] == code) acc[e] += g[e];
+    }
+  }
+  T* dp = dx + pix * dx_ldc + dx_coff + c;
+  if (accumulate) {
+    float o[EPL];
+    ys_unpack<T>(ys_ld16(dp), o);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) acc[e] += o[e];
+  }
+  ys_st16(dp, ys_pack<T>(acc));
+}
+int ys_maxpool5_bwd_launch(hipStream_t st, int dtype, const void* dy, int dy_ldc, int dy_coff, int B, int H, int W,
+                           int C, const unsigned char* argmax, void* dx, int dx_ldc, int dx_coff, int accumulate) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = (long)B * H * W * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((maxpool5_bwd_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)dy, dy_ldc, dy_coff, B, H, W, C, argmax, (bf16_t*)dx, dx_ldc, dx_coff, accumulate);
+  else
+    YS_LAUNCH((maxpool5_bwd_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)dy, dy_ldc, dy_coff, B, H, W, C, argmax, (float*)dx, dx_ldc, dx_coff, accumulate);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ nearest 2x upsample
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+upsample2x_fwd_kernel(const T* __restrict__ x, int x_ldc, int x_coff, int B, int H, int W, int C, T* __restrict__ y,
+                      int y_ldc, int y_coff) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const int OH = 2 * H, OW = 2 * W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * OH * OW * CG;
+  if (i >= n) return;
+  const int c = (int)(i % CG) * EPL;
+  const long pix = i / CG;
+  const int ow = (int)(pix % OW);
+  const int oh = (int)((pix / OW) % OH);
+  const long b = pix / ((long)OW * OH);
+  const uint4 v = ys_ld16(x + ((b * H + (oh >> 1)) * W + (ow >> 1)) * x_ldc + x_coff + c);
+  ys_st16(y + pix * y_ldc + y_coff + c, v);
+}
+int ys_upsample2x_fwd_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
+                             void* y, int y_ldc, int y_coff) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = (long)B * 4 * H * W * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((upsample2x_fwd_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)x, x_ldc, x_coff, B, H, W, C, (bf16_t*)y, y_ldc, y_coff);
+  else
+    YS_LAUNCH((upsample2x_fwd_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)x, x_ldc, x_coff, B, H, W, C, (float*)y, y_ldc, y_coff);
+  return YS_OK;
+}
+
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+upsample2x_bwd_kernel(const T* __restrict__ dy, int dy_ldc, int dy_coff, int B, int H, int W, int C, T* __restrict__ dx,
+                      int dx_ldc, int dx_coff, int accumulate) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * H * W * CG;
+  if (i >= n) return;
+  const int c = (int)(i % CG) * EPL;
+  const long pix = i / CG;
+  const int w = (int)(pix % W);
+  const int h = (int)((pix / W) % H);
+  const long b = pix / ((long)W * H);
+  float acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) acc[e] = 0.f;
+  for (int dh = 0; dh < 2; dh++)
+    for (int dw = 0; dw < 2; dw++) {
+      float g[EPL];
+      ys_unpack<T>(ys_ld16(dy + ((b * 2 * H + 2 * h + dh) * 2 * W + 2 * w + dw) * dy_ldc + dy_coff + c), g);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) acc[e] += g[e];
+    }
+  T* dp = dx + pix * dx_ldc + dx_coff + c;
+  if (accumulate) {
+    float o[EPL];
+    ys_unpack<T>(ys_ld16(dp), o);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) acc[e] += o[e];
+  }
+  ys_st16(dp, ys_pack<T>(acc));
+}
+int ys_upsample2x_bwd_launch(hipStream_t st, int dtype, const void* dy, int dy_ldc, int dy_coff, int B, int H, int W,
+                             int C, void* dx, int dx_ldc, int dx_coff, int accumulate) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = (long)B * H * W * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((upsample2x_bwd_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)dy, dy_ldc, dy_coff, B, H, W, C, (bf16_t*)dx, dx_ldc, dx_coff, accumulate);
+  else
+    YS_LAUNCH((upsample2x_bwd_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)dy, dy_ldc, dy_coff, B, H, W, C, (float*)dx, dx_ldc, dx_coff, accumulate);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ view copy / accumulate
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+copy_view_kernel(const T* __restrict__ src, int s_ldc, int s_coff, long rows, int C, T* __restrict__ dst, int d_ldc,
+                 int d_coff, int accumulate) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * CG) return;
+  const long row = i / CG;
+  const int c = (int)(i - row * CG) * EPL;
+  uint4 v = ys_ld16(src + row * s_ldc + s_coff + c);
+  T* dp = dst + row * d_ldc + d_coff + c;
+  if (accumulate) {
+    float a[EPL], o[EPL];
+    ys_unpack<T>(v, a);
+    ys_unpack<T>(ys_ld16(dp), o);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) a[e] += o[e];
+    v = ys_pack<T>(a);
+  }
+  ys_st16(dp, v);
+}
+int ys_copy_view_launch(hipStream_t st, int dtype, const void* src, int s_ldc, int s_coff, long rows, int C, void* dst,
+                        int d_ldc, int d_coff, int accumulate) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = rows * (C / epl);
+  if (dtype == YS_BF16)
+    YS_LAUNCH((copy_view_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)src, s_ldc, s_coff, rows, C, (bf16_t*)dst, d_ldc, d_coff, accumulate);
+  else
+    YS_LAUNCH((copy_view_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)src, s_ldc, s_coff, rows, C, (float*)dst, d_ldc, d_coff, accumulate);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW single-tensor maths)
+__global__ void __launch_bounds__(EW_THREADS)
+adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+             float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.0f - lr * wd);           // param.mul_(1 - lr*weight_decay)
+  const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+}
+int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                    float beta2, float eps, float wd, float bc1, float bc2) {
+  if (n <= 0) return YS_OK;
+  YS_LAUNCH(adamw_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
+  return YS_OK;
+}
+
+__global__ void __launch_bounds__(EW_THREADS) fill_kernel(float* p, long n, float v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int ys_fill_launch(hipStream_t st, float* p, long n, float v) {
+  if (n <= 0) return YS_OK;
+  YS_LAUNCH(fill_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, n, v);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ Detect._inference decode
+// pred[b, 0:4, a] = dist2bbox(DFL(boxes), anchors, xywh) * stride ; pred[b, 4:4+nc, a] = sigmoid(scores)
+// (Head.cs:204-223; DFL = softmax over reg_max bins, expectation with weights 0..reg_max-1, Block.cs:40-45)
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ ps, int ld_ps, int B, int A, int nc,
+                     int reg_max, int nl, int o0, int o1, int o2, int w0, int w1, int w2, int s0, int s1, int s2,
+                     float* __restrict__ pred) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * A) return;
+  const int a = (int)(i % A);
+  const long b = i / A;
+  int lo = o0, lw = w0, ls = s0;
+  if (nl > 1 && a >= o1) { lo = o1; lw = w1; ls = s1; }
+  if (nl > 2 && a >= o2) { lo = o2; lw = w2; ls = s2; }
+  const int cell = a - lo;
+  const float ax = (float)(cell % lw) + 0.5f, ay = (float)(cell / lw) + 0.5f;
+  const T* row = pd + i * ld_pd;
+  float d[4];
+  for (int s = 0; s < 4; s++) {
+    float mx = -INFINITY;
+    for (int j = 0; j < reg_max; j++) mx = fmaxf(mx, Elem<T>::to_f(row[s * reg_max + j]));
+    float se = 0.f, sw = 0.f;
+    for (int j = 0; j < reg_max; j++) {
+      const float e = __expf(Elem<T>::to_f(row[s * reg_max + j]) - mx);
+      se += e;
+      sw += e * (float)j;
+    }
+    d[s] = sw / se;
+  }
+  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  float* o = pred + b * (long)(4 + nc) * A + a;
+  const float st = (float)ls;
+  o[0] = (x1 + x2) / 2.0f * st;
+  o[(long)A] = (y1 + y2) / 2.0f * st;
+  o[2 * (long)A] = (x2 - x1) * st;
+  o[3 * (long)A] = (y2 - y1) * st;
+  const T* srow = ps + i * ld_ps;
+  for (int c = 0; c < nc; c++) o[(long)(4 + c) * A] = ys_sigmoid(Elem<T>::to_f(srow[c]));
+}
+int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
+                            int nc, int reg_max, int nl, const int* lo, const int* lw, const int* ls, float* pred) {
+  const long n = (long)B * A;
+  const int o1 = nl > 1 ? lo[1] : 0, o2 = nl > 2 ? lo[2] : 0, w1 = nl > 1 ? lw[1] : 1, w2 = nl > 2 ? lw[2] : 1;
+  const int s1 = nl > 1 ? ls[1] : 1, s2 = nl > 2 ? ls[2] : 1;
+  if (dtype == YS_BF16)
+    YS_LAUNCH((detect_decode_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred);
+  else
+    YS_LAUNCH((detect_decode_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred);
+  return YS_OK;
+}

@@ -1,0 +1,131 @@
+// ys_kernels.h -- argument blocks and host launchers of the device kernels.
+#pragma once
+#include "ys_hip.h"
+
+struct ConvArgs {
+  const void* x;        // input activations (NHWC view)
+  const void* w;        // weights [Cout][KH*KW][Cin], storage type T
+  void* y;              // output (NHWC view)
+  const float* scale;   // optional per-cout multiplier (eval BN)          } v = acc*scale + shift
+  const float* shift;   // optional per-cout offset (eval BN shift / bias) }
+  const void* res;      // optional residual added after the activation (same row mapping as y)
+  float* stats;         // optional [gridM][2][Cout] partial (sum, sumsq) of the stored values
+  int B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW;
+  int SA, DIVS, DIVM, PAD;   // ih*DIV = oh*SA + kh - PAD ; DIVS = log2(DIV), DIVM = DIV-1
+  int in_ldc, in_coff;
+  long in_bstride;           // pixels between consecutive images of the input buffer
+  int out_ldc, out_coff;
+  long out_bstride;          // rows between consecutive images in the output addressing
+  int res_ldc, res_coff;
+  int act;                   // 1 = SiLU after scale/shift
+  int accumulate;            // y += result (gradient accumulation)
+  int vec_ok;                // out_ldc/out_coff (and res) allow 4-channel vector stores
+  int M;                     // B*Hout*Wout
+};
+
+struct WgradArgs {
+  const void* x;   // layer input (NHWC view)
+  const void* dy;  // gradient w.r.t. the conv output, [M][dy_ldc]
+  float* partial;  // [splits][Cout][KH*KW][Cin] fp32
+  int B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad;
+  int in_ldc, in_coff;
+  long in_bstride;
+  int dy_ldc, dy_coff;
+  int M;
+};
+
+int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
+int ys_conv_grid_m(const ConvArgs& a);
+int ys_wgrad_splits(const WgradArgs& a, int dtype);
+int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad);
+int ys_weight_prep_launch(hipStream_t st, int dtype, const float* w, int Cout, int taps, int cin_real, int cin_pad,
+                          int cout_pad, void* wf, void* wd);
+
+// ---- elementwise.hip
+// NCHW fp32 -> NHWC T with channels zero-padded to cpad
+int ys_pack_input_launch(hipStream_t st, int dtype, const float* x_nchw, int B, int C, int H, int W, int cpad, void* y);
+// NHWC view T -> NCHW fp32
+int ys_unpack_nchw_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, int B, int C, long rows_per_b,
+                          float* y_nchw);
+// BN (training) statistics finalize: partial [nblk][2][C] -> scale/shift (+ saved mean, rstd) and running-stat update
+int ys_bn_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, const float* gamma,
+                          const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                          float* nbt, float* scale, float* shift, float* mean, float* rstd);
+// eval: scale/shift from running stats
+int ys_bn_eval_coeffs_launch(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
+                             const float* run_var, float eps, float* scale, float* shift);
+// z[out view] = act(y*scale+shift) (+ residual view)
+int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const float* scale,
+                           const float* shift, int act, const void* res, int res_ldc, int res_coff, void* z,
+                           int z_ldc, int z_coff);
+// backward of z = act(BN(y)): pass 1 partial sums of du and du*xhat; optionally res_grad += dz
+int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
+                            int C, const float* scale, const float* shift, const float* mean, const float* rstd,
+                            int act, void* res_grad, int rg_ldc, int rg_coff, float* partial, int* nblk_out);
+// pass 1b: dgamma += sum(du*xhat), dbeta += sum(du), coefficients for pass 2
+int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, float* dgamma,
+                              float* dbeta, float* c1, float* c2);
+// pass 2: dy = gamma*rstd*(du - c1 - xhat*c2)
+int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
+                           int C, const float* scale, const float* shift, const float* mean, const float* rstd,
+                           const float* gamma, const float* c1, const float* c2, int act, void* dy);
+// column sums of a [rows][ldc] view into grad[C] (+=)   (bias gradients)
+int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, int C, float* partial,
+                     float* grad);
+int ys_colsum_blocks(long rows, int C, int dtype);
+// 5x5/s1/p2 max-pool on an NHWC view (+ argmax byte per output element for the backward)
+int ys_maxpool5_fwd_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
+                           void* y, int y_ldc, int y_coff, unsigned char* argmax);
+int ys_maxpool5_bwd_launch(hipStream_t st, int dtype, const void* dy, int dy_ldc, int dy_coff, int B, int H, int W,
+                           int C, const unsigned char* argmax, void* dx, int dx_ldc, int dx_coff, int accumulate);
+// nearest 2x upsample into a (concat) view, and its backward (2x2 sum)
+int ys_upsample2x_fwd_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
+                             void* y, int y_ldc, int y_coff);
+int ys_upsample2x_bwd_launch(hipStream_t st, int dtype, const void* dy, int dy_ldc, int dy_coff, int B, int H, int W,
+                             int C, void* dx, int dx_ldc, int dx_coff, int accumulate);
+// dst view (+)= src view
+int ys_copy_view_launch(hipStream_t st, int dtype, const void* src, int s_ldc, int s_coff, long rows, int C, void* dst,
+                        int d_ldc, int d_coff, int accumulate);
+// AdamW over a flat range
+int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                    float beta2, float eps, float wd, float bc1, float bc2);
+int ys_fill_launch(hipStream_t st, float* p, long n, float v);
+
+// ---- loss.hip
+struct LossArgs {
+  const void* pd;  // box logits   [B][A][ld_pd]  (4*reg_max used)
+  const void* ps;  // class logits [B][A][ld_ps]  (nc used)
+  void* dpd;       // gradients, same layouts
+  void* dps;
+  int ld_pd, ld_ps;
+  int B, A, nc, reg_max;
+  int H, W;            // input image size (imgsz = feats[0].shape[2:]*stride[0])
+  int nl;              // levels
+  int lvl_off[4], lvl_w[4], lvl_h[4], lvl_stride[4];
+  // labels (device): raw collate arrays
+  const float* batch_idx; const float* cls; const float* bboxes; int n_labels;
+  int gcap;            // GT capacity per image
+  // workspace (device)
+  int* gt_count;       // [B]
+  float* gt_box;       // [B][gcap][4] xyxy pixels
+  int* gt_cls;         // [B][gcap]
+  float* pbox;         // [B][A][4] decoded pred box, grid units (xyxy)
+  float* ov;           // [B][gcap][A]
+  float* align;        // [B][gcap][A]
+  unsigned char* mpos; // [B][gcap][A]
+  unsigned* pos_align; // [B][gcap] float bits (non-negative -> uint order)
+  unsigned* pos_ov;    // [B][gcap]
+  int* fg_gt;          // [B][A]  assigned gt index or -1
+  float* tnorm;        // [B][A]  normalised alignment (target score value)
+  float* partial;      // [nblk][4] partial sums
+  float* scalars;      // [8]: tss, loss_box, loss_cls, loss_dfl, total
+  float hyp_box, hyp_cls, hyp_dfl;
+  int topk;
+};
+int ys_loss_detect_launch(hipStream_t st, int dtype, const LossArgs& a);
+size_t ys_loss_partial_floats(int B, int A);
+
+// ---- decode (Head.cs:204-223)
+int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
+                            int nc, int reg_max, int nl, const int* lvl_off, const int* lvl_w, const int* lvl_stride,
+                            float* pred);
