@@ -139,12 +139,18 @@ YS_API int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int batch, in
                           float* out_rows, int64_t* out_keep, int32_t* out_count);
 
 /* ---- per-operator entry points (unit parity; a TorchSharp-free C# Conv wrapper) ---------------
- * Convs.Conv.forward (Convs.cs:36-62): y = act(BN(conv2d(x))) on device buffers in NCHW fp32 at the
- * edge.  training != 0 uses batch statistics and updates running stats (momentum 0.03, eps 1e-3). */
+ * Convs.Conv.forward (Convs.cs:36-62): y = act(BN(conv2d(x))) on fp32 NCHW / OIHW HOST arrays at the
+ * edge (the call stages them through HBM).  training != 0 uses batch statistics and updates running stats (momentum 0.03, eps 1e-3). */
 YS_API int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, int Cin, int H, int W,
                               const float* w_oihw, int Cout, int k, int stride,
                               const float* bn_gamma, const float* bn_beta, float* bn_mean, float* bn_var,
                               const float* bias, int act_silu, int training, float* y_nchw);
+
+/* autograd of the same conv2d (Amp.cs:348,370): given dy [B,Cout,Ho,Wo] returns dx [B,Cin,H,W] (optional, may be
+ * NULL) and dw [Cout,Cin,k,k]; all fp32 host arrays. */
+YS_API int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, int Cin, int H, int W,
+                       const float* w_oihw, int Cout, int k, int stride, const float* dy_nchw,
+                       float* dx_nchw, float* dw_oihw);
 
 /* device memory helpers for hosts without a HIP binding of their own */
 YS_API int ys_device_malloc(ys_ctx* ctx, size_t bytes, void** dptr);

@@ -61,6 +61,8 @@ PROTOTYPES = {
     "ys_conv_bn_act_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ys_conv_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ys_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ys_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ys_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -91,10 +93,17 @@ def load(path=None):
             "yolosharp_hip: native library %s not found. Build it with `python -m yolosharp_amd.build device` "
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % path)
     lib = C.CDLL(path)
+    missing = []
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
         fn.restype = res
         fn.argtypes = args
+    if missing:
+        raise ImportError("yolosharp_hip: %s does not export %s (ABI incomplete; rebuild)" % (path, ", ".join(missing)))
     _cache[path] = lib
     return lib
 

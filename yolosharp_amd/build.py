@@ -63,7 +63,7 @@ def build_device(verbose=False):
         objs.append(obj)
         if _newer(obj, [src] + hdrs):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                   "-Wno-unused-result", "-I", CSRC, "-c", src, "-o", obj]
+                   "-fno-strict-aliasing", "-Wno-unused-result", "-I", CSRC, "-c", src, "-o", obj]
             if s in NO_CONTRACT:
                 cmd.insert(4, "-ffp-contract=off")
             jobs.append(cmd)
@@ -85,7 +85,7 @@ def build_emu(verbose=False):
         obj = os.path.join(BUILD, "emu", name + ".o")
         objs.append(obj)
         if _newer(obj, [src] + hdrs):
-            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-fvisibility=hidden", "-DYS_EMU_BUILD",
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-fvisibility=hidden", "-fno-strict-aliasing", "-DYS_EMU_BUILD",
                          "-Wno-unused-result", "-I", CSRC, "-I", EMU, "-x", "c++", "-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(_run, jobs))

@@ -159,7 +159,7 @@ conv_igemm_kernel(ConvArgs a) {
         for (int r = 0; r < 4; r++)
           if (c + r < a.Cout) v[r] += Elem<T>::to_f(yp[r]);
       }
-      alignas(16) T o[4];
+      T o[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) o[r] = Elem<T>::from_f(v[r]);
       if (do_stats) {
@@ -175,11 +175,11 @@ conv_igemm_kernel(ConvArgs a) {
         if (a.vec_ok && c + 3 < a.Cout) {
           if (sizeof(T) == 2) {
             uint2 pk;
-            pk.x = (unsigned)((const unsigned short*)o)[0] | ((unsigned)((const unsigned short*)o)[1] << 16);
-            pk.y = (unsigned)((const unsigned short*)o)[2] | ((unsigned)((const unsigned short*)o)[3] << 16);
+            pk.x = ys_pack_bf16x2(v[0], v[1]);
+            pk.y = ys_pack_bf16x2(v[2], v[3]);
             *(uint2*)yp = pk;
           } else {
-            *(uint4*)yp = *(const uint4*)o;
+            *(uint4*)yp = make_uint4(ys_f2u(v[0]), ys_f2u(v[1]), ys_f2u(v[2]), ys_f2u(v[3]));
           }
         } else {
 #pragma unroll
@@ -309,8 +309,11 @@ conv_wgrad_kernel(WgradArgs a) {
       const long p = p0 + pr;
       const int c = co0 + cv * EPL;
       uint4 val = ys_zero16();
-      if (active && p < a.M && c < a.Cout)
-        val = ys_ld16(dyb + ((p * a.dy_ldc) + a.dy_coff + c) * (long)sizeof(T));
+      if (active && p < a.M && c < a.Cout) {
+        const long bb = p / HWo;
+        const long drow = bb * a.dy_bstride + (p - bb * HWo);
+        val = ys_ld16(dyb + ((drow * a.dy_ldc) + a.dy_coff + c) * (long)sizeof(T));
+      }
       *(uint4*)(myD + pr * PD + cv * EPL) = val;
     }
     for (int v = lane; v < KS * XV; v += 64) {
@@ -336,14 +339,14 @@ conv_wgrad_kernel(WgradArgs a) {
       alignas(16) T tmp[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; e++) tmp[e] = myD[(q * EPL + e) * PD + i * 16 + li];
-      fa[i] = *(const uint4*)tmp;
+      fa[i] = ys_pack_elems(tmp);
     }
 #pragma unroll
     for (int j = 0; j < NRB; j++) {
       alignas(16) T tmp[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; e++) tmp[e] = myX[(q * EPL + e) * PX + j * 16 + li];
-      fb[j] = *(const uint4*)tmp;
+      fb[j] = ys_pack_elems(tmp);
     }
 #pragma unroll
     for (int i = 0; i < MRA; i++)

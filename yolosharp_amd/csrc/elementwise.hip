@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(EW_THREADS)
 chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                    const float* __restrict__ rstd, int act, T* __restrict__ rg, int rg_ldc, int rg_coff,
-                   float* __restrict__ partial) {
+                   float* __restrict__ partial, long rpb, long bstride) {
   constexpr int EPL = Elem<T>::EPL;
   __shared__ float sAcc[EW_THREADS][EPL * 2];
   const int CG = C / EPL;
@@ -186,7 +186,9 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
     }
     for (long row = r0 + rl; row < r1; row += RP) {
       float g[EPL];
-      const uint4 gv = ys_ld16(dz + row * dz_ldc + dz_coff + c);
+      const long zb = row / rpb;
+      const long zrow = zb * bstride + (row - zb * rpb);   // dz rows may be strided per image (head outputs)
+      const uint4 gv = ys_ld16(dz + zrow * dz_ldc + dz_coff + c);
       ys_unpack<T>(gv, g);
       if (MODE == 0) {
         float f[EPL];
@@ -245,9 +247,9 @@ int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ld
   const int nb = reduce_blocks(rows, C, epl);
   *nblk_out = nb;
   if (dtype == YS_BF16)
-    YS_LAUNCH((chan_reduce_kernel<bf16_t, 0>), nb, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, act, (bf16_t*)res_grad, rg_ldc, rg_coff, partial);
+    YS_LAUNCH((chan_reduce_kernel<bf16_t, 0>), nb, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, act, (bf16_t*)res_grad, rg_ldc, rg_coff, partial, rows, rows);
   else
-    YS_LAUNCH((chan_reduce_kernel<float, 0>), nb, EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, act, (float*)res_grad, rg_ldc, rg_coff, partial);
+    YS_LAUNCH((chan_reduce_kernel<float, 0>), nb, EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, act, (float*)res_grad, rg_ldc, rg_coff, partial, rows, rows);
   return YS_OK;
 }
 
@@ -282,15 +284,16 @@ int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, in
   return YS_OK;
 }
 
-int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, int C, float* partial, float* grad) {
+int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
+                     long bstride, int C, float* partial, float* grad) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const int Cp = (C + epl - 1) / epl * epl;  // padded channels of the view are zero
   if (Cp / epl > EW_THREADS) { ys_set_error("colsum: unsupported channel count %d", C); return YS_ERR_UNSUPPORTED; }
   const int nb = reduce_blocks(rows, Cp, epl);
   if (dtype == YS_BF16)
-    YS_LAUNCH((chan_reduce_kernel<bf16_t, 1>), nb, EW_THREADS, st, (const bf16_t*)x, ldc, coff, (const bf16_t*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (bf16_t*)nullptr, 0, 0, partial);
+    YS_LAUNCH((chan_reduce_kernel<bf16_t, 1>), nb, EW_THREADS, st, (const bf16_t*)x, ldc, coff, (const bf16_t*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (bf16_t*)nullptr, 0, 0, partial, rows_per_b, bstride);
   else
-    YS_LAUNCH((chan_reduce_kernel<float, 1>), nb, EW_THREADS, st, (const float*)x, ldc, coff, (const float*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0, 0, partial);
+    YS_LAUNCH((chan_reduce_kernel<float, 1>), nb, EW_THREADS, st, (const float*)x, ldc, coff, (const float*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0, 0, partial, rows_per_b, bstride);
   // partial rows are Cp wide; finalize only the C real channels
   YS_LAUNCH((chan_finalize_kernel<1>), C, EW_THREADS, st, (const float*)partial, nb, Cp, 1.0, grad, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   return YS_OK;

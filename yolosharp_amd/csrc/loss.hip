@@ -1,0 +1,472 @@
+// loss.hip -- v8DetectionLoss forward + analytic backward, fully on device (no host syncs).
+//
+// Restates (reference file:line under YoloSharp/):
+//   Utils/Loss.cs:411-477   get_assigned_targets_and_loss, loss (x batch_size)
+//   Utils/Loss.cs:363-390   preprocess (pad GT per image, cxcywh*imgsz -> xyxy pixels)
+//   Utils/Loss.cs:398-409   bbox_decode (softmax . arange(reg_max), dist2bbox xyxy)
+//   Utils/Tal.cs:50-255     TaskAlignedAssigner (topk 10, alpha 0.5, beta 6, eps 1e-9)
+//   Utils/Loss.cs:94-167    DFLoss / BboxLoss
+//   Utils/Metrics.cs:36-111 bbox_iou(CIoU), eps 1e-7, alpha NOT detached
+//   Utils/Tal.cs:313-379    make_anchors / dist2bbox / bbox2dist
+// The reference reaches the host four times per step (Loss.cs:380,444,450; Tal.cs:231); here
+// n_max_boxes / target_scores_sum / fg counts stay in HBM and only ys_loss_read() synchronises.
+// Gradients of sum(loss*B) w.r.t. the head outputs are written directly (dpd, dps): the loss has
+// closed-form derivatives, CIoU's through forward-mode dual numbers (4 partials).
+// All arithmetic is fp32; pd/ps/dpd/dps are stored in the model dtype T.
+#include "ys_internal.h"
+#include "ys_kernels.h"
+
+#define LS_THREADS 256
+#define CIOU_EPS 1e-7f
+
+// ------------------------------------------------------------------ dual numbers (value + 4 partials)
+struct Dual4 {
+  float v;
+  float g[4];
+};
+__device__ inline Dual4 dconst(float c) { Dual4 r; r.v = c; r.g[0] = r.g[1] = r.g[2] = r.g[3] = 0.f; return r; }
+__device__ inline Dual4 dvar(float c, int i) { Dual4 r = dconst(c); r.g[i] = 1.f; return r; }
+__device__ inline Dual4 operator+(const Dual4& a, const Dual4& b) { Dual4 r; r.v = a.v + b.v; for (int i = 0; i < 4; i++) r.g[i] = a.g[i] + b.g[i]; return r; }
+__device__ inline Dual4 operator-(const Dual4& a, const Dual4& b) { Dual4 r; r.v = a.v - b.v; for (int i = 0; i < 4; i++) r.g[i] = a.g[i] - b.g[i]; return r; }
+__device__ inline Dual4 operator*(const Dual4& a, const Dual4& b) { Dual4 r; r.v = a.v * b.v; for (int i = 0; i < 4; i++) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
+__device__ inline Dual4 operator/(const Dual4& a, const Dual4& b) {
+  Dual4 r; r.v = a.v / b.v;
+  const float inv = 1.0f / b.v;
+  for (int i = 0; i < 4; i++) r.g[i] = (a.g[i] - r.v * b.g[i]) * inv;
+  return r;
+}
+__device__ inline Dual4 dmax(const Dual4& a, const Dual4& b) { return a.v >= b.v ? a : b; }
+__device__ inline Dual4 dmin(const Dual4& a, const Dual4& b) { return a.v <= b.v ? a : b; }
+__device__ inline Dual4 dclamp_min(const Dual4& a, float lo) { return a.v >= lo ? a : dconst(lo); }
+__device__ inline Dual4 datan(const Dual4& a) {
+  Dual4 r; r.v = atanf(a.v);
+  const float d = 1.0f / (1.0f + a.v * a.v);
+  for (int i = 0; i < 4; i++) r.g[i] = a.g[i] * d;
+  return r;
+}
+// plain-float overloads so ciou<R>() is written once
+__device__ inline float dconst_f(float c) { return c; }
+__device__ inline float dmax(float a, float b) { return a >= b ? a : b; }
+__device__ inline float dmin(float a, float b) { return a <= b ? a : b; }
+__device__ inline float dclamp_min(float a, float lo) { return a >= lo ? a : lo; }
+__device__ inline float datan(float a) { return atanf(a); }
+template <class R> __device__ inline R rconst(float c);
+template <> __device__ inline float rconst<float>(float c) { return c; }
+template <> __device__ inline Dual4 rconst<Dual4>(float c) { return dconst(c); }
+
+// Metrics.cs:36-111 with xywh=false, CIoU=true
+template <class R>
+__device__ inline R ciou_xyxy(const R b1[4], const R b2[4]) {
+  const R w1 = b1[2] - b1[0];
+  const R h1 = dclamp_min(b1[3] - b1[1], CIOU_EPS);
+  const R w2 = b2[2] - b2[0];
+  const R h2 = dclamp_min(b2[3] - b2[1], CIOU_EPS);
+  const R inter = dclamp_min(dmin(b1[2], b2[2]) - dmax(b1[0], b2[0]), 0.0f) *
+                  dclamp_min(dmin(b1[3], b2[3]) - dmax(b1[1], b2[1]), 0.0f);
+  const R uni = w1 * h1 + w2 * h2 - inter + rconst<R>(CIOU_EPS);
+  const R iou = inter / uni;
+  const R cw = dmax(b1[2], b2[2]) - dmin(b1[0], b2[0]);
+  const R ch = dmax(b1[3], b2[3]) - dmin(b1[1], b2[1]);
+  const R c2 = cw * cw + ch * ch + rconst<R>(CIOU_EPS);
+  const R dx = b2[0] + b2[2] - b1[0] - b1[2];
+  const R dy = b2[1] + b2[3] - b1[1] - b1[3];
+  const R rho2 = (dx * dx + dy * dy) / rconst<R>(4.0f);
+  const R da = datan(w2 / h2) - datan(w1 / h1);
+  const R v = rconst<R>(0.40528473456935108577f) * (da * da);  // 4/pi^2
+  const R alpha = v / (v - iou + rconst<R>(1.0f + CIOU_EPS));
+  return iou - (rho2 / c2 + v * alpha);
+}
+
+struct AnchorInfo { float ax, ay, stride; };
+__device__ inline AnchorInfo anchor_of(const LossArgs& a, int idx) {
+  int l = 0;
+  for (int i = 1; i < a.nl; i++) if (idx >= a.lvl_off[i]) l = i;
+  const int cell = idx - a.lvl_off[l];
+  AnchorInfo r;
+  r.ax = (float)(cell % a.lvl_w[l]) + 0.5f;   // Tal.cs:325-326 grid_cell_offset 0.5
+  r.ay = (float)(cell / a.lvl_w[l]) + 0.5f;
+  r.stride = (float)a.lvl_stride[l];
+  return r;
+}
+
+// ------------------------------------------------------------------ K0: GT padding (Loss.cs:363-390,431)
+__global__ void __launch_bounds__(LS_THREADS)
+loss_prep_kernel(LossArgs a, int* gt_valid) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.B; i += LS_THREADS) a.gt_count[i] = 0;
+  for (int i = tid; i < a.B * a.gcap; i += LS_THREADS) { a.pos_align[i] = 0u; a.pos_ov[i] = 0u; }
+  if (tid < 8) a.scalars[tid] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < a.n_labels; i += LS_THREADS) {
+    const int b = (int)a.batch_idx[i];
+    if (b < 0 || b >= a.B) continue;
+    int slot = 0;  // rank among labels of the same image, in order of appearance
+    for (int j = 0; j < i; j++) slot += ((int)a.batch_idx[j] == b) ? 1 : 0;
+    atomicAdd(&a.gt_count[b], 1);
+    if (slot >= a.gcap) continue;  // capacity exceeded (count is clamped below)
+    const float sw = (float)a.W, shh = (float)a.H;
+    const float cx = a.bboxes[4 * i + 0] * sw, cy = a.bboxes[4 * i + 1] * shh;
+    const float w = a.bboxes[4 * i + 2] * sw, h = a.bboxes[4 * i + 3] * shh;
+    float* gb = a.gt_box + ((long)b * a.gcap + slot) * 4;
+    gb[0] = cx - w / 2; gb[1] = cy - h / 2; gb[2] = cx + w / 2; gb[3] = cy + h / 2;  // Ops.cs:76-79
+    a.gt_cls[(long)b * a.gcap + slot] = (int)a.cls[i];
+    gt_valid[(long)b * a.gcap + slot] = (gb[0] + gb[1] + gb[2] + gb[3]) > 0.0f ? 1 : 0;  // Loss.cs:431
+  }
+  __syncthreads();
+  for (int i = tid; i < a.B; i += LS_THREADS)
+    if (a.gt_count[i] > a.gcap) a.gt_count[i] = a.gcap;
+}
+
+// ------------------------------------------------------------------ K1: bbox_decode (Loss.cs:398-409)
+template <class T>
+__global__ void __launch_bounds__(LS_THREADS)
+loss_decode_kernel(LossArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)a.B * a.A) return;
+  const int ai = (int)(i % a.A);
+  const AnchorInfo an = anchor_of(a, ai);
+  const T* row = (const T*)a.pd + i * a.ld_pd;
+  float d[4];
+  for (int s = 0; s < 4; s++) {
+    float mx = -INFINITY;
+    for (int j = 0; j < a.reg_max; j++) mx = fmaxf(mx, Elem<T>::to_f(row[s * a.reg_max + j]));
+    float se = 0.f, sw = 0.f;
+    for (int j = 0; j < a.reg_max; j++) {
+      const float e = __expf(Elem<T>::to_f(row[s * a.reg_max + j]) - mx);
+      se += e; sw += e * (float)j;
+    }
+    d[s] = sw / se;
+  }
+  float* pb = a.pbox + i * 4;
+  pb[0] = an.ax - d[0]; pb[1] = an.ay - d[1]; pb[2] = an.ax + d[2]; pb[3] = an.ay + d[3];  // Tal.cs:345-346
+}
+
+// ------------------------------------------------------------------ K2: metrics + top-k per (image, gt)
+template <class T>
+__global__ void __launch_bounds__(LS_THREADS)
+tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
+  __shared__ unsigned s_ingt[1056];   // A <= 33792 anchors
+  __shared__ unsigned s_taken[1056];
+  __shared__ float s_v[LS_THREADS / 64];
+  __shared__ int s_i[LS_THREADS / 64];
+  __shared__ int s_sel;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (g >= a.gt_count[b]) return;
+  const long gi = (long)b * a.gcap + g;
+  const bool valid = gt_valid[gi] != 0;
+  const float* gb = a.gt_box + gi * 4;
+  const float g4[4] = {gb[0], gb[1], gb[2], gb[3]};
+  const int cls = a.gt_cls[gi];
+  float* ovr = a.ov + gi * a.A;
+  float* alr = a.align + gi * a.A;
+  unsigned char* mp = a.mpos + gi * a.A;
+  const int nw = (a.A + 31) / 32;
+  for (int i = tid; i < nw; i += LS_THREADS) { s_ingt[i] = 0u; s_taken[i] = 0u; }
+  __syncthreads();
+  // select_candidates_in_gts (Tal.cs:202-223): boxes smaller than stride[0]=8 are inflated to stride[1]=16
+  float cx = (g4[0] + g4[2]) / 2, cy = (g4[1] + g4[3]) / 2, w = g4[2] - g4[0], h = g4[3] - g4[1];  // Ops.cs:98-101
+  if (valid && w < (float)a.lvl_stride[0]) w = (float)a.lvl_stride[a.nl > 1 ? 1 : 0];
+  if (valid && h < (float)a.lvl_stride[0]) h = (float)a.lvl_stride[a.nl > 1 ? 1 : 0];
+  const float ix1 = cx - w / 2, iy1 = cy - h / 2, ix2 = cx + w / 2, iy2 = cy + h / 2;
+  for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+    const AnchorInfo an = anchor_of(a, ai);
+    const float px = an.ax * an.stride, py = an.ay * an.stride;   // anchor_points * stride_tensor (Loss.cs:439)
+    const float dmin_ = fminf(fminf(px - ix1, py - iy1), fminf(ix2 - px, iy2 - py));
+    const bool ingt = dmin_ > 1e-9f;                               // Tal.cs:221
+    float o = 0.f, al = 0.f;
+    if (ingt && valid) {
+      const float* pb = a.pbox + ((long)b * a.A + ai) * 4;
+      const float p4[4] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride};  // Loss.cs:438
+      o = ciou_xyxy<float>(g4, p4);                                // Tal.cs:141 (box1 = gt, box2 = pred)
+      o = o > 0.f ? o : 0.f;                                        // .clamp(0)
+      const int cc = cls < 0 ? 0 : (cls >= a.nc ? a.nc - 1 : cls);
+      const float sc = ys_sigmoid(Elem<T>::to_f(((const T*)a.ps)[((long)b * a.A + ai) * a.ld_ps + cc]));
+      al = sqrtf(sc) * powf(o, 6.0f);                               // Tal.cs:134 (alpha 0.5, beta 6)
+    }
+    ovr[ai] = o;
+    alr[ai] = al;
+    mp[ai] = 0;
+    if (ingt) atomicOr(&s_ingt[ai >> 5], 1u << (ai & 31));
+  }
+  __syncthreads();
+  // select_topk_candidates (Tal.cs:144-168): 10 largest align values; ties -> lowest anchor index
+  for (int k = 0; k < a.topk; k++) {
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+      if (s_taken[ai >> 5] & (1u << (ai & 31))) continue;
+      const float v = alr[ai];
+      if (v > bv || (v == bv && ai < bi)) { bv = v; bi = ai; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov_ = __shfl_xor(bv, m);
+      const int oi = __shfl_xor(bi, m);
+      if (ov_ > bv || (ov_ == bv && oi < bi)) { bv = ov_; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = s_v[0]; int fi = s_i[0];
+      for (int wv = 1; wv < LS_THREADS / 64; wv++)
+        if (s_v[wv] > fv || (s_v[wv] == fv && s_i[wv] < fi)) { fv = s_v[wv]; fi = s_i[wv]; }
+      s_sel = fi;
+      if (fi < a.A) {
+        s_taken[fi >> 5] |= 1u << (fi & 31);
+        // mask_pos = mask_topk * mask_in_gts * mask_gt (Tal.cs:99); rows with mask_gt == 0 have their
+        // top-k indices forced to 0 and then dropped by the count>1 rule (Tal.cs:155,165)
+        if (valid && (s_ingt[fi >> 5] & (1u << (fi & 31)))) mp[fi] = 1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ K3: select_highest_overlaps (Tal.cs:225-255)
+__global__ void __launch_bounds__(LS_THREADS)
+tal_resolve_kernel(LossArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)a.B * a.A) return;
+  const int b = (int)(i / a.A), ai = (int)(i % a.A);
+  const int n = a.gt_count[b];
+  int cnt = 0, first = -1;
+  for (int g = 0; g < n; g++) {
+    if (a.mpos[((long)b * a.gcap + g) * a.A + ai]) { if (first < 0) first = g; cnt++; }
+  }
+  int sel = first;
+  if (cnt > 1) {
+    // anchors claimed by several GTs keep the GT with the largest overlap (argmax over ALL rows, first max)
+    float bo = a.ov[((long)b * a.gcap) * a.A + ai];
+    sel = 0;
+    for (int g = 1; g < n; g++) {
+      const float o = a.ov[((long)b * a.gcap + g) * a.A + ai];
+      if (o > bo) { bo = o; sel = g; }
+    }
+    for (int g = 0; g < n; g++) a.mpos[((long)b * a.gcap + g) * a.A + ai] = (g == sel) ? 1 : 0;
+  }
+  a.fg_gt[i] = sel;  // -1 = background
+  if (sel >= 0) {
+    const long gi = (long)b * a.gcap + sel;
+    // pos_align_metrics / pos_overlaps: amax over anchors of (metric * mask_pos) (Tal.cs:83-85);
+    // non-negative floats order like their bit patterns
+    atomicMax(&a.pos_align[gi], ys_f2u(a.align[gi * a.A + ai]));
+    atomicMax(&a.pos_ov[gi], ys_f2u(a.ov[gi * a.A + ai]));
+  }
+}
+
+// ------------------------------------------------------------------ K4: normalised target scores (Tal.cs:86-87)
+__device__ inline void block_partial4(float v0, float v1, float v2, float v3, float* out) {
+  __shared__ float s[LS_THREADS / 64][4];
+  v0 = ys_wave_sum(v0); v1 = ys_wave_sum(v1); v2 = ys_wave_sum(v2); v3 = ys_wave_sum(v3);
+  const int tid = threadIdx.x;
+  if ((tid & 63) == 0) { s[tid >> 6][0] = v0; s[tid >> 6][1] = v1; s[tid >> 6][2] = v2; s[tid >> 6][3] = v3; }
+  __syncthreads();
+  if (tid == 0) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < LS_THREADS / 64; w++) for (int k = 0; k < 4; k++) t[k] += s[w][k];
+    for (int k = 0; k < 4; k++) out[k] = t[k];
+  }
+}
+
+__global__ void __launch_bounds__(LS_THREADS)
+tal_targets_kernel(LossArgs a, float* partial) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float nrm = 0.f;
+  if (i < (long)a.B * a.A) {
+    const int b = (int)(i / a.A), ai = (int)(i % a.A);
+    const int g = a.fg_gt[i];
+    if (g >= 0) {
+      const long gi = (long)b * a.gcap + g;
+      const float pa = ys_u2f(a.pos_align[gi]), po = ys_u2f(a.pos_ov[gi]);
+      nrm = a.align[gi * a.A + ai] * po / (pa + 1e-9f);
+    }
+    a.tnorm[i] = nrm;
+  }
+  block_partial4(nrm, 0.f, 0.f, 0.f, partial + (long)blockIdx.x * 4);
+}
+
+// sums partial[nblk][4] column-wise (fixed order); mode 0: tss = max(sum0, 1) -> scalars[0]
+//                                                   mode 1: adds columns 1..3 into scalars[5..7]
+__global__ void __launch_bounds__(LS_THREADS)
+loss_sum_kernel(const float* __restrict__ partial, int nblk, float* scalars, int mode) {
+  __shared__ double sbuf[LS_THREADS];
+  const int tid = threadIdx.x;
+  for (int col = 0; col < 4; col++) {
+    double s = 0.0;
+    for (int k = tid; k < nblk; k += LS_THREADS) s += (double)partial[(long)k * 4 + col];
+    sbuf[tid] = s;
+    __syncthreads();
+    for (int st = LS_THREADS / 2; st > 0; st >>= 1) {
+      if (tid < st) sbuf[tid] += sbuf[tid + st];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (mode == 0 && col == 0) scalars[0] = (float)(sbuf[0] > 1.0 ? sbuf[0] : 1.0);  // Loss.cs:444
+      if (mode == 1 && col > 0) scalars[4 + col] += (float)sbuf[0];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ K5: BCE cls loss + gradient (Loss.cs:447)
+template <class T>
+__global__ void __launch_bounds__(LS_THREADS)
+loss_cls_kernel(LossArgs a, float* partial) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int vpr = a.ld_ps / EPL;  // 16-byte vectors per anchor row (row padded to EPL)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float lsum = 0.f;
+  if (i < (long)a.B * a.A * vpr) {
+    const long row = i / vpr;
+    const int c0 = (int)(i - row * vpr) * EPL;
+    const int b = (int)(row / a.A);
+    const int g = a.fg_gt[row];
+    int tc = -1;
+    float tv = 0.f;
+    if (g >= 0) {
+      tc = a.gt_cls[(long)b * a.gcap + g];
+      tc = tc < 0 ? 0 : tc;  // target_labels.clamp_(0) (Tal.cs:183)
+      tv = a.tnorm[row];
+    }
+    const float gs = a.hyp_cls * (float)a.B / a.scalars[0];
+    float x[EPL], gr[EPL];
+    ys_unpack<T>(ys_ld16((const T*)a.ps + row * a.ld_ps + c0), x);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      const int c = c0 + e;
+      if (c < a.nc) {
+        const float t = (c == tc) ? tv : 0.f;
+        const float xv = x[e];
+        lsum += fmaxf(xv, 0.f) - xv * t + log1pf(__expf(-fabsf(xv)));  // BCEWithLogits, reduction none
+        gr[e] = (ys_sigmoid(xv) - t) * gs;
+      } else {
+        gr[e] = 0.f;
+      }
+    }
+    ys_st16((T*)a.dps + row * a.ld_ps + c0, ys_pack<T>(gr));
+  }
+  block_partial4(0.f, lsum, 0.f, 0.f, partial + (long)blockIdx.x * 4);
+}
+
+// ------------------------------------------------------------------ K6: CIoU + DFL loss + gradient (Loss.cs:134-166)
+// four consecutive lanes own one anchor (one side l,t,r,b each)
+template <class T>
+__global__ void __launch_bounds__(LS_THREADS)
+loss_box_kernel(LossArgs a, float* partial) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.B * a.A * 4;
+  const bool inb = i < total;
+  const long row = inb ? i >> 2 : 0;
+  const int s = (int)(i & 3);
+  const int lane = threadIdx.x & 63;
+  const int R = a.reg_max;
+  const int g = inb ? a.fg_gt[row] : -1;
+  const int b = (int)(row / a.A), ai = (int)(row % a.A);
+  float p[32];
+  float dist = 0.f, lse = 0.f;
+  const T* lrow = (const T*)a.pd + row * a.ld_pd + s * R;
+  float xl[32];
+  if (inb) {
+    float mx = -INFINITY;
+    for (int j = 0; j < R; j++) { xl[j] = Elem<T>::to_f(lrow[j]); mx = fmaxf(mx, xl[j]); }
+    float se = 0.f;
+    for (int j = 0; j < R; j++) { p[j] = __expf(xl[j] - mx); se += p[j]; }
+    const float inv = 1.0f / se;
+    for (int j = 0; j < R; j++) { p[j] *= inv; dist += p[j] * (float)j; }
+    lse = mx + __logf(se);
+  }
+  // the four side distances of this anchor
+  const int base = lane & ~3;
+  const float d0 = __shfl(dist, base + 0), d1 = __shfl(dist, base + 1), d2 = __shfl(dist, base + 2), d3 = __shfl(dist, base + 3);
+  float l_iou = 0.f, l_dfl = 0.f;
+  float gl[32];
+  for (int j = 0; j < R; j++) gl[j] = 0.f;
+  if (g >= 0) {
+    const AnchorInfo an = anchor_of(a, ai);
+    const float w = a.tnorm[row];                      // weight = target_scores.sum(-1) (Loss.cs:138)
+    const float tss = a.scalars[0];
+    const float* gb = a.gt_box + ((long)b * a.gcap + g) * 4;
+    const float tb[4] = {gb[0] / an.stride, gb[1] / an.stride, gb[2] / an.stride, gb[3] / an.stride};  // Loss.cs:456
+    // CIoU(pred, target) with d/d(pred x1,y1,x2,y2)
+    Dual4 b1[4] = {dvar(an.ax - d0, 0), dvar(an.ay - d1, 1), dvar(an.ax + d2, 2), dvar(an.ay + d3, 3)};
+    Dual4 b2[4] = {dconst(tb[0]), dconst(tb[1]), dconst(tb[2]), dconst(tb[3])};
+    const Dual4 ci = ciou_xyxy<Dual4>(b1, b2);
+    if (s == 0) l_iou = (1.0f - ci.v) * w;
+    // d(total)/d(dist_s): loss_box*B = hyp_box*B/tss * sum((1-ciou)*w); x1 = ax - l, y1 = ay - t, x2 = ax + r, y2 = ay + b
+    const float gbox = a.hyp_box * (float)a.B / tss * w;
+    const float gd = (s < 2) ? (gbox * ci.g[s]) : (-gbox * ci.g[s]);   // -(dciou/dx1)*(-1) = +g ; -(dciou/dx2)*(+1) = -g
+    // DFL (Loss.cs:104-118, Tal.cs:365-379): target ltrb clamped to [0, reg_max-1-0.01]
+    float t = (s == 0) ? (an.ax - tb[0]) : (s == 1) ? (an.ay - tb[1]) : (s == 2) ? (tb[2] - an.ax) : (tb[3] - an.ay);
+    const float tmax = (float)(R - 1) - 0.01f;
+    t = fminf(fmaxf(t, 0.f), tmax);
+    const int tl = (int)t;
+    const int tr = tl + 1;
+    const float wl = (float)tr - t, wr = 1.0f - wl;
+    const float ce_l = lse - xl[tl], ce_r = lse - xl[tr];
+    l_dfl = (ce_l * wl + ce_r * wr) * 0.25f * w;        // mean over the 4 sides, x weight
+    const float gdfl = a.hyp_dfl * (float)a.B / tss * w * 0.25f;
+    for (int j = 0; j < R; j++) {
+      float gj = gd * p[j] * ((float)j - dist);          // through softmax expectation
+      gj += gdfl * (p[j] - (j == tl ? wl : 0.f) - (j == tr ? wr : 0.f));
+      gl[j] = gj;
+    }
+  }
+  if (inb) {
+    T* drow = (T*)a.dpd + row * a.ld_pd + s * R;
+    for (int j = 0; j < R; j++) drow[j] = Elem<T>::from_f(gl[j]);
+  }
+  block_partial4(0.f, 0.f, l_iou, l_dfl, partial + (long)blockIdx.x * 4);
+}
+
+// ------------------------------------------------------------------ K7: items (Loss.cs:463-476)
+__global__ void loss_items_kernel(LossArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float* sc = a.scalars;
+    const float tss = sc[0];
+    const float l_cls = sc[5] / tss, l_iou = sc[6] / tss, l_dfl = sc[7] / tss;
+    sc[1] = l_iou * a.hyp_box;
+    sc[2] = l_cls * a.hyp_cls;
+    sc[3] = l_dfl * a.hyp_dfl;
+    sc[4] = (sc[1] + sc[2] + sc[3]) * (float)a.B;
+  }
+}
+
+static int cls_blocks(const LossArgs& a, int epl) { return ys_cdiv((long)a.B * a.A * (a.ld_ps / epl), LS_THREADS); }
+static int box_blocks(const LossArgs& a) { return ys_cdiv((long)a.B * a.A * 4, LS_THREADS); }
+static int anc_blocks(const LossArgs& a) { return ys_cdiv((long)a.B * a.A, LS_THREADS); }
+
+size_t ys_loss_partial_floats(int B, int A) {
+  // three partial regions: targets (B*A/256 blocks), cls (<= B*A*ld/4/256), box (B*A*4/256); sized generously
+  const size_t anc = ((size_t)B * A + LS_THREADS - 1) / LS_THREADS;
+  return 4 * (anc + anc * 64 + anc * 4) + 64;
+}
+
+template <class T>
+static int loss_launch_t(hipStream_t st, const LossArgs& a) {
+  constexpr int EPL = Elem<T>::EPL;
+  if (a.reg_max > 32) { ys_set_error("loss: reg_max %d > 32 unsupported", a.reg_max); return YS_ERR_UNSUPPORTED; }
+  if (a.A > 1056 * 32) { ys_set_error("loss: %d anchors exceed the assigner capacity", a.A); return YS_ERR_UNSUPPORTED; }
+  if (a.ld_ps % EPL) { ys_set_error("loss: ld_ps %d must be a multiple of %d", a.ld_ps, EPL); return YS_ERR_INVALID_ARG; }
+  // gt_valid lives behind gt_cls ([B][gcap] ints each)
+  int* gt_valid = a.gt_cls + (long)a.B * a.gcap;
+  const int nb_a = anc_blocks(a), nb_c = cls_blocks(a, EPL), nb_b = box_blocks(a);
+  float* part_t = a.partial;
+  float* part_c = part_t + (size_t)nb_a * 4;
+  float* part_b = part_c + (size_t)nb_c * 4;
+  YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
+  YS_LAUNCH((loss_decode_kernel<T>), nb_a, LS_THREADS, st, a);
+  YS_LAUNCH((tal_metrics_kernel<T>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
+  YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
+  YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
+  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);
+  YS_LAUNCH((loss_cls_kernel<T>), nb_c, LS_THREADS, st, a, part_c);
+  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_c, nb_c, a.scalars, 1);
+  YS_LAUNCH((loss_box_kernel<T>), nb_b, LS_THREADS, st, a, part_b);
+  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_b, nb_b, a.scalars, 1);
+  YS_LAUNCH(loss_items_kernel, 1, 64, st, a);
+  return YS_OK;
+}
+
+int ys_loss_detect_launch(hipStream_t st, int dtype, const LossArgs& a) {
+  if (dtype == YS_BF16) return loss_launch_t<bf16_t>(st, a);
+  return loss_launch_t<float>(st, a);
+}

@@ -1,0 +1,923 @@
+// model.hip -- graph builder and step orchestration behind the ys_model_* / ys_loss_* / ys_optim_* ABI.
+//
+// Builds the reference's Yolov8 detect graph (Models/Yolo.cs:41-89: widths/depths table :43-55, layer list
+// :56-87, skip router :92-134) out of Conv units (Modules/Convs.cs:36-62), C2f/Bottleneck
+// (Modules/Block.cs:371-399, 572-608), SPPF (Block.cs:236-285), Upsample+Concat (Yolo.cs:70-75) and the
+// Detect head (Modules/Head.cs:35-53,71-106,204-223), as a flat list of device ops over NHWC buffers:
+//   * every Concat is a shared buffer: producers write their channel slice, chunk(2,1) is a view
+//   * Bottleneck's shortcut add is fused into the BN/SiLU apply pass of its cv2
+//   * Detect towers write straight into [B, A, C] (= the permuted layout the loss consumes)
+// Training forward keeps the raw conv output y per Conv unit (BN backward needs it); backward walks the op
+// list in reverse, gradient buffers mirror activation buffers, "first writer writes, later writers accumulate".
+#include "ys_internal.h"
+#include "ys_kernels.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+namespace {
+
+struct View { int buf = -1; int coff = 0; int C = 0; };
+
+struct Buf {
+  int H = 0, W = 0, ldc = 0;
+  long rows_per_b = 0;   // H*W (or A for head outputs)
+  void* act = nullptr;
+  void* grad = nullptr;
+  bool need_grad = true;
+  std::vector<char> gw;  // per-channel "gradient already written in this backward pass"
+};
+
+struct ConvL {
+  std::string name;      // state_dict prefix
+  int cin = 0, cout = 0, k = 1, s = 1;
+  int cin_pad = 0;       // channels of the input view (first layer: 3 -> EPL)
+  int cout_ld = 0;       // channels incl. padding in the dgrad weight matrix / dy rows
+  bool bn = true, act = true;
+  View in, out, res;
+  bool has_res = false;
+  int Hin = 0, Win = 0, Hout = 0, Wout = 0;
+  long out_rowoff = 0;   // head outputs: first row of this level inside [B][A]
+  long w_off = -1, g_off = -1, b_off = -1;   // flat parameter offsets (floats): weight, bn.weight|bias, bn.bias
+  long rm_off = -1, rv_off = -1, nbt_off = -1;  // running stats in `state`
+  long wf_off = 0, wd_off = 0;               // element offsets into wf_all / wd_all
+  long y_off = 0;                             // element offset into y_all (bn layers)
+  long ch_off = 0;                            // offset into per-channel scratch (scale.. c2), floats
+  int seg = 0;
+  bool first = false;
+};
+
+enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2 };
+struct Op { int type; int conv = -1; View in, out; int H = 0, W = 0; long aux_off = 0; int seg = 0; };
+
+struct TensorRec {
+  std::string name;
+  int ndim = 1; int64_t shape[4] = {1, 1, 1, 1};
+  bool is_param = true;
+  int kind = 0;     // 0 conv weight (OIHW at the edge), 1 vector in flat params, 2 vector in state, 3 dfl weight
+  int conv = -1;
+  long off = 0, count = 0;
+};
+
+struct PrepDesc { long w_off, wf_off, wd_off, nf_start, nd_start; int cout, taps, cin_real, cin_pad, cout_pad, has_wd; };
+
+}  // namespace
+
+struct ys_model {
+  ys_ctx* ctx = nullptr;
+  ys_model_desc d{};
+  int dtype = 0, epl = 4; size_t es = 4;
+  int maxB = 0, B = 0;
+  int A = 0, nl = 3;
+  int lvl_off[4] = {0}, lvl_w[4] = {0}, lvl_h[4] = {0}, lvl_stride[4] = {8, 16, 32, 64};
+  bool training = true;
+  std::vector<Buf> bufs;
+  std::vector<ConvL> convs;
+  std::vector<Op> ops;
+  std::vector<TensorRec> tensors;
+  int in_buf = -1, pd_buf = -1, ps_buf = -1;
+  int ld_pd = 0, ld_ps = 0;
+  // flat fp32 parameter state
+  long n_params = 0;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  float* state = nullptr; long n_state = 0;     // running_mean / running_var / num_batches_tracked
+  float dfl_w[64];
+  struct Range { long off, count; };
+  Range seg_group[3][3];                         // [segment][adamw group]
+  long step = 0;
+  // T weights
+  void *wf_all = nullptr, *wd_all = nullptr; long n_wf = 0, n_wd = 0;
+  PrepDesc* prep_dev = nullptr; int n_prep = 0; long prep_nf = 0, prep_nd = 0;
+  bool weights_dirty = true, eval_coeffs_dirty = true;
+  // activations
+  void* y_all = nullptr; long n_y = 0;
+  void* dy_scratch = nullptr; long n_dy = 0;
+  float* chan = nullptr; long n_chan = 0;       // per conv: scale, shift, mean, rstd, c1, c2 (6*cout)
+  float* stat_partial = nullptr; long n_stat = 0;
+  float* wg_partial = nullptr; long n_wgp = 0;
+  unsigned char* argmax = nullptr; long n_argmax = 0;
+  float* img_dev = nullptr;                      // staging for host images
+  float* pred = nullptr;                         // [B][4+nc][A] fp32 (eval)
+  float* out_stage = nullptr; long n_out_stage = 0;
+  // loss
+  int gcap = 64; int max_labels = 0;
+  float *lab_bidx = nullptr, *lab_cls = nullptr, *lab_box = nullptr;
+  int* gt_count = nullptr; float* gt_box = nullptr; int* gt_cls = nullptr; float* pbox = nullptr;
+  float *ov = nullptr, *align = nullptr; unsigned char* mpos = nullptr; unsigned *pos_align = nullptr, *pos_ov = nullptr;
+  int* fg_gt = nullptr; float* tnorm = nullptr; float* loss_partial = nullptr; float* scalars = nullptr;
+  bool have_fwd = false, have_loss = false;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+int dev_alloc(ys_model* m, void** p, size_t bytes, bool zero = true) {
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) { ys_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return YS_ERR_OOM; }
+  m->allocs.push_back(*p);
+  if (zero) { e = hipMemsetAsync(*p, 0, bytes, m->ctx->stream); if (e != hipSuccess) { ys_set_error("hipMemset failed"); return YS_ERR_HIP; } }
+  return YS_OK;
+}
+
+int new_buf(ys_model* m, int H, int W, int C) {
+  Buf b; b.H = H; b.W = W; b.ldc = C; b.rows_per_b = (long)H * W; b.gw.assign(C, 0);
+  m->bufs.push_back(b);
+  return (int)m->bufs.size() - 1;
+}
+
+void add_tensor(ys_model* m, const std::string& name, int kind, int conv, long off, std::vector<int64_t> shape, bool is_param) {
+  TensorRec t; t.name = name; t.kind = kind; t.conv = conv; t.off = off; t.is_param = is_param;
+  t.ndim = (int)shape.size(); t.count = 1;
+  for (int i = 0; i < t.ndim; i++) { t.shape[i] = shape[i]; t.count *= shape[i]; }
+  m->tensors.push_back(t);
+}
+
+// one Conv unit (conv+BN+act) or plain biased Conv2d; returns conv index and appends the op
+int add_conv(ys_model* m, const std::string& name, View in, View out, int cin, int cout, int k, int s, bool bn, bool act,
+             int Hin, int Win, int seg, const View* res = nullptr) {
+  ConvL c; c.name = name; c.in = in; c.out = out; c.cin = cin; c.cout = cout; c.k = k; c.s = s; c.bn = bn; c.act = act;
+  c.cin_pad = in.C; c.Hin = Hin; c.Win = Win;
+  const int p = k / 2;
+  c.Hout = (Hin + 2 * p - k) / s + 1; c.Wout = (Win + 2 * p - k) / s + 1;
+  c.cout_ld = (cout + m->epl - 1) / m->epl * m->epl;
+  c.seg = seg;
+  if (res) { c.res = *res; c.has_res = true; }
+  m->convs.push_back(c);
+  Op op; op.type = OP_CONV; op.conv = (int)m->convs.size() - 1; op.in = in; op.out = out; op.H = Hin; op.W = Win; op.seg = seg;
+  m->ops.push_back(op);
+  return op.conv;
+}
+
+// C2f (Block.cs:371-399): cv1 1x1 -> chunk -> n Bottlenecks (3x3,3x3, e=1.0) -> cat -> cv2 1x1
+void add_c2f(ys_model* m, const std::string& name, View xin, View xout, int c1, int c2, int n, bool shortcut, int H, int W, int seg) {
+  const int c = (int)(c2 * 0.5f);
+  const int cat = new_buf(m, H, W, (2 + n) * c);
+  add_conv(m, name + ".cv1", xin, View{cat, 0, 2 * c}, c1, 2 * c, 1, 1, true, true, H, W, seg);
+  std::vector<std::pair<View, View>> bn_views;
+  // registration order in the reference: cv1, cv2, m.* -- ops must run m.* before cv2, names are independent
+  for (int i = 0; i < n; i++) {
+    const View bin{cat, (1 + i) * c, c};
+    const View bout{cat, (2 + i) * c, c};
+    const int tmp = new_buf(m, H, W, c);
+    const std::string bp = name + ".m." + std::to_string(i);
+    add_conv(m, bp + ".cv1", bin, View{tmp, 0, c}, c, c, 3, 1, true, true, H, W, seg);
+    add_conv(m, bp + ".cv2", View{tmp, 0, c}, bout, c, c, 3, 1, true, true, H, W, seg, shortcut ? &bin : nullptr);
+  }
+  add_conv(m, name + ".cv2", View{cat, 0, (2 + n) * c}, xout, (2 + n) * c, c2, 1, 1, true, true, H, W, seg);
+}
+
+int build_v8_detect(ys_model* m) {
+  const ys_model_desc& d = m->d;
+  static const float dm[5] = {0.34f, 0.34f, 0.67f, 1.0f, 1.0f};
+  static const float wm[5] = {0.25f, 0.5f, 0.75f, 1.0f, 1.25f};
+  static const int mc[5] = {1024, 1024, 576, 512, 640};
+  const int base_w[5] = {64, 128, 256, 512, 1024};
+  int w[5];
+  for (int i = 0; i < 5; i++) w[i] = std::min((int)(base_w[i] * wm[d.size]), mc[d.size]);   // Yolo.cs:53
+  const int dep[3] = {(int)(3 * dm[d.size]), (int)(6 * dm[d.size]), (int)(9 * dm[d.size])};  // Yolo.cs:54
+  const int H = d.height, W = d.width;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
+  for (int i = 0; i < 5; i++)
+    if (w[i] % m->epl || ((int)(w[i] * 0.5f)) % m->epl) { ys_set_error("model: width %d not a multiple of %d", w[i], m->epl); return YS_ERR_UNSUPPORTED; }
+
+  m->in_buf = new_buf(m, H, W, m->epl);
+  m->bufs[m->in_buf].need_grad = false;
+  // concat buffers of the neck (Yolo.cs:70-84; concat order [x, skip], Yolo.cs:107)
+  const int cat11 = new_buf(m, H16, W16, w[4] + w[3]);
+  const int cat14 = new_buf(m, H8, W8, w[3] + w[2]);
+  const int cat17 = new_buf(m, H16, W16, w[2] + w[3]);
+  const int cat20 = new_buf(m, H32, W32, w[3] + w[4]);
+  const int b0 = new_buf(m, H2, W2, w[0]), b1 = new_buf(m, H4, W4, w[1]), b2 = new_buf(m, H4, W4, w[1]);
+  const int b3 = new_buf(m, H8, W8, w[2]), b5 = new_buf(m, H16, W16, w[3]), b7 = new_buf(m, H32, W32, w[4]);
+  const int b8 = new_buf(m, H32, W32, w[4]);
+  const int b15 = new_buf(m, H8, W8, w[2]), b18 = new_buf(m, H16, W16, w[3]), b21 = new_buf(m, H32, W32, w[4]);
+  const View v4{cat14, w[3], w[2]}, v6{cat11, w[4], w[3]}, v9{cat20, w[3], w[4]}, v12{cat17, w[2], w[3]};
+  const int SB = 2, SN = 1, SH = 0;  // backward segments: head first, stem last
+
+  int ci = add_conv(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SB);
+  m->convs[ci].first = true;
+  add_conv(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SB);
+  add_c2f(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[1]}, w[1], w[1], dep[0], true, H4, W4, SB);
+  add_conv(m, "model.3", View{b2, 0, w[1]}, View{b3, 0, w[2]}, w[1], w[2], 3, 2, true, true, H4, W4, SB);
+  add_c2f(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[2], dep[1], true, H8, W8, SB);
+  add_conv(m, "model.5", v4, View{b5, 0, w[3]}, w[2], w[3], 3, 2, true, true, H8, W8, SB);
+  add_c2f(m, "model.6", View{b5, 0, w[3]}, v6, w[3], w[3], dep[1], true, H16, W16, SB);
+  add_conv(m, "model.7", v6, View{b7, 0, w[4]}, w[3], w[4], 3, 2, true, true, H16, W16, SB);
+  add_c2f(m, "model.8", View{b7, 0, w[4]}, View{b8, 0, w[4]}, w[4], w[4], dep[0], true, H32, W32, SB);
+  {  // SPPF (Block.cs:236-285): cv1 has NO activation (:257); three chained 5x5 pools
+    const int c_ = w[4] / 2;
+    const int catS = new_buf(m, H32, W32, 4 * c_);
+    add_conv(m, "model.9.cv1", View{b8, 0, w[4]}, View{catS, 0, c_}, w[4], c_, 1, 1, true, false, H32, W32, SB);
+    for (int i = 0; i < 3; i++) {
+      Op op; op.type = OP_MAXPOOL; op.in = View{catS, i * c_, c_}; op.out = View{catS, (i + 1) * c_, c_}; op.H = H32; op.W = W32; op.seg = SB;
+      m->ops.push_back(op);
+    }
+    add_conv(m, "model.9.cv2", View{catS, 0, 4 * c_}, v9, 4 * c_, w[4], 1, 1, true, true, H32, W32, SB);
+  }
+  { Op op; op.type = OP_UPSAMPLE; op.in = v9; op.out = View{cat11, 0, w[4]}; op.H = H32; op.W = W32; op.seg = SN; m->ops.push_back(op); }
+  add_c2f(m, "model.12", View{cat11, 0, w[4] + w[3]}, v12, w[4] + w[3], w[3], dep[0], false, H16, W16, SN);
+  { Op op; op.type = OP_UPSAMPLE; op.in = v12; op.out = View{cat14, 0, w[3]}; op.H = H16; op.W = W16; op.seg = SN; m->ops.push_back(op); }
+  add_c2f(m, "model.15", View{cat14, 0, w[3] + w[2]}, View{b15, 0, w[2]}, w[3] + w[2], w[2], dep[0], false, H8, W8, SN);
+  add_conv(m, "model.16", View{b15, 0, w[2]}, View{cat17, 0, w[2]}, w[2], w[2], 3, 2, true, true, H8, W8, SN);
+  add_c2f(m, "model.18", View{cat17, 0, w[2] + w[3]}, View{b18, 0, w[3]}, w[2] + w[3], w[3], dep[0], false, H16, W16, SN);
+  add_conv(m, "model.19", View{b18, 0, w[3]}, View{cat20, 0, w[3]}, w[3], w[3], 3, 2, true, true, H16, W16, SN);
+  add_c2f(m, "model.21", View{cat20, 0, w[3] + w[4]}, View{b21, 0, w[4]}, w[3] + w[4], w[4], dep[0], false, H32, W32, SN);
+
+  // Detect (Head.cs:35-53): c2 = max(16, ch0/4, 4*reg_max), c3 = max(ch0, min(nc,100)); strides fixed {8,16,32} (:43)
+  const int ch[3] = {w[2], w[3], w[4]};
+  const int hh[3] = {H8, H16, H32}, ww[3] = {W8, W16, W32};
+  const int pv[3] = {b15, b18, b21};
+  const int c2 = std::max(16, std::max(ch[0] / 4, d.reg_max * 4));
+  const int c3 = std::max(ch[0], std::min(d.nc, 100));
+  if (c2 % m->epl || c3 % m->epl) { ys_set_error("model: head widths c2=%d c3=%d must be multiples of %d", c2, c3, m->epl); return YS_ERR_UNSUPPORTED; }
+  m->nl = 3; m->A = 0;
+  for (int i = 0; i < 3; i++) { m->lvl_off[i] = m->A; m->lvl_w[i] = ww[i]; m->lvl_h[i] = hh[i]; m->A += hh[i] * ww[i]; }
+  m->ld_pd = (4 * d.reg_max + m->epl - 1) / m->epl * m->epl;
+  m->ld_ps = (d.nc + m->epl - 1) / m->epl * m->epl;
+  m->pd_buf = new_buf(m, 1, m->A, m->ld_pd);
+  m->ps_buf = new_buf(m, 1, m->A, m->ld_ps);
+  const std::string hp = "model.22";
+  for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
+    for (int i = 0; i < 3; i++) {
+      const int cm = t == 0 ? c2 : c3;
+      const int co = t == 0 ? 4 * d.reg_max : d.nc;
+      const int ob = t == 0 ? m->pd_buf : m->ps_buf;
+      const std::string tp = hp + (t == 0 ? ".cv2." : ".cv3.") + std::to_string(i);
+      const int t0 = new_buf(m, hh[i], ww[i], cm), t1 = new_buf(m, hh[i], ww[i], cm);
+      add_conv(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 3, 1, true, true, hh[i], ww[i], SH);
+      add_conv(m, tp + ".1", View{t0, 0, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], SH);
+      const int cc = add_conv(m, tp + ".2", View{t1, 0, cm}, View{ob, 0, co}, cm, co, 1, 1, false, false, hh[i], ww[i], SH);
+      m->convs[cc].out_rowoff = m->lvl_off[i];
+    }
+  }
+  return YS_OK;
+}
+
+// ---- parameter layout: [segment][group] contiguous ranges; group rule of YoloBaseTaskModel.cs:144-151 made disjoint:
+//      0 = "bias" (conv bias, bn.bias), 1 = conv "weight", 2 = "bn" weight
+int layout_params(ys_model* m) {
+  long off = 0;
+  for (int seg = 0; seg < 3; seg++)
+    for (int grp = 0; grp < 3; grp++) {
+      const long start = off;
+      for (auto& c : m->convs) {
+        if (c.seg != seg) continue;
+        if (grp == 0) { if (c.bn) { c.b_off = off; off += c.cout; } else { c.g_off = off; off += c.cout; } }   // bn.bias | conv bias (stored in g_off for plain convs)
+        if (grp == 1) { c.w_off = off; off += (long)c.cout * c.k * c.k * c.cin; }
+        if (grp == 2 && c.bn) { c.g_off = off; off += c.cout; }
+      }
+      m->seg_group[seg][grp] = {start, off - start};
+    }
+  m->n_params = off;
+  long so = 0;
+  for (auto& c : m->convs)
+    if (c.bn) { c.rm_off = so; so += c.cout; c.rv_off = so; so += c.cout; c.nbt_off = so; so += 1; }
+  m->n_state = so;
+  // state_dict listing: parameters in module order, then buffers (TorchSharp named_parameters + named_buffers)
+  // module order = reference registration order: C2f registers cv1, cv2, m.* (Block.cs:373-376)
+  std::vector<int> order(m->convs.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  auto key = [&](int i) {
+    // sort key reproducing registration order: split name into numeric-aware tokens, "cv1" < "cv2" < "m"
+    return m->convs[i].name;
+  };
+  (void)key;
+  // ops were appended as cv1, m.*, cv2 inside each C2f: move each C2f's cv2 right after its cv1
+  std::vector<int> reg;
+  for (size_t i = 0; i < m->convs.size(); i++) {
+    const std::string& n = m->convs[i].name;
+    const bool is_c2f_cv1 = n.size() > 4 && n.compare(n.size() - 4, 4, ".cv1") == 0 && n.find(".m.") == std::string::npos && n.find("model.9") != 0;
+    reg.push_back((int)i);
+    if (is_c2f_cv1) {
+      const std::string pre = n.substr(0, n.size() - 4);
+      for (size_t j = i + 1; j < m->convs.size(); j++)
+        if (m->convs[j].name == pre + ".cv2") { reg.push_back((int)j); break; }
+    }
+  }
+  std::vector<int> reg2;
+  std::vector<char> seen(m->convs.size(), 0);
+  for (int i : reg) if (!seen[i]) { seen[i] = 1; reg2.push_back(i); }
+  for (int i : reg2) {
+    const ConvL& c = m->convs[i];
+    if (c.bn) {
+      add_tensor(m, c.name + ".conv.weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
+      add_tensor(m, c.name + ".bn.weight", 1, i, c.g_off, {c.cout}, true);
+      add_tensor(m, c.name + ".bn.bias", 1, i, c.b_off, {c.cout}, true);
+    } else {
+      add_tensor(m, c.name + ".weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
+      add_tensor(m, c.name + ".bias", 1, i, c.g_off, {c.cout}, true);
+    }
+  }
+  add_tensor(m, "model.22.dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
+  for (int i : reg2) {
+    const ConvL& c = m->convs[i];
+    if (!c.bn) continue;
+    add_tensor(m, c.name + ".bn.running_mean", 2, i, c.rm_off, {c.cout}, false);
+    add_tensor(m, c.name + ".bn.running_var", 2, i, c.rv_off, {c.cout}, false);
+    add_tensor(m, c.name + ".bn.num_batches_tracked", 2, i, c.nbt_off, {1}, false);
+  }
+  return YS_OK;
+}
+
+// ---- batched weight preparation: fp32 master [Cout][taps][Cin] -> T forward [Cout][taps][Cin_pad]
+//                                                                  -> T dgrad   [Cin][taps flipped][Cout_pad]
+template <class T>
+__global__ void __launch_bounds__(256)
+weight_prep_all_kernel(const float* __restrict__ params, const PrepDesc* __restrict__ desc, int n, long total_f, long total_d,
+                       T* __restrict__ wf_all, T* __restrict__ wd_all) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total_f) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].nf_start <= i) lo = mid; else hi = mid - 1; }
+    const PrepDesc d = desc[lo];
+    const long e = i - d.nf_start;
+    const int ci = (int)(e % d.cin_pad);
+    const long r = e / d.cin_pad;
+    wf_all[d.wf_off + e] = Elem<T>::from_f(ci < d.cin_real ? params[d.w_off + r * d.cin_real + ci] : 0.f);
+  }
+  if (i < total_d) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].nd_start <= i) lo = mid; else hi = mid - 1; }
+    const PrepDesc d = desc[lo];
+    if (d.has_wd) {
+      const long e = i - d.nd_start;
+      const int co = (int)(e % d.cout_pad);
+      const long r = e / d.cout_pad;
+      const int tapf = (int)(r % d.taps);
+      const int ci = (int)(r / d.taps);
+      const int tap = d.taps - 1 - tapf;
+      wd_all[d.wd_off + e] = Elem<T>::from_f(co < d.cout ? params[d.w_off + ((long)co * d.taps + tap) * d.cin_real + ci] : 0.f);
+    }
+  }
+}
+
+int prep_weights(ys_model* m) {
+  if (!m->weights_dirty) return YS_OK;
+  const long total = std::max(m->prep_nf, m->prep_nd);
+  if (m->dtype == YS_BF16)
+    YS_LAUNCH((weight_prep_all_kernel<bf16_t>), ys_cdiv(total, 256), 256, m->ctx->stream, (const float*)m->params, (const PrepDesc*)m->prep_dev, m->n_prep, m->prep_nf, m->prep_nd, (bf16_t*)m->wf_all, (bf16_t*)m->wd_all);
+  else
+    YS_LAUNCH((weight_prep_all_kernel<float>), ys_cdiv(total, 256), 256, m->ctx->stream, (const float*)m->params, (const PrepDesc*)m->prep_dev, m->n_prep, m->prep_nf, m->prep_nd, (float*)m->wf_all, (float*)m->wd_all);
+  m->weights_dirty = false;
+  return YS_OK;
+}
+
+inline char* view_ptr(ys_model* m, void* base, const Buf& b, long row0) { return (char*)base + (size_t)row0 * b.ldc * m->es; }
+
+float* chan_ptr(ys_model* m, const ConvL& c, int which) { return m->chan + c.ch_off + (long)which * c.cout; }
+
+int allocate(ys_model* m) {
+  const int B = m->maxB;
+  hipStream_t st = m->ctx->stream; (void)st;
+  for (auto& b : m->bufs) {
+    const size_t bytes = (size_t)B * b.rows_per_b * b.ldc * m->es;
+    YS_TRY(dev_alloc(m, &b.act, bytes));
+    if (b.need_grad) YS_TRY(dev_alloc(m, &b.grad, bytes));
+  }
+  YS_TRY(dev_alloc(m, (void**)&m->params, (size_t)m->n_params * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->grads, (size_t)m->n_params * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->adam_m, (size_t)m->n_params * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->adam_v, (size_t)m->n_params * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->state, (size_t)m->n_state * 4));
+  long nf = 0, nd = 0, ny = 0, nch = 0, dy_max = 0, stat_max = 0, amax = 0;
+  std::vector<PrepDesc> pd;
+  for (auto& c : m->convs) {
+    const int taps = c.k * c.k;
+    c.wf_off = nf; nf += (long)c.cout * taps * c.cin_pad;
+    c.wd_off = nd;
+    PrepDesc d{}; d.w_off = c.w_off; d.wf_off = c.wf_off; d.wd_off = c.wd_off; d.cout = c.cout; d.taps = taps;
+    d.cin_real = c.cin; d.cin_pad = c.cin_pad; d.cout_pad = c.cout_ld; d.has_wd = c.first ? 0 : 1;
+    d.nf_start = c.wf_off; d.nd_start = c.wd_off;
+    if (!c.first) nd += (long)c.cin * taps * c.cout_ld;
+    pd.push_back(d);
+    const long M = (long)B * c.Hout * c.Wout;
+    if (c.bn) { c.y_off = ny; ny += M * c.cout; }
+    c.ch_off = nch; nch += 6L * c.cout;
+    dy_max = std::max(dy_max, M * c.cout_ld);
+    stat_max = std::max(stat_max, (long)ys_cdiv(M, 128) * 2 * c.cout);
+    stat_max = std::max(stat_max, 2048L * 2 * c.cout_ld);   // channel-reduction partials (<= 2048 workgroups)
+  }
+  for (auto& op : m->ops) if (op.type == OP_MAXPOOL) { op.aux_off = amax; amax += (long)B * op.H * op.W * op.in.C; }
+  m->n_wf = nf; m->n_wd = nd; m->n_y = ny; m->n_chan = nch; m->n_dy = dy_max; m->n_stat = stat_max; m->n_argmax = amax;
+  m->prep_nf = nf; m->prep_nd = nd; m->n_prep = (int)pd.size();
+  YS_TRY(dev_alloc(m, &m->wf_all, (size_t)nf * m->es));
+  YS_TRY(dev_alloc(m, &m->wd_all, (size_t)nd * m->es));
+  YS_TRY(dev_alloc(m, (void**)&m->prep_dev, pd.size() * sizeof(PrepDesc)));
+  YS_CHECK_HIP(hipMemcpyAsync(m->prep_dev, pd.data(), pd.size() * sizeof(PrepDesc), hipMemcpyHostToDevice, m->ctx->stream));
+  YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));   // pd is a host temporary
+  YS_TRY(dev_alloc(m, &m->y_all, (size_t)ny * m->es));
+  YS_TRY(dev_alloc(m, &m->dy_scratch, (size_t)dy_max * m->es));
+  YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->argmax, (size_t)amax));
+  // wgrad partial workspace: max over layers of splits * |W|
+  long wgp = 0;
+  for (auto& c : m->convs) {
+    WgradArgs a{}; a.Cin = c.cin_pad; a.Cout = c.cout; a.KH = a.KW = c.k; a.M = (int)((long)B * c.Hout * c.Wout);
+    wgp = std::max(wgp, (long)ys_wgrad_splits(a, m->dtype) * c.cout * c.k * c.k * c.cin_pad);
+  }
+  m->n_wgp = wgp;
+  YS_TRY(dev_alloc(m, (void**)&m->wg_partial, (size_t)wgp * 4));
+  const ys_model_desc& d = m->d;
+  YS_TRY(dev_alloc(m, (void**)&m->img_dev, (size_t)B * 3 * d.height * d.width * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->pred, (size_t)B * (4 + d.nc) * m->A * 4));
+  m->n_out_stage = (long)B * m->A * std::max(std::max(m->ld_pd, m->ld_ps), 4 + d.nc);
+  YS_TRY(dev_alloc(m, (void**)&m->out_stage, (size_t)m->n_out_stage * 4));
+  // loss workspace
+  m->gcap = d.max_labels > 0 ? d.max_labels : 64;
+  m->max_labels = m->gcap * B;
+  const size_t GA = (size_t)B * m->gcap * m->A;
+  YS_TRY(dev_alloc(m, (void**)&m->lab_bidx, (size_t)m->max_labels * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->lab_cls, (size_t)m->max_labels * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->lab_box, (size_t)m->max_labels * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_count, (size_t)B * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_box, (size_t)B * m->gcap * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_cls, (size_t)B * m->gcap * 8));   // gt_cls + gt_valid
+  YS_TRY(dev_alloc(m, (void**)&m->pbox, (size_t)B * m->A * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->ov, GA * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->align, GA * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->mpos, GA));
+  YS_TRY(dev_alloc(m, (void**)&m->pos_align, (size_t)B * m->gcap * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->pos_ov, (size_t)B * m->gcap * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->fg_gt, (size_t)B * m->A * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->tnorm, (size_t)B * m->A * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->loss_partial, ys_loss_partial_floats(B, m->A) * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->scalars, 64));
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ forward
+int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[c.in.buf];
+  const Buf& ob = m->bufs[c.out.buf];
+  ConvArgs a{};
+  a.x = ib.act; a.w = (char*)m->wf_all + (size_t)c.wf_off * m->es;
+  a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.cin_pad; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.cout; a.KH = a.KW = c.k;
+  a.SA = c.s; a.DIVS = 0; a.DIVM = 0; a.PAD = c.k / 2;
+  a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
+  a.M = B * c.Hout * c.Wout;
+  const long M = a.M;
+  const bool vec = (ob.ldc % 4 == 0) && (c.out.coff % 4 == 0);
+  if (c.bn && m->training) {
+    void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
+    a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
+    a.stats = m->stat_partial;
+    YS_TRY(ys_conv_launch(st, m->dtype, a));
+    const int gm = ys_conv_grid_m(a);
+    YS_TRY(ys_bn_finalize_launch(st, m->stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
+                                 m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
+                                 chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
+    const void* res = nullptr; int rl = 0, rc = 0;
+    if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
+    YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, res, rl, rc,
+                                  ob.act, ob.ldc, c.out.coff));
+  } else {
+    a.y = view_ptr(m, ob.act, ob, c.out_rowoff);
+    a.out_ldc = ob.ldc; a.out_coff = c.out.coff; a.out_bstride = ob.rows_per_b; a.vec_ok = vec ? 1 : 0;
+    if (c.bn) {
+      a.scale = chan_ptr(m, c, 0); a.shift = chan_ptr(m, c, 1); a.act = c.act ? 1 : 0;
+      if (c.has_res) { const Buf& rb = m->bufs[c.res.buf]; a.res = rb.act; a.res_ldc = rb.ldc; a.res_coff = c.res.coff; }
+    } else {
+      a.shift = m->params + c.g_off;  // conv bias
+    }
+    YS_TRY(ys_conv_launch(st, m->dtype, a));
+  }
+  return YS_OK;
+}
+
+int forward_impl(ys_model* m, int B) {
+  hipStream_t st = m->ctx->stream;
+  YS_TRY(prep_weights(m));
+  if (!m->training && m->eval_coeffs_dirty) {
+    for (auto& c : m->convs)
+      if (c.bn) YS_TRY(ys_bn_eval_coeffs_launch(st, c.cout, m->params + c.g_off, m->params + c.b_off, m->state + c.rm_off,
+                                                m->state + c.rv_off, 1e-3f, chan_ptr(m, c, 0), chan_ptr(m, c, 1)));
+    m->eval_coeffs_dirty = false;
+  }
+  for (auto& op : m->ops) {
+    const Buf& ib = m->bufs[op.in.buf];
+    const Buf& ob = m->bufs[op.out.buf];
+    if (op.type == OP_CONV) {
+      YS_TRY(run_conv_fwd(m, m->convs[op.conv], B));
+    } else if (op.type == OP_MAXPOOL) {
+      YS_TRY(ys_maxpool5_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc,
+                                    op.out.coff, m->training ? m->argmax + op.aux_off : nullptr));
+    } else {
+      YS_TRY(ys_upsample2x_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc, op.out.coff));
+    }
+  }
+  if (!m->training) {
+    YS_TRY(ys_detect_decode_launch(st, m->dtype, m->bufs[m->pd_buf].act, m->ld_pd, m->bufs[m->ps_buf].act, m->ld_ps, B, m->A,
+                                   m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred));
+  }
+  YS_CHECK_HIP(hipGetLastError());
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ backward
+// returns 0 = first writer (overwrite), 1 = accumulate; -1 = inconsistent slice state
+int grad_mode(ys_model* m, const View& v) {
+  Buf& b = m->bufs[v.buf];
+  int nw = 0;
+  for (int c = v.coff; c < v.coff + v.C; c++) nw += b.gw[c] ? 1 : 0;
+  if (nw != 0 && nw != v.C) return -1;
+  for (int c = v.coff; c < v.coff + v.C; c++) b.gw[c] = 1;
+  return nw ? 1 : 0;
+}
+
+int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[c.in.buf];
+  const Buf& ob = m->bufs[c.out.buf];
+  const long M = (long)B * c.Hout * c.Wout;
+  const void* dy = nullptr; int dy_ldc = 0, dy_coff = 0; long dy_bstride = (long)c.Hout * c.Wout;
+  if (c.bn) {
+    const void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
+    void* rg = nullptr; int rgl = 0, rgc = 0;
+    if (c.has_res) {
+      Buf& rb = m->bufs[c.res.buf];
+      for (int ch = c.res.coff; ch < c.res.coff + c.res.C; ch++)
+        if (!rb.gw[ch]) { ys_set_error("backward: residual gradient of %s not initialised", c.name.c_str()); return YS_ERR_STATE; }
+      rg = rb.grad; rgl = rb.ldc; rgc = c.res.coff;
+    }
+    int nblk = 0;
+    YS_TRY(ys_bn_bwd_reduce_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
+                                   chan_ptr(m, c, 2), chan_ptr(m, c, 3), c.act ? 1 : 0, rg, rgl, rgc, m->stat_partial, &nblk));
+    YS_TRY(ys_bn_bwd_finalize_launch(st, m->stat_partial, nblk, c.cout, M, m->grads + c.g_off, m->grads + c.b_off,
+                                     chan_ptr(m, c, 4), chan_ptr(m, c, 5)));
+    YS_TRY(ys_bn_bwd_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
+                                  chan_ptr(m, c, 2), chan_ptr(m, c, 3), m->params + c.g_off, chan_ptr(m, c, 4), chan_ptr(m, c, 5),
+                                  c.act ? 1 : 0, m->dy_scratch));
+    dy = m->dy_scratch; dy_ldc = c.cout; dy_coff = 0;
+  } else {
+    // plain Conv2d with bias (head outputs): dy is the loss gradient itself
+    dy = view_ptr(m, ob.grad, ob, c.out_rowoff); dy_ldc = ob.ldc; dy_coff = c.out.coff; dy_bstride = ob.rows_per_b;
+    YS_TRY(ys_colsum_launch(st, m->dtype, dy, dy_ldc, dy_coff, M, (long)c.Hout * c.Wout, dy_bstride, c.cout, m->stat_partial,
+                            m->grads + c.g_off));
+  }
+  // ---- wgrad
+  {
+    WgradArgs a{};
+    a.x = ib.act; a.dy = dy; a.partial = m->wg_partial;
+    a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.cin_pad; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.cout;
+    a.KH = a.KW = c.k; a.stride = c.s; a.pad = c.k / 2;
+    a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
+    a.dy_ldc = dy_ldc; a.dy_coff = dy_coff; a.dy_bstride = dy_bstride; a.M = (int)M;
+    const int splits = ys_wgrad_splits(a, m->dtype);
+    if ((long)splits * c.cout * c.k * c.k * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
+    YS_TRY(ys_wgrad_launch(st, m->dtype, a, splits, c.cin, m->grads + c.w_off));
+  }
+  // ---- dgrad (gather form with flipped/transposed weights)
+  if (!c.first) {
+    const int mode = grad_mode(m, c.in);
+    if (mode < 0) { ys_set_error("backward: inconsistent gradient slice state at %s", c.name.c_str()); return YS_ERR_STATE; }
+    ConvArgs a{};
+    a.x = dy; a.w = (char*)m->wd_all + (size_t)c.wd_off * m->es;
+    a.y = ib.grad;
+    a.B = B; a.Hin = c.Hout; a.Win = c.Wout; a.Cin = c.cout_ld; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cin; a.KH = a.KW = c.k;
+    a.SA = 1; a.DIVS = c.s == 2 ? 1 : 0; a.DIVM = c.s - 1; a.PAD = c.k - 1 - c.k / 2;
+    a.in_ldc = dy_ldc; a.in_coff = dy_coff; a.in_bstride = dy_bstride;
+    a.out_ldc = ib.ldc; a.out_coff = c.in.coff; a.out_bstride = ib.rows_per_b;
+    a.vec_ok = (ib.ldc % 4 == 0 && c.in.coff % 4 == 0) ? 1 : 0;
+    a.accumulate = mode;
+    a.M = B * c.Hin * c.Win;
+    if (c.bn && c.cout_ld != c.cout) { ys_set_error("backward: padded BN conv unsupported"); return YS_ERR_UNSUPPORTED; }
+    YS_TRY(ys_conv_launch(st, m->dtype, a));
+  }
+  return YS_OK;
+}
+
+int backward_range(ys_model* m, int seg_lo, int seg_hi) {
+  hipStream_t st = m->ctx->stream;
+  const int B = m->B;
+  for (int i = (int)m->ops.size() - 1; i >= 0; i--) {
+    const Op& op = m->ops[i];
+    if (op.seg < seg_lo || op.seg > seg_hi) continue;
+    if (op.type == OP_CONV) {
+      YS_TRY(run_conv_bwd(m, m->convs[op.conv], B));
+    } else {
+      const Buf& ib = m->bufs[op.in.buf];
+      const Buf& ob = m->bufs[op.out.buf];
+      const int mode = grad_mode(m, op.in);
+      if (mode < 0) { ys_set_error("backward: inconsistent gradient slice state at op %d", i); return YS_ERR_STATE; }
+      if (op.type == OP_MAXPOOL)
+        YS_TRY(ys_maxpool5_bwd_launch(st, m->dtype, ob.grad, ob.ldc, op.out.coff, B, op.H, op.W, op.in.C, m->argmax + op.aux_off,
+                                      ib.grad, ib.ldc, op.in.coff, mode));
+      else
+        YS_TRY(ys_upsample2x_bwd_launch(st, m->dtype, ob.grad, ob.ldc, op.out.coff, B, op.H, op.W, op.in.C, ib.grad, ib.ldc,
+                                        op.in.coff, mode));
+    }
+  }
+  YS_CHECK_HIP(hipGetLastError());
+  return YS_OK;
+}
+
+void reset_grad_state(ys_model* m) {
+  for (auto& b : m->bufs) std::fill(b.gw.begin(), b.gw.end(), 0);
+  // the loss wrote the head gradients
+  std::fill(m->bufs[m->pd_buf].gw.begin(), m->bufs[m->pd_buf].gw.end(), 1);
+  std::fill(m->bufs[m->ps_buf].gw.begin(), m->bufs[m->ps_buf].gw.end(), 1);
+}
+
+TensorRec* find_tensor(ys_model* m, const char* name) {
+  for (auto& t : m->tensors) if (t.name == name) return &t;
+  return nullptr;
+}
+
+// splitmix64 -> uniform(-bound, bound)
+struct Rng {
+  uint64_t s;
+  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  float uni(float b) { return ((float)((next() >> 40) & 0xFFFFFF) / 16777216.0f * 2.0f - 1.0f) * b; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
+  YS_REQUIRE(ctx && desc && out, "ys_model_create: null argument");
+  YS_REQUIRE(desc->dtype == YS_F32 || desc->dtype == YS_BF16, "ys_model_create: dtype %d unsupported", desc->dtype);
+  if (desc->family != YS_YOLOV8 || desc->task != YS_DETECT) {
+    ys_set_error("ys_model_create: only YOLOv8 detect is built in this round (family %d task %d)", desc->family, desc->task);
+    return YS_ERR_UNSUPPORTED;
+  }
+  YS_REQUIRE(desc->size >= 0 && desc->size <= 4, "ys_model_create: size %d out of range", desc->size);
+  YS_REQUIRE(desc->nc > 0 && desc->reg_max > 1 && desc->reg_max <= 32, "ys_model_create: nc=%d reg_max=%d", desc->nc, desc->reg_max);
+  YS_REQUIRE(desc->height > 0 && desc->width > 0 && desc->height % 32 == 0 && desc->width % 32 == 0,
+             "ys_model_create: image size %dx%d must be a positive multiple of 32", desc->height, desc->width);
+  YS_REQUIRE(desc->max_batch > 0, "ys_model_create: max_batch %d", desc->max_batch);
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  ys_model* m = new ys_model();
+  m->ctx = ctx; m->d = *desc; m->dtype = desc->dtype; m->epl = desc->dtype == YS_BF16 ? 8 : 4; m->es = desc->dtype == YS_BF16 ? 2 : 4;
+  m->maxB = desc->max_batch;
+  for (int j = 0; j < 64; j++) m->dfl_w[j] = (float)j;
+  int st = build_v8_detect(m);
+  if (st == YS_OK) st = layout_params(m);
+  if (st == YS_OK) st = allocate(m);
+  if (st != YS_OK) { ys_model_destroy(m); return st; }
+  st = ys_model_init_weights(m, 0);
+  if (st != YS_OK) { ys_model_destroy(m); return st; }
+  *out = m;
+  return YS_OK;
+}
+
+int ys_model_destroy(ys_model* m) {
+  if (!m) return YS_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->allocs) hipFree(p);
+  delete m;
+  return YS_OK;
+}
+
+int ys_model_num_tensors(ys_model* m) { return m ? (int)m->tensors.size() : 0; }
+int ys_model_num_anchors(ys_model* m) { return m ? m->A : 0; }
+int64_t ys_model_num_params(ys_model* m) { return m ? (int64_t)m->n_params : 0; }
+
+int ys_model_tensor_info(ys_model* m, int index, char* name, int name_cap, int32_t* ndim, int64_t shape[4], int32_t* is_param) {
+  YS_REQUIRE(m && index >= 0 && index < (int)m->tensors.size(), "ys_model_tensor_info: index %d out of range", index);
+  const TensorRec& t = m->tensors[index];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (ndim) *ndim = t.ndim;
+  if (shape) for (int i = 0; i < 4; i++) shape[i] = i < t.ndim ? t.shape[i] : 1;
+  if (is_param) *is_param = t.is_param ? 1 : 0;
+  return YS_OK;
+}
+
+static int tensor_io(ys_model* m, const char* name, float* host, size_t count, int what /*0 set,1 get,2 get grad*/) {
+  YS_REQUIRE(m && name && host, "tensor io: null argument");
+  TensorRec* t = find_tensor(m, name);
+  YS_REQUIRE(t != nullptr, "unknown tensor '%s'", name);
+  YS_REQUIRE((long)count == t->count, "tensor '%s' has %ld elements, caller passed %zu", name, t->count, count);
+  hipStream_t st = m->ctx->stream;
+  if (t->kind == 3) {
+    YS_REQUIRE(what != 2, "'%s' has no gradient (DFL is only used in eval, Head.cs:221)", name);
+    if (what == 0) memcpy(m->dfl_w, host, count * 4); else memcpy(host, m->dfl_w, count * 4);
+    return YS_OK;
+  }
+  float* dev = t->kind == 2 ? m->state + t->off : (what == 2 ? m->grads + t->off : m->params + t->off);
+  YS_REQUIRE(!(what == 2 && t->kind == 2), "'%s' is a buffer and has no gradient", name);
+  if (t->kind == 0) {
+    // OIHW at the edge <-> [Cout][taps][Cin] inside
+    const ConvL& c = m->convs[t->conv];
+    const int taps = c.k * c.k;
+    std::vector<float> tmp(count);
+    if (what == 0) {
+      for (int co = 0; co < c.cout; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
+        tmp[((size_t)co * taps + tp) * c.cin + ci] = host[((size_t)co * c.cin + ci) * taps + tp];
+      YS_CHECK_HIP(hipMemcpyAsync(dev, tmp.data(), count * 4, hipMemcpyHostToDevice, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      m->weights_dirty = true;
+    } else {
+      YS_CHECK_HIP(hipMemcpyAsync(tmp.data(), dev, count * 4, hipMemcpyDeviceToHost, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      for (int co = 0; co < c.cout; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
+        host[((size_t)co * c.cin + ci) * taps + tp] = tmp[((size_t)co * taps + tp) * c.cin + ci];
+    }
+  } else {
+    if (what == 0) YS_CHECK_HIP(hipMemcpyAsync(dev, host, count * 4, hipMemcpyHostToDevice, st));
+    else YS_CHECK_HIP(hipMemcpyAsync(host, dev, count * 4, hipMemcpyDeviceToHost, st));
+    YS_CHECK_HIP(hipStreamSynchronize(st));
+    if (what == 0) m->eval_coeffs_dirty = true;
+  }
+  return YS_OK;
+}
+int ys_model_set_tensor(ys_model* m, const char* name, const float* host, size_t count) { return tensor_io(m, name, (float*)host, count, 0); }
+int ys_model_get_tensor(ys_model* m, const char* name, float* host, size_t count) { return tensor_io(m, name, host, count, 1); }
+int ys_model_get_grad(ys_model* m, const char* name, float* host, size_t count) { return tensor_io(m, name, host, count, 2); }
+
+int ys_model_init_weights(ys_model* m, uint64_t seed) {
+  YS_REQUIRE(m, "null model");
+  std::vector<float> p(m->n_params, 0.f), s(m->n_state, 0.f);
+  Rng rng{seed * 0x9E3779B97F4A7C15ull + 0x1234567ull};
+  for (const auto& c : m->convs) {
+    const long nw = (long)c.cout * c.k * c.k * c.cin;
+    const float bound = 1.0f / sqrtf((float)(c.cin * c.k * c.k));   // kaiming_uniform(a=sqrt 5): 1/sqrt(fan_in)
+    for (long i = 0; i < nw; i++) p[c.w_off + i] = rng.uni(bound);
+    if (c.bn) {
+      for (int i = 0; i < c.cout; i++) { p[c.g_off + i] = 1.f; p[c.b_off + i] = 0.f; s[c.rm_off + i] = 0.f; s[c.rv_off + i] = 1.f; }
+      s[c.nbt_off] = 0.f;
+    } else {
+      for (int i = 0; i < c.cout; i++) p[c.g_off + i] = rng.uni(bound);   // Conv2d bias: U(-1/sqrt(fan_in), +)
+    }
+  }
+  hipStream_t st = m->ctx->stream;
+  YS_CHECK_HIP(hipMemcpyAsync(m->params, p.data(), p.size() * 4, hipMemcpyHostToDevice, st));
+  YS_CHECK_HIP(hipMemcpyAsync(m->state, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
+  YS_CHECK_HIP(hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, st));
+  YS_CHECK_HIP(hipMemsetAsync(m->adam_m, 0, (size_t)m->n_params * 4, st));
+  YS_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, (size_t)m->n_params * 4, st));
+  YS_CHECK_HIP(hipStreamSynchronize(st));
+  m->step = 0; m->weights_dirty = true; m->eval_coeffs_dirty = true;
+  return YS_OK;
+}
+
+int ys_model_set_training(ys_model* m, int training) {
+  YS_REQUIRE(m, "null model");
+  m->training = training != 0;
+  if (!m->training) m->eval_coeffs_dirty = true;
+  return YS_OK;
+}
+
+int ys_model_forward(ys_model* m, const float* images, int on_device, int batch) {
+  YS_REQUIRE(m && images, "ys_model_forward: null argument");
+  YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_forward: batch %d outside (0, %d]", batch, m->maxB);
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const float* src = images;
+  if (!on_device) {
+    YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, images, (size_t)batch * 3 * m->d.height * m->d.width * 4, hipMemcpyHostToDevice, st));
+    src = m->img_dev;
+  }
+  YsTimer timer(m->ctx, "forward");
+  m->B = batch;
+  YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, 3, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
+  YS_TRY(forward_impl(m, batch));
+  m->have_fwd = true; m->have_loss = false;
+  return YS_OK;
+}
+
+int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count) {
+  YS_REQUIRE(m && key && host, "ys_model_get_output: null argument");
+  YS_REQUIRE(m->have_fwd, "ys_model_get_output: no forward has run");
+  hipStream_t st = m->ctx->stream;
+  const int B = m->B;
+  const std::string k(key);
+  if (k == "boxes" || k == "scores") {
+    const bool bx = k == "boxes";
+    const int C = bx ? 4 * m->d.reg_max : m->d.nc;
+    YS_REQUIRE(count == (size_t)B * C * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * C * m->A);
+    const Buf& b = m->bufs[bx ? m->pd_buf : m->ps_buf];
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, b.act, b.ldc, 0, B, C, m->A, m->out_stage));
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
+  } else if (k == "dboxes" || k == "dscores") {
+    const bool bx = k == "dboxes";
+    const int C = bx ? 4 * m->d.reg_max : m->d.nc;
+    YS_REQUIRE(m->have_loss, "ys_model_get_output(%s): no loss has run", key);
+    YS_REQUIRE(count == (size_t)B * C * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * C * m->A);
+    const Buf& b = m->bufs[bx ? m->pd_buf : m->ps_buf];
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, b.grad, b.ldc, 0, B, C, m->A, m->out_stage));
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
+  } else if (k == "pred") {
+    YS_REQUIRE(!m->training, "ys_model_get_output(pred): model is in training mode (Detect returns preds only, Head.cs:103-106)");
+    YS_REQUIRE(count == (size_t)B * (4 + m->d.nc) * m->A, "ys_model_get_output(pred): expected %zu elements", (size_t)B * (4 + m->d.nc) * m->A);
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->pred, count * 4, hipMemcpyDeviceToHost, st));
+  } else {
+    ys_set_error("ys_model_get_output: unknown key '%s'", key);
+    return YS_ERR_INVALID_ARG;
+  }
+  YS_CHECK_HIP(hipStreamSynchronize(st));
+  return YS_OK;
+}
+
+int ys_model_pred_device(ys_model* m, float** dptr) {
+  YS_REQUIRE(m && dptr, "null argument");
+  *dptr = m->pred;
+  return YS_OK;
+}
+
+int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device) {
+  YS_REQUIRE(m, "null model");
+  YS_REQUIRE(m->have_fwd && m->training, "ys_loss_detect: needs a training-mode forward first");
+  YS_REQUIRE(n >= 0 && n <= m->max_labels, "ys_loss_detect: %d labels exceed capacity %d (max_labels per image %d)", n, m->max_labels, m->gcap);
+  YS_REQUIRE(n == 0 || (batch_idx && cls && bboxes), "ys_loss_detect: null label arrays");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const float *bi = batch_idx, *cl = cls, *bb = bboxes;
+  if (!on_device && n > 0) {
+    YS_CHECK_HIP(hipMemcpyAsync(m->lab_bidx, batch_idx, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    YS_CHECK_HIP(hipMemcpyAsync(m->lab_cls, cls, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    YS_CHECK_HIP(hipMemcpyAsync(m->lab_box, bboxes, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    bi = m->lab_bidx; cl = m->lab_cls; bb = m->lab_box;
+  }
+  YsTimer timer(m->ctx, "loss");
+  LossArgs a{};
+  a.pd = m->bufs[m->pd_buf].act; a.ps = m->bufs[m->ps_buf].act; a.dpd = m->bufs[m->pd_buf].grad; a.dps = m->bufs[m->ps_buf].grad;
+  a.ld_pd = m->ld_pd; a.ld_ps = m->ld_ps; a.B = m->B; a.A = m->A; a.nc = m->d.nc; a.reg_max = m->d.reg_max;
+  a.H = m->d.height; a.W = m->d.width; a.nl = m->nl;
+  for (int i = 0; i < 4; i++) { a.lvl_off[i] = m->lvl_off[i]; a.lvl_w[i] = m->lvl_w[i]; a.lvl_h[i] = m->lvl_h[i]; a.lvl_stride[i] = m->lvl_stride[i]; }
+  a.batch_idx = bi; a.cls = cl; a.bboxes = bb; a.n_labels = n; a.gcap = m->gcap;
+  a.gt_count = m->gt_count; a.gt_box = m->gt_box; a.gt_cls = m->gt_cls; a.pbox = m->pbox; a.ov = m->ov; a.align = m->align;
+  a.mpos = m->mpos; a.pos_align = m->pos_align; a.pos_ov = m->pos_ov; a.fg_gt = m->fg_gt; a.tnorm = m->tnorm;
+  a.partial = m->loss_partial; a.scalars = m->scalars;
+  a.hyp_box = 7.5f; a.hyp_cls = 0.5f; a.hyp_dfl = 1.5f; a.topk = 10;   // Loss.cs:344,357
+  YS_TRY(ys_loss_detect_launch(st, m->dtype, a));
+  YS_CHECK_HIP(hipGetLastError());
+  m->have_loss = true;
+  return YS_OK;
+}
+
+int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum) {
+  YS_REQUIRE(m && m->have_loss, "ys_loss_read: no loss has run");
+  float h[8];
+  YS_CHECK_HIP(hipMemcpyAsync(h, m->scalars, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
+  YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+  if (loss_items) { loss_items[0] = h[1]; loss_items[1] = h[2]; loss_items[2] = h[3]; }
+  if (loss_sum) *loss_sum = h[4];
+  return YS_OK;
+}
+
+int ys_model_backward_segments(ys_model* m) { (void)m; return 3; }
+
+int ys_model_backward_segment(ys_model* m, int seg) {
+  YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
+  YS_REQUIRE(seg >= 0 && seg < 3, "ys_model_backward_segment: segment %d out of range", seg);
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  if (seg == 0) reset_grad_state(m);
+  return backward_range(m, seg, seg);
+}
+
+int ys_model_backward(ys_model* m) {
+  YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  YsTimer timer(m->ctx, "backward");
+  reset_grad_state(m);
+  return backward_range(m, 0, 2);
+}
+
+int ys_model_segment_grad_range(ys_model* m, int seg, int64_t* offset, int64_t* count) {
+  YS_REQUIRE(m && offset && count && seg >= 0 && seg < 3, "ys_model_segment_grad_range: bad argument");
+  *offset = m->seg_group[seg][0].off;
+  *count = m->seg_group[seg][0].count + m->seg_group[seg][1].count + m->seg_group[seg][2].count;
+  return YS_OK;
+}
+
+int ys_model_zero_grad(ys_model* m) {
+  YS_REQUIRE(m, "null model");
+  YS_CHECK_HIP(hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, m->ctx->stream));
+  return YS_OK;
+}
+
+int ys_model_grad_buffer(ys_model* m, float** dptr, int64_t* count) {
+  YS_REQUIRE(m && dptr && count, "null argument");
+  *dptr = m->grads; *count = m->n_params;
+  return YS_OK;
+}
+int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count) {
+  YS_REQUIRE(m && dptr && count, "null argument");
+  *dptr = m->params; *count = m->n_params;
+  return YS_OK;
+}
+
+int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, float beta1, float beta2, float eps, float wd) {
+  YS_REQUIRE(m && lr_per_group && ngroups >= 1, "ys_optim_adamw_step: bad argument");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  YsTimer timer(m->ctx, "optim");
+  m->step += 1;
+  const float bc1 = 1.0f - powf(beta1, (float)m->step), bc2 = 1.0f - powf(beta2, (float)m->step);
+  for (int seg = 0; seg < 3; seg++)
+    for (int g = 0; g < 3; g++) {
+      const auto r = m->seg_group[seg][g];
+      const float lr = lr_per_group[g < ngroups ? g : ngroups - 1];
+      YS_TRY(ys_adamw_launch(m->ctx->stream, m->params + r.off, m->grads + r.off, m->adam_m + r.off, m->adam_v + r.off, r.count, lr,
+                             beta1, beta2, eps, wd, bc1, bc2));
+    }
+  m->weights_dirty = true; m->eval_coeffs_dirty = true;
+  YS_CHECK_HIP(hipGetLastError());
+  return YS_OK;
+}
+
+}  // extern "C"

@@ -104,3 +104,72 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;
 }
+
+// Gradients of y = conv2d(x, w, stride, padding=k/2) given dy (autograd of torch.nn.Conv2d, reached from
+// Amp.cs:348,370): dx [B,Cin,H,W] (may be null) and dw [Cout,Cin,k,k], all fp32 NCHW/OIHW host arrays.
+extern "C" int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, int Cin, int H, int W,
+                           const float* w_oihw, int Cout, int k, int stride, const float* dy_nchw,
+                           float* dx_nchw, float* dw_oihw) {
+  YS_REQUIRE(ctx && x_nchw && w_oihw && dy_nchw && dw_oihw, "ys_conv_bwd: null argument");
+  YS_REQUIRE(dtype == YS_F32 || dtype == YS_BF16, "ys_conv_bwd: bad dtype %d", dtype);
+  YS_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "ys_conv_bwd: k=%d stride=%d unsupported", k, stride);
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const size_t es = dtype == YS_BF16 ? 2 : 4;
+  const int cpad = (Cin + epl - 1) / epl * epl, copad = (Cout + epl - 1) / epl * epl;
+  const int pad = k / 2, taps = k * k;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const long M = (long)B * Ho * Wo;
+  std::vector<float> wint((size_t)Cout * taps * Cin);
+  for (int co = 0; co < Cout; co++)
+    for (int ci = 0; ci < Cin; ci++)
+      for (int t = 0; t < taps; t++) wint[((size_t)co * taps + t) * Cin + ci] = w_oihw[((size_t)co * Cin + ci) * taps + t];
+  DevBuf dx, dxn, ddy, ddyn, dwm, dwf, dwd, dgx, dgxo, dgw, dpart;
+  YS_TRY(dx.alloc((size_t)B * Cin * H * W * 4));
+  YS_TRY(dxn.alloc((size_t)B * H * W * cpad * es));
+  YS_TRY(ddy.alloc((size_t)M * Cout * 4));
+  YS_TRY(ddyn.alloc((size_t)M * copad * es));
+  YS_TRY(dwm.alloc(wint.size() * 4));
+  YS_TRY(dwf.alloc((size_t)Cout * taps * cpad * es));
+  YS_TRY(dwd.alloc((size_t)Cin * taps * copad * es));
+  YS_TRY(dgx.alloc((size_t)B * H * W * cpad * es));
+  YS_TRY(dgxo.alloc((size_t)B * Cin * H * W * 4));
+  YS_TRY(dgw.alloc(wint.size() * 4));
+  YS_CHECK_HIP(hipMemsetAsync(dgx.p, 0, (size_t)B * H * W * cpad * es, st));
+  YS_CHECK_HIP(hipMemsetAsync(dgw.p, 0, wint.size() * 4, st));
+  YS_CHECK_HIP(hipMemcpyAsync(dx.p, x_nchw, (size_t)B * Cin * H * W * 4, hipMemcpyHostToDevice, st));
+  YS_CHECK_HIP(hipMemcpyAsync(ddy.p, dy_nchw, (size_t)M * Cout * 4, hipMemcpyHostToDevice, st));
+  YS_CHECK_HIP(hipMemcpyAsync(dwm.p, wint.data(), wint.size() * 4, hipMemcpyHostToDevice, st));
+  YS_TRY(ys_pack_input_launch(st, dtype, (const float*)dx.p, B, Cin, H, W, cpad, dxn.p));
+  YS_TRY(ys_pack_input_launch(st, dtype, (const float*)ddy.p, B, Cout, Ho, Wo, copad, ddyn.p));
+  YS_TRY(ys_weight_prep_launch(st, dtype, (const float*)dwm.p, Cout, taps, Cin, cpad, copad, dwf.p, dwd.p));
+  WgradArgs wa{};
+  wa.x = dxn.p; wa.dy = ddyn.p;
+  wa.B = B; wa.Hin = H; wa.Win = W; wa.Cin = cpad; wa.Hout = Ho; wa.Wout = Wo; wa.Cout = Cout; wa.KH = wa.KW = k;
+  wa.stride = stride; wa.pad = pad; wa.in_ldc = cpad; wa.in_coff = 0; wa.in_bstride = (long)H * W;
+  wa.dy_ldc = copad; wa.dy_coff = 0; wa.dy_bstride = (long)Ho * Wo; wa.M = (int)M;
+  const int splits = ys_wgrad_splits(wa, dtype);
+  YS_TRY(dpart.alloc((size_t)splits * Cout * taps * cpad * 4));
+  wa.partial = (float*)dpart.p;
+  YS_TRY(ys_wgrad_launch(st, dtype, wa, splits, Cin, (float*)dgw.p));
+  std::vector<float> gw(wint.size());
+  YS_CHECK_HIP(hipMemcpyAsync(gw.data(), dgw.p, gw.size() * 4, hipMemcpyDeviceToHost, st));
+  if (dx_nchw) {
+    ConvArgs a{};
+    a.x = ddyn.p; a.w = dwd.p; a.y = dgx.p;
+    a.B = B; a.Hin = Ho; a.Win = Wo; a.Cin = copad; a.Hout = H; a.Wout = W; a.Cout = Cin; a.KH = a.KW = k;
+    a.SA = 1; a.DIVS = stride == 2 ? 1 : 0; a.DIVM = stride - 1; a.PAD = k - 1 - pad;
+    a.in_ldc = copad; a.in_coff = 0; a.in_bstride = (long)Ho * Wo;
+    a.out_ldc = cpad; a.out_coff = 0; a.out_bstride = (long)H * W; a.vec_ok = 1; a.M = B * H * W;
+    YS_TRY(ys_conv_launch(st, dtype, a));
+    YS_TRY(ys_unpack_nchw_launch(st, dtype, dgx.p, cpad, 0, B, Cin, (long)H * W, (float*)dgxo.p));
+    YS_CHECK_HIP(hipMemcpyAsync(dx_nchw, dgxo.p, (size_t)B * Cin * H * W * 4, hipMemcpyDeviceToHost, st));
+  }
+  YS_CHECK_HIP(hipStreamSynchronize(st));
+  for (int co = 0; co < Cout; co++)
+    for (int ci = 0; ci < Cin; ci++)
+      for (int t = 0; t < taps; t++) dw_oihw[((size_t)co * Cin + ci) * taps + t] = gw[((size_t)co * taps + t) * Cin + ci];
+  YS_CHECK_HIP(hipGetLastError());
+  return YS_OK;
+}

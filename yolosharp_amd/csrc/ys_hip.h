@@ -72,6 +72,15 @@ template <> __device__ inline uint4 ys_pack<bf16_t>(const float* f) {
                     ys_pack_bf16x2(f[4], f[5]), ys_pack_bf16x2(f[6], f[7]));
 }
 
+// gather EPL storage elements into one 16-byte fragment (no type punning through memory)
+__device__ inline uint4 ys_pack_elems(const float* e) {
+  return make_uint4(ys_f2u(e[0]), ys_f2u(e[1]), ys_f2u(e[2]), ys_f2u(e[3]));
+}
+__device__ inline uint4 ys_pack_elems(const bf16_t* e) {
+  return make_uint4((unsigned)e[0].v | ((unsigned)e[1].v << 16), (unsigned)e[2].v | ((unsigned)e[3].v << 16),
+                    (unsigned)e[4].v | ((unsigned)e[5].v << 16), (unsigned)e[6].v | ((unsigned)e[7].v << 16));
+}
+
 // ---------------------------------------------------------------- accumulator vector
 #ifdef YS_EMU_BUILD
 struct f32x4 {

@@ -31,6 +31,7 @@ struct WgradArgs {
   int in_ldc, in_coff;
   long in_bstride;
   int dy_ldc, dy_coff;
+  long dy_bstride;  // rows between consecutive images of dy (Hout*Wout when dense)
   int M;
 };
 
@@ -70,8 +71,8 @@ int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc
                            int C, const float* scale, const float* shift, const float* mean, const float* rstd,
                            const float* gamma, const float* c1, const float* c2, int act, void* dy);
 // column sums of a [rows][ldc] view into grad[C] (+=)   (bias gradients)
-int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, int C, float* partial,
-                     float* grad);
+int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
+                     long bstride, int C, float* partial, float* grad);
 int ys_colsum_blocks(long rows, int C, int dtype);
 // 5x5/s1/p2 max-pool on an NHWC view (+ argmax byte per output element for the backward)
 int ys_maxpool5_fwd_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,

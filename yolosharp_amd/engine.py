@@ -1,0 +1,134 @@
+"""Host-side mirror of the reference's operator surface over the C ABI (include/yolosharp_hip.h).
+
+The reference is C# (TorchSharp); there is no dotnet toolchain in the build image, so the host side
+is written in Python with the reference's names and argument meaning:
+
+  Ops.non_max_suppression  <- YoloSharp/Utils/Ops.cs:239-371
+  Convs.Conv.forward       <- YoloSharp/Modules/Convs.cs:36-62
+  Yolov8 / v8DetectionLoss / AMPWrapper.TrainStep  (see model.py)
+
+Everything numeric runs in libyolosharp_hip.so (hand-written HIP, gfx950).  numpy arrays cross the
+boundary as plain fp32 host pointers; torch is not involved in the data path.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """One device context (ys_ctx): owns a HIP stream; not thread-safe (callers serialise)."""
+
+    def __init__(self, device=0, lib_path=None, stream=None):
+        self.lib = _lib.load(lib_path)
+        self.ctx = C.c_void_p()
+        if stream is None:
+            _lib.check(self.lib, self.lib.ys_ctx_create(device, C.byref(self.ctx)))
+        else:
+            _lib.check(self.lib, self.lib.ys_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(self.ctx)))
+        self.device = device
+
+    def close(self):
+        if self.ctx:
+            self.lib.ys_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def is_device_build(self):
+        return bool(self.lib.ys_is_device_build())
+
+    def synchronize(self):
+        _lib.check(self.lib, self.lib.ys_ctx_synchronize(self.ctx))
+
+    def profile(self, enable=True):
+        _lib.check(self.lib, self.lib.ys_ctx_profile_enable(self.ctx, int(enable)))
+
+    def last_ms(self, name):
+        ms = C.c_float()
+        _lib.check(self.lib, self.lib.ys_ctx_last_ms(self.ctx, name.encode(), C.byref(ms)))
+        return ms.value
+
+    # ---- device memory helpers (bench keeps inputs resident in HBM)
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(self.lib, self.lib.ys_device_malloc(self.ctx, nbytes, C.byref(p)))
+        return p
+
+    def free(self, p):
+        _lib.check(self.lib, self.lib.ys_device_free(self.ctx, p))
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        _lib.check(self.lib, self.lib.ys_memcpy_h2d(self.ctx, p, _ptr(arr), arr.nbytes))
+        return p
+
+    def from_device(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        _lib.check(self.lib, self.lib.ys_memcpy_d2h(self.ctx, _ptr(out), p, out.nbytes))
+        return out
+
+    # ---- Ops.non_max_suppression (Ops.cs:239-371)
+    def non_max_suppression(self, prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False, max_det=300, nc=0,
+                            max_time_img=0.05, max_nms=30000, max_wh=7680, in_place=True, rotated=False,
+                            end2end=False):
+        """prediction: float32 ndarray [B, 4+nc+extra, A] (xywh, probabilities).  Returns (output, keepi):
+        lists of [n_i, 6+extra] float32 rows (x1,y1,x2,y2,conf,cls,extra) and [n_i] int64 anchor indices.
+        Like the reference, `prediction[:, 0:4]` is converted to xyxy in place when in_place=True, the
+        `agnostic` flag is accepted but ignored (Ops.cs:345), and invalid thresholds raise (YsError status 1)."""
+        if rotated or end2end:
+            raise NotImplementedError("rotated / end2end NMS are outside the hot path (SURVEY.md 8a)")
+        pred = prediction if in_place else prediction.copy()
+        if pred.dtype != np.float32 or not pred.flags["C_CONTIGUOUS"]:
+            raise TypeError("prediction must be a C-contiguous float32 array [B, C, A]")
+        B, Cc, A = pred.shape
+        ncc = int(nc) if nc else Cc - 4
+        extra = Cc - 4 - ncc
+        rows = np.zeros((B, max_det, 6 + extra), np.float32)
+        keep = np.zeros((B, max_det), np.int64)
+        cnt = np.zeros((B,), np.int32)
+        _lib.check(self.lib, self.lib.ys_nms_batched(self.ctx, _ptr(pred), 0, B, Cc, A, conf_thres, iou_thres, max_det,
+                                                     int(nc), max_nms, max_wh, _ptr(rows), _ptr(keep), _ptr(cnt)))
+        output = [rows[b, :cnt[b]].copy() for b in range(B)]
+        keepi = [keep[b, :cnt[b]].copy() for b in range(B)]
+        return output, keepi
+
+    def nms_device(self, pred_dev, B, Cc, A, conf_thres, iou_thres, max_det, nc, rows_dev, keep_dev, cnt_dev,
+                   max_nms=30000, max_wh=7680):
+        """Device-resident variant (no copies, asynchronous): all pointers are HIP device pointers."""
+        _lib.check(self.lib, self.lib.ys_nms_batched(self.ctx, pred_dev, 1, B, Cc, A, conf_thres, iou_thres, max_det,
+                                                     nc, max_nms, max_wh, rows_dev, keep_dev, cnt_dev))
+
+    # ---- Convs.Conv.forward (Convs.cs:36-62) / plain Conv2d with bias (Head.cs:47-50)
+    def conv_bn_act(self, x, weight, k, s, bn=None, bias=None, act=True, training=True, dtype="f32"):
+        """x [B,Cin,H,W], weight [Cout,Cin,k,k] float32.  bn = dict(weight, bias, running_mean, running_var)
+        (running stats are updated in place when training).  Returns y [B,Cout,Ho,Wo] float32."""
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(weight, np.float32)
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        p = k // 2
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        y = np.empty((B, Cout, Ho, Wo), np.float32)
+        dt = 1 if dtype in ("bf16", 1) else 0
+        g = b = rm = rv = None
+        if bn is not None:
+            g = np.ascontiguousarray(bn["weight"], np.float32)
+            b = np.ascontiguousarray(bn["bias"], np.float32)
+            rm, rv = bn["running_mean"], bn["running_var"]
+            assert rm.dtype == np.float32 and rv.dtype == np.float32
+        bs = np.ascontiguousarray(bias, np.float32) if bias is not None else None
+        _lib.check(self.lib, self.lib.ys_conv_bn_act_fwd(self.ctx, dt, _ptr(x), B, Cin, H, W, _ptr(w), Cout, k, s,
+                                                         _ptr(g), _ptr(b), _ptr(rm), _ptr(rv), _ptr(bs), int(act),
+                                                         int(training), _ptr(y)))
+        return y

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's model / loss / step-executor surface over the C ABI.
+
+  Yolov8            <- YoloSharp/Models/Yolo.cs:10-135  (Module<Tensor,(inference,preds)>; train()/eval();
+                       state_dict names "model.{i}...."; forward(x NCHW fp32))
+  v8DetectionLoss   <- YoloSharp/Utils/Loss.cs:328-484  (forward(preds, batch) -> (loss*B [3], loss_detach [3]))
+  AMPWrapper        <- YoloSharp/Utils/Amp.cs:187-286,338-373 (TrainStep / Step / Evaluate)
+
+All arithmetic happens in libyolosharp_hip.so; these classes only marshal plain fp32 arrays and keep the
+reference's call order (forward -> criterion -> backward -> optimizer.step -> zero_grad).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine, _ptr
+
+SIZES = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
+DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+class Yolov8:
+    def __init__(self, engine: Engine, nc=80, reg_max=16, size="n", height=640, width=640, max_batch=1, dtype="bf16",
+                 max_labels=0):
+        self.engine, self.lib = engine, engine.lib
+        self.nc, self.reg_max, self.height, self.width, self.max_batch = nc, reg_max, height, width, max_batch
+        self.dtype = dtype
+        desc = _lib.ModelDesc(8, SIZES[size], 0, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib, self.lib.ys_model_create(engine.ctx, C.byref(desc), C.byref(self.handle)))
+        self.training = True
+        self.A = self.lib.ys_model_num_anchors(self.handle)
+        self._batch = 0
+        self._info = None
+
+    def close(self):
+        if self.handle:
+            self.lib.ys_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state_dict surface
+    def tensor_info(self):
+        if self._info is None:
+            info = []
+            n = self.lib.ys_model_num_tensors(self.handle)
+            name = C.create_string_buffer(256)
+            nd, isp = C.c_int32(), C.c_int32()
+            shape = (C.c_int64 * 4)()
+            for i in range(n):
+                _lib.check(self.lib, self.lib.ys_model_tensor_info(self.handle, i, name, 256, C.byref(nd), shape, C.byref(isp)))
+                info.append((name.value.decode(), tuple(shape[k] for k in range(nd.value)), bool(isp.value)))
+            self._info = info
+        return self._info
+
+    def named_parameters(self):
+        return [(n, s) for n, s, p in self.tensor_info() if p]
+
+    def num_params(self):
+        return int(self.lib.ys_model_num_params(self.handle))
+
+    def state_dict(self):
+        out = {}
+        for name, shape, _ in self.tensor_info():
+            a = np.empty(shape, np.float32)
+            _lib.check(self.lib, self.lib.ys_model_get_tensor(self.handle, name.encode(), _ptr(a), a.size))
+            out[name] = a
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        for name, shape, _ in self.tensor_info():
+            if name not in sd:
+                if strict:
+                    raise KeyError(name)
+                continue
+            a = np.ascontiguousarray(np.asarray(sd[name], dtype=np.float32).reshape(shape))
+            _lib.check(self.lib, self.lib.ys_model_set_tensor(self.handle, name.encode(), _ptr(a), a.size))
+
+    def grads(self):
+        out = {}
+        for name, shape, is_param in self.tensor_info():
+            if not is_param or name.endswith("dfl.conv.weight"):
+                continue
+            a = np.empty(shape, np.float32)
+            _lib.check(self.lib, self.lib.ys_model_get_grad(self.handle, name.encode(), _ptr(a), a.size))
+            out[name] = a
+        return out
+
+    def init_weights(self, seed=0):
+        _lib.check(self.lib, self.lib.ys_model_init_weights(self.handle, seed))
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        _lib.check(self.lib, self.lib.ys_model_set_training(self.handle, int(self.training)))
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- forward (Yolo.cs:92-134)
+    def forward_device(self, images_dev, batch):
+        """images_dev: device pointer to fp32 NCHW [batch,3,H,W] (already resident in HBM). Asynchronous."""
+        _lib.check(self.lib, self.lib.ys_model_forward(self.handle, images_dev, 1, batch))
+        self._batch = batch
+
+    def forward(self, x, fetch=True):
+        """x: float32 ndarray [B,3,H,W].  Returns (inference, preds) like the reference: training -> (None, preds);
+        eval -> ({"boxes": [B,4+nc,A]}, preds) with preds = {"boxes": [B,4*reg_max,A], "scores": [B,nc,A]}."""
+        x = np.ascontiguousarray(x, np.float32)
+        B = x.shape[0]
+        assert x.shape == (B, 3, self.height, self.width), x.shape
+        _lib.check(self.lib, self.lib.ys_model_forward(self.handle, _ptr(x), 0, B))
+        self._batch = B
+        if not fetch:
+            return None, None
+        preds = {"boxes": self.get_output("boxes"), "scores": self.get_output("scores")}
+        if self.training:
+            return None, preds
+        return {"boxes": self.get_output("pred")}, preds
+
+    __call__ = forward
+
+    def get_output(self, key):
+        B = self._batch
+        C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc, "dboxes": 4 * self.reg_max, "dscores": self.nc}[key]
+        a = np.empty((B, C_, self.A), np.float32)
+        _lib.check(self.lib, self.lib.ys_model_get_output(self.handle, key.encode(), _ptr(a), a.size))
+        return a
+
+    def pred_device(self):
+        p = C.c_void_p()
+        _lib.check(self.lib, self.lib.ys_model_pred_device(self.handle, C.byref(p)))
+        return p
+
+    # ---- backward / optimizer (Amp.cs:338-373)
+    def backward(self):
+        _lib.check(self.lib, self.lib.ys_model_backward(self.handle))
+
+    def backward_segment(self, seg):
+        _lib.check(self.lib, self.lib.ys_model_backward_segment(self.handle, seg))
+
+    def num_segments(self):
+        return self.lib.ys_model_backward_segments(self.handle)
+
+    def segment_grad_range(self, seg):
+        o, c = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.ys_model_segment_grad_range(self.handle, seg, C.byref(o), C.byref(c)))
+        return o.value, c.value
+
+    def zero_grad(self):
+        _lib.check(self.lib, self.lib.ys_model_zero_grad(self.handle))
+
+    def grad_buffer(self):
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib, self.lib.ys_model_grad_buffer(self.handle, C.byref(p), C.byref(n)))
+        return p, n.value
+
+    def param_buffer(self):
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib, self.lib.ys_model_param_buffer(self.handle, C.byref(p), C.byref(n)))
+        return p, n.value
+
+    def adamw_step(self, lrs, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4):
+        arr = (C.c_float * len(lrs))(*lrs)
+        _lib.check(self.lib, self.lib.ys_optim_adamw_step(self.handle, arr, len(lrs), beta1, beta2, eps, weight_decay))
+
+
+class v8DetectionLoss:
+    """Loss.cs:328-484.  forward(preds, batch): `preds` is implicit (the model's last training forward stays on the
+    device); batch = {"batch_idx": [N], "cls": [N], "bboxes": [N,4] normalised cxcywh} (YoloDataLoader.cs:18-44)."""
+
+    def __init__(self, model: Yolov8):
+        self.model, self.lib = model, model.lib
+
+    def forward_device(self, bidx_dev, cls_dev, box_dev, n):
+        _lib.check(self.lib, self.lib.ys_loss_detect(self.model.handle, bidx_dev, cls_dev, box_dev, n, 1))
+
+    def forward(self, preds, batch, read=True):
+        bi = np.ascontiguousarray(np.asarray(batch["batch_idx"], np.float32).reshape(-1))
+        cl = np.ascontiguousarray(np.asarray(batch["cls"], np.float32).reshape(-1))
+        bb = np.ascontiguousarray(np.asarray(batch["bboxes"], np.float32).reshape(-1, 4))
+        n = bi.shape[0]
+        _lib.check(self.lib, self.lib.ys_loss_detect(self.model.handle, _ptr(bi), _ptr(cl), _ptr(bb), n, 0))
+        return self.read() if read else None
+
+    __call__ = forward
+
+    def read(self):
+        items = (C.c_float * 3)()
+        total = C.c_float()
+        _lib.check(self.lib, self.lib.ys_loss_read(self.model.handle, items, C.byref(total)))
+        loss_detach = np.array(list(items), np.float32)
+        return loss_detach * self.model._batch, loss_detach      # (loss * batch_size, loss.detach()), Loss.cs:476
+
+
+class AMPWrapper:
+    """Amp.cs:187-286: TrainStep = forward + criterion + Step (backward, optimizer.step, zero_grad).  The reference's
+    half-precision branch never updates weights (SURVEY.md 5 'AMP quirk'); here bf16 keeps fp32 master weights inside
+    the engine and the update is applied in every dtype."""
+
+    def __init__(self, model: Yolov8, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4):
+        self.model = model
+        lr0 = round(0.002 * 5 / (4 + model.nc), 6) if lr is None else lr     # YoloBaseTaskModel.cs:142
+        self.lrs = [lr0, lr0, lr0]                                            # ParamGroups[i].LearningRate
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+
+    def TrainStep(self, images, batch, loss_func: v8DetectionLoss):
+        self.model.train()
+        self.model.forward(images, fetch=False)
+        loss, items = loss_func.forward(None, batch)
+        self.Step()
+        return loss, items
+
+    def Step(self):
+        self.model.backward()
+        self.model.adamw_step(self.lrs, self.betas[0], self.betas[1], self.eps, self.wd)
+        self.model.zero_grad()
+
+    def Evaluate(self, images):
+        self.model.eval()
+        return self.model.forward(images)
