@@ -1,0 +1,54 @@
+"""Test configuration.
+
+Backends:
+  "emu" -- the kernel sources compiled by g++ against tools/hipemu (a TEST-ONLY SIMT interpreter).  Lets the
+           `-m "not gpu"` suite execute every kernel against the oracle in the GPU-less dev container.
+  "gpu" -- the product library yolosharp_amd/libyolosharp_hip.so on a real MI355X (marked @pytest.mark.gpu).
+Only tests/ (and smoke()/bench.py's cpu_baseline leg) may touch oracle/.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+BACKENDS = ["emu", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(scope="session")
+def emu_lib_path():
+    from yolosharp_amd import build
+    return build.build_emu()
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import ctypes
+    from yolosharp_amd import build
+    return ctypes.CDLL(build.build_oracle())
+
+
+_engines = {}
+
+
+@pytest.fixture
+def engine(request, emu_lib_path):
+    """Engine for the backend named by the test's `backend` parameter."""
+    backend = request.getfixturevalue("backend")
+    if backend not in _engines:
+        from yolosharp_amd import Engine
+        if backend == "emu":
+            _engines[backend] = Engine(lib_path=emu_lib_path)
+        else:
+            eng = Engine()  # product library; raises loudly if missing or no HIP device
+            assert eng.is_device_build, "GPU tests must run the hipcc-built library"
+            _engines[backend] = eng
+    return _engines[backend]

@@ -1,0 +1,97 @@
+"""Conv unit parity (Convs.cs:36-62, Head.cs:47-50 plain Conv2d) against plain PyTorch fp32 ops, forward and backward."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import BACKENDS
+
+FWD_CASES = [
+    # B, Cin, H, W, Cout, k, s, bn, bias, act, train
+    (2, 16, 12, 12, 32, 3, 1, True, False, True, True),
+    (2, 3, 16, 16, 16, 3, 2, True, False, True, True),      # stem: Cin=3 padded to the fragment width
+    (1, 48, 8, 8, 24, 1, 1, True, False, True, True),       # C2f cv2 of v8m-like widths (Cout not a multiple of 16)
+    (2, 80, 6, 6, 80, 3, 1, True, False, True, False),      # eval: BN folded into the conv epilogue
+    (2, 64, 5, 5, 80, 1, 1, False, True, False, True),      # Detect cv3[i][2]: plain conv + bias
+    (1, 16, 9, 11, 16, 3, 2, True, False, True, True),      # odd spatial size, stride 2
+    (1, 256, 4, 4, 128, 1, 1, True, False, False, True),    # SPPF.cv1: no activation (Block.cs:257)
+    (1, 272, 4, 4, 16, 1, 1, True, False, True, True),      # K tail: Cin not a multiple of the k-step
+    (2, 64, 5, 5, 7, 1, 1, False, True, False, True),       # nc not a multiple of 4 (masked stores)
+]
+
+
+def ref_forward(x, w, k, s, bn, bias, act, train, dtype):
+    if dtype == "bf16":
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    y = F.conv2d(x, w, bias, stride=s, padding=k // 2)
+    if bn is not None:
+        if dtype == "bf16":
+            y = y.bfloat16().float()
+        y = F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], training=train, momentum=0.03, eps=1e-3)
+    if act:
+        y = F.silu(y)
+    return y
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", range(len(FWD_CASES)))
+def test_conv_bn_act_forward(backend, engine, dtype, case):
+    B, Cin, H, W, Cout, k, s, has_bn, has_bias, act, train = FWD_CASES[case]
+    g = torch.Generator().manual_seed(case)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.2
+    bn = None
+    if has_bn:
+        bn = {"weight": torch.rand(Cout, generator=g) + 0.5, "bias": torch.randn(Cout, generator=g) * 0.1,
+              "running_mean": torch.randn(Cout, generator=g) * 0.1, "running_var": torch.rand(Cout, generator=g) + 0.5}
+    bias = torch.randn(Cout, generator=g) if has_bias else None
+    bn_np = {kk: v.numpy().copy() for kk, v in bn.items()} if bn else None
+    ref = ref_forward(x, w, k, s, {kk: v.clone() for kk, v in bn.items()} if bn else None, bias, act, train, dtype)
+    bn_ref = {kk: v.clone() for kk, v in bn.items()} if bn else None
+    if bn and train:
+        ref_forward(x, w, k, s, bn_ref, bias, act, train, dtype)     # updates running stats in place
+    y = engine.conv_bn_act(x.numpy(), w.numpy(), k, s, bn=bn_np, bias=None if bias is None else bias.numpy(), act=act,
+                           training=train, dtype=dtype)
+    ref = ref.numpy()
+    scale = np.abs(ref).max()
+    # f32: north-star tolerance 1e-3 (measured ~1e-6); bf16: output rounding 2^-8 relative + bf16 products
+    tol = 1e-3 if dtype == "f32" else 2e-2
+    assert np.abs(y - ref).max() <= tol * max(scale, 1.0), (np.abs(y - ref).max(), scale)
+    if bn and train:
+        rtol = 1e-4 if dtype == "f32" else 2e-2
+        assert np.allclose(bn_np["running_mean"], bn_ref["running_mean"].numpy(), rtol=rtol, atol=rtol)
+        assert np.allclose(bn_np["running_var"], bn_ref["running_var"].numpy(), rtol=rtol, atol=rtol)
+
+
+BWD_CASES = [(2, 16, 8, 8, 32, 3, 1), (2, 16, 8, 8, 16, 1, 1), (1, 32, 9, 7, 80, 3, 2), (2, 3, 8, 8, 16, 3, 2),
+             (2, 64, 6, 6, 80, 3, 2), (2, 80, 4, 4, 80, 1, 1), (1, 96, 6, 6, 64, 1, 1)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", range(len(BWD_CASES)))
+def test_conv_backward(backend, engine, dtype, case):
+    """dgrad (gather form, stride-2 included) and wgrad (deterministic split-K) vs torch autograd."""
+    import ctypes as C
+    B, Cin, H, W, Cout, k, s = BWD_CASES[case]
+    g = torch.Generator().manual_seed(10 + case)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.2
+    if dtype == "bf16":
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    if dtype == "bf16":
+        dy = dy.bfloat16().float()
+    y.backward(dy)
+    dx = np.zeros(x.shape, np.float32); dw = np.zeros(w.shape, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    xn, wn, dyn = x.detach().numpy().copy(), w.detach().numpy().copy(), dy.numpy().copy()
+    from yolosharp_amd import _lib
+    _lib.check(engine.lib, engine.lib.ys_conv_bwd(engine.ctx, 1 if dtype == "bf16" else 0, vp(xn), B, Cin, H, W, vp(wn), Cout, k, s,
+                                                 vp(dyn), vp(dx), vp(dw)))
+    tol = 1e-4 if dtype == "f32" else 1e-2   # bf16: dx is rounded to bf16 on store; dw stays fp32
+    assert np.abs(dx - x.grad.numpy()).max() <= tol * np.abs(x.grad.numpy()).max()
+    assert np.abs(dw - w.grad.numpy()).max() <= 1e-4 * np.abs(w.grad.numpy()).max()
