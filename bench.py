@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: train images/s of YOLOv8n, 640x640, batch 64 per GPU, bf16, synthetic COCO-80.
+
+A "step" is one pass of the hot path over one batch already resident in HBM:
+  Yolov8.forward (train) -> v8DetectionLoss (TAL + CIoU + DFL + BCE, on device) -> backward -> [grad all-reduce] -> AdamW -> zero_grad
+Nothing is skipped inside the timed region.  N > 1: one process per GPU (torch.distributed.run), batch sharded by image
+(weak scaling: 64 images per GPU), SUM all-reduce of gradients over RCCL overlapped with the backward segments.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), extended with
+  roofline     -- dominant kernel class (conv_igemm: forward + dgrad implicit-GEMM launches), HBM-bound:
+                  algorithmic bytes of those launches / their HIP-event durations (measured on the engine's stream in
+                  extra untimed steps after the timed region), peak 8000 GB/s
+  cpu_baseline -- the oracle (ATen-CPU restatement of the reference, NOT TorchSharp) timed on this host's cores on a
+                  bounded sample (B=8 train step), rank 0 / N=1 only
+  nms          -- secondary metric: NMS boxes/s on [64, 84, 8400] (candidates entering greedy NMS per second)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synth_labels(B, nc, seed=1, kmax=16):
+    rng = np.random.default_rng(seed)
+    bi, cl, bb = [], [], []
+    for b in range(B):
+        k = int(rng.integers(1, kmax + 1))
+        wh = rng.uniform(0.03, 0.6, (k, 2))
+        c = wh / 2 + rng.uniform(0, 1, (k, 2)) * (1 - wh)
+        bi.append(np.full(k, b, np.float32)); cl.append(rng.integers(0, nc, k).astype(np.float32))
+        bb.append(np.concatenate([c, wh], 1).astype(np.float32))
+    return np.concatenate(bi), np.concatenate(cl), np.concatenate(bb)
+
+
+def cpu_baseline(nc, H, W, sample_b=8):
+    """Oracle (port) train step on the host cores: forward + loss + backward + AdamW, fp32."""
+    import torch
+    from oracle import yolo_oracle as O
+    torch.manual_seed(0)
+    ref = O.Yolov8(nc=nc, size="n").train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=5e-4)
+    crit = O.v8DetectionLoss(nc)
+    x = torch.rand(sample_b, 3, H, W)
+    batch = O.synthetic_batch(sample_b, H, W, nc, seed=1)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        _, preds = ref(x)
+        loss, _ = crit(preds, batch)
+        opt.zero_grad(); loss.sum().backward(); opt.step()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": round(sample_b / t, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/yolo_oracle.py (ATen-CPU restatement, not TorchSharp) YOLOv8n fp32 train step, B={sample_b} {H}x{W}, best of 2 after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", default="n")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nms", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from yolosharp_amd import Engine
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    from yolosharp_amd import dist as ysd
+    from yolosharp_amd.workload import step_work
+
+    nc, H, W, B = 80, 640, 640, args.batch
+    stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
+    eng = Engine(local_rank, stream=stream)          # N>1: run on torch's stream so RCCL orders against our kernels
+    model = Yolov8(eng, nc=nc, size=args.size, height=H, width=W, max_batch=B, dtype=args.dtype)
+    model.init_weights(2)
+    model.train()
+    crit = v8DetectionLoss(model)
+    rng = np.random.default_rng(0 + rank)
+    images = rng.random((B, 3, H, W), dtype=np.float32)
+    bi, cl, bb = synth_labels(B, nc, seed=1 + rank)
+    d_img = eng.to_device(images)
+    d_lab = (eng.to_device(bi), eng.to_device(cl), eng.to_device(bb), len(bi))
+    lr0 = round(0.002 * 5 / (4 + nc), 6)
+    lrs = [lr0, lr0, lr0]
+    gptr, gn = model.grad_buffer()
+    sync = None
+    if distributed:
+        flat = ysd.device_view(gptr.value, gn, dev)
+        sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())])
+
+    def step():
+        if sync is not None:
+            ysd.train_step_dp(model, crit, sync, d_img, B, d_lab, lrs)
+        else:
+            model.forward_device(d_img, B)
+            crit.forward_device(*d_lab)
+            model.backward()
+            model.adamw_step(lrs)
+            model.zero_grad()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        eng.synchronize()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    items, total = crit.read()[1], None
+    ms = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        es = 2 if args.dtype == "bf16" else 4
+        wk = step_work(args.size, nc, H, W, es)
+        # ---- dominant kernel class, HIP events on the engine stream, untimed extra steps
+        eng.kernel_profile(True)
+        for _ in range(2):
+            step()
+        eng.synchronize()
+        n_ig, ms_ig = eng.kernel_profile_read("conv_igemm")
+        n_wg, ms_wg = eng.kernel_profile_read("conv_wgrad")
+        eng.kernel_profile(False)
+        steps_prof = 2
+        bytes_per_launch = wk["igemm_bytes"] * B / wk["igemm_launches"]
+        avg_ms = ms_ig / max(n_ig, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "conv_igemm_kernel (forward + dgrad launches)", "achieved": round(achieved, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "launches_per_step": n_ig // steps_prof, "avg_launch_ms": round(avg_ms, 5),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "class_ms_per_step": {"conv_igemm": round(ms_ig / steps_prof, 3), "conv_wgrad": round(ms_wg / steps_prof, 3)},
+                    "step_algorithmic_GBps": round(wk["train_bytes"] * B / (ms * 1e-3) / 1e9, 1),
+                    "step_TFLOPs": round(wk["train_flop"] * B / (ms * 1e-3) / 1e12, 2)}
+        out = {"metric": "train images/sec YOLOv8n 640x640 bs=64/GPU", "value": round(value, 2), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"YOLOv8{args.size} detect train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, COCO-80 synthetic labels",
+                          "global_batch": B * world, "parallelism": f"dp{world}"},
+               "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
+        # ---- secondary metric: NMS boxes/s on [64, 84, 8400]
+        if not args.no_nms:
+            prng = np.random.default_rng(3)
+            A = 8400
+            wh = prng.uniform(0.03, 0.6, (64, 2, A)) * 640; c = prng.uniform(0, 640, (64, 2, A))
+            sc = 1 / (1 + np.exp(-prng.normal(-3, 1.5, (64, nc, A))))
+            sc[:, :, prng.random(A) < 0.92] *= 0.05                      # ~8 % of anchors pass conf 0.25
+            pred = np.concatenate([c, wh, sc], 1).astype(np.float32)
+            ncand = int(((pred[:, 4:].max(1)) > 0.25).sum())
+            d_pred = eng.malloc(pred.nbytes)
+            d_rows = eng.malloc(64 * 300 * 6 * 4); d_keep = eng.malloc(64 * 300 * 8); d_cnt = eng.malloc(64 * 4)
+            import ctypes as C
+            times = []
+            for it in range(6):
+                # restore the xywh input (NMS converts boxes in place), untimed
+                eng.lib.ys_memcpy_h2d(eng.ctx, d_pred, pred.ctypes.data_as(C.c_void_p), pred.nbytes)
+                eng.synchronize()
+                t1 = time.perf_counter()
+                eng.nms_device(d_pred, 64, 84, A, 0.25, 0.45, 300, 0, d_rows, d_keep, d_cnt)
+                eng.synchronize()
+                times.append(time.perf_counter() - t1)
+            tn = float(np.median(times[1:]))
+            out["nms"] = {"boxes_per_s": round(ncand / tn, 1), "candidates": ncand, "ms": round(tn * 1e3, 3),
+                          "shape": [64, 84, A], "conf": 0.25, "iou": 0.45}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nc, H, W)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

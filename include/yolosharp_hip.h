@@ -163,6 +163,11 @@ YS_API int ys_memcpy_d2h(ys_ctx* ctx, void* dst, const void* src, size_t bytes);
 YS_API int ys_ctx_profile_enable(ys_ctx* ctx, int enable);
 YS_API int ys_ctx_last_ms(ys_ctx* ctx, const char* name, float* ms);
 
+/* per-kernel-class timing (HIP events on this ctx's stream around every launch of a class, e.g. "conv_igemm",
+ * "conv_wgrad", "bn_act", "nms"); enable for a few UNTIMED steps, then read the launch count and summed duration. */
+YS_API int ys_ctx_kernel_profile(ys_ctx* ctx, int enable);
+YS_API int ys_ctx_kernel_profile_read(ys_ctx* ctx, const char* name, int32_t* launches, float* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,8 @@ PROTOTYPES = {
     "ys_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ys_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ys_ctx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_ctx_kernel_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_ctx_kernel_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, c_i32_p, c_float_p]),
     "ys_ctx_last_ms": (C.c_int, [C.c_void_p, C.c_char_p, c_float_p]),
 }
 

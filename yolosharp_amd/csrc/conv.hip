@@ -219,6 +219,7 @@ conv_igemm_kernel(ConvArgs a) {
 template <class T, int MR, int NR>
 static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
   dim3 grid(ys_cdiv(a.M, 4 * MR * 16), ys_cdiv(a.Cout, NR * 16));
+  YsKprofScope prof(st, "conv_igemm");
   YS_LAUNCH((conv_igemm_kernel<T, MR, NR>), grid, 256, st, a);
 }
 
@@ -392,6 +393,7 @@ template <class T, int MRA, int NRB>
 static void wgrad_launch_t(hipStream_t st, const WgradArgs& a, int splits) {
   const int co_tiles = ys_cdiv(a.Cout, MRA * 16), ci_tiles = ys_cdiv(a.Cin, NRB * 16);
   dim3 grid(splits, co_tiles * ci_tiles, a.KH * a.KW);
+  YsKprofScope prof(st, "conv_wgrad");
   YS_LAUNCH((conv_wgrad_kernel<T, MRA, NRB>), grid, 256, st, a);
 }
 

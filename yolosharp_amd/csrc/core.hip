@@ -11,7 +11,56 @@ void ys_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+namespace {
+struct KprofEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; hipEvent_t open = nullptr; };
+bool g_kprof_on = false;
+std::map<std::string, KprofEntry> g_kprof;
+}  // namespace
+
+void ys_kprof_begin(hipStream_t st, const char* name) {
+  if (!g_kprof_on) return;
+  KprofEntry& e = g_kprof[name];
+  hipEvent_t a = nullptr;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  hipEventRecord(a, st);
+  e.open = a;
+}
+void ys_kprof_end(hipStream_t st, const char* name) {
+  if (!g_kprof_on) return;
+  KprofEntry& e = g_kprof[name];
+  if (!e.open) return;
+  hipEvent_t b = nullptr;
+  if (hipEventCreate(&b) != hipSuccess) return;
+  hipEventRecord(b, st);
+  e.ev.push_back({e.open, b});
+  e.open = nullptr;
+}
+
 extern "C" {
+
+int ys_ctx_kernel_profile(ys_ctx* ctx, int enable) {
+  YS_REQUIRE(ctx, "null ctx");
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (enable) {
+    for (auto& kv : g_kprof) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    g_kprof.clear();
+  }
+  g_kprof_on = enable != 0;
+  return YS_OK;
+}
+
+int ys_ctx_kernel_profile_read(ys_ctx* ctx, const char* name, int32_t* launches, float* total_ms) {
+  YS_REQUIRE(ctx && name && launches && total_ms, "ys_ctx_kernel_profile_read: null argument");
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  *launches = 0; *total_ms = 0.f;
+  auto it = g_kprof.find(name);
+  if (it == g_kprof.end()) return YS_OK;
+  for (auto& p : it->second.ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { *total_ms += ms; *launches += 1; }
+  }
+  return YS_OK;
+}
 
 const char* ys_last_error(void) { return g_err; }
 int ys_version(void) { return 100; }

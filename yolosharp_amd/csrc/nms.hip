@@ -197,6 +197,7 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   char* ws = (char*)ctx->nms_ws;
   int* count = (int*)(ws + o_count);
   YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));
+  YsKprofScope prof(ctx->stream, "nms");
   dim3 g1(ys_cdiv(A, 256), B);
   YS_LAUNCH(nms_filter_kernel, g1, 256, ctx->stream, pred, C, A, nc, conf, count,
             (unsigned long long*)(ws + o_keys), np2, (float*)(ws + o_conf), (int*)(ws + o_cls));

@@ -63,6 +63,16 @@ struct YsTimer {
   }
 };
 
+// ---- per-kernel-class timing with HIP events on the launch stream (off by default; bench.py enables it
+//      for a few untimed steps to measure the dominant kernel's average launch duration)
+void ys_kprof_begin(hipStream_t st, const char* name);
+void ys_kprof_end(hipStream_t st, const char* name);
+struct YsKprofScope {
+  hipStream_t st; const char* name;
+  YsKprofScope(hipStream_t s, const char* n) : st(s), name(n) { ys_kprof_begin(st, name); }
+  ~YsKprofScope() { ys_kprof_end(st, name); }
+};
+
 // ---- kernels' host launchers (defined in the .hip files) ----
 int ys_nms_launch(ys_ctx* ctx, float* pred_dev, int B, int C, int A, float conf, float iou, int max_det,
                   int nc, int max_nms, int max_wh, float* out_rows, int64_t* out_keep, int32_t* out_count);

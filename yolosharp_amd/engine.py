@@ -58,6 +58,14 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_ctx_last_ms(self.ctx, name.encode(), C.byref(ms)))
         return ms.value
 
+    def kernel_profile(self, enable=True):
+        _lib.check(self.lib, self.lib.ys_ctx_kernel_profile(self.ctx, int(enable)))
+
+    def kernel_profile_read(self, name):
+        n, ms = C.c_int32(), C.c_float()
+        _lib.check(self.lib, self.lib.ys_ctx_kernel_profile_read(self.ctx, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     # ---- device memory helpers (bench keeps inputs resident in HBM)
     def malloc(self, nbytes):
         p = C.c_void_p()
