@@ -26,8 +26,10 @@ __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvArgs a) {
   constexpr int EPL = Elem<T>::EPL;
   constexpr int BN = NR * 16;
-  constexpr int CK = 32 * EPL;  // channels per LDS weight chunk (32 x 16-byte units per row)
-  __shared__ uint4 sW[BN][33];
+  constexpr int LDS_UNITS = 3072;                       // 48 KiB of staged weights (3 workgroups per CU)
+  constexpr int PITCH = ((LDS_UNITS / BN) - 1) | 1;     // odd row pitch in 16-byte units (bank spread)
+  constexpr int GSTEPS = PITCH / 4;                     // k-steps whose weights fit in LDS at once
+  __shared__ uint4 sW[BN * PITCH];
   __shared__ float sStat[4][BN][2];
 
   const int tid = threadIdx.x;
@@ -40,7 +42,11 @@ conv_igemm_kernel(ConvArgs a) {
   const int HWo = a.Hout * a.Wout;
   const char* xb = (const char*)a.x;
   const char* wb = (const char*)a.w;
-  const int Ktot = a.KH * a.KW * a.Cin;
+  const int taps = a.KH * a.KW;
+  const int Ktot = taps * a.Cin;
+  const int cu = a.Cin / EPL;        // 16-byte units per tap
+  const int spt = (cu + 3) >> 2;     // k-steps per tap (4 units each, tail predicated off)
+  const int total = taps * spt;
 
   // per m-fragment pixel coordinates of this lane's column (pixel j = li)
   int pb[MR], poh[MR], pow_[MR];
@@ -63,54 +69,73 @@ conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
 
-  for (int kh = 0; kh < a.KH; kh++) {
-    for (int kw = 0; kw < a.KW; kw++) {
-      const int tap = kh * a.KW + kw;
-      // gather base pointer of each m-fragment's pixel for this tap
-      const char* px[MR];
-      bool pvt[MR];
+  // ---- activation stream: software-pipelined one k-step ahead (HBM/L2 -> VGPR fragments)
+  const char* px[MR];
+  bool pvt[MR];
+  auto set_tap = [&](int kh, int kw) {
 #pragma unroll
-      for (int mf = 0; mf < MR; mf++) {
-        const int ihn = poh[mf] * a.SA + kh - a.PAD;
-        const int iwn = pow_[mf] * a.SA + kw - a.PAD;
-        const int ih = ihn >> a.DIVS, iw = iwn >> a.DIVS;
-        const bool ok = pv[mf] && ihn >= 0 && iwn >= 0 && ((ihn | iwn) & a.DIVM) == 0 && ih < a.Hin && iw < a.Win;
-        pvt[mf] = ok;
-        const long pix = ok ? ((long)pb[mf] * a.in_bstride + (long)ih * a.Win + iw) : 0;
-        px[mf] = xb + (pix * a.in_ldc + a.in_coff) * (long)sizeof(T);
-      }
-      for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        __syncthreads();
-        // stage W[n0..n0+BN)[tap][c0..c0+CK) into LDS, zero-filled outside [Cout) x [Cin)
-        for (int idx = tid; idx < BN * 32; idx += 256) {
-          const int n = idx >> 5, u = idx & 31;
-          const int c = c0 + u * EPL;
-          uint4 v = ys_zero16();
-          if (n0 + n < a.Cout && c < a.Cin)
-            v = ys_ld16(wb + ((long)(n0 + n) * Ktot + (long)tap * a.Cin + c) * (long)sizeof(T));
-          sW[n][u] = v;
-        }
-        __syncthreads();
-        const int cend = (a.Cin - c0) < CK ? (a.Cin - c0) : CK;
-        const int nsteps = (cend + 4 * EPL - 1) / (4 * EPL);
-        for (int s = 0; s < nsteps; s++) {
-          const int u = 4 * s + q;
-          const int c = c0 + u * EPL;
-          uint4 xf[MR];
-#pragma unroll
-          for (int mf = 0; mf < MR; mf++) {
-            xf[mf] = ys_zero16();
-            if (pvt[mf] && c < a.Cin) xf[mf] = ys_ld16(px[mf] + (long)c * (long)sizeof(T));
-          }
-#pragma unroll
-          for (int nf = 0; nf < NR; nf++) {
-            const uint4 wf = sW[nf * 16 + li][u];
-#pragma unroll
-            for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf, xf[mf], acc[mf][nf]);
-          }
-        }
-      }
+    for (int mf = 0; mf < MR; mf++) {
+      const int ihn = poh[mf] * a.SA + kh - a.PAD;
+      const int iwn = pow_[mf] * a.SA + kw - a.PAD;
+      const int ih = ihn >> a.DIVS, iw = iwn >> a.DIVS;
+      const bool ok = pv[mf] && ihn >= 0 && iwn >= 0 && ((ihn | iwn) & a.DIVM) == 0 && ih < a.Hin && iw < a.Win;
+      pvt[mf] = ok;
+      const long pix = ok ? ((long)pb[mf] * a.in_bstride + (long)ih * a.Win + iw) : 0;
+      px[mf] = xb + (pix * a.in_ldc + a.in_coff) * (long)sizeof(T);
     }
+  };
+  auto load_step = [&](uint4* xf, int s) {
+    const int c = (4 * s + q) * EPL;
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) {
+      xf[mf] = ys_zero16();
+      if (pvt[mf] && c < a.Cin) xf[mf] = ys_ld16(px[mf] + (long)c * (long)sizeof(T));
+    }
+  };
+  uint4 xc[MR], xn[MR];
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++) xn[mf] = ys_zero16();
+  int ltap = 0, ls = 0, lkh = 0, lkw = 0;   // position of the NEXT load
+  set_tap(0, 0);
+  load_step(xc, 0);
+  int lt = 0;                                // k-step index inside the staged weight group
+  for (int t = 0; t < total; t++) {
+    // advance the load position and prefetch step t+1
+    ls++;
+    if (ls == spt) {
+      ls = 0; ltap++; lkw++;
+      if (lkw == a.KW) { lkw = 0; lkh++; }
+      if (ltap < taps) set_tap(lkh, lkw);
+    }
+    if (t + 1 < total) load_step(xn, ls);
+    if (lt == 0) {
+      // stage the weights of k-steps [t, t+GSTEPS) for this workgroup's BN output channels
+      __syncthreads();
+      const int gs = (total - t) < GSTEPS ? (total - t) : GSTEPS;
+      const int gu = gs * 4;
+      for (int idx = tid; idx < BN * gu; idx += 256) {
+        const int n = idx / gu, lu = idx - n * gu;
+        const int tt = t + (lu >> 2);
+        const int tp = tt / spt;
+        const int c = (((tt - tp * spt) << 2) + (lu & 3)) * EPL;
+        uint4 v = ys_zero16();
+        if (n0 + n < a.Cout && c < a.Cin)
+          v = ys_ld16(wb + ((long)(n0 + n) * Ktot + (long)tp * a.Cin + c) * (long)sizeof(T));
+        sW[n * PITCH + lu] = v;
+      }
+      __syncthreads();
+    }
+    const int u = 4 * lt + q;
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++) {
+      const uint4 wf = sW[(nf * 16 + li) * PITCH + u];
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf, xc[mf], acc[mf][nf]);
+    }
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) xc[mf] = xn[mf];
+    lt++;
+    if (lt == GSTEPS) lt = 0;
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -300,29 +325,37 @@ conv_wgrad_kernel(WgradArgs a) {
   constexpr int DV = COT / EPL;  // 16-byte vectors per pixel row of the dy tile
   constexpr int XV = CIT / EPL;
 
-  for (long it = 0; it < iters; it++) {
+  // Each wave stages and consumes its own LDS region: no workgroup barrier inside the loop, so the 4 waves (and the
+  // other resident workgroups) drift apart and overlap each other's load / transpose / MFMA phases.  The global loads
+  // of wave-step it+1 are issued into registers before the MFMAs of wave-step it.
+  constexpr int ND = (KS * DV + 63) / 64, NX = (KS * XV + 63) / 64;
+  uint4 rd[ND], rx[NX];
+  auto fetch = [&](long it) {
     const long step = sb + it * 4 + wave;
     const bool active = step < se;
     const long p0 = step * KS;
-    // ---- stage dy tile [KS][COT] and gathered x tile [KS][CIT]
-    for (int v = lane; v < KS * DV; v += 64) {
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const int v = lane + 64 * k;
       const int pr = v / DV, cv = v % DV;
       const long p = p0 + pr;
       const int c = co0 + cv * EPL;
       uint4 val = ys_zero16();
-      if (active && p < a.M && c < a.Cout) {
+      if (v < KS * DV && active && p < a.M && c < a.Cout) {
         const long bb = p / HWo;
         const long drow = bb * a.dy_bstride + (p - bb * HWo);
         val = ys_ld16(dyb + ((drow * a.dy_ldc) + a.dy_coff + c) * (long)sizeof(T));
       }
-      *(uint4*)(myD + pr * PD + cv * EPL) = val;
+      rd[k] = val;
     }
-    for (int v = lane; v < KS * XV; v += 64) {
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int v = lane + 64 * k;
       const int pr = v / XV, cv = v % XV;
       const long p = p0 + pr;
       const int c = ci0 + cv * EPL;
       uint4 val = ys_zero16();
-      if (active && p < a.M && c < a.Cin) {
+      if (v < KS * XV && active && p < a.M && c < a.Cin) {
         const int b = (int)(p / HWo);
         const int r = (int)(p - (long)b * HWo);
         const int oh = r / a.Wout, ow = r - oh * a.Wout;
@@ -330,9 +363,24 @@ conv_wgrad_kernel(WgradArgs a) {
         if (ih >= 0 && ih < a.Hin && iw >= 0 && iw < a.Win)
           val = ys_ld16(xb + ((((long)b * a.in_bstride + (long)ih * a.Win + iw) * a.in_ldc) + a.in_coff + c) * (long)sizeof(T));
       }
-      *(uint4*)(myX + pr * PX + cv * EPL) = val;
+      rx[k] = val;
     }
-    __syncthreads();
+  };
+  fetch(0);
+  for (long it = 0; it < iters; it++) {
+    // ---- registers -> this wave's LDS tiles: dy [KS][COT], gathered x [KS][CIT]
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const int v = lane + 64 * k;
+      if (v < KS * DV) *(uint4*)(myD + (v / DV) * PD + (v % DV) * EPL) = rd[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int v = lane + 64 * k;
+      if (v < KS * XV) *(uint4*)(myX + (v / XV) * PX + (v % XV) * EPL) = rx[k];
+    }
+    ys_wave_sync();
+    if (it + 1 < iters) fetch(it + 1);
     // ---- transposed fragment reads + MFMA
     uint4 fa[MRA], fb[NRB];
 #pragma unroll
@@ -353,8 +401,9 @@ conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < MRA; i++)
 #pragma unroll
       for (int j = 0; j < NRB; j++) acc[i][j] = ys_mma<T>(fa[i], fb[j], acc[i][j]);
-    __syncthreads();
+    ys_wave_sync();
   }
+  __syncthreads();
   // ---- combine the 4 waves, write the partial tile
   float* sR = (float*)smem;  // [4][COT][CIT]
 #pragma unroll
@@ -379,14 +428,20 @@ __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int cin_pad, int cin_real,
                     float* __restrict__ grad) {
   // grad[(row)*cin_real + ci] += sum_s partial[s][row*cin_pad + ci]   (drops padded input channels)
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const long row = i / cin_pad;
-  const int ci = (int)(i - row * cin_pad);
-  if (ci >= cin_real) return;
+  // 64 outputs x 4 split lanes per workgroup: the sum over splits is 4 interleaved chains combined in a fixed order
+  __shared__ float sred[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;
   float s = 0.f;
-  for (int k = 0; k < splits; k++) s += partial[(long)k * n + i];
-  grad[row * cin_real + ci] += s;
+  if (i < n)
+    for (int k = sl; k < splits; k += 4) s += partial[(long)k * n + i];
+  sred[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    const long row = i / cin_pad;
+    const int ci = (int)(i - row * cin_pad);
+    if (ci < cin_real) grad[row * cin_real + ci] += (sred[0][o] + sred[1][o]) + (sred[2][o] + sred[3][o]);
+  }
 }
 
 template <class T, int MRA, int NRB>
@@ -423,7 +478,7 @@ int ys_wgrad_splits(const WgradArgs& a, int dtype) {
   const long smax = (steps + 15) / 16;          // at least 16 wave-steps (4 iterations) per workgroup
   if (s > smax) s = smax;
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
+  if (s > 128) s = 128;
   return (int)s;
 }
 
@@ -436,7 +491,7 @@ int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, i
   if (dtype == YS_BF16) wgrad_dispatch<bf16_t>(st, a, splits);
   else wgrad_dispatch<float>(st, a, splits);
   const long n = (long)a.Cout * a.KH * a.KW * a.Cin;
-  YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 256), 256, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
+  YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 64), 256, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
   return YS_OK;
 }
 

@@ -131,12 +131,14 @@ bn_act_apply_kernel(const T* __restrict__ y, long rows, int C, const float* __re
   if (i >= rows * CG) return;
   const long row = i / CG;
   const int c = (int)(i - row * CG) * EPL;
-  float f[EPL], r[EPL];
+  float f[EPL], r[EPL], sc[EPL], sh[EPL];
   ys_unpack<T>(ys_ld16(y + row * C + c), f);
   if (res) ys_unpack<T>(ys_ld16(res + row * res_ldc + res_coff + c), r);
+  ys_ldcoef<EPL>(scale + c, sc);
+  ys_ldcoef<EPL>(shift + c, sh);
 #pragma unroll
   for (int e = 0; e < EPL; e++) {
-    float u = f[e] * scale[c + e] + shift[c + e];
+    float u = f[e] * sc[e] + sh[e];
     if (act) u = ys_silu(u);
     if (res) u += r[e];
     f[e] = u;
@@ -181,8 +183,7 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
   if (rl < RP) {
     float sc[EPL], sh[EPL], mu[EPL], rs[EPL];
     if (MODE == 0) {
-#pragma unroll
-      for (int e = 0; e < EPL; e++) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; rs[e] = rstd[c + e]; }
+      ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(mean + c, mu); ys_ldcoef<EPL>(rstd + c, rs);
     }
     for (long row = r0 + rl; row < r1; row += RP) {
       float g[EPL];
@@ -257,7 +258,8 @@ int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ld
 template <int MODE>
 __global__ void __launch_bounds__(EW_THREADS)
 chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count, float* __restrict__ g0,
-                     float* __restrict__ g1, float* __restrict__ c1, float* __restrict__ c2) {
+                     float* __restrict__ g1, float* __restrict__ c1, float* __restrict__ c2,
+                     const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd) {
   __shared__ double sbuf[EW_THREADS];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -271,16 +273,19 @@ chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double 
     if (MODE == 0) {
       g0[c] += (float)s2;  // dgamma = sum(du * xhat)
       g1[c] += (float)s1;  // dbeta  = sum(du)
-      c1[c] = (float)(s1 / count);
-      c2[c] = (float)(s2 / count);
+      // dy = gamma*rstd*(du - m1 - xhat*m2) = scale*du - k2 - y*k3  (m1 = mean(du), m2 = mean(du*xhat))
+      const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+      const float sc = scale[c], mu = mean[c], rs = rstd[c];
+      c1[c] = sc * (m1 - mu * rs * m2);   // k2
+      c2[c] = sc * rs * m2;               // k3
     } else {
       g0[c] += (float)s1;
     }
   }
 }
 int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, float* dgamma,
-                              float* dbeta, float* c1, float* c2) {
-  YS_LAUNCH((chan_finalize_kernel<0>), C, EW_THREADS, st, partial, nblk, C, (double)count, dgamma, dbeta, c1, c2);
+                              float* dbeta, float* c1, float* c2, const float* scale, const float* mean, const float* rstd) {
+  YS_LAUNCH((chan_finalize_kernel<0>), C, EW_THREADS, st, partial, nblk, C, (double)count, dgamma, dbeta, c1, c2, scale, mean, rstd);
   return YS_OK;
 }
 
@@ -295,43 +300,41 @@ int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff
   else
     YS_LAUNCH((chan_reduce_kernel<float, 1>), nb, EW_THREADS, st, (const float*)x, ldc, coff, (const float*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0, 0, partial, rows_per_b, bstride);
   // partial rows are Cp wide; finalize only the C real channels
-  YS_LAUNCH((chan_finalize_kernel<1>), C, EW_THREADS, st, (const float*)partial, nb, Cp, 1.0, grad, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  YS_LAUNCH((chan_finalize_kernel<1>), C, EW_THREADS, st, (const float*)partial, nb, Cp, 1.0, grad, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   return YS_OK;
 }
 
 template <class T>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
-                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ c1,
-                    const float* __restrict__ c2, int act, T* __restrict__ dy) {
+                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k2,
+                    const float* __restrict__ k3, int act, T* __restrict__ dy) {
   constexpr int EPL = Elem<T>::EPL;
   const int CG = C / EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * CG) return;
   const long row = i / CG;
   const int c = (int)(i - row * CG) * EPL;
-  float g[EPL], f[EPL];
+  float g[EPL], f[EPL], sc[EPL], sh[EPL], a2[EPL], a3[EPL];
   ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
   ys_unpack<T>(ys_ld16(y + row * C + c), f);
+  ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(k2 + c, a2); ys_ldcoef<EPL>(k3 + c, a3);
 #pragma unroll
   for (int e = 0; e < EPL; e++) {
-    const float u = f[e] * scale[c + e] + shift[c + e];
+    const float u = f[e] * sc[e] + sh[e];
     const float du = act ? g[e] * ys_silu_grad(u) : g[e];
-    const float xh = (f[e] - mean[c + e]) * rstd[c + e];
-    f[e] = gamma[c + e] * rstd[c + e] * (du - c1[c + e] - xh * c2[c + e]);
+    f[e] = sc[e] * du - a2[e] - f[e] * a3[e];
   }
   ys_st16(dy + row * C + c, ys_pack<T>(f));
 }
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
-                           int C, const float* scale, const float* shift, const float* mean, const float* rstd,
-                           const float* gamma, const float* c1, const float* c2, int act, void* dy) {
+                           int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
   if (dtype == YS_BF16)
-    YS_LAUNCH((bn_bwd_apply_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, gamma, c1, c2, act, (bf16_t*)dy);
+    YS_LAUNCH((bn_bwd_apply_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, k2, k3, act, (bf16_t*)dy);
   else
-    YS_LAUNCH((bn_bwd_apply_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, gamma, c1, c2, act, (float*)dy);
+    YS_LAUNCH((bn_bwd_apply_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, k2, k3, act, (float*)dy);
   return YS_OK;
 }
 

@@ -118,27 +118,36 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
 }
 
 // ------------------------------------------------------------------ K1: bbox_decode (Loss.cs:398-409)
+// four consecutive lanes own one anchor (one side each): 32-byte contiguous logit reads instead of a 128-byte stride per lane
 template <class T>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_decode_kernel(LossArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)a.B * a.A) return;
-  const int ai = (int)(i % a.A);
-  const AnchorInfo an = anchor_of(a, ai);
-  const T* row = (const T*)a.pd + i * a.ld_pd;
-  float d[4];
-  for (int s = 0; s < 4; s++) {
+  const long total = (long)a.B * a.A * 4;
+  const bool inb = i < total;
+  const long row = inb ? i >> 2 : 0;
+  const int s = (int)(i & 3);
+  const int lane = threadIdx.x & 63;
+  float d = 0.f;
+  if (inb) {
+    const T* lr = (const T*)a.pd + row * a.ld_pd + s * a.reg_max;
     float mx = -INFINITY;
-    for (int j = 0; j < a.reg_max; j++) mx = fmaxf(mx, Elem<T>::to_f(row[s * a.reg_max + j]));
+    for (int j = 0; j < a.reg_max; j++) mx = fmaxf(mx, Elem<T>::to_f(lr[j]));
     float se = 0.f, sw = 0.f;
     for (int j = 0; j < a.reg_max; j++) {
-      const float e = __expf(Elem<T>::to_f(row[s * a.reg_max + j]) - mx);
+      const float e = __expf(Elem<T>::to_f(lr[j]) - mx);
       se += e; sw += e * (float)j;
     }
-    d[s] = sw / se;
+    d = sw / se;
   }
-  float* pb = a.pbox + i * 4;
-  pb[0] = an.ax - d[0]; pb[1] = an.ay - d[1]; pb[2] = an.ax + d[2]; pb[3] = an.ay + d[3];  // Tal.cs:345-346
+  const int base = lane & ~3;
+  const float d0 = __shfl(d, base + 0), d1 = __shfl(d, base + 1), d2 = __shfl(d, base + 2), d3 = __shfl(d, base + 3);
+  if (inb && s == 0) {
+    const AnchorInfo an = anchor_of(a, (int)(row % a.A));
+    float4 o;
+    o.x = an.ax - d0; o.y = an.ay - d1; o.z = an.ax + d2; o.w = an.ay + d3;   // Tal.cs:345-346
+    *(float4*)(a.pbox + row * 4) = o;
+  }
 }
 
 // ------------------------------------------------------------------ K2: metrics + top-k per (image, gt)
@@ -453,7 +462,7 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   float* part_c = part_t + (size_t)nb_a * 4;
   float* part_b = part_c + (size_t)nb_c * 4;
   YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
-  YS_LAUNCH((loss_decode_kernel<T>), nb_a, LS_THREADS, st, a);
+  YS_LAUNCH((loss_decode_kernel<T>), nb_b, LS_THREADS, st, a);
   YS_LAUNCH((tal_metrics_kernel<T>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
   YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);

@@ -365,7 +365,7 @@ int prep_weights(ys_model* m) {
 
 inline char* view_ptr(ys_model* m, void* base, const Buf& b, long row0) { return (char*)base + (size_t)row0 * b.ldc * m->es; }
 
-float* chan_ptr(ys_model* m, const ConvL& c, int which) { return m->chan + c.ch_off + (long)which * c.cout; }
+float* chan_ptr(ys_model* m, const ConvL& c, int which) { return m->chan + c.ch_off + (long)which * ((c.cout + 3) / 4 * 4); }
 
 int allocate(ys_model* m) {
   const int B = m->maxB;
@@ -393,7 +393,7 @@ int allocate(ys_model* m) {
     pd.push_back(d);
     const long M = (long)B * c.Hout * c.Wout;
     if (c.bn) { c.y_off = ny; ny += M * c.cout; }
-    c.ch_off = nch; nch += 6L * c.cout;
+    c.ch_off = nch; nch += 6L * ((c.cout + 3) / 4 * 4);   // 16-byte aligned coefficient vectors
     dy_max = std::max(dy_max, M * c.cout_ld);
     stat_max = std::max(stat_max, (long)ys_cdiv(M, 128) * 2 * c.cout);
     stat_max = std::max(stat_max, 2048L * 2 * c.cout_ld);   // channel-reduction partials (<= 2048 workgroups)
@@ -546,10 +546,9 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
     YS_TRY(ys_bn_bwd_reduce_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
                                    chan_ptr(m, c, 2), chan_ptr(m, c, 3), c.act ? 1 : 0, rg, rgl, rgc, m->stat_partial, &nblk));
     YS_TRY(ys_bn_bwd_finalize_launch(st, m->stat_partial, nblk, c.cout, M, m->grads + c.g_off, m->grads + c.b_off,
-                                     chan_ptr(m, c, 4), chan_ptr(m, c, 5)));
+                                     chan_ptr(m, c, 4), chan_ptr(m, c, 5), chan_ptr(m, c, 0), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
     YS_TRY(ys_bn_bwd_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
-                                  chan_ptr(m, c, 2), chan_ptr(m, c, 3), m->params + c.g_off, chan_ptr(m, c, 4), chan_ptr(m, c, 5),
-                                  c.act ? 1 : 0, m->dy_scratch));
+                                  chan_ptr(m, c, 4), chan_ptr(m, c, 5), c.act ? 1 : 0, m->dy_scratch));
     dy = m->dy_scratch; dy_ldc = c.cout; dy_coff = 0;
   } else {
     // plain Conv2d with bias (head outputs): dy is the loss gradient itself

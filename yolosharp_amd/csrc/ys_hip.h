@@ -178,6 +178,15 @@ __device__ inline uint4 ys_ld16(const void* p) { return *(const uint4*)p; }
 __device__ inline void ys_st16(void* p, const uint4& v) { *(uint4*)p = v; }
 __device__ inline uint4 ys_zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 
+// EPL consecutive per-channel fp32 coefficients (16-byte aligned) as float4 loads
+template <int EPL> __device__ inline void ys_ldcoef(const float* p, float* o) {
+#pragma unroll
+  for (int v = 0; v < EPL / 4; v++) {
+    const float4 t = *(const float4*)(p + 4 * v);
+    o[4 * v + 0] = t.x; o[4 * v + 1] = t.y; o[4 * v + 2] = t.z; o[4 * v + 3] = t.w;
+  }
+}
+
 // wave reductions (64 lanes)
 __device__ inline float ys_wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -186,6 +195,19 @@ __device__ inline float ys_wave_sum(float v) {
 __device__ inline float ys_wave_max(float v) {
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
   return v;
+}
+
+// wave-level ordering point for LDS traffic that is private to one wave: LDS operations of a wave execute in order on
+// the hardware, so only the compiler must not reorder across it (the interpreter needs a real rendezvous).
+__device__ inline void ys_wave_sync() {
+#ifdef YS_EMU_BUILD
+  int z = 0;
+  emu::wave_collective(&z, sizeof(z), [](unsigned char (*)[128]) {});
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

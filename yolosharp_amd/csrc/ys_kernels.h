@@ -65,11 +65,10 @@ int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ld
                             int act, void* res_grad, int rg_ldc, int rg_coff, float* partial, int* nblk_out);
 // pass 1b: dgamma += sum(du*xhat), dbeta += sum(du), coefficients for pass 2
 int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, float* dgamma,
-                              float* dbeta, float* c1, float* c2);
-// pass 2: dy = gamma*rstd*(du - c1 - xhat*c2)
+                              float* dbeta, float* k2, float* k3, const float* scale, const float* mean, const float* rstd);
+// pass 2: dy = gamma*rstd*(du - mean(du) - xhat*mean(du*xhat)) = scale*du - k2 - y*k3
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
-                           int C, const float* scale, const float* shift, const float* mean, const float* rstd,
-                           const float* gamma, const float* c1, const float* c2, int act, void* dy);
+                           int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy);
 // column sums of a [rows][ldc] view into grad[C] (+=)   (bias gradients)
 int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
                      long bstride, int C, float* partial, float* grad);
