@@ -76,7 +76,10 @@ static void run_block(Block& b) {
   }
 }
 
-void launch(dim3 grid, dim3 block, std::function<void()> fn) {
+static thread_local std::vector<uint4>* g_dyn = nullptr;
+unsigned char* dyn_lds() { return (unsigned char*)g_dyn->data(); }
+
+void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t dyn_lds_bytes) {
   const long total = (long)grid.x * grid.y * grid.z;
   const int nthreads = block.x * block.y * block.z;
   if (total <= 0 || nthreads <= 0) return;
@@ -86,6 +89,9 @@ void launch(dim3 grid, dim3 block, std::function<void()> fn) {
     if (!tl) { tl = new Block(); tl->stack_size = 96 * 1024; }
     Block& b = *tl;
     g_blk = &b;
+    static thread_local std::vector<uint4> dynbuf;
+    if (dynbuf.size() * 16 < dyn_lds_bytes + 16) dynbuf.resize(dyn_lds_bytes / 16 + 1);
+    g_dyn = &dynbuf;
     b.fn = &fn;
     b.bdim = block;
     b.gdim = grid;

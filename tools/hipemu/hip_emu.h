@@ -81,7 +81,8 @@ struct Block {
 
 Block& blk();
 void yield();
-void launch(dim3 grid, dim3 block, std::function<void()> fn);
+void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t dyn_lds_bytes = 0);
+unsigned char* dyn_lds();   // dynamic LDS of the running block (16-byte aligned)
 
 inline Thread& cur() { return *blk().cur; }
 inline Wave& wave() { return blk().waves[cur().lin >> 6]; }
@@ -258,3 +259,5 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
 hipError_t hipMemGetInfo(size_t* free_, size_t* total);
 #define hipStreamNonBlocking 1
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

@@ -20,13 +20,139 @@
 // (SA = 1, DIV = stride, PAD = k-1-k/2, spatially flipped + transposed weights).
 #include "ys_internal.h"
 #include "ys_kernels.h"
+#include <cstdlib>
+
+// ------------------------------------------------------------------ shared epilogue
+// Lane (li,q) holds acc[mf][nf][r] = D[channel n0+nf*16+4q+r][pixel mf*16+li].  Per pixel fragment the wave rounds its
+// 16 x BN tile to T into a wave-private LDS slice and writes it back out as full 16-byte vectors, consecutive lanes
+// covering consecutive channels of one pixel row (whole 64-256 B rows per pixel instead of 8-byte fragments); the
+// residual add (eval Bottleneck) and gradient accumulation (dgrad into an already written view) happen on that
+// wide path.  BN batch statistics are taken from the rounded values in the fragment layout.
+template <class T, int MR, int NR, int NW>
+__device__ inline void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const long (&orow)[MR], const bool (&mv)[MR],
+                                     int n0, T* wst, float* sStat, long stat_row) {
+  constexpr int EPL = Elem<T>::EPL;
+  constexpr int BN = NR * 16;
+  constexpr int BNP = BN + EPL;        // staging row pitch (elements), rows stay 16-byte aligned
+  constexpr int VPP = BN / EPL;        // 16-byte vectors per pixel
+  constexpr int NIT = (16 * VPP + 63) / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const bool do_stats = a.stats != nullptr;
+  float s1[NR][4], s2[NR][4];
+#pragma unroll
+  for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
+  char* yb = (char*)a.y;
+  const char* rb = (const char*)a.res;
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++) {
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++) {
+      const int c = n0 + nf * 16 + 4 * q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
+      if (a.scale || a.shift) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int cc = (c + r) < a.Cout ? (c + r) : 0;
+          const float sc = a.scale ? a.scale[cc] : 1.0f;
+          const float sh = a.shift ? a.shift[cc] : 0.0f;
+          v[r] = v[r] * sc + sh;
+          if (a.act) v[r] = ys_silu(v[r]);
+        }
+      }
+      T o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (c + r >= a.Cout) v[r] = 0.f;     // padded channels of the output row stay zero
+        o[r] = Elem<T>::from_f(v[r]);
+      }
+      if (do_stats && mv[mf]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float f = Elem<T>::to_f(o[r]);
+          s1[nf][r] += f;
+          s2[nf][r] += f * f;
+        }
+      }
+      T* wp = wst + li * BNP + nf * 16 + 4 * q;
+      if (sizeof(T) == 2) {
+        uint2 pk;
+        pk.x = ys_pack_bf16x2(v[0], v[1]);
+        pk.y = ys_pack_bf16x2(v[2], v[3]);
+        *(uint2*)wp = pk;
+      } else {
+        *(uint4*)wp = make_uint4(ys_f2u(v[0]), ys_f2u(v[1]), ys_f2u(v[2]), ys_f2u(v[3]));
+      }
+    }
+    ys_wave_sync();
+    const unsigned rlo = (unsigned)(unsigned long)orow[mf], rhi = (unsigned)((unsigned long)orow[mf] >> 32);
+    const int mvi = mv[mf] ? 1 : 0;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int vv = lane + 64 * it;
+      const int px = vv < 16 * VPP ? vv / VPP : 0;
+      const int cv = vv - px * VPP;
+      const unsigned plo = __shfl(rlo, px), phi = __shfl(rhi, px);
+      const int pok = __shfl(mvi, px);
+      const int c = n0 + cv * EPL;
+      if (vv < 16 * VPP && pok && c < a.Cout) {
+        const long row = (long)(((unsigned long)phi << 32) | plo);
+        uint4 val = *(const uint4*)(wst + px * BNP + cv * EPL);
+        T* yp = (T*)(yb + (row * a.out_ldc + a.out_coff + c) * (long)sizeof(T));
+        if (rb || a.accumulate) {
+          float f[EPL], g[EPL];
+          ys_unpack<T>(val, f);
+          if (rb) {
+            ys_unpack<T>(ys_ld16(rb + (row * a.res_ldc + a.res_coff + c) * (long)sizeof(T)), g);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) f[e] += g[e];
+          }
+          if (a.accumulate) {
+            ys_unpack<T>(ys_ld16(yp), g);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) f[e] += g[e];
+          }
+          val = ys_pack<T>(f);
+        }
+        ys_st16(yp, val);
+      }
+    }
+    ys_wave_sync();
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float x1 = s1[nf][r], x2 = s2[nf][r];
+        for (int msk = 1; msk <= 8; msk <<= 1) {
+          x1 += __shfl_xor(x1, msk);
+          x2 += __shfl_xor(x2, msk);
+        }
+        if (li == 0) {
+          sStat[((wave * BN) + nf * 16 + 4 * q + r) * 2 + 0] = x1;
+          sStat[((wave * BN) + nf * 16 + 4 * q + r) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < NW; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
+      a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
+      a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
+    }
+  }
+}
 
 template <class T, int MR, int NR>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvArgs a) {
   constexpr int EPL = Elem<T>::EPL;
   constexpr int BN = NR * 16;
-  constexpr int LDS_UNITS = 3072;                       // 48 KiB of staged weights (3 workgroups per CU)
+  constexpr int LDS_UNITS = NR <= 2 ? 1024 : 3072;      // 16 / 48 KiB of staged weights
   constexpr int PITCH = ((LDS_UNITS / BN) - 1) | 1;     // odd row pitch in 16-byte units (bank spread)
   constexpr int GSTEPS = PITCH / 4;                     // k-steps whose weights fit in LDS at once
   __shared__ uint4 sW[BN * PITCH];
@@ -138,108 +264,247 @@ conv_igemm_kernel(ConvArgs a) {
     if (lt == GSTEPS) lt = 0;
   }
 
-  // ------------------------------------------------------------------ epilogue
-  const bool do_stats = a.stats != nullptr;
-  float s1[NR][4], s2[NR][4];
-#pragma unroll
-  for (int nf = 0; nf < NR; nf++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
-
-  char* yb = (char*)a.y;
-  const char* rb = (const char*)a.res;
+  // ------------------------------------------------------------------ epilogue (weights in LDS are dead: reuse as staging)
+  __syncthreads();
+  long orow[MR];
+  bool mvv[MR];
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
     const int m = m0 + mf * 16 + li;
-    const bool mv = m < a.M;
-    const int mm = mv ? m : 0;
-    const int b = mm / HWo;
-    const int pix = mm - b * HWo;
-    const long orow = (long)b * a.out_bstride + pix;
-#pragma unroll
-    for (int nf = 0; nf < NR; nf++) {
-      const int c = n0 + nf * 16 + 4 * q;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
-      if (a.scale || a.shift) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int cc = (c + r) < a.Cout ? (c + r) : 0;
-          const float sc = a.scale ? a.scale[cc] : 1.0f;
-          const float sh = a.shift ? a.shift[cc] : 0.0f;
-          v[r] = v[r] * sc + sh;
-          if (a.act) v[r] = ys_silu(v[r]);
-        }
-      }
-      if (rb && mv) {
-        const T* rp = (const T*)(rb + (orow * a.res_ldc + a.res_coff + c) * (long)sizeof(T));
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (c + r < a.Cout) v[r] += Elem<T>::to_f(rp[r]);
-      }
-      T* yp = (T*)(yb + (orow * a.out_ldc + a.out_coff + c) * (long)sizeof(T));
-      if (a.accumulate && mv) {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (c + r < a.Cout) v[r] += Elem<T>::to_f(yp[r]);
-      }
-      T o[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) o[r] = Elem<T>::from_f(v[r]);
-      if (do_stats) {
-        // statistics of the values actually stored (what BN will normalise)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float f = Elem<T>::to_f(o[r]);
-          s1[nf][r] += f;
-          s2[nf][r] += f * f;
-        }
-      }
-      if (mv) {
-        if (a.vec_ok && c + 3 < a.Cout) {
-          if (sizeof(T) == 2) {
-            uint2 pk;
-            pk.x = ys_pack_bf16x2(v[0], v[1]);
-            pk.y = ys_pack_bf16x2(v[2], v[3]);
-            *(uint2*)yp = pk;
-          } else {
-            *(uint4*)yp = make_uint4(ys_f2u(v[0]), ys_f2u(v[1]), ys_f2u(v[2]), ys_f2u(v[3]));
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (c + r < a.Cout) yp[r] = o[r];
-        }
-      }
+    mvv[mf] = m < a.M;
+    const int mm = mvv[mf] ? m : 0;
+    const int bb = mm / HWo;
+    orow[mf] = (long)bb * a.out_bstride + (mm - bb * HWo);
+  }
+  T* wst = (T*)sW + wave * (16 * (BN + EPL));
+  conv_epilogue<T, MR, NR, 4>(a, acc, orow, mvv, n0, wst, &sStat[0][0][0], (long)blockIdx.x);
+}
+
+// ===================================================================================== 3x3: LDS patch kernel
+// 3x3 convolutions (forward s1/s2 and dgrad s1/s2) re-use every input pixel up to 9 times.  Instead of fetching the
+// operand fragments of each tap from L1/L2 (latency- and TA-bound), one workgroup owns a 2-D output tile TH x TW
+// (<= 64*MR pixels) and stages, per 32-channel (bf16) / 16-channel (f32) chunk, the input PATCH = tile + halo once
+// in LDS ([PH][PW] pixels x 4 sixteen-byte units, pitch 5 units) together with the chunk's weights of all 9 taps
+// ([BN][9*4] units, pitch 37).  All global loads of a chunk are issued back-to-back by the 256 threads (deep
+// memory-level parallelism), then the 9 taps x MR x NR MFMAs run from LDS only.  Zero padding and stride-2 dgrad
+// holes are handled by zero-filled patch pixels / predicated fragments.
+#define PATCH_UNITS 1664
+#define C3_THREADS 512
+// Persistent variant: grid.x workgroups (about one per CU) walk the tiles; when the weights of this workgroup's BN
+// output channels fit in LDS for the whole K range (wres) they are staged ONCE per workgroup, otherwise per chunk.
+// The global loads of the next (tile, chunk) are issued into registers before the MFMAs of the current one.
+template <class T, int MR, int NR>
+__global__ void __launch_bounds__(C3_THREADS)
+conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, int patch_units) {
+  constexpr int EPL = Elem<T>::EPL;
+  constexpr int BN = NR * 16;
+  constexpr int PP = 5;                                     // patch pixel pitch: 4 units + 1
+  constexpr int PATCH_DATA = (PATCH_UNITS / PP) * 4;          // data units of the largest patch (pitch 5 holds 4)
+  constexpr int NPU = (PATCH_DATA + C3_THREADS - 1) / C3_THREADS;    // patch units fetched per thread
+  constexpr int NWU = (BN * 36 + C3_THREADS - 1) / C3_THREADS;       // weight units per thread (non-resident mode)
+  YS_DYN_LDS(lds);
+  uint4* sW = lds;                                          // [BN][wpitch]
+  uint4* sP = lds + BN * wpitch;                            // [PATCH_UNITS]
+  float* sStat = (float*)(sP + patch_units);                // [8][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+  const char* xb = (const char*)a.x;
+  const char* wb = (const char*)a.w;
+  const int Ktot = 9 * a.Cin;
+
+  if (wres) {
+    const int per_row = nchunks * 36;
+    for (int idx = tid; idx < BN * per_row; idx += C3_THREADS) {
+      const int n = idx / per_row, cu = idx - n * per_row;
+      const int chunk = cu / 36, tu = cu - chunk * 36;
+      const int ch = chunk * 4 * EPL + (tu & 3) * EPL;
+      uint4 v = ys_zero16();
+      if (n0 + n < a.Cout && ch < a.Cin)
+        v = ys_ld16(wb + ((long)(n0 + n) * Ktot + (long)(tu >> 2) * a.Cin + ch) * (long)sizeof(T));
+      sW[n * wpitch + cu] = v;
     }
   }
 
-  if (do_stats) {
-    // reduce over the 16 pixels held by lanes with equal q (xor 1,2,4,8), then over waves via LDS
+  uint4 rp[NPU], rw[NWU];
+  auto fetch = [&](int tile, int chunk) {
+    int t = tile;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = tyi * a.TH, ox0 = txi * a.TW;
+    const int iy_lo = (oy0 * a.SA - a.PAD) >> a.DIVS, ix_lo = (ox0 * a.SA - a.PAD) >> a.DIVS;
+    const int iy_hi = ((oy0 + a.TH - 1) * a.SA + 2 - a.PAD) >> a.DIVS, ix_hi = ((ox0 + a.TW - 1) * a.SA + 2 - a.PAD) >> a.DIVS;
+    const int PH = iy_hi - iy_lo + 1, PW = ix_hi - ix_lo + 1;
+    const int npatch = PH * PW * 4;
+    const int c0 = chunk * 4 * EPL;
 #pragma unroll
-    for (int nf = 0; nf < NR; nf++)
+    for (int k = 0; k < NPU; k++) {
+      const int idx = tid + C3_THREADS * k;
+      uint4 v = ys_zero16();
+      if (idx < npatch) {
+        const int pix = idx >> 2, u = idx & 3;
+        const int r = pix / PW, cc = pix - r * PW;
+        const int iy = iy_lo + r, ix = ix_lo + cc;
+        const int ch = c0 + u * EPL;
+        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && ch < a.Cin && !(a.dbg & 1))
+          v = ys_ld16(xb + ((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) + a.in_coff + ch) * (long)sizeof(T));
+      }
+      rp[k] = v;
+    }
+    if (!wres) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float x1 = s1[nf][r], x2 = s2[nf][r];
-        for (int msk = 1; msk <= 8; msk <<= 1) {
-          x1 += __shfl_xor(x1, msk);
-          x2 += __shfl_xor(x2, msk);
+      for (int k = 0; k < NWU; k++) {
+        const int idx = tid + C3_THREADS * k;
+        uint4 v = ys_zero16();
+        if (idx < BN * 36) {
+          const int n = idx / 36, tu = idx - n * 36;
+          const int ch = c0 + (tu & 3) * EPL;
+          if (n0 + n < a.Cout && ch < a.Cin)
+            v = ys_ld16(wb + ((long)(n0 + n) * Ktot + (long)(tu >> 2) * a.Cin + ch) * (long)sizeof(T));
         }
-        if (li == 0) {
-          sStat[wave][nf * 16 + 4 * q + r][0] = x1;
-          sStat[wave][nf * 16 + 4 * q + r][1] = x2;
+        rw[k] = v;
+      }
+    }
+  };
+
+  int tile = blockIdx.x, chunk = 0;
+  if (tile < ntiles) fetch(tile, 0);
+  // geometry of the tile being computed
+  int b = 0, oy0 = 0, ox0 = 0, iy_lo = 0, ix_lo = 0, PW = 1;
+  int poy[MR], pox[MR];
+  bool pv[MR];
+  f32x4 acc[MR][NR];
+  while (tile < ntiles) {
+    __syncthreads();                       // every wave finished reading the previous chunk
+#pragma unroll
+    for (int k = 0; k < NPU; k++) {
+      const int idx = tid + C3_THREADS * k;
+      if (idx < PATCH_DATA) sP[(idx >> 2) * PP + (idx & 3)] = rp[k];
+    }
+    if (!wres) {
+#pragma unroll
+      for (int k = 0; k < NWU; k++) {
+        const int idx = tid + C3_THREADS * k;
+        if (idx < BN * 36) { const int n = idx / 36; sW[n * wpitch + (idx - n * 36)] = rw[k]; }
+      }
+    }
+    __syncthreads();
+    // ---- prefetch the next (tile, chunk)
+    int ntile = tile, nchunk = chunk + 1;
+    if (nchunk == nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
+    if (ntile < ntiles) fetch(ntile, nchunk);
+    // ---- compute this chunk from LDS
+    if (chunk == 0) {
+      int t = tile;
+      const int txi = t % a.tiles_x; t /= a.tiles_x;
+      const int tyi = t % a.tiles_y;
+      b = t / a.tiles_y;
+      oy0 = tyi * a.TH; ox0 = txi * a.TW;
+      iy_lo = (oy0 * a.SA - a.PAD) >> a.DIVS; ix_lo = (ox0 * a.SA - a.PAD) >> a.DIVS;
+      const int ix_hi = ((ox0 + a.TW - 1) * a.SA + 2 - a.PAD) >> a.DIVS;
+      PW = ix_hi - ix_lo + 1;
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++) {
+        const int p = wave * (MR * 16) + mf * 16 + li;
+        const int ty = p / a.TW, tx = p - ty * a.TW;
+        poy[mf] = oy0 + ty; pox[mf] = ox0 + tx;
+        pv[mf] = p < a.TH * a.TW && poy[mf] < a.Hout && pox[mf] < a.Wout;
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+      }
+    }
+    const int wbase = wres ? chunk * 36 : 0;
+    if (!(a.dbg & 2))
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++) {
+#pragma unroll
+      for (int kw = 0; kw < 3; kw++) {
+        uint4 xf[MR];
+#pragma unroll
+        for (int mf = 0; mf < MR; mf++) {
+          const int ihn = poy[mf] * a.SA + kh - a.PAD, iwn = pox[mf] * a.SA + kw - a.PAD;
+          const bool ok = pv[mf] && ((ihn | iwn) & a.DIVM) == 0;
+          const int r = (ihn >> a.DIVS) - iy_lo, cc = (iwn >> a.DIVS) - ix_lo;
+          xf[mf] = ys_zero16();
+          if (ok) xf[mf] = sP[(r * PW + cc) * PP + q];
+        }
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++) {
+          const uint4 wf = sW[(nf * 16 + li) * wpitch + wbase + (kh * 3 + kw) * 4 + q];
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf, xf[mf], acc[mf][nf]);
         }
       }
-    __syncthreads();
-    if (tid < BN && n0 + tid < a.Cout) {
-      const float t1 = sStat[0][tid][0] + sStat[1][tid][0] + sStat[2][tid][0] + sStat[3][tid][0];
-      const float t2 = sStat[0][tid][1] + sStat[1][tid][1] + sStat[2][tid][1] + sStat[3][tid][1];
-      a.stats[((long)blockIdx.x * 2 + 0) * a.Cout + n0 + tid] = t1;
-      a.stats[((long)blockIdx.x * 2 + 1) * a.Cout + n0 + tid] = t2;
     }
+    if (chunk == nchunks - 1 && !(a.dbg & 4)) {
+      // ---------------------------------------------------------------- epilogue (patch region becomes the staging area)
+      __syncthreads();
+      long orow[MR];
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++) orow[mf] = (long)b * a.out_bstride + (pv[mf] ? ((long)poy[mf] * a.Wout + pox[mf]) : 0);
+      T* wst = (T*)sP + wave * (16 * (BN + EPL));
+      conv_epilogue<T, MR, NR, C3_THREADS / 64>(a, acc, orow, pv, n0, wst, sStat, (long)tile);
+    }  // last chunk of the tile
+    tile = ntile; chunk = nchunk;
   }
 }
+
+// host-side tile choice for the patch kernel: largest pixel tile (64*MR) whose patch fits PATCH_UNITS, shaped to
+// minimise (patch pixels loaded) + (idle tile pixels), keeping a few workgroups per CU
+struct TileChoice { int mr, th, tw, tx, ty; };
+static TileChoice conv3x3_pick_tile(const ConvArgs& a, int nr) {
+  const int gy = ys_cdiv(a.Cout, nr * 16);
+  const int div = a.DIVM + 1;
+  TileChoice best{0, 0, 0, 0, 0};
+  for (int mr = 2; mr >= 1; mr >>= 1) {
+    const int npx = 128 * mr;   // 8 waves x MR fragments x 16 pixels
+    double best_cost = 1e30;
+    TileChoice cur{0, 0, 0, 0, 0};
+    for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
+      const int th_max = (npx / tw) < a.Hout ? (npx / tw) : a.Hout;
+      for (int th = th_max; th >= 1; th--) {
+        const int ph = div == 1 ? (th - 1) * a.SA + 3 : (th + 1) / 2 + 2, pw = div == 1 ? (tw - 1) * a.SA + 3 : (tw + 1) / 2 + 2;
+        if ((long)ph * pw * 5 > PATCH_UNITS) continue;
+        const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
+        const double cost = (double)tx * ty * ((double)ph * pw + 0.5 * npx);
+        if (cost < best_cost) { best_cost = cost; cur = TileChoice{mr, th, tw, tx, ty}; }
+      }
+    }
+    if (cur.mr == 0) continue;
+    if (best.mr == 0) best = cur;
+    if ((long)cur.tx * cur.ty * a.B * gy >= 512) return cur;   // enough tiles to feed every CU: take the largest
+    best = cur;                                                // otherwise keep shrinking
+  }
+  return best;
+}
+struct C3Plan { int nr, wres, nchunks, wpitch, patch_units; size_t lds_bytes; };
+static C3Plan conv3x3_plan(const ConvArgs& a, int epl) {
+  const int nfr = (a.Cout + 15) / 16;
+  const int nchunks = (a.Cin + 4 * epl - 1) / (4 * epl);
+  C3Plan p{};
+  p.nchunks = nchunks;
+  const int es = epl == 8 ? 2 : 4;
+  auto patch_units_for = [&](int nr) {   // patch region doubles as the epilogue staging area (8 waves x 16 x (BN+EPL) elements)
+    const int need = (8 * 16 * (nr * 16 + epl) * es + 15) / 16;
+    return need > PATCH_UNITS ? need : PATCH_UNITS;
+  };
+  for (int nr = nfr < 5 ? nfr : 5; nr >= 1; nr--) {       // weights of all chunks resident in LDS?
+    const size_t fixed = (size_t)patch_units_for(nr) * 16;
+    const size_t bytes = (size_t)nr * 16 * (nchunks * 36 + 1) * 16 + fixed + (size_t)nr * 16 * 64;
+    if (bytes <= 144 * 1024 && (nr == nfr || nr * 2 >= (nfr < 5 ? nfr : 5))) {   // do not shrink NR below half for residency
+      p.nr = nr; p.wres = 1; p.wpitch = nchunks * 36 + 1; p.lds_bytes = bytes; p.patch_units = patch_units_for(nr);
+      return p;
+    }
+  }
+  p.nr = nfr <= 5 ? nfr : (nfr % 5 == 0 ? 5 : 4);
+  p.wres = 0; p.wpitch = 37; p.patch_units = patch_units_for(p.nr);
+  p.lds_bytes = (size_t)p.nr * 16 * 37 * 16 + (size_t)p.patch_units * 16 + (size_t)p.nr * 16 * 64;
+  return p;
+}
+// stride-2 forward convs have a 4x larger input patch per output pixel: their tiles would be patch-limited to ~64 pixels,
+// so they stay on the direct-fragment kernel; stride-1 forward and all dgrads (SA == 1) use the LDS patch kernel
+static bool conv_use_patch(const ConvArgs& a) { return a.KH == 3 && a.KW == 3 && a.SA == 1; }
 
 template <class T, int MR, int NR>
 static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
@@ -248,22 +513,78 @@ static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
   YS_LAUNCH((conv_igemm_kernel<T, MR, NR>), grid, 256, st, a);
 }
 
-int ys_conv_grid_m(const ConvArgs& a) { return ys_cdiv(a.M, 4 * 2 * 16); }
+// Tile selection.  NR = output-channel fragments per workgroup (all of Cout when it fits, so activations are read
+// once); MR = pixel fragments per wave: as many as the accumulator budget allows (MR*NR <= 16) because every extra
+// fragment is one more independent 16-byte load in flight per lane, but small feature maps (20x20, 40x40 at the
+// deep end of the net) fall back to smaller MR so that the grid still covers the 256 CUs a few times.
+static int conv_pick_nr(int cout) {
+  const int nfr = (cout + 15) / 16;
+  if (nfr <= 6) return nfr;
+  if (nfr % 8 == 0 || nfr > 10) return 8;
+  if (nfr % 5 == 0) return 5;
+  return 4;
+}
+static int conv_pick_mr(int M, int cout) {
+  const int nr = conv_pick_nr(cout);
+  const int gy = ys_cdiv(cout, nr * 16);
+  int mr = nr == 1 ? 8 : nr == 2 ? 8 : nr <= 4 ? 4 : 2;
+  while (mr > 1 && (long)ys_cdiv(M, 64 * mr) * gy < 768) mr >>= 1;
+  return mr;
+}
+
+int ys_conv_grid_m(const ConvArgs& a) {
+  if (conv_use_patch(a)) {
+    // tile shape does not depend on dtype-specific chunking; NR only enters through the workgroup-count heuristic
+    const TileChoice t = conv3x3_pick_tile(a, conv3x3_plan(a, 8).nr);
+    return t.tx * t.ty * a.B;
+  }
+  return ys_cdiv(a.M, 64 * conv_pick_mr(a.M, a.Cout));
+}
+
+template <class T, int MR, int NR>
+static int conv3x3_launch_t(hipStream_t st, ConvArgs a, const TileChoice& t, const C3Plan& p) {
+  a.TH = t.th; a.TW = t.tw; a.tiles_x = t.tx; a.tiles_y = t.ty;
+  static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;
+  a.dbg = dbg;
+  const int ntiles = t.tx * t.ty * a.B;
+  const int gy = ys_cdiv(a.Cout, NR * 16);
+  const int per_cu = p.lds_bytes <= 76 * 1024 ? 2 : 1;
+  int gx = (256 * per_cu + gy - 1) / gy;
+  if (gx > ntiles) gx = ntiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, MR, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  YsKprofScope prof(st, "conv_igemm");
+  YS_LAUNCH_LDS((conv3x3_tile_kernel<T, MR, NR>), dim3(gx, gy), C3_THREADS, p.lds_bytes, st, a, ntiles, p.nchunks, p.wres, p.wpitch, p.patch_units);
+  return YS_OK;
+}
 
 template <class T>
 static int conv_launch_dtype(hipStream_t st, const ConvArgs& a) {
-  const int nfr = (a.Cout + 15) / 16;
-  // MR is fixed at 2 (128 pixels per workgroup) so that the BN partial-statistics grid is known
-  if (nfr <= 1) conv_launch_t<T, 2, 1>(st, a);
-  else if (nfr == 2) conv_launch_t<T, 2, 2>(st, a);
-  else if (nfr == 3) conv_launch_t<T, 2, 3>(st, a);
-  else if (nfr == 4) conv_launch_t<T, 2, 4>(st, a);
-  else if (nfr == 5) conv_launch_t<T, 2, 5>(st, a);
-  else if (nfr == 6) conv_launch_t<T, 2, 6>(st, a);
-  else if (nfr % 8 == 0 || nfr > 10) conv_launch_t<T, 2, 8>(st, a);
-  else if (nfr % 5 == 0) conv_launch_t<T, 2, 5>(st, a);
-  else conv_launch_t<T, 2, 4>(st, a);
-  return YS_OK;
+  if (conv_use_patch(a)) {
+    const C3Plan p = conv3x3_plan(a, Elem<T>::EPL);
+    const TileChoice t = conv3x3_pick_tile(a, conv3x3_plan(a, 8).nr);   // same tile for both dtypes (stats grid)
+    if (t.mr == 0) { ys_set_error("conv3x3: no tile fits"); return YS_ERR_UNSUPPORTED; }
+#define C3(M_, N_) if (t.mr == M_ && p.nr == N_) return conv3x3_launch_t<T, M_, N_>(st, a, t, p);
+    C3(1, 1) C3(2, 1) C3(1, 2) C3(2, 2) C3(1, 3) C3(2, 3) C3(1, 4) C3(2, 4) C3(1, 5) C3(2, 5)
+#undef C3
+    ys_set_error("conv3x3: no kernel for tile MR=%d NR=%d", t.mr, p.nr);
+    return YS_ERR_UNSUPPORTED;
+  }
+  const int nr = conv_pick_nr(a.Cout), mr = conv_pick_mr(a.M, a.Cout);
+#define CV(M_, N_) if (mr == M_ && nr == N_) { conv_launch_t<T, M_, N_>(st, a); return YS_OK; }
+  CV(1, 1) CV(2, 1) CV(4, 1) CV(8, 1)
+  CV(1, 2) CV(2, 2) CV(4, 2) CV(8, 2)
+  CV(1, 3) CV(2, 3) CV(4, 3)
+  CV(1, 4) CV(2, 4) CV(4, 4)
+  CV(1, 5) CV(2, 5)
+  CV(1, 6) CV(2, 6)
+  CV(1, 8) CV(2, 8)
+#undef CV
+  ys_set_error("conv: no kernel for tile MR=%d NR=%d", mr, nr);
+  return YS_ERR_UNSUPPORTED;
 }
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {

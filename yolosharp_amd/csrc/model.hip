@@ -395,7 +395,7 @@ int allocate(ys_model* m) {
     if (c.bn) { c.y_off = ny; ny += M * c.cout; }
     c.ch_off = nch; nch += 6L * ((c.cout + 3) / 4 * 4);   // 16-byte aligned coefficient vectors
     dy_max = std::max(dy_max, M * c.cout_ld);
-    stat_max = std::max(stat_max, (long)ys_cdiv(M, 128) * 2 * c.cout);
+    stat_max = std::max(stat_max, 2L * ys_cdiv(M, 64) * 2 * c.cout);   // conv epilogue partials (smallest pixel tile, ragged 2-D tiles)
     stat_max = std::max(stat_max, 2048L * 2 * c.cout_ld);   // channel-reduction partials (<= 2048 workgroups)
   }
   for (auto& op : m->ops) if (op.type == OP_MAXPOOL) { op.aux_off = amax; amax += (long)B * op.H * op.W * op.in.C; }

@@ -22,6 +22,17 @@
   hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__)
 #endif
 
+// launch with dynamic LDS; YS_DYN_LDS(name) declares the dynamic region inside a kernel as `uint4* name`
+#ifdef YS_EMU_BUILD
+#define YS_LAUNCH_LDS(KERNEL, GRID, BLOCK, LDS_BYTES, STREAM, ...) \
+  emu::launch(dim3(GRID), dim3(BLOCK), [=]() { KERNEL(__VA_ARGS__); }, (size_t)(LDS_BYTES))
+#define YS_DYN_LDS(name) uint4* name = (uint4*)emu::dyn_lds()
+#else
+#define YS_LAUNCH_LDS(KERNEL, GRID, BLOCK, LDS_BYTES, STREAM, ...) \
+  hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), (LDS_BYTES), STREAM, __VA_ARGS__)
+#define YS_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) uint4 name[]
+#endif
+
 // ---------------------------------------------------------------- bf16 storage type
 struct bf16_t { unsigned short v; };
 

@@ -21,6 +21,8 @@ struct ConvArgs {
   int accumulate;            // y += result (gradient accumulation)
   int vec_ok;                // out_ldc/out_coff (and res) allow 4-channel vector stores
   int M;                     // B*Hout*Wout
+  int TH, TW, tiles_x, tiles_y;  // 2-D output tile of the 3x3 LDS-patch kernel (filled by the launcher)
+  int dbg;                       // ablation switches for performance triage (YS_DBG env; 0 in production)
 };
 
 struct WgradArgs {
