@@ -156,8 +156,15 @@ def main():
         bytes_per_launch = wk["igemm_bytes"] * B / wk["igemm_launches"]
         avg_ms = ms_ig / max(n_ig, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "conv_igemm_kernel (forward + dgrad launches)", "achieved": round(achieved, 1),
-                    "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the timed process)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if tj["conv_igemm_class"]["config"] == f"YOLOv8{args.size} B={B} {H}x{W} {args.dtype}":
+                traffic = tj["conv_igemm_class"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
+        roofline = {"bound": "hbm", "kernel": "conv_igemm class = conv_igemm_kernel (1x1, stride-2) + conv3x3_tile_kernel (3x3 s1 fwd, all 3x3 dgrads): 125 forward+dgrad launches/step", "achieved": round(achieved, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "launches_per_step": n_ig // steps_prof, "avg_launch_ms": round(avg_ms, 5),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "class_ms_per_step": {"conv_igemm": round(ms_ig / steps_prof, 3), "conv_wgrad": round(ms_wg / steps_prof, 3)},
