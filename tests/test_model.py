@@ -228,3 +228,83 @@ def test_bf16_full_size_properties(backend, engine):
     num = sum(float((ga[k].ravel() * gb[k].ravel()).sum()) for k in ga)
     den = np.sqrt(sum(float((ga[k] ** 2).sum()) for k in ga) * sum(float((gb[k] ** 2).sum()) for k in gb))
     assert num / den > 0.98, num / den
+
+
+# ----------------------------------------------------------------------------- YOLOv11
+def make_ref11(nc=80, size="n", seed=0):
+    torch.manual_seed(seed)
+    ref = O.Yolov11(nc=nc, size=size)
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.1)
+            mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+    return ref
+
+
+def _v11_parity(engine, size, B, H, W, tol_fwd, tol_grad):
+    """C3k2 / C3k / C2PSA(attention + depthwise pe) / Detect(legacy=false): forward, loss and every gradient vs the oracle."""
+    from yolosharp_amd.model import Yolov11, v8DetectionLoss
+    nc = 80
+    ref = make_ref11(size=size)
+    m = Yolov11(engine, nc=nc, size=size, height=H, width=W, max_batch=B, dtype="f32")
+    info = m.tensor_info()
+    assert [n for n, s, p in info if p] == [k for k, _ in ref.named_parameters()]          # registration order incl. nested C3k
+    assert {n: tuple(s) for n, s, p in info} == {k: (tuple(v.shape) if v.dim() else (1,)) for k, v in ref.state_dict().items()}
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3))
+    batch = O.synthetic_batch(B, H, W, nc, seed=1, kmax=6)
+    m.eval(); ref.eval()
+    inf, preds = m.forward(x.numpy())
+    with torch.no_grad():
+        rinf, rpreds = ref(x)
+    assert relerr(preds["boxes"], rpreds["boxes"]) < tol_fwd and relerr(preds["scores"], rpreds["scores"]) < tol_fwd
+    assert relerr(inf["boxes"], rinf["boxes"]) < tol_fwd
+    m.train(); ref.train()
+    _, preds = m.forward(x.numpy())
+    _, rpreds = ref(x)
+    assert relerr(preds["boxes"], rpreds["boxes"]) < tol_fwd and relerr(preds["scores"], rpreds["scores"]) < tol_fwd
+    loss, items = v8DetectionLoss(m)(None, {k: v.numpy() for k, v in batch.items()})
+    rloss, ritems = O.v8DetectionLoss(nc)(rpreds, batch)
+    assert np.allclose(items, ritems.numpy(), rtol=1e-3, atol=1e-5), (items, ritems)
+    rloss.sum().backward()
+    m.zero_grad(); m.backward()
+    grads = m.grads()
+    gscale = max(float(p.grad.abs().max()) for _, p in ref.named_parameters() if p.grad is not None)
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        r = p.grad.numpy()
+        assert np.abs(grads[name] - r).max() <= tol_grad * np.abs(r).max() + 1e-6 * gscale, name
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_yolov11n_forward_loss_backward_f32(backend, engine):
+    _v11_parity(engine, "n", 2, 64, 64, 1e-3, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_yolov11m_full_resolution_f32(backend, engine):
+    """c3k=True everywhere (nested C3k), 400-token attention at 640x640."""
+    _v11_parity(engine, "m", 2, 640, 640, 1e-3, 2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_yolov11s_bf16_train_step(backend, engine):
+    from yolosharp_amd.model import Yolov11, v8DetectionLoss
+    B, H, W, nc = 16, 640, 640, 80
+    rng = np.random.default_rng(0)
+    x = rng.random((B, 3, H, W), dtype=np.float32)
+    batch = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=1).items()}
+    items = {}
+    for dt in ("bf16", "f32"):
+        m = Yolov11(engine, nc=nc, size="s", height=H, width=W, max_batch=B, dtype=dt)
+        m.init_weights(4); m.train()
+        m.forward(x, fetch=False)
+        _, it = v8DetectionLoss(m)(None, batch)
+        m.zero_grad(); m.backward(); m.adamw_step([1e-3] * 3)
+        items[dt] = it
+        m.close()
+    assert np.all(np.isfinite(items["bf16"])) and np.allclose(items["bf16"], items["f32"], rtol=5e-2), items

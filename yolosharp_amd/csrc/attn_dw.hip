@@ -1,0 +1,311 @@
+// attn_dw.hip -- YOLOv11-only operators:
+//   * depthwise 3x3/s1 convolution (Convs.DWConv, Modules/Convs.cs:108-114: groups = gcd(c1,c2) = C) used by the
+//     legacy=false cls towers of Detect (Modules/Head.cs:50) and by Attention.pe (Modules/Block.cs:746)
+//   * the attention core of C2PSA/PSABlock/Attention (Modules/Block.cs:763-805): per head
+//       attn = softmax(q^T k * key_dim^-0.5) ; x = v @ attn^T        (N = H*W tokens, 400 at 640x640)
+//     forward, and the two-pass backward (dS/dq per query row, dk/dv per key column).
+// All of it is HBM/latency-bound small-tensor work (the 20x20 level): no MFMA, fp32 math, T storage, NHWC views.
+#include "ys_internal.h"
+#include "ys_kernels.h"
+
+#define AD_THREADS 256
+
+// ------------------------------------------------------------------ depthwise 3x3, stride 1, pad 1
+// FLIP = 0: y[p,c] = sum_t w[t][c] * x[p + off(t), c]            (forward)
+// FLIP = 1: dx[p,c] = sum_t w[t][c] * dy[p - off(t), c]          (input gradient)
+template <class T, int FLIP>
+__global__ void __launch_bounds__(AD_THREADS)
+dwconv3x3_kernel(const T* __restrict__ x, int x_ldc, int x_coff, int B, int H, int W, int C, const float* __restrict__ w,
+                 T* __restrict__ y, int y_ldc, int y_coff, int accumulate) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int CG = C / EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * CG) return;
+  const int c = (int)(i % CG) * EPL;
+  const long pix = i / CG;
+  const int ww = (int)(pix % W), hh = (int)((pix / W) % H);
+  const long b = pix / ((long)W * H);
+  float acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) acc[e] = 0.f;
+  for (int kh = 0; kh < 3; kh++) {
+    const int ih = FLIP ? hh - kh + 1 : hh + kh - 1;
+    if (ih < 0 || ih >= H) continue;
+    for (int kw = 0; kw < 3; kw++) {
+      const int iw = FLIP ? ww - kw + 1 : ww + kw - 1;
+      if (iw < 0 || iw >= W) continue;
+      float f[EPL], wt[EPL];
+      ys_unpack<T>(ys_ld16(x + ((b * H + ih) * W + iw) * x_ldc + x_coff + c), f);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) wt[e] = w[(kh * 3 + kw) * C + c + e];   // flat-buffer offsets are not 16-byte aligned in general
+#pragma unroll
+      for (int e = 0; e < EPL; e++) acc[e] += f[e] * wt[e];
+    }
+  }
+  T* yp = y + pix * y_ldc + y_coff + c;
+  if (accumulate) {
+    float o[EPL];
+    ys_unpack<T>(ys_ld16(yp), o);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) acc[e] += o[e];
+  }
+  ys_st16(yp, ys_pack<T>(acc));
+}
+
+int ys_dwconv_launch(hipStream_t st, int dtype, int flip, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
+                     const float* w, void* y, int y_ldc, int y_coff, int accumulate) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (C % epl) { ys_set_error("dwconv: C=%d must be a multiple of %d", C, epl); return YS_ERR_UNSUPPORTED; }
+  const long n = (long)B * H * W * (C / epl);
+  const int g = ys_cdiv(n, AD_THREADS);
+#define DW(TT, FL) YS_LAUNCH((dwconv3x3_kernel<TT, FL>), g, AD_THREADS, st, (const TT*)x, x_ldc, x_coff, B, H, W, C, w, (TT*)y, y_ldc, y_coff, accumulate)
+  if (dtype == YS_BF16) { if (flip) DW(bf16_t, 1); else DW(bf16_t, 0); }
+  else { if (flip) DW(float, 1); else DW(float, 0); }
+#undef DW
+  return YS_OK;
+}
+
+// dW[t][c] = sum_p dy[p,c] * x[p + off(t), c]: workgroup partials [nblk][9][C], summed in order by the finalize kernel
+template <class T>
+__global__ void __launch_bounds__(AD_THREADS)
+dwconv_wgrad_kernel(const T* __restrict__ x, int x_ldc, int x_coff, const T* __restrict__ dy, int B, int H, int W, int C,
+                    float* __restrict__ partial) {
+  constexpr int EPL = Elem<T>::EPL;
+  __shared__ float sAcc[AD_THREADS][EPL];
+  const int CG = C / EPL;
+  const int RP = AD_THREADS / CG;
+  const int tid = threadIdx.x;
+  const int cv = tid % CG, rl = tid / CG;
+  const int c = cv * EPL;
+  const long rows = (long)B * H * W;
+  const long rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  long r1 = r0 + rows_per_blk;
+  if (r1 > rows) r1 = rows;
+  float acc[9][EPL];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int e = 0; e < EPL; e++) acc[t][e] = 0.f;
+  if (rl < RP) {
+    for (long row = r0 + rl; row < r1; row += RP) {
+      const int ww = (int)(row % W), hh = (int)((row / W) % H);
+      const long b = row / ((long)W * H);
+      float g[EPL];
+      ys_unpack<T>(ys_ld16(dy + row * C + c), g);
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) {
+        const int ih = hh + kh - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          const int iw = ww + kw - 1;
+          if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+            float f[EPL];
+            ys_unpack<T>(ys_ld16(x + ((b * H + ih) * W + iw) * x_ldc + x_coff + c), f);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) acc[kh * 3 + kw][e] += g[e] * f[e];
+          }
+        }
+      }
+    }
+  }
+  for (int t = 0; t < 9; t++) {
+#pragma unroll
+    for (int e = 0; e < EPL; e++) sAcc[tid][e] = acc[t][e];
+    __syncthreads();
+    if (tid < CG) {
+#pragma unroll
+      for (int e = 0; e < EPL; e++) {
+        float s = 0.f;
+        for (int k = 0; k < RP; k++) s += sAcc[k * CG + tid][e];
+        partial[((long)blockIdx.x * 9 + t) * C + c + e] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(AD_THREADS)
+dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ grad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; k++) s += partial[(long)k * n + i];
+  grad[i] += s;
+}
+
+int ys_dwconv_wgrad_blocks(long rows, int C, int dtype) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const int rp = AD_THREADS / (C / epl);
+  long nb = (rows + (long)rp * 8 - 1) / ((long)rp * 8);
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+int ys_dwconv_wgrad_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, const void* dy, int B, int H, int W,
+                           int C, float* partial, float* grad) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (C % epl || C / epl > AD_THREADS) { ys_set_error("dwconv wgrad: unsupported C=%d", C); return YS_ERR_UNSUPPORTED; }
+  const int nb = ys_dwconv_wgrad_blocks((long)B * H * W, C, dtype);
+  if (dtype == YS_BF16) YS_LAUNCH((dwconv_wgrad_kernel<bf16_t>), nb, AD_THREADS, st, (const bf16_t*)x, x_ldc, x_coff, (const bf16_t*)dy, B, H, W, C, partial);
+  else YS_LAUNCH((dwconv_wgrad_kernel<float>), nb, AD_THREADS, st, (const float*)x, x_ldc, x_coff, (const float*)dy, B, H, W, C, partial);
+  YS_LAUNCH(dwconv_wgrad_finalize_kernel, ys_cdiv(9 * C, AD_THREADS), AD_THREADS, st, (const float*)partial, nb, 9 * C, grad);
+  return YS_OK;
+}
+
+// ------------------------------------------------------------------ attention core
+// qkv: [B][N][ldq] with channel layout head*(2*kd+hd) + {q: 0..kd | k: kd..2kd | v: 2kd..2kd+hd}  (Block.cs:772-775)
+// ao : [B][N][ldo] at channel head*hd + d                                                        (view(B,C,H,W), :782)
+// P  : [B*heads][N][N] fp32 softmax probabilities (kept for the backward)
+#define ATT_NMAX 1600
+template <class T>
+__global__ void __launch_bounds__(AD_THREADS)
+attn_fwd_kernel(const T* __restrict__ qkv, int ldq, int B, int N, int heads, int kd, int hd, float scale,
+                T* __restrict__ ao, int ldo, float* __restrict__ P) {
+  __shared__ float sP[AD_THREADS / 64][ATT_NMAX];
+  __shared__ float sQ[AD_THREADS / 64][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (AD_THREADS / 64) + wave;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const int hs = 2 * kd + hd;
+  if (n >= N) return;                       // whole wave (no workgroup barrier below)
+  float* pr = sP[wave];
+  float* sq = sQ[wave];
+  const T* base = qkv + (long)b * N * ldq + h * hs;
+  for (int d = lane; d < kd; d += 64) sq[d] = Elem<T>::to_f(base[(long)n * ldq + d]);
+  ys_wave_sync();
+  float mx = -INFINITY;
+  for (int m = lane; m < N; m += 64) {
+    const T* kr = base + (long)m * ldq + kd;
+    float s = 0.f;
+    for (int d = 0; d < kd; d++) s += sq[d] * Elem<T>::to_f(kr[d]);
+    s *= scale;
+    pr[m] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = ys_wave_max(mx);
+  float sum = 0.f;
+  for (int m = lane; m < N; m += 64) { const float e = __expf(pr[m] - mx); pr[m] = e; sum += e; }
+  sum = ys_wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float* Prow = P + ((long)bh * N + n) * N;
+  for (int m = lane; m < N; m += 64) { const float p = pr[m] * inv; pr[m] = p; Prow[m] = p; }
+  ys_wave_sync();
+  for (int d = lane; d < hd; d += 64) {
+    float acc = 0.f;
+    for (int m = 0; m < N; m++) acc += pr[m] * Elem<T>::to_f(base[(long)m * ldq + 2 * kd + d]);
+    ao[((long)b * N + n) * ldo + h * hd + d] = Elem<T>::from_f(acc);
+  }
+}
+
+// pass 1 (per query row n): dP = dO^T v ; dS = P o (dP - sum(dP o P)) ; dq = scale * dS k^T
+template <class T>
+__global__ void __launch_bounds__(AD_THREADS)
+attn_bwd_q_kernel(const T* __restrict__ qkv, int ldq, int B, int N, int heads, int kd, int hd, float scale,
+                  const T* __restrict__ dao, int ldo, const float* __restrict__ P, float* __restrict__ dS,
+                  T* __restrict__ dqkv) {
+  __shared__ float sS[AD_THREADS / 64][ATT_NMAX];
+  __shared__ float sO[AD_THREADS / 64][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (AD_THREADS / 64) + wave;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const int hs = 2 * kd + hd;
+  if (n >= N) return;
+  float* ds = sS[wave];
+  float* so = sO[wave];
+  const T* base = qkv + (long)b * N * ldq + h * hs;
+  for (int d = lane; d < hd; d += 64) so[d] = Elem<T>::to_f(dao[((long)b * N + n) * ldo + h * hd + d]);
+  ys_wave_sync();
+  const float* Prow = P + ((long)bh * N + n) * N;
+  float t = 0.f;
+  for (int m = lane; m < N; m += 64) {
+    const T* vr = base + (long)m * ldq + 2 * kd;
+    float dp = 0.f;
+    for (int d = 0; d < hd; d++) dp += so[d] * Elem<T>::to_f(vr[d]);
+    ds[m] = dp;
+    t += dp * Prow[m];
+  }
+  t = ys_wave_sum(t);
+  float* dSrow = dS + ((long)bh * N + n) * N;
+  for (int m = lane; m < N; m += 64) { const float v = Prow[m] * (ds[m] - t); ds[m] = v; dSrow[m] = v; }
+  ys_wave_sync();
+  for (int d = lane; d < kd; d += 64) {
+    float acc = 0.f;
+    for (int m = 0; m < N; m++) acc += ds[m] * Elem<T>::to_f(base[(long)m * ldq + kd + d]);
+    dqkv[((long)b * N + n) * ldq + h * hs + d] = Elem<T>::from_f(acc * scale);
+  }
+}
+
+// pass 2 (per key column m): dk = scale * dS^T q ; dv = dO P  (added to the gradient that arrived through pe(v))
+template <class T>
+__global__ void __launch_bounds__(AD_THREADS)
+attn_bwd_kv_kernel(const T* __restrict__ qkv, int ldq, int B, int N, int heads, int kd, int hd, float scale,
+                   const T* __restrict__ dao, int ldo, const float* __restrict__ P, const float* __restrict__ dS,
+                   T* __restrict__ dqkv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (AD_THREADS / 64) + wave;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const int hs = 2 * kd + hd;
+  if (m >= N) return;
+  const T* base = qkv + (long)b * N * ldq + h * hs;
+  const float* Pc = P + (long)bh * N * N + m;
+  const float* Sc = dS + (long)bh * N * N + m;
+  for (int d = lane; d < kd; d += 64) {
+    float acc = 0.f;
+    for (int n = 0; n < N; n++) acc += Sc[(long)n * N] * Elem<T>::to_f(base[(long)n * ldq + d]);
+    dqkv[((long)b * N + m) * ldq + h * hs + kd + d] = Elem<T>::from_f(acc * scale);
+  }
+  for (int d = lane; d < hd; d += 64) {
+    float acc = 0.f;
+    for (int n = 0; n < N; n++) acc += Pc[(long)n * N] * Elem<T>::to_f(dao[((long)b * N + n) * ldo + h * hd + d]);
+    T* dst = dqkv + ((long)b * N + m) * ldq + h * hs + 2 * kd + d;
+    *dst = Elem<T>::from_f(acc + Elem<T>::to_f(*dst));
+  }
+}
+
+int ys_attn_fwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int B, int N, int heads, int kd, int hd,
+                       void* ao, int ldo, float* P) {
+  if (N > ATT_NMAX || kd > 128 || hd > 256) { ys_set_error("attention: N=%d kd=%d hd=%d outside the supported range", N, kd, hd); return YS_ERR_UNSUPPORTED; }
+  const float scale = 1.0f / sqrtf((float)kd);   // Math.Pow(key_dim, -0.5) (Block.cs:733)
+  dim3 grid(ys_cdiv(N, AD_THREADS / 64), B * heads);
+  if (dtype == YS_BF16) YS_LAUNCH((attn_fwd_kernel<bf16_t>), grid, AD_THREADS, st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (bf16_t*)ao, ldo, P);
+  else YS_LAUNCH((attn_fwd_kernel<float>), grid, AD_THREADS, st, (const float*)qkv, ldq, B, N, heads, kd, hd, scale, (float*)ao, ldo, P);
+  return YS_OK;
+}
+
+int ys_attn_bwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int B, int N, int heads, int kd, int hd,
+                       const void* dao, int ldo, const float* P, float* dS, void* dqkv) {
+  const float scale = 1.0f / sqrtf((float)kd);
+  dim3 grid(ys_cdiv(N, AD_THREADS / 64), B * heads);
+  if (dtype == YS_BF16) {
+    YS_LAUNCH((attn_bwd_q_kernel<bf16_t>), grid, AD_THREADS, st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (const bf16_t*)dao, ldo, P, dS, (bf16_t*)dqkv);
+    YS_LAUNCH((attn_bwd_kv_kernel<bf16_t>), grid, AD_THREADS, st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (const bf16_t*)dao, ldo, P, (const float*)dS, (bf16_t*)dqkv);
+  } else {
+    YS_LAUNCH((attn_bwd_q_kernel<float>), grid, AD_THREADS, st, (const float*)qkv, ldq, B, N, heads, kd, hd, scale, (const float*)dao, ldo, P, dS, (float*)dqkv);
+    YS_LAUNCH((attn_bwd_kv_kernel<float>), grid, AD_THREADS, st, (const float*)qkv, ldq, B, N, heads, kd, hd, scale, (const float*)dao, ldo, P, (const float*)dS, (float*)dqkv);
+  }
+  return YS_OK;
+}
+
+// v channels of qkv -> contiguous [B*N][C] (input of Attention.pe) and back (gradient of that view)
+template <class T>
+__global__ void __launch_bounds__(AD_THREADS)
+attn_v_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int ldq, int heads, int kd, int hd, int ldv, int to_qkv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = heads * hd;
+  if (i >= rows * C) return;
+  const long row = i / C;
+  const int c = (int)(i - row * C);
+  const int h = c / hd, d = c - h * hd;
+  const long qi = row * ldq + h * (2 * kd + hd) + 2 * kd + d;
+  if (to_qkv) dst[qi] = src[row * ldv + c];
+  else dst[row * ldv + c] = src[qi];
+}
+int ys_attn_v_copy_launch(hipStream_t st, int dtype, const void* src, void* dst, long rows, int ldq, int heads, int kd, int hd,
+                          int ldv, int to_qkv) {
+  const long n = rows * heads * hd;
+  if (dtype == YS_BF16) YS_LAUNCH((attn_v_copy_kernel<bf16_t>), ys_cdiv(n, AD_THREADS), AD_THREADS, st, (const bf16_t*)src, (bf16_t*)dst, rows, ldq, heads, kd, hd, ldv, to_qkv);
+  else YS_LAUNCH((attn_v_copy_kernel<float>), ys_cdiv(n, AD_THREADS), AD_THREADS, st, (const float*)src, (float*)dst, rows, ldq, heads, kd, hd, ldv, to_qkv);
+  return YS_OK;
+}

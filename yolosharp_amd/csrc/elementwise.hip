@@ -210,6 +210,9 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
           a1[e] += du;
           a2[e] += du * xh;
         }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { a1[e] += g[e]; a2[e] += g[e] * g[e]; }
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; e++) a1[e] += g[e];
@@ -251,6 +254,19 @@ int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ld
     YS_LAUNCH((chan_reduce_kernel<bf16_t, 0>), nb, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, act, (bf16_t*)res_grad, rg_ldc, rg_coff, partial, rows, rows);
   else
     YS_LAUNCH((chan_reduce_kernel<float, 0>), nb, EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, act, (float*)res_grad, rg_ldc, rg_coff, partial, rows, rows);
+  return YS_OK;
+}
+
+// per-channel (sum, sum of squares) partials of a dense [rows][C] tensor (BN statistics of depthwise conv outputs)
+int ys_chan_stats_launch(hipStream_t st, int dtype, const void* y, long rows, int C, float* partial, int* nblk_out) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (C % epl || C / epl > EW_THREADS) { ys_set_error("chan_stats: unsupported channel count %d", C); return YS_ERR_UNSUPPORTED; }
+  const int nb = reduce_blocks(rows, C, epl);
+  *nblk_out = nb;
+  if (dtype == YS_BF16)
+    YS_LAUNCH((chan_reduce_kernel<bf16_t, 2>), nb, EW_THREADS, st, (const bf16_t*)y, C, 0, (const bf16_t*)nullptr, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (bf16_t*)nullptr, 0, 0, partial, rows, rows);
+  else
+    YS_LAUNCH((chan_reduce_kernel<float, 2>), nb, EW_THREADS, st, (const float*)y, C, 0, (const float*)nullptr, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0, 0, partial, rows, rows);
   return YS_OK;
 }
 

@@ -45,10 +45,11 @@ struct ConvL {
   long ch_off = 0;                            // offset into per-channel scratch (scale.. c2), floats
   int seg = 0;
   bool first = false;
+  bool dw = false;       // depthwise 3x3 (groups = channels): weights [9][C] fp32, no MFMA path
 };
 
-enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2 };
-struct Op { int type; int conv = -1; View in, out; int H = 0, W = 0; long aux_off = 0; int seg = 0; };
+enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2, OP_ATTN = 3, OP_VCOPY = 4, OP_COPY = 5 };
+struct Op { int type; int conv = -1; View in, out; int H = 0, W = 0; long aux_off = 0; int seg = 0; int heads = 0, kd = 0, hd = 0; };
 
 struct TensorRec {
   std::string name;
@@ -75,6 +76,9 @@ struct ys_model {
   std::vector<ConvL> convs;
   std::vector<Op> ops;
   std::vector<TensorRec> tensors;
+  std::vector<int> reg;          // conv indices in the reference's module REGISTRATION order (state_dict order)
+  std::string head_prefix;       // "model.22" (v8) / "model.23" (v11)
+  float* attn_ws = nullptr; long n_attn = 0;   // softmax probabilities + dS of the C2PSA attention ops
   int in_buf = -1, pd_buf = -1, ps_buf = -1;
   int ld_pd = 0, ld_ps = 0;
   // flat fp32 parameter state
@@ -135,8 +139,8 @@ void add_tensor(ys_model* m, const std::string& name, int kind, int conv, long o
 
 // one Conv unit (conv+BN+act) or plain biased Conv2d; returns conv index and appends the op
 int add_conv(ys_model* m, const std::string& name, View in, View out, int cin, int cout, int k, int s, bool bn, bool act,
-             int Hin, int Win, int seg, const View* res = nullptr) {
-  ConvL c; c.name = name; c.in = in; c.out = out; c.cin = cin; c.cout = cout; c.k = k; c.s = s; c.bn = bn; c.act = act;
+             int Hin, int Win, int seg, const View* res = nullptr, bool dw = false) {
+  ConvL c; c.name = name; c.in = in; c.out = out; c.cin = cin; c.cout = cout; c.k = k; c.s = s; c.bn = bn; c.act = act; c.dw = dw;
   c.cin_pad = in.C; c.Hin = Hin; c.Win = Win;
   const int p = k / 2;
   c.Hout = (Hin + 2 * p - k) / s + 1; c.Wout = (Win + 2 * p - k) / s + 1;
@@ -153,18 +157,161 @@ int add_conv(ys_model* m, const std::string& name, View in, View out, int cin, i
 void add_c2f(ys_model* m, const std::string& name, View xin, View xout, int c1, int c2, int n, bool shortcut, int H, int W, int seg) {
   const int c = (int)(c2 * 0.5f);
   const int cat = new_buf(m, H, W, (2 + n) * c);
-  add_conv(m, name + ".cv1", xin, View{cat, 0, 2 * c}, c1, 2 * c, 1, 1, true, true, H, W, seg);
-  std::vector<std::pair<View, View>> bn_views;
-  // registration order in the reference: cv1, cv2, m.* -- ops must run m.* before cv2, names are independent
+  const int i1 = add_conv(m, name + ".cv1", xin, View{cat, 0, 2 * c}, c1, 2 * c, 1, 1, true, true, H, W, seg);
+  std::vector<int> mids;
   for (int i = 0; i < n; i++) {
     const View bin{cat, (1 + i) * c, c};
     const View bout{cat, (2 + i) * c, c};
     const int tmp = new_buf(m, H, W, c);
     const std::string bp = name + ".m." + std::to_string(i);
-    add_conv(m, bp + ".cv1", bin, View{tmp, 0, c}, c, c, 3, 1, true, true, H, W, seg);
-    add_conv(m, bp + ".cv2", View{tmp, 0, c}, bout, c, c, 3, 1, true, true, H, W, seg, shortcut ? &bin : nullptr);
+    mids.push_back(add_conv(m, bp + ".cv1", bin, View{tmp, 0, c}, c, c, 3, 1, true, true, H, W, seg));
+    mids.push_back(add_conv(m, bp + ".cv2", View{tmp, 0, c}, bout, c, c, 3, 1, true, true, H, W, seg, shortcut ? &bin : nullptr));
   }
-  add_conv(m, name + ".cv2", View{cat, 0, (2 + n) * c}, xout, (2 + n) * c, c2, 1, 1, true, true, H, W, seg);
+  const int i2 = add_conv(m, name + ".cv2", View{cat, 0, (2 + n) * c}, xout, (2 + n) * c, c2, 1, 1, true, true, H, W, seg);
+  m->reg.push_back(i1); m->reg.push_back(i2);            // registration order: cv1, cv2, m.* (Block.cs:373-376)
+  for (int i : mids) m->reg.push_back(i);
+}
+
+int add_conv_reg(ys_model* m, const std::string& name, View in, View out, int cin, int cout, int k, int s, bool bn, bool act,
+                 int Hin, int Win, int seg, const View* res = nullptr, bool dw = false) {
+  const int i = add_conv(m, name, in, out, cin, cout, k, s, bn, act, Hin, Win, seg, res, dw);
+  m->reg.push_back(i);
+  return i;
+}
+
+// Bottleneck (Block.cs:572-608) 3x3,3x3 with hidden = int(c*e); returns conv indices {cv1, cv2}
+std::pair<int, int> add_bottleneck(ys_model* m, const std::string& name, View in, View out, int c, float e, bool shortcut, int H, int W, int seg) {
+  const int c_ = (int)(c * e);
+  const int tmp = new_buf(m, H, W, c_);
+  const int a = add_conv(m, name + ".cv1", in, View{tmp, 0, c_}, c, c_, 3, 1, true, true, H, W, seg);
+  const int b = add_conv(m, name + ".cv2", View{tmp, 0, c_}, out, c_, c, 3, 1, true, true, H, W, seg, shortcut ? &in : nullptr);
+  return {a, b};
+}
+
+// C3k (Block.cs:611-620 over C3 :404-442): cv3(cat(m(cv1(x)), cv2(x))), m = n Bottlenecks(c_, c_, 3x3, e=1.0); registration
+// order cv1, cv2, cv3, m.* ; appends its conv indices (registration order) to `regs`
+void add_c3k(ys_model* m, const std::string& name, View in, View out, int c1, int c2, int n, bool shortcut, int H, int W, int seg,
+             std::vector<int>& regs) {
+  const int c_ = (int)(c2 * 0.5f);
+  const int cat = new_buf(m, H, W, 2 * c_);
+  int cur = new_buf(m, H, W, c_);
+  const int i1 = add_conv(m, name + ".cv1", in, View{cur, 0, c_}, c1, c_, 1, 1, true, true, H, W, seg);
+  std::vector<int> mids;
+  for (int i = 0; i < n; i++) {
+    const View bin{cur, 0, c_};
+    View bout;
+    if (i == n - 1) bout = View{cat, 0, c_};
+    else { cur = new_buf(m, H, W, c_); bout = View{cur, 0, c_}; }
+    auto pr = add_bottleneck(m, name + ".m." + std::to_string(i), bin, bout, c_, 1.0f, shortcut, H, W, seg);
+    mids.push_back(pr.first); mids.push_back(pr.second);
+  }
+  const int i2 = add_conv(m, name + ".cv2", in, View{cat, c_, c_}, c1, c_, 1, 1, true, true, H, W, seg);
+  const int i3 = add_conv(m, name + ".cv3", View{cat, 0, 2 * c_}, out, 2 * c_, c2, 1, 1, true, true, H, W, seg);
+  regs.push_back(i1); regs.push_back(i2); regs.push_back(i3);
+  for (int i : mids) regs.push_back(i);
+}
+
+// C3k2 (Block.cs:623-662): like C2f but m[i] = C3k(c,c,2) or Bottleneck(c,c,e=0.5); shortcut defaults to true
+void add_c3k2(ys_model* m, const std::string& name, View xin, View xout, int c1, int c2, int n, bool c3k, float e, int H, int W, int seg) {
+  const int c = (int)(c2 * e);
+  const int cat = new_buf(m, H, W, (2 + n) * c);
+  const int i1 = add_conv(m, name + ".cv1", xin, View{cat, 0, 2 * c}, c1, 2 * c, 1, 1, true, true, H, W, seg);
+  std::vector<int> mids;
+  for (int i = 0; i < n; i++) {
+    const View bin{cat, (1 + i) * c, c};
+    const View bout{cat, (2 + i) * c, c};
+    const std::string bp = name + ".m." + std::to_string(i);
+    if (c3k) add_c3k(m, bp, bin, bout, c, c, 2, true, H, W, seg, mids);
+    else { auto pr = add_bottleneck(m, bp, bin, bout, c, 0.5f, true, H, W, seg); mids.push_back(pr.first); mids.push_back(pr.second); }
+  }
+  const int i2 = add_conv(m, name + ".cv2", View{cat, 0, (2 + n) * c}, xout, (2 + n) * c, c2, 1, 1, true, true, H, W, seg);
+  m->reg.push_back(i1); m->reg.push_back(i2);
+  for (int i : mids) m->reg.push_back(i);
+}
+
+// C2PSA (Block.cs:664-810).  Reference quirks kept: qkv / proj / pe and both ffn convs all use the default SiLU.
+void add_c2psa(ys_model* m, const std::string& name, View xin, View xout, int c1, int n, int H, int W, int seg) {
+  const int c = (int)(c1 * 0.5f);
+  const int cat = new_buf(m, H, W, 2 * c);       // cv1 output: a | b
+  const int cat2 = new_buf(m, H, W, 2 * c);      // cv2 input:  a | b_final
+  const int i1 = add_conv(m, name + ".cv1", xin, View{cat, 0, 2 * c}, c1, 2 * c, 1, 1, true, true, H, W, seg);
+  { Op op; op.type = OP_COPY; op.in = View{cat, 0, c}; op.out = View{cat2, 0, c}; op.H = H; op.W = W; op.seg = seg; m->ops.push_back(op); }
+  std::vector<int> mids;
+  View bcur{cat, c, c};
+  const int heads = c / 64, hd = c / heads, kd = (int)(hd * 0.5f);
+  const int hq = c + 2 * kd * heads;
+  for (int i = 0; i < n; i++) {
+    const std::string bp = name + ".m." + std::to_string(i);
+    const int qb = new_buf(m, H, W, hq), ao = new_buf(m, H, W, c), vb = new_buf(m, H, W, c), sb = new_buf(m, H, W, c);
+    const int b1 = new_buf(m, H, W, c), f1 = new_buf(m, H, W, 2 * c);
+    const int iq = add_conv(m, bp + ".attn.qkv", bcur, View{qb, 0, hq}, c, hq, 1, 1, true, true, H, W, seg);
+    { Op op; op.type = OP_ATTN; op.in = View{qb, 0, hq}; op.out = View{ao, 0, c}; op.H = H; op.W = W; op.seg = seg; op.heads = heads; op.kd = kd; op.hd = hd; m->ops.push_back(op); }
+    { Op op; op.type = OP_VCOPY; op.in = View{qb, 0, hq}; op.out = View{vb, 0, c}; op.H = H; op.W = W; op.seg = seg; op.heads = heads; op.kd = kd; op.hd = hd; m->ops.push_back(op); }
+    const View aov{ao, 0, c};
+    const int ipe = add_conv(m, bp + ".attn.pe", View{vb, 0, c}, View{sb, 0, c}, c, c, 3, 1, true, true, H, W, seg, &aov, true);
+    const int ipr = add_conv(m, bp + ".attn.proj", View{sb, 0, c}, View{b1, 0, c}, c, c, 1, 1, true, true, H, W, seg, &bcur);
+    const int if0 = add_conv(m, bp + ".ffn.0", View{b1, 0, c}, View{f1, 0, 2 * c}, c, 2 * c, 1, 1, true, true, H, W, seg);
+    const View b1v{b1, 0, c};
+    View bnext;
+    if (i == n - 1) bnext = View{cat2, c, c};
+    else { const int nb = new_buf(m, H, W, c); bnext = View{nb, 0, c}; }
+    const int if1 = add_conv(m, bp + ".ffn.1", View{f1, 0, 2 * c}, bnext, 2 * c, c, 1, 1, true, true, H, W, seg, &b1v);
+    mids.push_back(iq); mids.push_back(ipr); mids.push_back(ipe); mids.push_back(if0); mids.push_back(if1);   // qkv, proj, pe (Block.cs:744-746)
+    bcur = bnext;
+  }
+  const int i2 = add_conv(m, name + ".cv2", View{cat2, 0, 2 * c}, xout, 2 * c, c1, 1, 1, true, true, H, W, seg);
+  m->reg.push_back(i1); m->reg.push_back(i2);
+  for (int i : mids) m->reg.push_back(i);
+}
+
+void add_sppf(ys_model* m, const std::string& name, View xin, View xout, int c1, int H, int W, int seg) {
+  // SPPF (Block.cs:236-285): cv1 has NO activation (:257); three chained 5x5 pools
+  const int c_ = c1 / 2;
+  const int catS = new_buf(m, H, W, 4 * c_);
+  add_conv_reg(m, name + ".cv1", xin, View{catS, 0, c_}, c1, c_, 1, 1, true, false, H, W, seg);
+  for (int i = 0; i < 3; i++) {
+    Op op; op.type = OP_MAXPOOL; op.in = View{catS, i * c_, c_}; op.out = View{catS, (i + 1) * c_, c_}; op.H = H; op.W = W; op.seg = seg;
+    m->ops.push_back(op);
+  }
+  add_conv_reg(m, name + ".cv2", View{catS, 0, 4 * c_}, xout, 4 * c_, c1, 1, 1, true, true, H, W, seg);
+}
+
+// Detect (Head.cs:35-53): c2 = max(16, ch0/4, 4*reg_max), c3 = max(ch0, min(nc,100)); strides fixed {8,16,32} (:43).
+// legacy=false (v11, Head.cs:50): each 3x3 Conv of the cls tower becomes DWConv3x3(x->x) + Conv1x1(x->c3).
+int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch, const int* hh, const int* ww, bool legacy, int seg) {
+  const ys_model_desc& d = m->d;
+  const int c2 = std::max(16, std::max(ch[0] / 4, d.reg_max * 4));
+  const int c3 = std::max(ch[0], std::min(d.nc, 100));
+  if (c2 % m->epl || c3 % m->epl) { ys_set_error("model: head widths c2=%d c3=%d must be multiples of %d", c2, c3, m->epl); return YS_ERR_UNSUPPORTED; }
+  m->head_prefix = hp;
+  m->nl = 3; m->A = 0;
+  for (int i = 0; i < 3; i++) { m->lvl_off[i] = m->A; m->lvl_w[i] = ww[i]; m->lvl_h[i] = hh[i]; m->A += hh[i] * ww[i]; }
+  m->ld_pd = (4 * d.reg_max + m->epl - 1) / m->epl * m->epl;
+  m->ld_ps = (d.nc + m->epl - 1) / m->epl * m->epl;
+  m->pd_buf = new_buf(m, 1, m->A, m->ld_pd);
+  m->ps_buf = new_buf(m, 1, m->A, m->ld_ps);
+  for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
+    for (int i = 0; i < 3; i++) {
+      const int cm = t == 0 ? c2 : c3;
+      const int co = t == 0 ? 4 * d.reg_max : d.nc;
+      const int ob = t == 0 ? m->pd_buf : m->ps_buf;
+      const std::string tp = hp + (t == 0 ? ".cv2." : ".cv3.") + std::to_string(i);
+      const int t0 = new_buf(m, hh[i], ww[i], cm), t1 = new_buf(m, hh[i], ww[i], cm);
+      if (t == 0 || legacy) {
+        add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 3, 1, true, true, hh[i], ww[i], seg);
+        add_conv_reg(m, tp + ".1", View{t0, 0, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg);
+      } else {
+        const int d0 = new_buf(m, hh[i], ww[i], ch[i]), d1 = new_buf(m, hh[i], ww[i], cm);
+        add_conv_reg(m, tp + ".0.0", View{pv[i], 0, ch[i]}, View{d0, 0, ch[i]}, ch[i], ch[i], 3, 1, true, true, hh[i], ww[i], seg, nullptr, true);
+        add_conv_reg(m, tp + ".0.1", View{d0, 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 1, 1, true, true, hh[i], ww[i], seg);
+        add_conv_reg(m, tp + ".1.0", View{t0, 0, cm}, View{d1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg, nullptr, true);
+        add_conv_reg(m, tp + ".1.1", View{d1, 0, cm}, View{t1, 0, cm}, cm, cm, 1, 1, true, true, hh[i], ww[i], seg);
+      }
+      const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, cm}, View{ob, 0, co}, cm, co, 1, 1, false, false, hh[i], ww[i], seg);
+      m->convs[cc].out_rowoff = m->lvl_off[i];
+    }
+  }
+  return YS_OK;
 }
 
 int build_v8_detect(ys_model* m) {
@@ -195,63 +342,86 @@ int build_v8_detect(ys_model* m) {
   const View v4{cat14, w[3], w[2]}, v6{cat11, w[4], w[3]}, v9{cat20, w[3], w[4]}, v12{cat17, w[2], w[3]};
   const int SB = 2, SN = 1, SH = 0;  // backward segments: head first, stem last
 
-  int ci = add_conv(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SB);
+  int ci = add_conv_reg(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SB);
   m->convs[ci].first = true;
-  add_conv(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SB);
+  add_conv_reg(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SB);
   add_c2f(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[1]}, w[1], w[1], dep[0], true, H4, W4, SB);
-  add_conv(m, "model.3", View{b2, 0, w[1]}, View{b3, 0, w[2]}, w[1], w[2], 3, 2, true, true, H4, W4, SB);
+  add_conv_reg(m, "model.3", View{b2, 0, w[1]}, View{b3, 0, w[2]}, w[1], w[2], 3, 2, true, true, H4, W4, SB);
   add_c2f(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[2], dep[1], true, H8, W8, SB);
-  add_conv(m, "model.5", v4, View{b5, 0, w[3]}, w[2], w[3], 3, 2, true, true, H8, W8, SB);
+  add_conv_reg(m, "model.5", v4, View{b5, 0, w[3]}, w[2], w[3], 3, 2, true, true, H8, W8, SB);
   add_c2f(m, "model.6", View{b5, 0, w[3]}, v6, w[3], w[3], dep[1], true, H16, W16, SB);
-  add_conv(m, "model.7", v6, View{b7, 0, w[4]}, w[3], w[4], 3, 2, true, true, H16, W16, SB);
+  add_conv_reg(m, "model.7", v6, View{b7, 0, w[4]}, w[3], w[4], 3, 2, true, true, H16, W16, SB);
   add_c2f(m, "model.8", View{b7, 0, w[4]}, View{b8, 0, w[4]}, w[4], w[4], dep[0], true, H32, W32, SB);
-  {  // SPPF (Block.cs:236-285): cv1 has NO activation (:257); three chained 5x5 pools
-    const int c_ = w[4] / 2;
-    const int catS = new_buf(m, H32, W32, 4 * c_);
-    add_conv(m, "model.9.cv1", View{b8, 0, w[4]}, View{catS, 0, c_}, w[4], c_, 1, 1, true, false, H32, W32, SB);
-    for (int i = 0; i < 3; i++) {
-      Op op; op.type = OP_MAXPOOL; op.in = View{catS, i * c_, c_}; op.out = View{catS, (i + 1) * c_, c_}; op.H = H32; op.W = W32; op.seg = SB;
-      m->ops.push_back(op);
-    }
-    add_conv(m, "model.9.cv2", View{catS, 0, 4 * c_}, v9, 4 * c_, w[4], 1, 1, true, true, H32, W32, SB);
-  }
+  add_sppf(m, "model.9", View{b8, 0, w[4]}, v9, w[4], H32, W32, SB);
   { Op op; op.type = OP_UPSAMPLE; op.in = v9; op.out = View{cat11, 0, w[4]}; op.H = H32; op.W = W32; op.seg = SN; m->ops.push_back(op); }
   add_c2f(m, "model.12", View{cat11, 0, w[4] + w[3]}, v12, w[4] + w[3], w[3], dep[0], false, H16, W16, SN);
   { Op op; op.type = OP_UPSAMPLE; op.in = v12; op.out = View{cat14, 0, w[3]}; op.H = H16; op.W = W16; op.seg = SN; m->ops.push_back(op); }
   add_c2f(m, "model.15", View{cat14, 0, w[3] + w[2]}, View{b15, 0, w[2]}, w[3] + w[2], w[2], dep[0], false, H8, W8, SN);
-  add_conv(m, "model.16", View{b15, 0, w[2]}, View{cat17, 0, w[2]}, w[2], w[2], 3, 2, true, true, H8, W8, SN);
+  add_conv_reg(m, "model.16", View{b15, 0, w[2]}, View{cat17, 0, w[2]}, w[2], w[2], 3, 2, true, true, H8, W8, SN);
   add_c2f(m, "model.18", View{cat17, 0, w[2] + w[3]}, View{b18, 0, w[3]}, w[2] + w[3], w[3], dep[0], false, H16, W16, SN);
-  add_conv(m, "model.19", View{b18, 0, w[3]}, View{cat20, 0, w[3]}, w[3], w[3], 3, 2, true, true, H16, W16, SN);
+  add_conv_reg(m, "model.19", View{b18, 0, w[3]}, View{cat20, 0, w[3]}, w[3], w[3], 3, 2, true, true, H16, W16, SN);
   add_c2f(m, "model.21", View{cat20, 0, w[3] + w[4]}, View{b21, 0, w[4]}, w[3] + w[4], w[4], dep[0], false, H32, W32, SN);
-
-  // Detect (Head.cs:35-53): c2 = max(16, ch0/4, 4*reg_max), c3 = max(ch0, min(nc,100)); strides fixed {8,16,32} (:43)
   const int ch[3] = {w[2], w[3], w[4]};
   const int hh[3] = {H8, H16, H32}, ww[3] = {W8, W16, W32};
   const int pv[3] = {b15, b18, b21};
-  const int c2 = std::max(16, std::max(ch[0] / 4, d.reg_max * 4));
-  const int c3 = std::max(ch[0], std::min(d.nc, 100));
-  if (c2 % m->epl || c3 % m->epl) { ys_set_error("model: head widths c2=%d c3=%d must be multiples of %d", c2, c3, m->epl); return YS_ERR_UNSUPPORTED; }
-  m->nl = 3; m->A = 0;
-  for (int i = 0; i < 3; i++) { m->lvl_off[i] = m->A; m->lvl_w[i] = ww[i]; m->lvl_h[i] = hh[i]; m->A += hh[i] * ww[i]; }
-  m->ld_pd = (4 * d.reg_max + m->epl - 1) / m->epl * m->epl;
-  m->ld_ps = (d.nc + m->epl - 1) / m->epl * m->epl;
-  m->pd_buf = new_buf(m, 1, m->A, m->ld_pd);
-  m->ps_buf = new_buf(m, 1, m->A, m->ld_ps);
-  const std::string hp = "model.22";
-  for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
-    for (int i = 0; i < 3; i++) {
-      const int cm = t == 0 ? c2 : c3;
-      const int co = t == 0 ? 4 * d.reg_max : d.nc;
-      const int ob = t == 0 ? m->pd_buf : m->ps_buf;
-      const std::string tp = hp + (t == 0 ? ".cv2." : ".cv3.") + std::to_string(i);
-      const int t0 = new_buf(m, hh[i], ww[i], cm), t1 = new_buf(m, hh[i], ww[i], cm);
-      add_conv(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 3, 1, true, true, hh[i], ww[i], SH);
-      add_conv(m, tp + ".1", View{t0, 0, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], SH);
-      const int cc = add_conv(m, tp + ".2", View{t1, 0, cm}, View{ob, 0, co}, cm, co, 1, 1, false, false, hh[i], ww[i], SH);
-      m->convs[cc].out_rowoff = m->lvl_off[i];
-    }
+  return add_detect(m, "model.22", pv, ch, hh, ww, true, SH);
+}
+
+// Yolov11 detect (Yolo.cs:200-258): C3k2 backbone/neck (shortcut=true everywhere: C3k2's default), SPPF, C2PSA, Detect(legacy=false)
+int build_v11_detect(ys_model* m) {
+  const ys_model_desc& d = m->d;
+  static const float dm[5] = {0.5f, 0.5f, 0.5f, 1.0f, 1.0f};
+  static const float wm[5] = {0.25f, 0.5f, 1.0f, 1.0f, 1.5f};
+  static const int mc[5] = {1024, 1024, 512, 512, 768};
+  static const bool c3k_sz[5] = {false, false, true, true, true};
+  const int base_w[5] = {64, 128, 256, 512, 1024};
+  int w[5];
+  for (int i = 0; i < 5; i++) w[i] = std::min((int)(base_w[i] * wm[d.size]), mc[d.size]);
+  const int n = (int)(2 * dm[d.size]);
+  const bool uc = c3k_sz[d.size];
+  const int H = d.height, W = d.width;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
+  if (((int)(w[2] * 0.25f) / 2) % m->epl) {
+    ys_set_error("model: YOLOv11 size %d needs hidden widths that are multiples of %d (use the f32 model for n)", d.size, m->epl);
+    return YS_ERR_UNSUPPORTED;
   }
-  return YS_OK;
+  if ((w[4] / 2) % 64) { ys_set_error("model: C2PSA needs c %% 64 == 0"); return YS_ERR_UNSUPPORTED; }
+  m->in_buf = new_buf(m, H, W, m->epl);
+  m->bufs[m->in_buf].need_grad = false;
+  const int cat12 = new_buf(m, H16, W16, w[4] + w[3]);   // [up(L10) | L6]
+  const int cat15 = new_buf(m, H8, W8, w[3] + w[3]);     // [up(L13) | L4]
+  const int cat18 = new_buf(m, H16, W16, w[2] + w[3]);   // [L17 | L13]
+  const int cat21 = new_buf(m, H32, W32, w[3] + w[4]);   // [L20 | L10]
+  const int b0 = new_buf(m, H2, W2, w[0]), b1 = new_buf(m, H4, W4, w[1]), b2 = new_buf(m, H4, W4, w[2]);
+  const int b3 = new_buf(m, H8, W8, w[2]), b5 = new_buf(m, H16, W16, w[3]), b7 = new_buf(m, H32, W32, w[4]);
+  const int b8 = new_buf(m, H32, W32, w[4]), b9 = new_buf(m, H32, W32, w[4]);
+  const int b16 = new_buf(m, H8, W8, w[2]), b19 = new_buf(m, H16, W16, w[3]), b22 = new_buf(m, H32, W32, w[4]);
+  const View v4{cat15, w[3], w[3]}, v6{cat12, w[4], w[3]}, v10{cat21, w[3], w[4]}, v13{cat18, w[2], w[3]};
+  const int SB = 2, SN = 1, SH = 0;
+  int ci = add_conv_reg(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SB);
+  m->convs[ci].first = true;
+  add_conv_reg(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SB);
+  add_c3k2(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[2]}, w[1], w[2], n, uc, 0.25f, H4, W4, SB);
+  add_conv_reg(m, "model.3", View{b2, 0, w[2]}, View{b3, 0, w[2]}, w[2], w[2], 3, 2, true, true, H4, W4, SB);
+  add_c3k2(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[3], n, uc, 0.25f, H8, W8, SB);
+  add_conv_reg(m, "model.5", v4, View{b5, 0, w[3]}, w[3], w[3], 3, 2, true, true, H8, W8, SB);
+  add_c3k2(m, "model.6", View{b5, 0, w[3]}, v6, w[3], w[3], n, true, 0.5f, H16, W16, SB);
+  add_conv_reg(m, "model.7", v6, View{b7, 0, w[4]}, w[3], w[4], 3, 2, true, true, H16, W16, SB);
+  add_c3k2(m, "model.8", View{b7, 0, w[4]}, View{b8, 0, w[4]}, w[4], w[4], n, true, 0.5f, H32, W32, SB);
+  add_sppf(m, "model.9", View{b8, 0, w[4]}, View{b9, 0, w[4]}, w[4], H32, W32, SB);
+  add_c2psa(m, "model.10", View{b9, 0, w[4]}, v10, w[4], n, H32, W32, SB);
+  { Op op; op.type = OP_UPSAMPLE; op.in = v10; op.out = View{cat12, 0, w[4]}; op.H = H32; op.W = W32; op.seg = SN; m->ops.push_back(op); }
+  add_c3k2(m, "model.13", View{cat12, 0, w[4] + w[3]}, v13, w[4] + w[3], w[3], n, uc, 0.5f, H16, W16, SN);
+  { Op op; op.type = OP_UPSAMPLE; op.in = v13; op.out = View{cat15, 0, w[3]}; op.H = H16; op.W = W16; op.seg = SN; m->ops.push_back(op); }
+  add_c3k2(m, "model.16", View{cat15, 0, w[3] + w[3]}, View{b16, 0, w[2]}, w[3] + w[3], w[2], n, uc, 0.5f, H8, W8, SN);
+  add_conv_reg(m, "model.17", View{b16, 0, w[2]}, View{cat18, 0, w[2]}, w[2], w[2], 3, 2, true, true, H8, W8, SN);
+  add_c3k2(m, "model.19", View{cat18, 0, w[2] + w[3]}, View{b19, 0, w[3]}, w[2] + w[3], w[3], n, uc, 0.5f, H16, W16, SN);
+  add_conv_reg(m, "model.20", View{b19, 0, w[3]}, View{cat21, 0, w[3]}, w[3], w[3], 3, 2, true, true, H16, W16, SN);
+  add_c3k2(m, "model.22", View{cat21, 0, w[3] + w[4]}, View{b22, 0, w[4]}, w[3] + w[4], w[4], n, true, 0.5f, H32, W32, SN);
+  const int ch[3] = {w[2], w[3], w[4]};
+  const int hh[3] = {H8, H16, H32}, ww[3] = {W8, W16, W32};
+  const int pv[3] = {b16, b19, b22};
+  return add_detect(m, "model.23", pv, ch, hh, ww, false, SH);
 }
 
 // ---- parameter layout: [segment][group] contiguous ranges; group rule of YoloBaseTaskModel.cs:144-151 made disjoint:
@@ -264,7 +434,7 @@ int layout_params(ys_model* m) {
       for (auto& c : m->convs) {
         if (c.seg != seg) continue;
         if (grp == 0) { if (c.bn) { c.b_off = off; off += c.cout; } else { c.g_off = off; off += c.cout; } }   // bn.bias | conv bias (stored in g_off for plain convs)
-        if (grp == 1) { c.w_off = off; off += (long)c.cout * c.k * c.k * c.cin; }
+        if (grp == 1) { c.w_off = off; off += c.dw ? (long)c.cout * 9 : (long)c.cout * c.k * c.k * c.cin; }
         if (grp == 2 && c.bn) { c.g_off = off; off += c.cout; }
       }
       m->seg_group[seg][grp] = {start, off - start};
@@ -274,34 +444,16 @@ int layout_params(ys_model* m) {
   for (auto& c : m->convs)
     if (c.bn) { c.rm_off = so; so += c.cout; c.rv_off = so; so += c.cout; c.nbt_off = so; so += 1; }
   m->n_state = so;
-  // state_dict listing: parameters in module order, then buffers (TorchSharp named_parameters + named_buffers)
-  // module order = reference registration order: C2f registers cv1, cv2, m.* (Block.cs:373-376)
-  std::vector<int> order(m->convs.size());
-  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-  auto key = [&](int i) {
-    // sort key reproducing registration order: split name into numeric-aware tokens, "cv1" < "cv2" < "m"
-    return m->convs[i].name;
-  };
-  (void)key;
-  // ops were appended as cv1, m.*, cv2 inside each C2f: move each C2f's cv2 right after its cv1
-  std::vector<int> reg;
-  for (size_t i = 0; i < m->convs.size(); i++) {
-    const std::string& n = m->convs[i].name;
-    const bool is_c2f_cv1 = n.size() > 4 && n.compare(n.size() - 4, 4, ".cv1") == 0 && n.find(".m.") == std::string::npos && n.find("model.9") != 0;
-    reg.push_back((int)i);
-    if (is_c2f_cv1) {
-      const std::string pre = n.substr(0, n.size() - 4);
-      for (size_t j = i + 1; j < m->convs.size(); j++)
-        if (m->convs[j].name == pre + ".cv2") { reg.push_back((int)j); break; }
-    }
-  }
+  // state_dict listing: parameters in module REGISTRATION order, then buffers (TorchSharp named_parameters + named_buffers)
   std::vector<int> reg2;
   std::vector<char> seen(m->convs.size(), 0);
-  for (int i : reg) if (!seen[i]) { seen[i] = 1; reg2.push_back(i); }
+  for (int i : m->reg) if (!seen[i]) { seen[i] = 1; reg2.push_back(i); }
+  if (reg2.size() != m->convs.size()) { ys_set_error("internal: registration list covers %zu of %zu convs", reg2.size(), m->convs.size()); return YS_ERR_STATE; }
   for (int i : reg2) {
     const ConvL& c = m->convs[i];
     if (c.bn) {
-      add_tensor(m, c.name + ".conv.weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
+      if (c.dw) add_tensor(m, c.name + ".conv.weight", 4, i, c.w_off, {c.cout, 1, 3, 3}, true);
+      else add_tensor(m, c.name + ".conv.weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
       add_tensor(m, c.name + ".bn.weight", 1, i, c.g_off, {c.cout}, true);
       add_tensor(m, c.name + ".bn.bias", 1, i, c.b_off, {c.cout}, true);
     } else {
@@ -309,7 +461,7 @@ int layout_params(ys_model* m) {
       add_tensor(m, c.name + ".bias", 1, i, c.g_off, {c.cout}, true);
     }
   }
-  add_tensor(m, "model.22.dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
+  add_tensor(m, m->head_prefix + ".dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
   for (int i : reg2) {
     const ConvL& c = m->convs[i];
     if (!c.bn) continue;
@@ -384,6 +536,15 @@ int allocate(ys_model* m) {
   std::vector<PrepDesc> pd;
   for (auto& c : m->convs) {
     const int taps = c.k * c.k;
+    if (c.dw) {   // depthwise: fp32 master weights are used directly
+      const long M = (long)B * c.Hout * c.Wout;
+      c.y_off = ny; ny += M * c.cout;
+      c.ch_off = nch; nch += 6L * ((c.cout + 3) / 4 * 4);
+      dy_max = std::max(dy_max, M * c.cout_ld);
+      stat_max = std::max(stat_max, 2048L * 2 * c.cout_ld);
+      stat_max = std::max(stat_max, 256L * 9 * c.cout);
+      continue;
+    }
     c.wf_off = nf; nf += (long)c.cout * taps * c.cin_pad;
     c.wd_off = nd;
     PrepDesc d{}; d.w_off = c.w_off; d.wf_off = c.wf_off; d.wd_off = c.wd_off; d.cout = c.cout; d.taps = taps;
@@ -399,6 +560,10 @@ int allocate(ys_model* m) {
     stat_max = std::max(stat_max, 2048L * 2 * c.cout_ld);   // channel-reduction partials (<= 2048 workgroups)
   }
   for (auto& op : m->ops) if (op.type == OP_MAXPOOL) { op.aux_off = amax; amax += (long)B * op.H * op.W * op.in.C; }
+  long nattn = 0;
+  for (auto& op : m->ops) if (op.type == OP_ATTN) { op.aux_off = nattn; nattn += 2L * B * op.heads * (long)(op.H * op.W) * (op.H * op.W); }
+  m->n_attn = nattn;
+  YS_TRY(dev_alloc(m, (void**)&m->attn_ws, (size_t)nattn * 4));
   m->n_wf = nf; m->n_wd = nd; m->n_y = ny; m->n_chan = nch; m->n_dy = dy_max; m->n_stat = stat_max; m->n_argmax = amax;
   m->prep_nf = nf; m->prep_nd = nd; m->n_prep = (int)pd.size();
   YS_TRY(dev_alloc(m, &m->wf_all, (size_t)nf * m->es));
@@ -414,6 +579,7 @@ int allocate(ys_model* m) {
   // wgrad partial workspace: max over layers of splits * |W|
   long wgp = 0;
   for (auto& c : m->convs) {
+    if (c.dw) continue;
     WgradArgs a{}; a.Cin = c.cin_pad; a.Cout = c.cout; a.KH = a.KW = c.k; a.M = (int)((long)B * c.Hout * c.Wout);
     wgp = std::max(wgp, (long)ys_wgrad_splits(a, m->dtype) * c.cout * c.k * c.k * c.cin_pad);
   }
@@ -448,7 +614,30 @@ int allocate(ys_model* m) {
 }
 
 // ------------------------------------------------------------------ forward
+// depthwise Conv unit: y = dwconv(x) (dense), then BN statistics / apply exactly like the dense path
+int run_dwconv_fwd(ys_model* m, const ConvL& c, int B) {
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[c.in.buf];
+  const Buf& ob = m->bufs[c.out.buf];
+  const long M = (long)B * c.Hout * c.Wout;
+  void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
+  YS_TRY(ys_dwconv_launch(st, m->dtype, 0, ib.act, ib.ldc, c.in.coff, B, c.Hin, c.Win, c.cout, m->params + c.w_off, y, c.cout, 0, 0));
+  if (m->training) {
+    int nblk = 0;
+    YS_TRY(ys_chan_stats_launch(st, m->dtype, y, M, c.cout, m->stat_partial, &nblk));
+    YS_TRY(ys_bn_finalize_launch(st, m->stat_partial, nblk, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
+                                 m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
+                                 chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
+  }
+  const void* res = nullptr; int rl = 0, rc = 0;
+  if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
+  YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, res, rl, rc,
+                                ob.act, ob.ldc, c.out.coff));
+  return YS_OK;
+}
+
 int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
+  if (c.dw) return run_dwconv_fwd(m, c, B);
   hipStream_t st = m->ctx->stream;
   const Buf& ib = m->bufs[c.in.buf];
   const Buf& ob = m->bufs[c.out.buf];
@@ -504,8 +693,14 @@ int forward_impl(ys_model* m, int B) {
     } else if (op.type == OP_MAXPOOL) {
       YS_TRY(ys_maxpool5_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc,
                                     op.out.coff, m->training ? m->argmax + op.aux_off : nullptr));
-    } else {
+    } else if (op.type == OP_UPSAMPLE) {
       YS_TRY(ys_upsample2x_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc, op.out.coff));
+    } else if (op.type == OP_ATTN) {
+      YS_TRY(ys_attn_fwd_launch(st, m->dtype, ib.act, ib.ldc, B, op.H * op.W, op.heads, op.kd, op.hd, ob.act, ob.ldc, m->attn_ws + op.aux_off));
+    } else if (op.type == OP_VCOPY) {
+      YS_TRY(ys_attn_v_copy_launch(st, m->dtype, ib.act, ob.act, (long)B * op.H * op.W, ib.ldc, op.heads, op.kd, op.hd, ob.ldc, 0));
+    } else if (op.type == OP_COPY) {
+      YS_TRY(ys_copy_view_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, (long)B * op.H * op.W, op.in.C, ob.act, ob.ldc, op.out.coff, 0));
     }
   }
   if (!m->training) {
@@ -537,10 +732,15 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
     const void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     void* rg = nullptr; int rgl = 0, rgc = 0;
     if (c.has_res) {
+      // d(residual input) += dz.  First contribution to that view: plain copy; later ones accumulate inside the reduce pass.
       Buf& rb = m->bufs[c.res.buf];
-      for (int ch = c.res.coff; ch < c.res.coff + c.res.C; ch++)
-        if (!rb.gw[ch]) { ys_set_error("backward: residual gradient of %s not initialised", c.name.c_str()); return YS_ERR_STATE; }
-      rg = rb.grad; rgl = rb.ldc; rgc = c.res.coff;
+      const int rmode = grad_mode(m, c.res);
+      if (rmode < 0) { ys_set_error("backward: inconsistent residual gradient state at %s", c.name.c_str()); return YS_ERR_STATE; }
+      if (rmode == 0) {
+        YS_TRY(ys_copy_view_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, M, c.cout, rb.grad, rb.ldc, c.res.coff, 0));
+      } else {
+        rg = rb.grad; rgl = rb.ldc; rgc = c.res.coff;
+      }
     }
     int nblk = 0;
     YS_TRY(ys_bn_bwd_reduce_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
@@ -555,6 +755,13 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
     dy = view_ptr(m, ob.grad, ob, c.out_rowoff); dy_ldc = ob.ldc; dy_coff = c.out.coff; dy_bstride = ob.rows_per_b;
     YS_TRY(ys_colsum_launch(st, m->dtype, dy, dy_ldc, dy_coff, M, (long)c.Hout * c.Wout, dy_bstride, c.cout, m->stat_partial,
                             m->grads + c.g_off));
+  }
+  if (c.dw) {
+    YS_TRY(ys_dwconv_wgrad_launch(st, m->dtype, ib.act, ib.ldc, c.in.coff, dy, B, c.Hin, c.Win, c.cout, m->stat_partial, m->grads + c.w_off));
+    const int mode = grad_mode(m, c.in);
+    if (mode < 0) { ys_set_error("backward: inconsistent gradient slice state at %s", c.name.c_str()); return YS_ERR_STATE; }
+    YS_TRY(ys_dwconv_launch(st, m->dtype, 1, dy, c.cout, 0, B, c.Hin, c.Win, c.cout, m->params + c.w_off, ib.grad, ib.ldc, c.in.coff, mode));
+    return YS_OK;
   }
   // ---- wgrad
   {
@@ -596,6 +803,25 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
     if (op.seg < seg_lo || op.seg > seg_hi) continue;
     if (op.type == OP_CONV) {
       YS_TRY(run_conv_bwd(m, m->convs[op.conv], B));
+    } else if (op.type == OP_ATTN) {
+      // d(qkv) = [dq | dk | dv]; the v part already holds the gradient that arrived through pe(v) (OP_VCOPY backward)
+      const Buf& ib = m->bufs[op.in.buf];
+      const Buf& ob = m->bufs[op.out.buf];
+      const long nn = (long)B * op.heads * (long)(op.H * op.W) * (op.H * op.W);
+      YS_TRY(ys_attn_bwd_launch(st, m->dtype, ib.act, ib.ldc, B, op.H * op.W, op.heads, op.kd, op.hd, ob.grad, ob.ldc,
+                                m->attn_ws + op.aux_off, m->attn_ws + op.aux_off + nn, ib.grad));
+      Buf& qb = m->bufs[op.in.buf];
+      std::fill(qb.gw.begin(), qb.gw.end(), 1);
+    } else if (op.type == OP_VCOPY) {
+      const Buf& ib = m->bufs[op.in.buf];
+      const Buf& ob = m->bufs[op.out.buf];
+      YS_TRY(ys_attn_v_copy_launch(st, m->dtype, ob.grad, ib.grad, (long)B * op.H * op.W, ib.ldc, op.heads, op.kd, op.hd, ob.ldc, 1));
+    } else if (op.type == OP_COPY) {
+      const Buf& ib = m->bufs[op.in.buf];
+      const Buf& ob = m->bufs[op.out.buf];
+      const int mode = grad_mode(m, op.in);
+      if (mode < 0) { ys_set_error("backward: inconsistent gradient slice state at op %d", i); return YS_ERR_STATE; }
+      YS_TRY(ys_copy_view_launch(st, m->dtype, ob.grad, ob.ldc, op.out.coff, (long)B * op.H * op.W, op.in.C, ib.grad, ib.ldc, op.in.coff, mode));
     } else {
       const Buf& ib = m->bufs[op.in.buf];
       const Buf& ob = m->bufs[op.out.buf];
@@ -639,8 +865,8 @@ extern "C" {
 int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
   YS_REQUIRE(ctx && desc && out, "ys_model_create: null argument");
   YS_REQUIRE(desc->dtype == YS_F32 || desc->dtype == YS_BF16, "ys_model_create: dtype %d unsupported", desc->dtype);
-  if (desc->family != YS_YOLOV8 || desc->task != YS_DETECT) {
-    ys_set_error("ys_model_create: only YOLOv8 detect is built in this round (family %d task %d)", desc->family, desc->task);
+  if ((desc->family != YS_YOLOV8 && desc->family != YS_YOLOV11) || desc->task != YS_DETECT) {
+    ys_set_error("ys_model_create: YOLOv8 / YOLOv11 detect are built in this round (family %d task %d)", desc->family, desc->task);
     return YS_ERR_UNSUPPORTED;
   }
   YS_REQUIRE(desc->size >= 0 && desc->size <= 4, "ys_model_create: size %d out of range", desc->size);
@@ -653,7 +879,7 @@ int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
   m->ctx = ctx; m->d = *desc; m->dtype = desc->dtype; m->epl = desc->dtype == YS_BF16 ? 8 : 4; m->es = desc->dtype == YS_BF16 ? 2 : 4;
   m->maxB = desc->max_batch;
   for (int j = 0; j < 64; j++) m->dfl_w[j] = (float)j;
-  int st = build_v8_detect(m);
+  int st = desc->family == YS_YOLOV11 ? build_v11_detect(m) : build_v8_detect(m);
   if (st == YS_OK) st = layout_params(m);
   if (st == YS_OK) st = allocate(m);
   if (st != YS_OK) { ys_model_destroy(m); return st; }
@@ -699,6 +925,20 @@ static int tensor_io(ys_model* m, const char* name, float* host, size_t count, i
   }
   float* dev = t->kind == 2 ? m->state + t->off : (what == 2 ? m->grads + t->off : m->params + t->off);
   YS_REQUIRE(!(what == 2 && t->kind == 2), "'%s' is a buffer and has no gradient", name);
+  if (t->kind == 4) {
+    const ConvL& c = m->convs[t->conv];
+    std::vector<float> tmp(count);
+    if (what == 0) {
+      for (int ch = 0; ch < c.cout; ch++) for (int tp = 0; tp < 9; tp++) tmp[(size_t)tp * c.cout + ch] = host[(size_t)ch * 9 + tp];
+      YS_CHECK_HIP(hipMemcpyAsync(dev, tmp.data(), count * 4, hipMemcpyHostToDevice, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+    } else {
+      YS_CHECK_HIP(hipMemcpyAsync(tmp.data(), dev, count * 4, hipMemcpyDeviceToHost, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      for (int ch = 0; ch < c.cout; ch++) for (int tp = 0; tp < 9; tp++) host[(size_t)ch * 9 + tp] = tmp[(size_t)tp * c.cout + ch];
+    }
+    return YS_OK;
+  }
   if (t->kind == 0) {
     // OIHW at the edge <-> [Cout][taps][Cin] inside
     const ConvL& c = m->convs[t->conv];
@@ -733,8 +973,8 @@ int ys_model_init_weights(ys_model* m, uint64_t seed) {
   std::vector<float> p(m->n_params, 0.f), s(m->n_state, 0.f);
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 0x1234567ull};
   for (const auto& c : m->convs) {
-    const long nw = (long)c.cout * c.k * c.k * c.cin;
-    const float bound = 1.0f / sqrtf((float)(c.cin * c.k * c.k));   // kaiming_uniform(a=sqrt 5): 1/sqrt(fan_in)
+    const long nw = c.dw ? (long)c.cout * 9 : (long)c.cout * c.k * c.k * c.cin;
+    const float bound = 1.0f / sqrtf((float)((c.dw ? 1 : c.cin) * c.k * c.k));   // kaiming_uniform(a=sqrt 5): 1/sqrt(fan_in)
     for (long i = 0; i < nw; i++) p[c.w_off + i] = rng.uni(bound);
     if (c.bn) {
       for (int i = 0; i < c.cout; i++) { p[c.g_off + i] = 1.f; p[c.b_off + i] = 0.f; s[c.rm_off + i] = 0.f; s[c.rv_off + i] = 1.f; }

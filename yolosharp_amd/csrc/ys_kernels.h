@@ -93,6 +93,21 @@ int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v
                     float beta2, float eps, float wd, float bc1, float bc2);
 int ys_fill_launch(hipStream_t st, float* p, long n, float v);
 
+int ys_chan_stats_launch(hipStream_t st, int dtype, const void* y, long rows, int C, float* partial, int* nblk_out);
+
+// ---- attn_dw.hip (YOLOv11 operators)
+int ys_dwconv_launch(hipStream_t st, int dtype, int flip, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
+                     const float* w /*[9][C]*/, void* y, int y_ldc, int y_coff, int accumulate);
+int ys_dwconv_wgrad_blocks(long rows, int C, int dtype);
+int ys_dwconv_wgrad_launch(hipStream_t st, int dtype, const void* x, int x_ldc, int x_coff, const void* dy, int B, int H, int W,
+                           int C, float* partial /*[blocks][9][C]*/, float* grad /*[9][C] +=*/);
+int ys_attn_fwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int B, int N, int heads, int kd, int hd,
+                       void* ao, int ldo, float* P);
+int ys_attn_bwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int B, int N, int heads, int kd, int hd,
+                       const void* dao, int ldo, const float* P, float* dS, void* dqkv);
+int ys_attn_v_copy_launch(hipStream_t st, int dtype, const void* src, void* dst, long rows, int ldq, int heads, int kd, int hd,
+                          int ldv, int to_qkv);
+
 // ---- loss.hip
 struct LossArgs {
   const void* pd;  // box logits   [B][A][ld_pd]  (4*reg_max used)

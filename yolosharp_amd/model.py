@@ -20,12 +20,14 @@ DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 
 class Yolov8:
+    FAMILY = 8          # ys_family: Models/Yolo.cs:10-135
+
     def __init__(self, engine: Engine, nc=80, reg_max=16, size="n", height=640, width=640, max_batch=1, dtype="bf16",
                  max_labels=0):
         self.engine, self.lib = engine, engine.lib
         self.nc, self.reg_max, self.height, self.width, self.max_batch = nc, reg_max, height, width, max_batch
         self.dtype = dtype
-        desc = _lib.ModelDesc(8, SIZES[size], 0, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels)
+        desc = _lib.ModelDesc(self.FAMILY, SIZES[size], 0, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels)
         self.handle = C.c_void_p()
         _lib.check(self.lib, self.lib.ys_model_create(engine.ctx, C.byref(desc), C.byref(self.handle)))
         self.training = True
@@ -168,6 +170,11 @@ class Yolov8:
     def adamw_step(self, lrs, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4):
         arr = (C.c_float * len(lrs))(*lrs)
         _lib.check(self.lib, self.lib.ys_optim_adamw_step(self.handle, arr, len(lrs), beta1, beta2, eps, weight_decay))
+
+
+class Yolov11(Yolov8):
+    """Models/Yolo.cs:200-258: C3k2 / C2PSA graph with Detect(legacy=false)."""
+    FAMILY = 11
 
 
 class v8DetectionLoss:
