@@ -93,7 +93,10 @@ YS_API int64_t ys_model_num_params(ys_model* m);
  * training: Detect returns preds only (Head.cs:89-106): "boxes" [B,4*reg_max,A], "scores" [B,nc,A].
  * eval: additionally Detect._inference (Head.cs:204-223): "pred" [B,4+nc,A] (xywh*stride, sigmoid). */
 YS_API int ys_model_forward(ys_model* m, const float* images, int on_device, int batch);
-/* Copy an output to a host fp32 array in the reference layout: key = "boxes" | "scores" | "pred". */
+/* Copy an output to a host fp32 array in the reference layout: key = "boxes" | "scores" | "pred";
+ * Segment models (Head.cs:283-313) add "mask_coefficient" [B,nm,A] and "proto" [B,nm,H/4,W/4], and their eval
+ * "pred" is [B,4+nc+nm,A] (raw mask coefficients appended).  "dboxes" | "dscores" | "dmask_coefficient" | "dproto"
+ * return the loss gradients w.r.t. those outputs after a loss call. */
 YS_API int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count);
 /* Device pointer of the eval prediction [B,4+nc,A] fp32 (input of ys_nms_batched). */
 YS_API int ys_model_pred_device(ys_model* m, float** dptr);
@@ -107,6 +110,18 @@ YS_API int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls,
 /* loss_items[3] = (box, cls, dfl) un-multiplied (the reference's loss_detach), *loss_sum = sum(items)*B
  * (the scalar the reference calls backward() on, Amp.cs:340).  Synchronises the stream. */
 YS_API int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum);
+
+/* v8SegmentationLoss.forward (Utils/Loss.cs:688-863) for task = YS_SEGMENT models: the detection terms and
+ * assignment above, then calculate_segmentation_loss / single_mask_loss (:794-863) with Ops.crop_mask
+ * (Utils/Ops.cs:409-449) and the gradients w.r.t. "mask_coefficient" and "proto".
+ * masks: fp32 [B, H/4, W/4] overlap-encoded instance ids (0 = background, k = the image's k-th label, 1-based;
+ * Data/YoloDataset.cs:265-267, overlap_mask = true).  crop_mode 0 = crop_mask's broadcast form (:437-447, the
+ * branch an accelerator run takes); 1 = its CPU "n < 50" integer-truncation branch (:421-435). */
+YS_API int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
+                           int n_labels, const float* masks, int on_device, int crop_mode);
+/* Loss items in the criterion's own order: detect n_items = 3 (box, cls, dfl; Loss.cs:414);
+ * segment n_items = 5 (box, seg, cls, dfl, semseg = 0; Loss.cs:719).  *loss_sum = sum(items)*B. */
+YS_API int ys_loss_read_items(ys_model* m, float* loss_items, int n_items, float* loss_sum);
 
 /* autograd backward of sum(loss*B) through the whole graph (Amp.cs:348,370). Gradients accumulate
  * into the flat fp32 gradient buffer like torch's .grad (call ys_model_zero_grad between steps). */
@@ -137,6 +152,13 @@ YS_API int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngrou
 YS_API int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int batch, int channels, int anchors,
                           float conf_thres, float iou_thres, int max_det, int nc, int max_nms, int max_wh,
                           float* out_rows, int64_t* out_keep, int32_t* out_count);
+
+/* Ops.process_mask (Utils/Ops.cs:462-489), used by Segmenter post-processing (Models/Segmenter.cs:131-160 region):
+ * masks = masks_in[n,nm] @ protos[nm,mh,mw], cropped to boxes (xyxy, image pixels) scaled to the mask grid,
+ * optionally bilinearly upsampled (align_corners = false) to (ih, iw), thresholded > 0.
+ * out: uint8 [n, oh, ow], (oh, ow) = upsample ? (ih, iw) : (mh, mw).  `on_device` applies to all pointers. */
+YS_API int ys_process_mask(ys_ctx* ctx, const float* protos, const float* masks_in, const float* boxes, int on_device,
+                           int n, int nm, int mh, int mw, int ih, int iw, int upsample, int crop_mode, uint8_t* out);
 
 /* ---- per-operator entry points (unit parity; a TorchSharp-free C# Conv wrapper) ---------------
  * Convs.Conv.forward (Convs.cs:36-62): y = act(BN(conv2d(x))) on fp32 NCHW / OIHW HOST arrays at the

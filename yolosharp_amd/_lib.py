@@ -48,6 +48,10 @@ PROTOTYPES = {
     "ys_model_pred_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ys_loss_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "ys_loss_read": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "ys_loss_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "ys_loss_read_items": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_float_p]),
+    "ys_process_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ys_model_backward": (C.c_int, [C.c_void_p]),
     "ys_model_backward_segments": (C.c_int, [C.c_void_p]),
     "ys_model_backward_segment": (C.c_int, [C.c_void_p, C.c_int]),

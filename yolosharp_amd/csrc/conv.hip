@@ -202,7 +202,7 @@ conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int mf = 0; mf < MR; mf++) {
       const int ihn = poh[mf] * a.SA + kh - a.PAD;
-      const int iwn = pow_[mf] * a.SA + kw - a.PAD;
+      const int iwn = pow_[mf] * a.SA + kw - a.PAD - a.pad_w_delta;
       const int ih = ihn >> a.DIVS, iw = iwn >> a.DIVS;
       const bool ok = pv[mf] && ihn >= 0 && iwn >= 0 && ((ihn | iwn) & a.DIVM) == 0 && ih < a.Hin && iw < a.Win;
       pvt[mf] = ok;
@@ -274,7 +274,9 @@ conv_igemm_kernel(ConvArgs a) {
     mvv[mf] = m < a.M;
     const int mm = mvv[mf] ? m : 0;
     const int bb = mm / HWo;
-    orow[mf] = (long)bb * a.out_bstride + (mm - bb * HWo);
+    const int rr = mm - bb * HWo;
+    orow[mf] = a.out_rh ? (long)bb * a.out_bstride + (long)(rr / a.Wout) * a.out_rh + (long)(rr % a.Wout) * a.out_rw + a.out_r0
+                        : (long)bb * a.out_bstride + rr;
   }
   T* wst = (T*)sW + wave * (16 * (BN + EPL));
   conv_epilogue<T, MR, NR, 4>(a, acc, orow, mvv, n0, wst, &sStat[0][0][0], (long)blockIdx.x);
@@ -664,7 +666,9 @@ conv_wgrad_kernel(WgradArgs a) {
       uint4 val = ys_zero16();
       if (v < KS * DV && active && p < a.M && c < a.Cout) {
         const long bb = p / HWo;
-        const long drow = bb * a.dy_bstride + (p - bb * HWo);
+        const long rr = p - bb * HWo;
+        const long drow = a.dy_rh ? bb * a.dy_bstride + (rr / a.Wout) * a.dy_rh + (rr % a.Wout) * a.dy_rw + a.dy_r0
+                                  : bb * a.dy_bstride + rr;
         val = ys_ld16(dyb + ((drow * a.dy_ldc) + a.dy_coff + c) * (long)sizeof(T));
       }
       rd[k] = val;

@@ -1,5 +1,6 @@
 // core.hip -- context, error reporting, memory helpers and the NMS entry point of the C ABI.
 #include "ys_internal.h"
+#include "ys_kernels.h"
 #include <cstring>
 
 static thread_local char g_err[1024] = "";
@@ -193,6 +194,35 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
   hipFree(d_pred); hipFree(d_rows); hipFree(d_keep); hipFree(d_cnt);
   if (st != YS_OK) return st;
   if (e != hipSuccess) { ys_set_error("ys_nms_batched: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
+  return YS_OK;
+}
+
+// Ops.process_mask (Utils/Ops.cs:462-489): masks_in[n][nm] @ protos[nm][mh][mw], crop to the boxes, optional bilinear upsample
+// to (ih, iw), threshold > 0.  out: uint8 [n][oh][ow] with (oh, ow) = upsample ? (ih, iw) : (mh, mw).
+int ys_process_mask(ys_ctx* ctx, const float* protos, const float* masks_in, const float* boxes, int on_device, int n, int nm,
+                    int mh, int mw, int ih, int iw, int upsample, int crop_mode, uint8_t* out) {
+  YS_REQUIRE(ctx && protos && out, "ys_process_mask: null argument");
+  YS_REQUIRE(n >= 0 && nm > 0 && mh > 0 && mw > 0 && ih > 0 && iw > 0, "ys_process_mask: bad shape n=%d nm=%d mask %dx%d image %dx%d", n, nm, mh, mw, ih, iw);
+  if (n == 0) return YS_OK;
+  YS_REQUIRE(masks_in && boxes, "ys_process_mask: null argument");
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  YsTimer timer(ctx, "process_mask");
+  if (on_device) return ys_process_mask_launch(ctx->stream, protos, masks_in, boxes, n, nm, mh, mw, ih, iw, upsample, crop_mode, out);
+  const size_t np = (size_t)nm * mh * mw, no = (size_t)n * (upsample ? (size_t)ih * iw : (size_t)mh * mw);
+  float *d_p = nullptr, *d_m = nullptr, *d_b = nullptr; unsigned char* d_o = nullptr;
+  YS_CHECK_HIP(hipMalloc(&d_p, np * 4));
+  YS_CHECK_HIP(hipMalloc(&d_m, (size_t)n * nm * 4));
+  YS_CHECK_HIP(hipMalloc(&d_b, (size_t)n * 16));
+  YS_CHECK_HIP(hipMalloc(&d_o, no));
+  hipMemcpyAsync(d_p, protos, np * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(d_m, masks_in, (size_t)n * nm * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(d_b, boxes, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+  int st = ys_process_mask_launch(ctx->stream, d_p, d_m, d_b, n, nm, mh, mw, ih, iw, upsample, crop_mode, d_o);
+  if (st == YS_OK) hipMemcpyAsync(out, d_o, no, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_p); hipFree(d_m); hipFree(d_b); hipFree(d_o);
+  if (st != YS_OK) return st;
+  if (e != hipSuccess) { ys_set_error("ys_process_mask: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
   return YS_OK;
 }
 

@@ -48,6 +48,26 @@ int ys_unpack_nchw_launch(hipStream_t st, int dtype, const void* x, int ldc, int
   return YS_OK;
 }
 
+// [B][rpb][ldc] view -> channel block of a wider NCHW tensor: y[b*y_bstride + y_off + c*rpb + p]
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+unpack_nchw_strided_kernel(const T* __restrict__ x, int ldc, int coff, int B, int C, long rpb, float* __restrict__ y, long y_bstride, long y_off) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * rpb) return;
+  const long p = i % rpb;
+  const long bc = i / rpb;
+  const int c = (int)(bc % C);
+  const long b = bc / C;
+  y[b * y_bstride + y_off + (long)c * rpb + p] = Elem<T>::to_f(x[(b * rpb + p) * ldc + coff + c]);
+}
+int ys_unpack_nchw_strided_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, int B, int C, long rpb, float* y,
+                                  long y_bstride, long y_off) {
+  const long n = (long)B * C * rpb;
+  if (dtype == YS_BF16) YS_LAUNCH((unpack_nchw_strided_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)x, ldc, coff, B, C, rpb, y, y_bstride, y_off);
+  else YS_LAUNCH((unpack_nchw_strided_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)x, ldc, coff, B, C, rpb, y, y_bstride, y_off);
+  return YS_OK;
+}
+
 // ------------------------------------------------------------------ block reduction helper (double)
 __device__ inline double block_sum_d(double v, double* sbuf) {
   const int tid = threadIdx.x;
@@ -604,7 +624,7 @@ template <class T>
 __global__ void __launch_bounds__(EW_THREADS)
 detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ ps, int ld_ps, int B, int A, int nc,
                      int reg_max, int nl, int o0, int o1, int o2, int w0, int w1, int w2, int s0, int s1, int s2,
-                     float* __restrict__ pred) {
+                     float* __restrict__ pred, int pred_C) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * A) return;
   const int a = (int)(i % A);
@@ -628,7 +648,7 @@ detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ 
     d[s] = sw / se;
   }
   const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
-  float* o = pred + b * (long)(4 + nc) * A + a;
+  float* o = pred + b * (long)pred_C * A + a;
   const float st = (float)ls;
   o[0] = (x1 + x2) / 2.0f * st;
   o[(long)A] = (y1 + y2) / 2.0f * st;
@@ -638,13 +658,13 @@ detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ 
   for (int c = 0; c < nc; c++) o[(long)(4 + c) * A] = ys_sigmoid(Elem<T>::to_f(srow[c]));
 }
 int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
-                            int nc, int reg_max, int nl, const int* lo, const int* lw, const int* ls, float* pred) {
+                            int nc, int reg_max, int nl, const int* lo, const int* lw, const int* ls, float* pred, int pred_C) {
   const long n = (long)B * A;
   const int o1 = nl > 1 ? lo[1] : 0, o2 = nl > 2 ? lo[2] : 0, w1 = nl > 1 ? lw[1] : 1, w2 = nl > 2 ? lw[2] : 1;
   const int s1 = nl > 1 ? ls[1] : 1, s2 = nl > 2 ? ls[2] : 1;
   if (dtype == YS_BF16)
-    YS_LAUNCH((detect_decode_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred);
+    YS_LAUNCH((detect_decode_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
   else
-    YS_LAUNCH((detect_decode_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred);
+    YS_LAUNCH((detect_decode_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
   return YS_OK;
 }

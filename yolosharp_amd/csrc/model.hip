@@ -46,6 +46,7 @@ struct ConvL {
   int seg = 0;
   bool first = false;
   bool dw = false;       // depthwise 3x3 (groups = channels): weights [9][C] fp32, no MFMA path
+  bool ct = false;       // ConvTranspose2d(k=2,s=2,bias) = four 1x1 phase GEMMs (Proto.upsample, Block.cs:69); weights [4][Cout][Cin]
 };
 
 enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2, OP_ATTN = 3, OP_VCOPY = 4, OP_COPY = 5 };
@@ -79,6 +80,11 @@ struct ys_model {
   std::vector<int> reg;          // conv indices in the reference's module REGISTRATION order (state_dict order)
   std::string head_prefix;       // "model.22" (v8) / "model.23" (v11)
   float* attn_ws = nullptr; long n_attn = 0;   // softmax probabilities + dS of the C2PSA attention ops
+  // segmentation (Head.cs:238-324): mask coefficients [B][A][ld_mc], prototypes [B][mh*mw][ld_pr]
+  bool segment = false; int nm = 0, mc_buf = -1, pr_buf = -1, ld_mc = 0, ld_pr = 0, mh = 0, mw = 0;
+  float* masks_dev = nullptr; int *seg_cnt = nullptr, *seg_off = nullptr, *seg_list = nullptr; float *seg_ent = nullptr, *seg_part = nullptr;
+  int n_items = 3; bool have_seg_loss = false;
+  int dfl_after_conv = -1;   // the DFL weight registers right after Detect's cv2/cv3 (Head.cs:52-56), before Segment's proto/cv4
   int in_buf = -1, pd_buf = -1, ps_buf = -1;
   int ld_pd = 0, ld_ps = 0;
   // flat fp32 parameter state
@@ -311,6 +317,35 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       m->convs[cc].out_rowoff = m->lvl_off[i];
     }
   }
+  m->dfl_after_conv = m->reg.back();
+  if (d.task == YS_SEGMENT) {
+    // Segment (Head.cs:238-324): Proto(ch0, npr = ch0, nm = 32) on P3 (Yolo.cs:348,366) and the cv4 towers (c4 = max(ch0/4, nm))
+    m->segment = true; m->nm = 32; m->n_items = 5;
+    const int nm = m->nm, npr = ch[0];
+    const int c4 = std::max(ch[0] / 4, nm);
+    if (c4 % m->epl || npr % m->epl) { ys_set_error("model: segment widths c4=%d npr=%d must be multiples of %d", c4, npr, m->epl); return YS_ERR_UNSUPPORTED; }
+    m->ld_mc = (nm + m->epl - 1) / m->epl * m->epl;
+    m->ld_pr = m->ld_mc;
+    m->mh = 2 * hh[0]; m->mw = 2 * ww[0];
+    // Proto (Block.cs:51-84); field/registration order cv1, cv2, cv3, upsample (:53-56)
+    const int pa = new_buf(m, hh[0], ww[0], npr), pu = new_buf(m, m->mh, m->mw, npr), pb = new_buf(m, m->mh, m->mw, npr);
+    m->pr_buf = new_buf(m, m->mh, m->mw, m->ld_pr);
+    const int p1 = add_conv(m, hp + ".proto.cv1", View{pv[0], 0, ch[0]}, View{pa, 0, npr}, ch[0], npr, 3, 1, true, true, hh[0], ww[0], seg);
+    const int pup = add_conv(m, hp + ".proto.upsample", View{pa, 0, npr}, View{pu, 0, npr}, npr, npr, 1, 1, false, false, hh[0], ww[0], seg);
+    m->convs[pup].ct = true; m->convs[pup].Hout = m->mh; m->convs[pup].Wout = m->mw;
+    const int p2 = add_conv(m, hp + ".proto.cv2", View{pu, 0, npr}, View{pb, 0, npr}, npr, npr, 3, 1, true, true, m->mh, m->mw, seg);
+    const int p3 = add_conv(m, hp + ".proto.cv3", View{pb, 0, npr}, View{m->pr_buf, 0, nm}, npr, nm, 1, 1, true, true, m->mh, m->mw, seg);
+    m->reg.push_back(p1); m->reg.push_back(p2); m->reg.push_back(p3); m->reg.push_back(pup);
+    m->mc_buf = new_buf(m, 1, m->A, m->ld_mc);
+    for (int i = 0; i < 3; i++) {
+      const std::string tp = hp + ".cv4." + std::to_string(i);
+      const int t0 = new_buf(m, hh[i], ww[i], c4), t1 = new_buf(m, hh[i], ww[i], c4);
+      add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, c4}, ch[i], c4, 3, 1, true, true, hh[i], ww[i], seg);
+      add_conv_reg(m, tp + ".1", View{t0, 0, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
+      const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4}, View{m->mc_buf, 0, nm}, c4, nm, 1, 1, false, false, hh[i], ww[i], seg);
+      m->convs[cc].out_rowoff = m->lvl_off[i];
+    }
+  }
   return YS_OK;
 }
 
@@ -434,7 +469,7 @@ int layout_params(ys_model* m) {
       for (auto& c : m->convs) {
         if (c.seg != seg) continue;
         if (grp == 0) { if (c.bn) { c.b_off = off; off += c.cout; } else { c.g_off = off; off += c.cout; } }   // bn.bias | conv bias (stored in g_off for plain convs)
-        if (grp == 1) { c.w_off = off; off += c.dw ? (long)c.cout * 9 : (long)c.cout * c.k * c.k * c.cin; }
+        if (grp == 1) { c.w_off = off; off += c.dw ? (long)c.cout * 9 : c.ct ? 4L * c.cout * c.cin : (long)c.cout * c.k * c.k * c.cin; }
         if (grp == 2 && c.bn) { c.g_off = off; off += c.cout; }
       }
       m->seg_group[seg][grp] = {start, off - start};
@@ -457,11 +492,13 @@ int layout_params(ys_model* m) {
       add_tensor(m, c.name + ".bn.weight", 1, i, c.g_off, {c.cout}, true);
       add_tensor(m, c.name + ".bn.bias", 1, i, c.b_off, {c.cout}, true);
     } else {
-      add_tensor(m, c.name + ".weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
+      if (c.ct) add_tensor(m, c.name + ".weight", 5, i, c.w_off, {c.cin, c.cout, 2, 2}, true);   // ConvTranspose2d: [Cin][Cout][kh][kw]
+      else add_tensor(m, c.name + ".weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
       add_tensor(m, c.name + ".bias", 1, i, c.g_off, {c.cout}, true);
     }
+    if (i == m->dfl_after_conv)
+      add_tensor(m, m->head_prefix + ".dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
   }
-  add_tensor(m, m->head_prefix + ".dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
   for (int i : reg2) {
     const ConvL& c = m->convs[i];
     if (!c.bn) continue;
@@ -545,13 +582,16 @@ int allocate(ys_model* m) {
       stat_max = std::max(stat_max, 256L * 9 * c.cout);
       continue;
     }
-    c.wf_off = nf; nf += (long)c.cout * taps * c.cin_pad;
+    c.wf_off = nf;
     c.wd_off = nd;
-    PrepDesc d{}; d.w_off = c.w_off; d.wf_off = c.wf_off; d.wd_off = c.wd_off; d.cout = c.cout; d.taps = taps;
-    d.cin_real = c.cin; d.cin_pad = c.cin_pad; d.cout_pad = c.cout_ld; d.has_wd = c.first ? 0 : 1;
-    d.nf_start = c.wf_off; d.nd_start = c.wd_off;
-    if (!c.first) nd += (long)c.cin * taps * c.cout_ld;
-    pd.push_back(d);
+    for (int ph = 0; ph < (c.ct ? 4 : 1); ph++) {   // ConvTranspose: one 1x1 weight matrix per output phase
+      PrepDesc d{}; d.w_off = c.w_off + (long)ph * c.cout * c.cin; d.wf_off = nf; d.wd_off = nd; d.cout = c.cout; d.taps = taps;
+      d.cin_real = c.cin; d.cin_pad = c.cin_pad; d.cout_pad = c.cout_ld; d.has_wd = c.first ? 0 : 1;
+      d.nf_start = nf; d.nd_start = nd;
+      nf += (long)c.cout * taps * c.cin_pad;
+      if (!c.first) nd += (long)c.cin * taps * c.cout_ld;
+      pd.push_back(d);
+    }
     const long M = (long)B * c.Hout * c.Wout;
     if (c.bn) { c.y_off = ny; ny += M * c.cout; }
     c.ch_off = nch; nch += 6L * ((c.cout + 3) / 4 * 4);   // 16-byte aligned coefficient vectors
@@ -587,8 +627,16 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->wg_partial, (size_t)wgp * 4));
   const ys_model_desc& d = m->d;
   YS_TRY(dev_alloc(m, (void**)&m->img_dev, (size_t)B * 3 * d.height * d.width * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->pred, (size_t)B * (4 + d.nc) * m->A * 4));
-  m->n_out_stage = (long)B * m->A * std::max(std::max(m->ld_pd, m->ld_ps), 4 + d.nc);
+  YS_TRY(dev_alloc(m, (void**)&m->pred, (size_t)B * (4 + d.nc + m->nm) * m->A * 4));
+  m->n_out_stage = std::max((long)B * m->A * std::max(std::max(m->ld_pd, m->ld_ps), 4 + d.nc + m->nm), (long)B * m->mh * m->mw * std::max(m->ld_pr, 1));
+  if (m->segment) {
+    YS_TRY(dev_alloc(m, (void**)&m->masks_dev, (size_t)B * m->mh * m->mw * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_cnt, (size_t)B * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_off, (size_t)(B + 1) * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_list, (size_t)B * m->A * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_ent, (size_t)B * m->A * 8 * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_part, (size_t)B * m->A * 4));
+  }
   YS_TRY(dev_alloc(m, (void**)&m->out_stage, (size_t)m->n_out_stage * 4));
   // loss workspace
   m->gcap = d.max_labels > 0 ? d.max_labels : 64;
@@ -636,8 +684,31 @@ int run_dwconv_fwd(ys_model* m, const ConvL& c, int B) {
   return YS_OK;
 }
 
+// ConvTranspose2d(k=2, s=2, bias): out[b, 2h+dh, 2w+dw, :] = W[dh,dw] x[b,h,w,:] + bias  -> four 1x1 GEMMs with a strided output map
+int run_convT_fwd(ys_model* m, const ConvL& c, int B) {
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[c.in.buf];
+  const Buf& ob = m->bufs[c.out.buf];
+  for (int ph = 0; ph < 4; ph++) {
+    const int dh = ph >> 1, dw = ph & 1;
+    ConvArgs a{};
+    a.x = ib.act; a.w = (char*)m->wf_all + (size_t)(c.wf_off + (long)ph * c.cout * c.cin_pad) * m->es; a.y = ob.act;
+    a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.cin_pad; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cout; a.KH = a.KW = 1;
+    a.SA = 1; a.PAD = 0;
+    a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
+    a.out_ldc = ob.ldc; a.out_coff = c.out.coff; a.out_bstride = ob.rows_per_b;
+    a.out_rh = 4 * c.Win; a.out_rw = 2; a.out_r0 = (long)dh * 2 * c.Win + dw;
+    a.vec_ok = (ob.ldc % 4 == 0 && c.out.coff % 4 == 0) ? 1 : 0;
+    a.shift = m->params + c.g_off;
+    a.M = B * c.Hin * c.Win;
+    YS_TRY(ys_conv_launch(st, m->dtype, a));
+  }
+  return YS_OK;
+}
+
 int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
   if (c.dw) return run_dwconv_fwd(m, c, B);
+  if (c.ct) return run_convT_fwd(m, c, B);
   hipStream_t st = m->ctx->stream;
   const Buf& ib = m->bufs[c.in.buf];
   const Buf& ob = m->bufs[c.out.buf];
@@ -705,7 +776,10 @@ int forward_impl(ys_model* m, int B) {
   }
   if (!m->training) {
     YS_TRY(ys_detect_decode_launch(st, m->dtype, m->bufs[m->pd_buf].act, m->ld_pd, m->bufs[m->ps_buf].act, m->ld_ps, B, m->A,
-                                   m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred));
+                                   m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred, 4 + m->d.nc + m->nm));
+    if (m->segment)   // Segment._inference: cat(preds, mask_coefficient) (Head.cs:309-313), raw coefficients
+      YS_TRY(ys_unpack_nchw_strided_launch(st, m->dtype, m->bufs[m->mc_buf].act, m->ld_mc, 0, B, m->nm, m->A, m->pred,
+                                           (long)(4 + m->d.nc + m->nm) * m->A, (long)(4 + m->d.nc) * m->A));
   }
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;
@@ -722,7 +796,43 @@ int grad_mode(ys_model* m, const View& v) {
   return nw ? 1 : 0;
 }
 
+int run_convT_bwd(ys_model* m, const ConvL& c, int B) {
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[c.in.buf];
+  const Buf& ob = m->bufs[c.out.buf];
+  const long Mup = (long)B * c.Hout * c.Wout;
+  YS_TRY(ys_colsum_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, Mup, Mup, Mup, c.cout, m->stat_partial, m->grads + c.g_off));
+  const int mode0 = grad_mode(m, c.in);
+  if (mode0 < 0) { ys_set_error("backward: inconsistent gradient slice state at %s", c.name.c_str()); return YS_ERR_STATE; }
+  for (int ph = 0; ph < 4; ph++) {
+    const int dh = ph >> 1, dw = ph & 1;
+    WgradArgs wa{};
+    wa.x = ib.act; wa.dy = ob.grad; wa.partial = m->wg_partial;
+    wa.B = B; wa.Hin = c.Hin; wa.Win = c.Win; wa.Cin = c.cin_pad; wa.Hout = c.Hin; wa.Wout = c.Win; wa.Cout = c.cout; wa.KH = wa.KW = 1;
+    wa.stride = 1; wa.pad = 0; wa.in_ldc = ib.ldc; wa.in_coff = c.in.coff; wa.in_bstride = ib.rows_per_b;
+    wa.dy_ldc = ob.ldc; wa.dy_coff = c.out.coff; wa.dy_bstride = ob.rows_per_b;
+    wa.dy_rh = 4 * c.Win; wa.dy_rw = 2; wa.dy_r0 = (long)dh * 2 * c.Win + dw;
+    wa.M = B * c.Hin * c.Win;
+    const int splits = ys_wgrad_splits(wa, m->dtype);
+    if ((long)splits * c.cout * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
+    YS_TRY(ys_wgrad_launch(st, m->dtype, wa, splits, c.cin, m->grads + c.w_off + (long)ph * c.cout * c.cin));
+    // dx[h,w] (+)= W[dh,dw]^T dy[2h+dh, 2w+dw]: 1x1 gather with stride 2 and offsets (dh, dw)
+    ConvArgs a{};
+    a.x = ob.grad; a.w = (char*)m->wd_all + (size_t)(c.wd_off + (long)ph * c.cin * c.cout_ld) * m->es; a.y = ib.grad;
+    a.B = B; a.Hin = c.Hout; a.Win = c.Wout; a.Cin = c.cout_ld; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cin; a.KH = a.KW = 1;
+    a.SA = 2; a.PAD = -dh; a.pad_w_delta = dh - dw;
+    a.in_ldc = ob.ldc; a.in_coff = c.out.coff; a.in_bstride = ob.rows_per_b;
+    a.out_ldc = ib.ldc; a.out_coff = c.in.coff; a.out_bstride = ib.rows_per_b;
+    a.vec_ok = (ib.ldc % 4 == 0 && c.in.coff % 4 == 0) ? 1 : 0;
+    a.accumulate = (ph == 0) ? mode0 : 1;
+    a.M = B * c.Hin * c.Win;
+    YS_TRY(ys_conv_launch(st, m->dtype, a));
+  }
+  return YS_OK;
+}
+
 int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
+  if (c.ct) return run_convT_bwd(m, c, B);
   hipStream_t st = m->ctx->stream;
   const Buf& ib = m->bufs[c.in.buf];
   const Buf& ob = m->bufs[c.out.buf];
@@ -844,6 +954,10 @@ void reset_grad_state(ys_model* m) {
   // the loss wrote the head gradients
   std::fill(m->bufs[m->pd_buf].gw.begin(), m->bufs[m->pd_buf].gw.end(), 1);
   std::fill(m->bufs[m->ps_buf].gw.begin(), m->bufs[m->ps_buf].gw.end(), 1);
+  if (m->segment) {
+    std::fill(m->bufs[m->mc_buf].gw.begin(), m->bufs[m->mc_buf].gw.end(), 1);
+    std::fill(m->bufs[m->pr_buf].gw.begin(), m->bufs[m->pr_buf].gw.end(), 1);
+  }
 }
 
 TensorRec* find_tensor(ys_model* m, const char* name) {
@@ -865,8 +979,8 @@ extern "C" {
 int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
   YS_REQUIRE(ctx && desc && out, "ys_model_create: null argument");
   YS_REQUIRE(desc->dtype == YS_F32 || desc->dtype == YS_BF16, "ys_model_create: dtype %d unsupported", desc->dtype);
-  if ((desc->family != YS_YOLOV8 && desc->family != YS_YOLOV11) || desc->task != YS_DETECT) {
-    ys_set_error("ys_model_create: YOLOv8 / YOLOv11 detect are built in this round (family %d task %d)", desc->family, desc->task);
+  if ((desc->family != YS_YOLOV8 && desc->family != YS_YOLOV11) || (desc->task != YS_DETECT && desc->task != YS_SEGMENT)) {
+    ys_set_error("ys_model_create: YOLOv8 / YOLOv11 detect and segment are built (family %d task %d)", desc->family, desc->task);
     return YS_ERR_UNSUPPORTED;
   }
   YS_REQUIRE(desc->size >= 0 && desc->size <= 4, "ys_model_create: size %d out of range", desc->size);
@@ -925,6 +1039,23 @@ static int tensor_io(ys_model* m, const char* name, float* host, size_t count, i
   }
   float* dev = t->kind == 2 ? m->state + t->off : (what == 2 ? m->grads + t->off : m->params + t->off);
   YS_REQUIRE(!(what == 2 && t->kind == 2), "'%s' is a buffer and has no gradient", name);
+  if (t->kind == 5) {   // ConvTranspose2d weight: edge [Cin][Cout][2][2] <-> internal [phase][Cout][Cin]
+    const ConvL& c = m->convs[t->conv];
+    std::vector<float> tmp(count);
+    if (what == 0) {
+      for (int ci = 0; ci < c.cin; ci++) for (int co = 0; co < c.cout; co++) for (int ph = 0; ph < 4; ph++)
+        tmp[((size_t)ph * c.cout + co) * c.cin + ci] = host[((size_t)ci * c.cout + co) * 4 + ph];
+      YS_CHECK_HIP(hipMemcpyAsync(dev, tmp.data(), count * 4, hipMemcpyHostToDevice, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      m->weights_dirty = true;
+    } else {
+      YS_CHECK_HIP(hipMemcpyAsync(tmp.data(), dev, count * 4, hipMemcpyDeviceToHost, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      for (int ci = 0; ci < c.cin; ci++) for (int co = 0; co < c.cout; co++) for (int ph = 0; ph < 4; ph++)
+        host[((size_t)ci * c.cout + co) * 4 + ph] = tmp[((size_t)ph * c.cout + co) * c.cin + ci];
+    }
+    return YS_OK;
+  }
   if (t->kind == 4) {
     const ConvL& c = m->convs[t->conv];
     std::vector<float> tmp(count);
@@ -973,8 +1104,8 @@ int ys_model_init_weights(ys_model* m, uint64_t seed) {
   std::vector<float> p(m->n_params, 0.f), s(m->n_state, 0.f);
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 0x1234567ull};
   for (const auto& c : m->convs) {
-    const long nw = c.dw ? (long)c.cout * 9 : (long)c.cout * c.k * c.k * c.cin;
-    const float bound = 1.0f / sqrtf((float)((c.dw ? 1 : c.cin) * c.k * c.k));   // kaiming_uniform(a=sqrt 5): 1/sqrt(fan_in)
+    const long nw = c.dw ? (long)c.cout * 9 : c.ct ? 4L * c.cout * c.cin : (long)c.cout * c.k * c.k * c.cin;
+    const float bound = c.ct ? 1.0f / sqrtf((float)(c.cout * 4)) : 1.0f / sqrtf((float)((c.dw ? 1 : c.cin) * c.k * c.k));   // kaiming_uniform(a=sqrt 5): 1/sqrt(fan_in)
     for (long i = 0; i < nw; i++) p[c.w_off + i] = rng.uni(bound);
     if (c.bn) {
       for (int i = 0; i < c.cout; i++) { p[c.g_off + i] = 1.f; p[c.b_off + i] = 0.f; s[c.rm_off + i] = 0.f; s[c.rv_off + i] = 1.f; }
@@ -1015,7 +1146,7 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
   m->B = batch;
   YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, 3, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
-  m->have_fwd = true; m->have_loss = false;
+  m->have_fwd = true; m->have_loss = false; m->have_seg_loss = false;
   return YS_OK;
 }
 
@@ -1040,9 +1171,25 @@ int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count)
     const Buf& b = m->bufs[bx ? m->pd_buf : m->ps_buf];
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, b.grad, b.ldc, 0, B, C, m->A, m->out_stage));
     YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
+  } else if (m->segment && (k == "mask_coefficient" || k == "dmask_coefficient")) {   // Head.cs:290-296: [B][nm][A]
+    const bool g = k[0] == 'd';
+    YS_REQUIRE(!g || m->have_seg_loss, "ys_model_get_output(%s): no segment loss has run", key);
+    YS_REQUIRE(count == (size_t)B * m->nm * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * m->nm * m->A);
+    const Buf& b = m->bufs[m->mc_buf];
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, g ? b.grad : b.act, b.ldc, 0, B, m->nm, m->A, m->out_stage));
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
+  } else if (m->segment && (k == "proto" || k == "dproto")) {                           // Head.cs:289: [B][nm][mh][mw]
+    const bool g = k[0] == 'd';
+    const long np = (long)m->mh * m->mw;
+    YS_REQUIRE(!g || m->have_seg_loss, "ys_model_get_output(%s): no segment loss has run", key);
+    YS_REQUIRE(count == (size_t)B * m->nm * np, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * m->nm * np);
+    const Buf& b = m->bufs[m->pr_buf];
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, g ? b.grad : b.act, b.ldc, 0, B, m->nm, np, m->out_stage));
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
   } else if (k == "pred") {
+    const size_t pc = (size_t)(4 + m->d.nc + m->nm);
     YS_REQUIRE(!m->training, "ys_model_get_output(pred): model is in training mode (Detect returns preds only, Head.cs:103-106)");
-    YS_REQUIRE(count == (size_t)B * (4 + m->d.nc) * m->A, "ys_model_get_output(pred): expected %zu elements", (size_t)B * (4 + m->d.nc) * m->A);
+    YS_REQUIRE(count == (size_t)B * pc * m->A, "ys_model_get_output(pred): expected %zu elements", (size_t)B * pc * m->A);
     YS_CHECK_HIP(hipMemcpyAsync(host, m->pred, count * 4, hipMemcpyDeviceToHost, st));
   } else {
     ys_set_error("ys_model_get_output: unknown key '%s'", key);
@@ -1089,6 +1236,48 @@ int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const 
   return YS_OK;
 }
 
+// v8SegmentationLoss (Loss.cs:711-780): detection part + assignment (loss.hip), then the mask term (segloss.hip).
+// masks: [B][mh][mw] fp32, overlap-encoded instance ids (0 = background, g+1 = the image's g-th label; YoloDataset.cs:265-267).
+int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, const float* masks, int on_device,
+                    int crop_mode) {
+  YS_REQUIRE(m && m->segment, "ys_loss_segment: model has no Segment head");
+  YS_REQUIRE(masks, "ys_loss_segment: null masks");
+  YS_TRY(ys_loss_detect(m, batch_idx, cls, bboxes, n, on_device));
+  m->have_loss = false;
+  hipStream_t st = m->ctx->stream;
+  const float* mk = masks;
+  if (!on_device) {
+    YS_CHECK_HIP(hipMemcpyAsync(m->masks_dev, masks, (size_t)m->B * m->mh * m->mw * 4, hipMemcpyHostToDevice, st));
+    mk = m->masks_dev;
+  }
+  YsTimer timer(m->ctx, "loss_seg");
+  const Buf& mc = m->bufs[m->mc_buf];
+  const Buf& pr = m->bufs[m->pr_buf];
+  YS_TRY(ys_loss_segment_launch(st, m->dtype, mc.act, mc.grad, m->ld_mc, pr.act, pr.grad, m->ld_pr, mk, m->fg_gt, m->gt_box, m->seg_cnt,
+                                m->seg_off, m->seg_list, m->seg_ent, m->seg_part, m->scalars, m->B, m->A, m->nm, m->mh, m->mw, m->gcap,
+                                m->d.height, m->d.width, crop_mode));
+  YS_CHECK_HIP(hipGetLastError());
+  m->have_loss = true; m->have_seg_loss = true;
+  return YS_OK;
+}
+
+// loss items in the reference's order: detect [box, cls, dfl] (Loss.cs:414); segment [box, seg, cls, dfl, semseg] (Loss.cs:719)
+int ys_loss_read_items(ys_model* m, float* items, int n_items, float* loss_sum) {
+  YS_REQUIRE(m && m->have_loss, "ys_loss_read_items: no loss has run");
+  YS_REQUIRE(items && n_items == m->n_items, "ys_loss_read_items: this model's criterion has %d items", m->n_items);
+  float h[16];
+  YS_CHECK_HIP(hipMemcpyAsync(h, m->scalars, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
+  YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+  if (m->segment) {
+    YS_REQUIRE(m->have_seg_loss, "ys_loss_read_items: the Segment model needs ys_loss_segment");
+    items[0] = h[1]; items[1] = h[8]; items[2] = h[2]; items[3] = h[3]; items[4] = 0.f;
+  } else {
+    items[0] = h[1]; items[1] = h[2]; items[2] = h[3];
+  }
+  if (loss_sum) *loss_sum = h[4];
+  return YS_OK;
+}
+
 int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum) {
   YS_REQUIRE(m && m->have_loss, "ys_loss_read: no loss has run");
   float h[8];
@@ -1111,6 +1300,7 @@ int ys_model_backward_segment(ys_model* m, int seg) {
 
 int ys_model_backward(ys_model* m) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
+  YS_REQUIRE(!m->segment || m->have_seg_loss, "ys_model_backward: the Segment model needs ys_loss_segment (mask gradients)");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   YsTimer timer(m->ctx, "backward");
   reset_grad_state(m);

@@ -23,6 +23,10 @@ struct ConvArgs {
   int M;                     // B*Hout*Wout
   int TH, TW, tiles_x, tiles_y;  // 2-D output tile of the 3x3 LDS-patch kernel (filled by the launcher)
   int dbg;                       // ablation switches for performance triage (YS_DBG env; 0 in production)
+  // ConvTranspose2d(2,2) phases (Proto.upsample, Block.cs:69) reuse the 1x1 direct kernel with two generalisations:
+  int pad_w_delta;               // width gather uses PAD + pad_w_delta (phase (dh,dw): PAD=-dh, delta=dh-dw)
+  int out_rh, out_rw;            // out_rh != 0: output row = b*out_bstride + oh*out_rh + ow*out_rw + out_r0
+  long out_r0;                   //   (writes phase (dh,dw) of a 2x upsampled grid: rh = 4W, rw = 2, r0 = dh*2W + dw)
 };
 
 struct WgradArgs {
@@ -35,6 +39,8 @@ struct WgradArgs {
   int dy_ldc, dy_coff;
   long dy_bstride;  // rows between consecutive images of dy (Hout*Wout when dense)
   int M;
+  int dy_rh, dy_rw; // dy_rh != 0: dy row = b*dy_bstride + oh*dy_rh + ow*dy_rw + dy_r0 (ConvTranspose phases)
+  long dy_r0;
 };
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
@@ -145,4 +151,12 @@ size_t ys_loss_partial_floats(int B, int A);
 // ---- decode (Head.cs:204-223)
 int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
                             int nc, int reg_max, int nl, const int* lvl_off, const int* lvl_w, const int* lvl_stride,
-                            float* pred);
+                            float* pred, int pred_C);
+int ys_unpack_nchw_strided_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, int B, int C, long rpb, float* y,
+                                  long y_bstride, long y_off);
+// ---- segloss.hip
+int ys_loss_segment_launch(hipStream_t st, int dtype, const void* mc, void* dmc, int ld_mc, const void* proto, void* dproto, int ld_pr,
+                           const float* masks, const int* fg_gt, const float* gt_box, int* cnt, int* off, int* list, float* ent,
+                           float* part, float* scalars, int B, int A, int nm, int mh, int mw, int gcap, int H, int W, int trunc_crop);
+int ys_process_mask_launch(hipStream_t st, const float* protos, const float* masks_in, const float* boxes, int n, int nm, int mh,
+                           int mw, int ih, int iw, int upsample, int trunc_crop, unsigned char* out);

@@ -86,6 +86,19 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_memcpy_d2h(self.ctx, _ptr(out), p, out.nbytes))
         return out
 
+    # ---- Ops.process_mask (Ops.cs:462-489)
+    def process_mask(self, protos, masks_in, bboxes, shape, upsample=False, cpu_crop_branch=False):
+        """protos [nm,mh,mw], masks_in [n,nm], bboxes [n,4] xyxy (image pixels), shape=(ih,iw) -> bool [n,oh,ow]."""
+        protos = np.ascontiguousarray(protos, np.float32)
+        masks_in = np.ascontiguousarray(masks_in, np.float32).reshape(-1, protos.shape[0])
+        bboxes = np.ascontiguousarray(bboxes, np.float32).reshape(-1, 4)
+        n, (nm, mh, mw), (ih, iw) = masks_in.shape[0], protos.shape, shape
+        assert bboxes.shape[0] == n
+        out = np.zeros((n, ih, iw) if upsample else (n, mh, mw), np.uint8)
+        _lib.check(self.lib, self.lib.ys_process_mask(self.ctx, _ptr(protos), _ptr(masks_in), _ptr(bboxes), 0, n, nm, mh, mw,
+                                                      ih, iw, int(bool(upsample)), int(bool(cpu_crop_branch)), _ptr(out)))
+        return out.astype(bool)
+
     # ---- Ops.non_max_suppression (Ops.cs:239-371)
     def non_max_suppression(self, prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False, max_det=300, nc=0,
                             max_time_img=0.05, max_nms=30000, max_wh=7680, in_place=True, rotated=False,

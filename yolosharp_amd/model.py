@@ -21,13 +21,15 @@ DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 class Yolov8:
     FAMILY = 8          # ys_family: Models/Yolo.cs:10-135
+    TASK = 0            # ys_task: 0 detect, 1 segment
+    NM = 0              # mask coefficients per anchor (Segment heads: 32)
 
     def __init__(self, engine: Engine, nc=80, reg_max=16, size="n", height=640, width=640, max_batch=1, dtype="bf16",
                  max_labels=0):
         self.engine, self.lib = engine, engine.lib
         self.nc, self.reg_max, self.height, self.width, self.max_batch = nc, reg_max, height, width, max_batch
         self.dtype = dtype
-        desc = _lib.ModelDesc(self.FAMILY, SIZES[size], 0, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels)
+        desc = _lib.ModelDesc(self.FAMILY, SIZES[size], self.TASK, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels)
         self.handle = C.c_void_p()
         _lib.check(self.lib, self.lib.ys_model_create(engine.ctx, C.byref(desc), C.byref(self.handle)))
         self.training = True
@@ -129,8 +131,12 @@ class Yolov8:
 
     def get_output(self, key):
         B = self._batch
-        C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc, "dboxes": 4 * self.reg_max, "dscores": self.nc}[key]
-        a = np.empty((B, C_, self.A), np.float32)
+        C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc + self.NM, "dboxes": 4 * self.reg_max,
+              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM}.get(key)
+        if key in ("proto", "dproto"):
+            a = np.empty((B, self.NM, self.height // 4, self.width // 4), np.float32)
+        else:
+            a = np.empty((B, C_, self.A), np.float32)
         _lib.check(self.lib, self.lib.ys_model_get_output(self.handle, key.encode(), _ptr(a), a.size))
         return a
 
@@ -177,6 +183,33 @@ class Yolov11(Yolov8):
     FAMILY = 11
 
 
+class _SegmentMixin:
+    """Head.Segment (Head.cs:238-324): preds gain "mask_coefficient" [B,32,A] and "proto" [B,32,H/4,W/4]; the eval
+    inference dict is {"boxes": [B,4+nc+32,A], "proto": ...} (Head.cs:303-313)."""
+    TASK = 1
+    NM = 32
+
+    def forward(self, x, fetch=True):
+        inf, preds = Yolov8.forward(self, x, fetch)
+        if not fetch:
+            return inf, preds
+        preds["mask_coefficient"] = self.get_output("mask_coefficient")
+        preds["proto"] = self.get_output("proto")
+        if inf is not None:
+            inf["proto"] = preds["proto"]
+        return inf, preds
+
+    __call__ = forward
+
+
+class Yolov8Segment(_SegmentMixin, Yolov8):
+    """Models/Yolo.cs:337-352."""
+
+
+class Yolov11Segment(_SegmentMixin, Yolov11):
+    """Models/Yolo.cs:354-370."""
+
+
 class v8DetectionLoss:
     """Loss.cs:328-484.  forward(preds, batch): `preds` is implicit (the model's last training forward stays on the
     device); batch = {"batch_idx": [N], "cls": [N], "bboxes": [N,4] normalised cxcywh} (YoloDataLoader.cs:18-44)."""
@@ -203,6 +236,38 @@ class v8DetectionLoss:
         _lib.check(self.lib, self.lib.ys_loss_read(self.model.handle, items, C.byref(total)))
         loss_detach = np.array(list(items), np.float32)
         return loss_detach * self.model._batch, loss_detach      # (loss * batch_size, loss.detach()), Loss.cs:476
+
+
+class v8SegmentationLoss(v8DetectionLoss):
+    """Loss.cs:688-863.  batch additionally carries "masks" [B, H/4, W/4] (overlap-encoded instance ids,
+    YoloDataset.cs:265-267).  Returns (loss*B [5], loss_detach [5]) in the order box, seg, cls, dfl, semseg.
+    cpu_crop_branch selects Ops.crop_mask's CPU-only integer branch (Ops.cs:421-435) instead of the broadcast form."""
+
+    def __init__(self, model, cpu_crop_branch=False):
+        super().__init__(model)
+        self.crop_mode = 1 if cpu_crop_branch else 0
+
+    def forward_device(self, bidx_dev, cls_dev, box_dev, n, masks_dev):
+        _lib.check(self.lib, self.lib.ys_loss_segment(self.model.handle, bidx_dev, cls_dev, box_dev, n, masks_dev, 1, self.crop_mode))
+
+    def forward(self, preds, batch, read=True):
+        bi = np.ascontiguousarray(np.asarray(batch["batch_idx"], np.float32).reshape(-1))
+        cl = np.ascontiguousarray(np.asarray(batch["cls"], np.float32).reshape(-1))
+        bb = np.ascontiguousarray(np.asarray(batch["bboxes"], np.float32).reshape(-1, 4))
+        mk = np.ascontiguousarray(np.asarray(batch["masks"], np.float32))
+        m = self.model
+        assert mk.shape == (m._batch, m.height // 4, m.width // 4), mk.shape
+        _lib.check(self.lib, self.lib.ys_loss_segment(m.handle, _ptr(bi), _ptr(cl), _ptr(bb), bi.shape[0], _ptr(mk), 0, self.crop_mode))
+        return self.read() if read else None
+
+    __call__ = forward
+
+    def read(self):
+        items = (C.c_float * 5)()
+        total = C.c_float()
+        _lib.check(self.lib, self.lib.ys_loss_read_items(self.model.handle, items, 5, C.byref(total)))
+        loss_detach = np.array(list(items), np.float32)
+        return loss_detach * self.model._batch, loss_detach
 
 
 class AMPWrapper:
