@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (class,label,us) of the profiled conv launches (triage)")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +152,8 @@ def main():
         eng.synchronize()
         n_ig, ms_ig = eng.kernel_profile_read("conv_igemm")
         n_wg, ms_wg = eng.kernel_profile_read("conv_wgrad")
+        if args.dump_launches:
+            eng.kernel_profile_dump(args.dump_launches)
         eng.kernel_profile(False)
         steps_prof = 2
         bytes_per_launch = wk["igemm_bytes"] * B / wk["igemm_launches"]

@@ -189,6 +189,8 @@ YS_API int ys_ctx_last_ms(ys_ctx* ctx, const char* name, float* ms);
  * "conv_wgrad", "bn_act", "nms"); enable for a few UNTIMED steps, then read the launch count and summed duration. */
 YS_API int ys_ctx_kernel_profile(ys_ctx* ctx, int enable);
 YS_API int ys_ctx_kernel_profile_read(ys_ctx* ctx, const char* name, int32_t* launches, float* total_ms);
+/* per-launch CSV (class,label,us) of everything recorded since profiling was enabled (triage tool) */
+YS_API int ys_ctx_kernel_profile_dump(ys_ctx* ctx, const char* path);
 
 #ifdef __cplusplus
 }

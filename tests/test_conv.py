@@ -65,7 +65,10 @@ def test_conv_bn_act_forward(backend, engine, dtype, case):
 
 
 BWD_CASES = [(2, 16, 8, 8, 32, 3, 1), (2, 16, 8, 8, 16, 1, 1), (1, 32, 9, 7, 80, 3, 2), (2, 3, 8, 8, 16, 3, 2),
-             (2, 64, 6, 6, 80, 3, 2), (2, 80, 4, 4, 80, 1, 1), (1, 96, 6, 6, 64, 1, 1)]
+             (2, 64, 6, 6, 80, 3, 2), (2, 80, 4, 4, 80, 1, 1), (1, 96, 6, 6, 64, 1, 1),
+             # multi-tile images, ragged tile edges, several (cout, cin) channel tiles (LDS-tile wgrad kernel)
+             (2, 32, 20, 40, 32, 3, 1), (1, 128, 12, 20, 144, 3, 1), (1, 256, 5, 5, 64, 1, 1), (2, 16, 18, 36, 16, 3, 2),
+             (3, 48, 13, 17, 32, 1, 1)]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "ys_ctx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ys_ctx_kernel_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ys_ctx_kernel_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, c_i32_p, c_float_p]),
+    "ys_ctx_kernel_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ys_ctx_last_ms": (C.c_int, [C.c_void_p, C.c_char_p, c_float_p]),
 }
 

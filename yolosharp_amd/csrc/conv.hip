@@ -511,7 +511,9 @@ static bool conv_use_patch(const ConvArgs& a) { return a.KH == 3 && a.KW == 3 &&
 template <class T, int MR, int NR>
 static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
   dim3 grid(ys_cdiv(a.M, 4 * MR * 16), ys_cdiv(a.Cout, NR * 16));
-  YsKprofScope prof(st, "conv_igemm");
+  char lab[128] = "";
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "direct k%d s%d div%d cin%d cout%d M%d acc%d mr%d nr%d", a.KH, a.SA, a.DIVM + 1, a.Cin, a.Cout, a.M, a.accumulate, MR, NR);
+  YsKprofScope prof(st, "conv_igemm", lab);
   YS_LAUNCH((conv_igemm_kernel<T, MR, NR>), grid, 256, st, a);
 }
 
@@ -558,7 +560,9 @@ static int conv3x3_launch_t(hipStream_t st, ConvArgs a, const TileChoice& t, con
     hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, MR, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  YsKprofScope prof(st, "conv_igemm");
+  char lab[160] = "";
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "patch k3 s%d div%d cin%d cout%d M%d acc%d mr%d nr%d tile%dx%d grid%dx%d lds%d", a.SA, a.DIVM + 1, a.Cin, a.Cout, a.M, a.accumulate, MR, NR, a.TH, a.TW, gx, gy, (int)p.lds_bytes);
+  YsKprofScope prof(st, "conv_igemm", lab);
   YS_LAUNCH_LDS((conv3x3_tile_kernel<T, MR, NR>), dim3(gx, gy), C3_THREADS, p.lds_bytes, st, a, ntiles, p.nchunks, p.wres, p.wpitch, p.patch_units);
   return YS_OK;
 }
@@ -769,11 +773,299 @@ wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int c
   }
 }
 
+// ------------------------------------------------------------------ wgrad, bf16: LDS tiles + hardware transpose reads
+// One workgroup owns a 2-D tile of TH x TW output pixels (TW a power of two).  It stages the dy tile [pixel][COT] and the
+// input PATCH [(TH-1)*S+KH][(TW-1)*S+KW] x [CIT] once in LDS in their natural NHWC row form, and every tap reads its
+// operands from that one patch: ds_read_b64_tr_b16 delivers 4 consecutive-K (pixel) values of one channel per lane from
+// four freely addressed rows, so the tap shift (and stride 2) is just a different row address -- no per-tap re-read of
+// dy / x from L2 (the round-1 kernel re-fetched both for each of the 9 taps) and no 2-byte transposing LDS traffic.
+//   TAPS == 9: 9 waves, wave w accumulates tap w over all pixels of every tile the workgroup walks (persistent);
+//   TAPS == 1: 4 waves split the 32-pixel K-blocks and are combined through LDS at the end.
+// K order inside a tile is the tile-local pixel index p = ty*TW + tx for both operands; pixels outside the image (or the
+// tile's 32-pixel rounding) read a zero dy row.  Partials go to partial[blockIdx.x][Cout][taps][Cin] (fixed-order reduce).
+template <int MRA, int NRB, int TAPS>
+__global__ void __launch_bounds__(TAPS == 9 ? 576 : 256)
+conv_wgrad_tr_kernel(WgradArgs a) {
+  constexpr int NT = TAPS == 9 ? 576 : 256;
+  constexpr int NW = NT / 64;
+  constexpr int COT = MRA * 16, CIT = NRB * 16;
+  constexpr int DV = COT / 8, XV = CIT / 8;            // 16-byte units per pixel row
+  constexpr int TPMAX = TAPS == 9 ? 256 : 128;
+  constexpr int ND = (TPMAX * DV + NT - 1) / NT;       // dy units fetched per thread
+  constexpr int NX = TAPS == 9 ? 5 : (TPMAX * XV + NT - 1) / NT;   // patch units per thread (host keeps PH*PW*XV <= NX*NT)
+  YS_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int TW = 1 << a.TWS, TP = a.TH * TW;
+  const int nkb = (TP + 31) >> 5;
+  const int ZR = nkb * 32;                              // zero row of the dy image
+  char* sDb = (char*)lds;                               // [ZR + 1][pdb]
+  char* sXb = sDb + (size_t)(ZR + 1) * a.pdb;           // [PH*PW][pxb]
+  const int ci_tiles = (a.Cin + CIT - 1) / CIT;
+  const int co0 = (blockIdx.y / ci_tiles) * COT;
+  const int ci0 = (blockIdx.y % ci_tiles) * CIT;
+  const char* dyb = (const char*)a.dy;
+  const char* xb = (const char*)a.x;
+  const int S = a.stride;
+  const int npatch = a.PH * a.PW * XV;
+
+  for (int i = tid; i < a.pdb / 4; i += NT) ((unsigned*)(sDb + (size_t)ZR * a.pdb))[i] = 0u;
+
+  uint4 rd[ND], rx[NX];
+  auto fetch = [&](int tile) {
+    int t = tile;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = tyi * a.TH, ox0 = txi * TW;
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const int idx = tid + NT * k;
+      uint4 v = ys_zero16();
+      if (idx < TP * DV) {
+        const int p = idx / DV, u = idx - p * DV;
+        const int oy = oy0 + (p >> a.TWS), ox = ox0 + (p & (TW - 1));
+        const int c = co0 + u * 8;
+        if (oy < a.Hout && ox < a.Wout && c < a.Cout)
+          v = ys_ld16(dyb + ((((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc) + a.dy_coff + c) * 2L);
+      }
+      rd[k] = v;
+    }
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int idx = tid + NT * k;
+      uint4 v = ys_zero16();
+      if (idx < npatch) {
+        const int pix = idx / XV, u = idx - pix * XV;
+        const int r = pix / a.PW, cc = pix - r * a.PW;
+        const int iy = iy0 + r, ix = ix0 + cc;
+        const int c = ci0 + u * 8;
+        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.Cin)
+          v = ys_ld16(xb + ((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) + a.in_coff + c) * 2L);
+      }
+      rx[k] = v;
+    }
+  };
+
+  f32x4 acc[MRA][NRB];
+#pragma unroll
+  for (int i = 0; i < MRA; i++)
+#pragma unroll
+    for (int j = 0; j < NRB; j++) acc[i][j] = f32x4_zero();
+
+  const int tap = TAPS == 9 ? wave : 0;
+  const int kh = tap / 3, kw = tap - kh * 3;
+  const int rr = li >> 2, c4 = li & 3;                  // this lane's row / 4-column group inside a [4][16] block
+  // K order: MFMA k = 8q + 4h + j  <->  tile pixel p = 32*kb + 16h + 4q + j (any bijection works as long as both operands
+  // use it); this one makes the 32 lanes the LDS services together (q, q+1) read 8 consecutive rows -> distinct banks with
+  // the odd-slot row pitch.  Per lane and h the pixel advances by 32 per K-block: constant LDS strides, no per-step divides.
+  unsigned dof[2], xof[2];
+  int ty0[2], tx0[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int p0 = 16 * h + 4 * q + rr;
+    ty0[h] = p0 >> a.TWS; tx0[h] = p0 & (TW - 1);
+    dof[h] = (unsigned)(p0 * a.pdb + c4 * 8);
+    xof[h] = (unsigned)((size_t)(ZR + 1) * a.pdb) + (unsigned)(((ty0[h] * S + kh) * a.PW + tx0[h] * S + kw) * a.pxb + c4 * 8);
+  }
+  const unsigned dstep = 32u * (unsigned)a.pdb;                          // 32 pixels further down the dy image
+  const unsigned xstep = (unsigned)((32 >> a.TWS) * S * a.PW * a.pxb);   // 32/TW tile rows further down the patch
+  const unsigned zof = (unsigned)(ZR * a.pdb + c4 * 8);
+  const unsigned xzero = (unsigned)((ZR + 1) * a.pdb + c4 * 8);
+  const int rows_kb = 32 >> a.TWS;
+  const char* lb = (const char*)lds;
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) fetch(tile);
+  while (tile < a.ntiles) {
+    __syncthreads();                                    // every wave finished reading the previous tile
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const int idx = tid + NT * k;
+      if (idx < TP * DV) { const int p = idx / DV; *(uint4*)(sDb + (size_t)p * a.pdb + (idx - p * DV) * 16) = rd[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int idx = tid + NT * k;
+      if (idx < npatch) { const int pix = idx / XV; *(uint4*)(sXb + (size_t)pix * a.pxb + (idx - pix * XV) * 16) = rx[k]; }
+    }
+    __syncthreads();
+    int t = tile;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int oy0 = tyi * a.TH, ox0 = txi * TW;
+    const int ntile = tile + gridDim.x;
+    if (ntile < a.ntiles) fetch(ntile);                 // in flight while this tile is consumed
+    // rows of the tile that hold image pixels (tile-local), and this lane's column validity
+    const int tylim = (a.Hout - oy0) < a.TH ? (a.Hout - oy0) : a.TH;
+    const bool colok0 = (ox0 + tx0[0]) < a.Wout, colok1 = (ox0 + tx0[1]) < a.Wout;
+    for (int kb = (TAPS == 9 ? 0 : wave); kb < nkb; kb += (TAPS == 9 ? 1 : NW)) {
+      // the transpose reads land asynchronously: their destination registers must not be touched before ys_lds_tr_wait
+      uint2 ra[2][MRA], rb[2][NRB];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int ty = ty0[h] + kb * rows_kb;
+        const bool ok = (h == 0 ? colok0 : colok1) && ty < tylim;
+        const unsigned d = ok ? dof[h] + (unsigned)kb * dstep : zof;
+        const unsigned x = ty < a.TH ? xof[h] + (unsigned)kb * xstep : xzero;   // rounding pixels: any initialised row
+#pragma unroll
+        for (int i = 0; i < MRA; i++) ra[h][i] = ys_lds_tr_b64(lb + d + i * 32);
+#pragma unroll
+        for (int j = 0; j < NRB; j++) rb[h][j] = ys_lds_tr_b64(lb + x + j * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < MRA; i++) ys_lds_tr_wait(ra[0][i], ra[1][i]);
+#pragma unroll
+      for (int j = 0; j < NRB; j++) ys_lds_tr_wait(rb[0][j], rb[1][j]);
+      uint4 fa[MRA], fb[NRB];
+#pragma unroll
+      for (int i = 0; i < MRA; i++) fa[i] = make_uint4(ra[0][i].x, ra[0][i].y, ra[1][i].x, ra[1][i].y);
+#pragma unroll
+      for (int j = 0; j < NRB; j++) fb[j] = make_uint4(rb[0][j].x, rb[0][j].y, rb[1][j].x, rb[1][j].y);
+#pragma unroll
+      for (int i = 0; i < MRA; i++)
+#pragma unroll
+        for (int j = 0; j < NRB; j++) acc[i][j] = ys_mma<bf16_t>(fa[i], fb[j], acc[i][j]);
+    }
+    tile = ntile;
+  }
+
+  float* outp = a.partial + (long)blockIdx.x * a.Cout * a.KH * a.KW * a.Cin;
+  const int taps = a.KH * a.KW;
+  if (TAPS == 9) {
+#pragma unroll
+    for (int i = 0; i < MRA; i++)
+#pragma unroll
+      for (int j = 0; j < NRB; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int co = co0 + i * 16 + 4 * q + r, ci = ci0 + j * 16 + li;
+          if (co < a.Cout && ci < a.Cin) outp[((long)co * taps + tap) * a.Cin + ci] = acc[i][j][r];
+        }
+  } else {
+    __syncthreads();
+    float* sR = (float*)lds;                            // [NW][COT][CIT]
+#pragma unroll
+    for (int i = 0; i < MRA; i++)
+#pragma unroll
+      for (int j = 0; j < NRB; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sR[(wave * COT + i * 16 + 4 * q + r) * CIT + j * 16 + li] = acc[i][j][r];
+    __syncthreads();
+    for (int e = tid; e < COT * CIT; e += NT) {
+      const int co = co0 + e / CIT, ci = ci0 + e % CIT;
+      if (co < a.Cout && ci < a.Cin) {
+        float v = 0.f;
+        for (int w = 0; w < NW; w++) v += sR[w * COT * CIT + e];
+        outp[(long)co * a.Cin + ci] = v;
+      }
+    }
+  }
+}
+
+// host-side plan of the LDS-tile wgrad kernel
+struct WgPlan { int ok, taps9, mra, nrb, th, tws, tx, ty, ph, pw, pdb, pxb, gx; size_t lds; };
+static int wg_pitch_bytes(int ch) {       // smallest row pitch >= ch*2 bytes whose 32-byte slot count is odd (8 rows -> 8 bank slots)
+  int s = (ch * 2 + 31) / 32;
+  if (!(s & 1)) s++;
+  return s * 32;
+}
+static WgPlan wgrad_tr_plan(const WgradArgs& a) {
+  WgPlan p{};
+  const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2);
+  const bool k1 = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1;
+  if (a.dy_rh || !(k3 || k1)) return p;
+  const int cof = (a.Cout + 15) / 16, cif = (a.Cin + 15) / 16;
+  p.mra = cof >= 4 ? ((cof % 5 == 0) ? 5 : 4) : cof;
+  p.nrb = cif >= 4 ? 4 : cif;
+  p.taps9 = k3 ? 1 : 0;
+  if (k3) {
+    // the 9-wave kernel has 168 registers per lane (3 waves/SIMD): fragment tiles that fit without spilling, cheapest re-read
+    static const int ok_pairs[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {3, 1}, {3, 2}, {3, 3}, {3, 4}, {4, 1}, {4, 2}, {5, 1}};
+    int best_cost = 1 << 30;
+    for (auto& pr : ok_pairs) {
+      const int m = pr[0], n = pr[1];
+      if (m > cof || n > cif) continue;
+      const int cost = ys_cdiv(cof, m) * ys_cdiv(cif, n) * (m + n) * 16 + (ys_cdiv(cof, m) * m - cof) + (ys_cdiv(cif, n) * n - cif) + (n > m ? 1 : 0);
+      if (cost < best_cost) { best_cost = cost; p.mra = m; p.nrb = n; }
+    }
+  }
+  const int nt = k3 ? 576 : 256, tpmax = k3 ? 256 : 128;
+  const int cot = p.mra * 16, cit = p.nrb * 16, xv = cit / 8;
+  const int nxu = (k3 ? 5 : (tpmax * xv + nt - 1) / nt) * nt;
+  const int S = a.stride;
+  p.pdb = wg_pitch_bytes(cot);
+  // stride-2 patches are read every other row: a pitch of 16 (mod 32) bytes makes the 2-row step an odd slot count
+  p.pxb = S == 1 ? wg_pitch_bytes(cit) : ((cit * 2 + 15) / 32) * 32 + 16;
+  double best = 1e30;
+  for (int tws = 2; tws <= 5; tws++) {
+    const int tw = 1 << tws;
+    if (tw > a.Wout && tws > 2 && (tw >> 1) >= a.Wout) continue;
+    for (int th = 1; th <= a.Hout && th * tw <= tpmax; th++) {
+      const int ph = (th - 1) * S + a.KH, pw = (tw - 1) * S + a.KW;
+      if (ph * pw * xv > nxu) continue;
+      const int nkb = (th * tw + 31) / 32;
+      size_t lds = (size_t)(nkb * 32 + 1) * p.pdb + (size_t)ph * pw * p.pxb;
+      if (!k3 && lds < (size_t)4 * cot * cit * 4) lds = (size_t)4 * cot * cit * 4;
+      if (lds > 150 * 1024) continue;
+      const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
+      const double cost = (double)tx * ty * ((double)ph * pw * cit + (double)nkb * 32 * cot + 0.5 * nkb * 32 * (cot + cit) + 3000.0);
+      if (cost < best) { best = cost; p.ok = 1; p.th = th; p.tws = tws; p.tx = tx; p.ty = ty; p.ph = ph; p.pw = pw; p.lds = lds; }
+    }
+  }
+  if (!p.ok) return p;
+  const int gy = ys_cdiv(a.Cout, cot) * ys_cdiv(a.Cin, cit);
+  const long ntiles = (long)p.tx * p.ty * a.B;
+  int per_cu = (int)((150 * 1024) / p.lds);
+  const int per_cu_max = k3 ? (p.mra * p.nrb <= 2 ? 2 : 1) : 4;   // 9-wave workgroups are register-limited to 1-2 per CU
+  if (per_cu > per_cu_max) per_cu = per_cu_max;
+  if (per_cu < 1) per_cu = 1;
+  long gx = (256L * per_cu) / gy;
+  gx = gx / 8 * 8;                                       // same-x workgroups (same pixels, other channel tiles) share an XCD
+  if (gx < 8) gx = 8;
+  const long wsmax = (48L << 20) / ((long)a.Cout * a.KH * a.KW * a.Cin * 4);   // bound the partial workspace to 48 MB per layer
+  if (gx > wsmax) gx = wsmax > 0 ? wsmax : 1;
+  if (gx > ntiles) gx = ntiles;
+  const long per = (ntiles + gx - 1) / gx;                // equal tile counts: no idle tail workgroups, fewer partials
+  gx = (ntiles + per - 1) / per;
+  p.gx = (int)gx;
+  return p;
+}
+
+template <int MRA, int NRB, int TAPS>
+static void wgrad_tr_launch_t(hipStream_t st, WgradArgs a, const WgPlan& p) {
+  a.TH = p.th; a.TWS = p.tws; a.tiles_x = p.tx; a.tiles_y = p.ty; a.ntiles = p.tx * p.ty * a.B;
+  a.PH = p.ph; a.PW = p.pw; a.pdb = p.pdb; a.pxb = p.pxb;
+  const int gy = ys_cdiv(a.Cout, MRA * 16) * ys_cdiv(a.Cin, NRB * 16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<MRA, NRB, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  char lab[160] = "";
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "wgrad_tr k%d s%d cin%d cout%d M%d tile%dx%d grid%dx%d lds%d", a.KH, a.stride, a.Cin, a.Cout, a.M, p.th, 1 << p.tws, p.gx, gy, (int)p.lds);
+  YsKprofScope prof(st, "conv_wgrad", lab);
+  YS_LAUNCH_LDS((conv_wgrad_tr_kernel<MRA, NRB, TAPS>), dim3(p.gx, gy), (TAPS == 9 ? 576 : 256), p.lds, st, a);
+}
+
+static bool wgrad_tr_dispatch(hipStream_t st, const WgradArgs& a, const WgPlan& p) {
+#define WT(M_, N_) if (p.mra == M_ && p.nrb == N_) { if (p.taps9) wgrad_tr_launch_t<M_, N_, 9>(st, a, p); else wgrad_tr_launch_t<M_, N_, 1>(st, a, p); return true; }
+  WT(1, 1) WT(1, 2) WT(1, 3) WT(1, 4)
+  WT(2, 1) WT(2, 2) WT(2, 3) WT(2, 4)
+  WT(3, 1) WT(3, 2) WT(3, 3) WT(3, 4)
+  WT(4, 1) WT(4, 2) WT(4, 3) WT(4, 4)
+  WT(5, 1) WT(5, 2) WT(5, 3) WT(5, 4)
+#undef WT
+  return false;
+}
+
 template <class T, int MRA, int NRB>
 static void wgrad_launch_t(hipStream_t st, const WgradArgs& a, int splits) {
   const int co_tiles = ys_cdiv(a.Cout, MRA * 16), ci_tiles = ys_cdiv(a.Cin, NRB * 16);
   dim3 grid(splits, co_tiles * ci_tiles, a.KH * a.KW);
-  YsKprofScope prof(st, "conv_wgrad");
+  char lab[128] = "";
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "wgrad k%d s%d cin%d cout%d M%d splits%d tiles%d", a.KH, a.stride, a.Cin, a.Cout, a.M, splits, co_tiles * ci_tiles);
+  YsKprofScope prof(st, "conv_wgrad", lab);
   YS_LAUNCH((conv_wgrad_kernel<T, MRA, NRB>), grid, 256, st, a);
 }
 
@@ -793,6 +1085,10 @@ static void wgrad_dispatch(hipStream_t st, const WgradArgs& a, int splits) {
 
 // number of pixel splits used for a layer (also sizes the partial workspace)
 int ys_wgrad_splits(const WgradArgs& a, int dtype) {
+  if (dtype == YS_BF16) {
+    const WgPlan p = wgrad_tr_plan(a);
+    if (p.ok) return p.gx;
+  }
   const int ks = dtype == YS_BF16 ? 32 : 16;
   const int cof = (a.Cout + 15) / 16, cif = (a.Cin + 15) / 16;
   const int mra = cof >= 4 ? ((cof % 5 == 0) ? 5 : 4) : cof;
@@ -813,8 +1109,19 @@ int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, i
     ys_set_error("wgrad: channel counts/strides must be multiples of %d (Cin %d Cout %d)", epl, a.Cin, a.Cout);
     return YS_ERR_INVALID_ARG;
   }
-  if (dtype == YS_BF16) wgrad_dispatch<bf16_t>(st, a, splits);
-  else wgrad_dispatch<float>(st, a, splits);
+  bool done = false;
+  if (dtype == YS_BF16) {
+    WgPlan p = wgrad_tr_plan(a);
+    if (p.ok) {
+      if (splits < p.gx) p.gx = splits;     // never exceed the caller's partial workspace
+      splits = p.gx;
+      done = wgrad_tr_dispatch(st, a, p);
+    }
+  }
+  if (!done) {
+    if (dtype == YS_BF16) wgrad_dispatch<bf16_t>(st, a, splits);
+    else wgrad_dispatch<float>(st, a, splits);
+  }
   const long n = (long)a.Cout * a.KH * a.KW * a.Cin;
   YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 64), 256, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
   return YS_OK;

@@ -13,14 +13,16 @@ void ys_set_error(const char* fmt, ...) {
 }
 
 namespace {
-struct KprofEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; hipEvent_t open = nullptr; };
+struct KprofEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; std::vector<std::string> labels; hipEvent_t open = nullptr; std::string open_label; };
 bool g_kprof_on = false;
 std::map<std::string, KprofEntry> g_kprof;
 }  // namespace
 
-void ys_kprof_begin(hipStream_t st, const char* name) {
+bool ys_kprof_enabled() { return g_kprof_on; }
+void ys_kprof_begin(hipStream_t st, const char* name, const char* label) {
   if (!g_kprof_on) return;
   KprofEntry& e = g_kprof[name];
+  e.open_label = label ? label : "";
   hipEvent_t a = nullptr;
   if (hipEventCreate(&a) != hipSuccess) return;
   hipEventRecord(a, st);
@@ -34,6 +36,7 @@ void ys_kprof_end(hipStream_t st, const char* name) {
   if (hipEventCreate(&b) != hipSuccess) return;
   hipEventRecord(b, st);
   e.ev.push_back({e.open, b});
+  e.labels.push_back(e.open_label);
   e.open = nullptr;
 }
 
@@ -60,6 +63,23 @@ int ys_ctx_kernel_profile_read(ys_ctx* ctx, const char* name, int32_t* launches,
     float ms = 0.f;
     if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { *total_ms += ms; *launches += 1; }
   }
+  return YS_OK;
+}
+
+// per-launch dump (class, label, microseconds) of everything recorded since profiling was enabled; triage tool
+int ys_ctx_kernel_profile_dump(ys_ctx* ctx, const char* path) {
+  YS_REQUIRE(ctx && path, "ys_ctx_kernel_profile_dump: null argument");
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  FILE* f = fopen(path, "w");
+  YS_REQUIRE(f, "ys_ctx_kernel_profile_dump: cannot open %s", path);
+  fprintf(f, "class,label,us\n");
+  for (auto& kv : g_kprof)
+    for (size_t i = 0; i < kv.second.ev.size(); i++) {
+      float ms = 0.f;
+      if (hipEventSynchronize(kv.second.ev[i].second) == hipSuccess && hipEventElapsedTime(&ms, kv.second.ev[i].first, kv.second.ev[i].second) == hipSuccess)
+        fprintf(f, "%s,%s,%.2f\n", kv.first.c_str(), kv.second.labels[i].c_str(), ms * 1000.f);
+    }
+  fclose(f);
   return YS_OK;
 }
 

@@ -621,6 +621,8 @@ int allocate(ys_model* m) {
   for (auto& c : m->convs) {
     if (c.dw) continue;
     WgradArgs a{}; a.Cin = c.cin_pad; a.Cout = c.cout; a.KH = a.KW = c.k; a.M = (int)((long)B * c.Hout * c.Wout);
+    a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout; a.stride = c.s; a.pad = c.k / 2;
+    if (c.ct) { a.Hout = c.Hin; a.Wout = c.Win; a.M = (int)((long)B * c.Hin * c.Win); a.dy_rh = 1; }
     wgp = std::max(wgp, (long)ys_wgrad_splits(a, m->dtype) * c.cout * c.k * c.k * c.cin_pad);
   }
   m->n_wgp = wgp;

@@ -221,4 +221,44 @@ __device__ inline void ys_wave_sync() {
 #endif
 }
 
+// ---------------------------------------------------------------- LDS transpose read (gfx950 ds_read_b64_tr_b16)
+// Every lane passes the LDS address of 4 contiguous 16-bit elements (8-byte aligned).  Within each 16-lane group the
+// lanes' 16 addresses describe a [4 rows][16 cols] block (lane 4*row + col/4 holds cols 4*(col/4)..+3 of its row; the row
+// stride is free) and lane `li` of the group receives column li of the 4 rows:
+//   result(l)[j] = elem[ addr(lane (l & ~15) + 4*j + ((l & 15) >> 2)) ][ (l & 15) & 3 ]      j = 0..3
+// (lane mapping measured on MI355X with tools/probe/probe_tr.hip).  Two reads give the 8 consecutive-K values an MFMA
+// operand lane needs when the LDS image has K as the row index (wgrad: K = pixels, NHWC rows).
+// The read is asynchronous: call ys_lds_tr_wait() on every value before it is used.
+__device__ inline uint2 ys_lds_tr_b64(const void* p) {
+#ifdef YS_EMU_BUILD
+  const void* mine = p;
+  uint2 out = make_uint2(0u, 0u);
+  const int l = emu::lane();
+  emu::wave_collective(&mine, sizeof(mine), [&](unsigned char (*slot)[128]) {
+    unsigned e[4];
+    for (int j = 0; j < 4; j++) {
+      const int src = (l & ~15) + 4 * j + ((l & 15) >> 2);
+      const unsigned short* sp;
+      memcpy(&sp, slot[src], sizeof(sp));
+      e[j] = sp[l & 3];
+    }
+    out.x = e[0] | (e[1] << 16);
+    out.y = e[2] | (e[3] << 16);
+  });
+  return out;
+#else
+  uint2 v;
+  const unsigned addr = (unsigned)(uintptr_t)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+#endif
+}
+__device__ inline void ys_lds_tr_wait(uint2& a, uint2& b) {
+#ifndef YS_EMU_BUILD
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+#else
+  (void)a; (void)b;
+#endif
+}
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

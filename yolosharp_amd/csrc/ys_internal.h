@@ -65,11 +65,12 @@ struct YsTimer {
 
 // ---- per-kernel-class timing with HIP events on the launch stream (off by default; bench.py enables it
 //      for a few untimed steps to measure the dominant kernel's average launch duration)
-void ys_kprof_begin(hipStream_t st, const char* name);
+bool ys_kprof_enabled();
+void ys_kprof_begin(hipStream_t st, const char* name, const char* label = nullptr);
 void ys_kprof_end(hipStream_t st, const char* name);
 struct YsKprofScope {
   hipStream_t st; const char* name;
-  YsKprofScope(hipStream_t s, const char* n) : st(s), name(n) { ys_kprof_begin(st, name); }
+  YsKprofScope(hipStream_t s, const char* n, const char* label = nullptr) : st(s), name(n) { ys_kprof_begin(st, name, label); }
   ~YsKprofScope() { ys_kprof_end(st, name); }
 };
 

@@ -41,6 +41,8 @@ struct WgradArgs {
   int M;
   int dy_rh, dy_rw; // dy_rh != 0: dy row = b*dy_bstride + oh*dy_rh + ow*dy_rw + dy_r0 (ConvTranspose phases)
   long dy_r0;
+  // tile geometry of the bf16 LDS-tile kernel (filled by the launcher)
+  int TH, TWS, tiles_x, tiles_y, ntiles, PH, PW, pdb, pxb;
 };
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);

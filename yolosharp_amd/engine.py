@@ -66,6 +66,9 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_ctx_kernel_profile_read(self.ctx, name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def kernel_profile_dump(self, path):
+        _lib.check(self.lib, self.lib.ys_ctx_kernel_profile_dump(self.ctx, str(path).encode()))
+
     # ---- device memory helpers (bench keeps inputs resident in HBM)
     def malloc(self, nbytes):
         p = C.c_void_p()
