@@ -17,6 +17,13 @@ FWD_CASES = [
     (1, 256, 4, 4, 128, 1, 1, True, False, False, True),    # SPPF.cv1: no activation (Block.cs:257)
     (1, 272, 4, 4, 16, 1, 1, True, False, True, True),      # K tail: Cin not a multiple of the k-step
     (2, 64, 5, 5, 7, 1, 1, False, True, False, True),       # nc not a multiple of 4 (masked stores)
+    # multi-tile images with ragged tile edges (whole-Cin LDS patch kernel): resident and streamed weights, stride 2,
+    # several output-channel tiles, Cin/8 odd (wider patch pitch)
+    (2, 32, 20, 40, 48, 3, 1, True, False, True, True),
+    (1, 128, 12, 20, 144, 3, 1, True, False, True, True),
+    (2, 16, 18, 36, 16, 3, 2, True, False, True, True),
+    (1, 40, 23, 17, 80, 3, 1, True, False, True, False),
+    (3, 64, 21, 21, 64, 3, 2, False, True, False, True),
 ]
 
 

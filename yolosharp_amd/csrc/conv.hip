@@ -452,6 +452,402 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
   }
 }
 
+// ===================================================================================== 3x3, bf16: whole-Cin LDS patch ("P2")
+// Round-1 follow-up of the patch kernel above for bf16 (the f32 parity path keeps the chunked kernel).  Differences:
+//  * the patch holds ALL input channels of the tile (+halo) in natural NHWC rows, so a tile needs one load phase and one
+//    barrier pair instead of two barriers per 32-channel chunk;
+//  * K runs over (tap, channel) in steps of 32 regardless of Cin (Cin = 16 packs two taps into one MFMA); the LDS offset
+//    of every (K-step, q) fragment is tile-independent and comes from a small table built once per workgroup, and each
+//    lane's pixel offsets are computed once per kernel -> the inner loop is 1 table read + adds + ds_read_b128 + MFMA;
+//  * small weight sets stay resident (persistent grid); large ones stream through a double-buffered LDS ring, one barrier
+//    per K-group, so the footprint stays <= ~75 KB and two workgroups share a CU (one loads while the other computes);
+//  * 256 threads, <= 128 VGPRs: register pressure no longer caps occupancy.
+// Handles forward (stride 1 and 2) and stride-1 dgrad (same gather, flipped weights); DIV = 2 dgrads stay on the old path.
+// Epilogue of the P2 kernel.  Phase 1: the wave rounds its whole 16*MR x BN accumulator tile into a wave-private LDS
+// slice (fragment layout -> pixel rows) and records each pixel's output row.  Phase 2: the wave streams the slice back
+// out as full 16-byte vectors -- consecutive lanes cover consecutive channels of one pixel row -- applying the residual /
+// gradient accumulation there, and takes the BN batch statistics per 8-channel column (fixed per lane).  Compared with
+// conv_epilogue the two phases keep few values live, which leaves the registers to the next tile's patch prefetch.
+template <int MR, int NR>
+__device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const long (&orow)[MR], const bool (&pv)[MR],
+                                   int n0, char* stg, float* sStat, long stat_row) {
+  typedef bf16_t T;
+  constexpr int BN = NR * 16;
+  constexpr int PITCH = (BN + 8) * 2;         // bytes per staged pixel row
+  constexpr int NPX = 16 * MR;
+  constexpr int VPP = BN / 8;                  // 16-byte vectors per pixel
+  constexpr int PPI = 64 / VPP;                // pixels per wave iteration
+  constexpr int NITER = (NPX + PPI - 1) / PPI;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  long* rowtab = (long*)(stg + NPX * PITCH);
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++) {
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++) {
+      const int c = n0 + nf * 16 + 4 * q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
+      if (a.scale || a.shift) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int cc = (c + r) < a.Cout ? (c + r) : 0;
+          v[r] = v[r] * (a.scale ? a.scale[cc] : 1.0f) + (a.shift ? a.shift[cc] : 0.0f);
+          if (a.act) v[r] = ys_silu(v[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) if (c + r >= a.Cout) v[r] = 0.f;   // padded channels of the output row stay zero
+      uint2 pk;
+      pk.x = ys_pack_bf16x2(v[0], v[1]);
+      pk.y = ys_pack_bf16x2(v[2], v[3]);
+      *(uint2*)(stg + (mf * 16 + li) * PITCH + (nf * 16 + 4 * q) * 2) = pk;
+    }
+    if (q == 0) rowtab[mf * 16 + li] = pv[mf] ? orow[mf] : -1L;
+  }
+  ys_wave_sync();
+  const int cv = lane % VPP, pl = lane / VPP;
+  const bool active = lane < PPI * VPP;
+  const int c = n0 + cv * 8;
+  const bool do_stats = a.stats != nullptr;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; }
+  char* yb = (char*)a.y;
+  const char* rb = (const char*)a.res;
+#pragma unroll 2
+  for (int it = 0; it < NITER; it++) {
+    const int px = it * PPI + pl;
+    if (active && px < NPX && c < a.Cout) {
+      const long row = rowtab[px];
+      if (row >= 0) {
+        uint4 val = *(const uint4*)(stg + px * PITCH + cv * 16);
+        float f[8];
+        ys_unpack<T>(val, f);
+        if (do_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+        }
+        T* yp = (T*)(yb + (row * a.out_ldc + a.out_coff + c) * 2L);
+        if (rb || a.accumulate) {
+          float gq[8];
+          if (rb) {
+            ys_unpack<T>(ys_ld16(rb + (row * a.res_ldc + a.res_coff + c) * 2L), gq);
+#pragma unroll
+            for (int e = 0; e < 8; e++) f[e] += gq[e];
+          }
+          if (a.accumulate) {
+            ys_unpack<T>(ys_ld16(yp), gq);
+#pragma unroll
+            for (int e = 0; e < 8; e++) f[e] += gq[e];
+          }
+          val = ys_pack<T>(f);
+        }
+        ys_st16(yp, val);
+      }
+    }
+  }
+  ys_wave_sync();
+  if (do_stats) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float x1 = s1[e], x2 = s2[e];
+      if ((VPP & (VPP - 1)) == 0) {
+        for (int msk = VPP; msk < 64; msk <<= 1) { x1 += __shfl_xor(x1, msk); x2 += __shfl_xor(x2, msk); }
+      } else {
+        float t1 = x1, t2 = x2;
+        for (int k = 1; k < PPI; k++) { t1 += __shfl(x1, (lane + k * VPP) & 63); t2 += __shfl(x2, (lane + k * VPP) & 63); }
+        x1 = t1; x2 = t2;
+      }
+      if (lane < VPP) {
+        sStat[((wave * BN) + cv * 8 + e) * 2 + 0] = x1;
+        sStat[((wave * BN) + cv * 8 + e) * 2 + 1] = x2;
+      }
+    }
+    ys_barrier_lds();
+    if (tid < BN && n0 + tid < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < 4; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
+      a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
+      a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
+    }
+  }
+}
+
+#define P2_NPU 12          // patch units (16 B) a thread keeps in flight: 12 x 256 x 16 B = 48 KB per workgroup
+struct P2Args {
+  int TH, TW, tiles_x, tiles_y, ntiles, PH, PW;
+  int ppb;       // patch pixel pitch (bytes)
+  int wpitch;    // weight row pitch in LDS (16-byte units)
+  int nsteps;    // K-steps (32 K each) = ceil(KH*KW*Cin / 32)
+  int kg;        // K-steps per streamed weight group
+  int off_w, off_p, off_stat;   // LDS byte offsets (offset table sits at 0)
+};
+
+template <int MR, int NR, int WRES>
+__global__ void __launch_bounds__(256, 2)   // >= 2 waves per SIMD: two workgroups per CU (matches the LDS budget)
+conv_p2_kernel(ConvArgs a, P2Args g) {
+  typedef bf16_t T;
+  constexpr int BN = NR * 16;
+  constexpr int NWU = WRES ? 1 : (BN * 2 * 4 + 255) / 256;     // streamed weight units per thread (kg = 2)
+  YS_DYN_LDS(lds);
+  char* lb = (char*)lds;
+  int* sOff = (int*)lb;                       // [nsteps][4]
+  uint4* sW = (uint4*)(lb + g.off_w);         // WRES: [BN][wpitch]; else [2][BN][wpitch]
+  char* sPb = lb + g.off_p;                   // [PH*PW][ppb]
+  float* sStat = (float*)(lb + g.off_stat);   // [4][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+  const char* xb = (const char*)a.x;
+  const char* wb = (const char*)a.w;
+  const int taps = a.KH * a.KW;
+  const int Ktot = taps * a.Cin;
+  const int cu = a.Cin >> 3;                  // 16-byte units per patch pixel
+  const int npatch = g.PH * g.PW * cu;
+
+  // ---- tile-independent tables
+  for (int e = tid; e < g.nsteps * 4; e += 256) {
+    const int k0 = (e >> 2) * 32 + (e & 3) * 8;
+    int off = 0;
+    if (k0 < Ktot) {
+      const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      off = (kh * g.PW + kw) * g.ppb + ch * 2;
+    }
+    sOff[e] = off;
+  }
+  int pixbase[MR], pty[MR], ptx[MR];
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++) {
+    const int p = wave * (MR * 16) + mf * 16 + li;
+    int ty = p / g.TW, tx = p - ty * g.TW;
+    if (ty >= g.TH) { ty = g.TH; tx = 0; }    // idle lane of a ragged tile: marked by ty == TH, reads pixel (0,0)
+    pty[mf] = ty; ptx[mf] = tx;
+    pixbase[mf] = ty < g.TH ? ((ty * a.SA) * g.PW + tx * a.SA) * g.ppb : 0;
+  }
+  if (WRES) {
+    const int per_row = g.nsteps * 4;
+    for (int idx = tid; idx < BN * per_row; idx += 256) {
+      const int n = idx / per_row, u = idx - n * per_row;
+      uint4 v = ys_zero16();
+      if (n0 + n < a.Cout && u * 8 < Ktot) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
+      sW[n * g.wpitch + u] = v;
+    }
+  }
+  const int ngroups = WRES ? 1 : (g.nsteps + g.kg - 1) / g.kg;
+  uint4 rw[NWU];
+  auto wfetch = [&](int grp) {                // global -> registers: weights of K-steps [grp*kg, grp*kg + kg)
+    const int gu = g.kg * 4;
+#pragma unroll
+    for (int k = 0; k < NWU; k++) {
+      const int idx = tid + 256 * k;
+      uint4 v = ys_zero16();
+      if (idx < BN * gu) {
+        const int n = idx / gu, u = grp * gu + (idx - n * gu);
+        if (n0 + n < a.Cout && u * 8 < Ktot) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
+      }
+      rw[k] = v;
+    }
+  };
+  auto wstore = [&](int buf) {
+    const int gu = g.kg * 4;
+#pragma unroll
+    for (int k = 0; k < NWU; k++) {
+      const int idx = tid + 256 * k;
+      if (idx < BN * gu) { const int n = idx / gu; sW[(buf * BN + n) * g.wpitch + (idx - n * gu)] = rw[k]; }
+    }
+  };
+
+  // ---- patch of a tile: global -> registers (all loads back-to-back); the NEXT tile's patch is in flight while the
+  // current one is consumed, so every resident workgroup always has a whole patch outstanding (HBM needs ~40 KB per CU
+  // in flight to reach its bandwidth)
+  uint4 rp[P2_NPU];
+  // per-thread patch unit descriptors (tile-independent): patch row (10 bits) | patch column (10) | channel unit (10);
+  // kept packed and re-opened per tile (the asm barrier stops the compiler from keeping 4 derived values per unit live)
+  unsigned pdesc[P2_NPU];
+#pragma unroll
+  for (int k = 0; k < P2_NPU; k++) {
+    const int idx = tid + 256 * k;
+    unsigned d = 0xffffffffu;
+    if (idx < npatch) {
+      const int pix = idx / cu, u = idx - pix * cu;
+      const int r = pix / g.PW, cc = pix - r * g.PW;
+      d = ((unsigned)r << 20) | ((unsigned)cc << 10) | (unsigned)u;
+    }
+    pdesc[k] = d;
+  }
+  auto pfetch = [&](int tile) {
+    int t = tile;
+    const int txi = t % g.tiles_x; t /= g.tiles_x;
+    const int tyi = t % g.tiles_y;
+    const int b = t / g.tiles_y;
+    const int iy0 = tyi * g.TH * a.SA - a.PAD, ix0 = txi * g.TW * a.SA - a.PAD;
+    const char* xbb = xb + ((long)b * a.in_bstride * a.in_ldc + a.in_coff) * 2L;
+#pragma unroll
+    for (int k = 0; k < P2_NPU; k++) {
+      unsigned d = pdesc[k];
+#ifndef YS_EMU_BUILD
+      asm volatile("" : "+v"(d));
+#endif
+      uint4 v = ys_zero16();
+      if (d != 0xffffffffu) {
+        const int iy = iy0 + (int)(d >> 20), ix = ix0 + (int)((d >> 10) & 1023u);
+        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && !(a.dbg & 1))
+          v = ys_ld16(xbb + ((long)(iy * a.Win + ix) * a.in_ldc + (int)(d & 1023u) * 8) * 2L);
+      }
+      rp[k] = v;
+    }
+  };
+  if ((int)blockIdx.x < g.ntiles) pfetch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int txi = t % g.tiles_x; t /= g.tiles_x;
+    const int tyi = t % g.tiles_y;
+    const int b = t / g.tiles_y;
+    const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
+    ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
+    if (!WRES) wfetch(0);
+#pragma unroll
+    for (int k = 0; k < P2_NPU; k++) {
+      unsigned d = pdesc[k];
+#ifndef YS_EMU_BUILD
+      asm volatile("" : "+v"(d));
+#endif
+      if (d != 0xffffffffu && !(a.dbg & 8))
+        *(uint4*)(sPb + ((int)(d >> 20) * g.PW + (int)((d >> 10) & 1023u)) * g.ppb + (int)(d & 1023u) * 16) = rp[k];
+    }
+    if (!WRES) wstore(0);
+    ys_barrier_lds();
+    if (tile + (int)gridDim.x < g.ntiles) pfetch(tile + gridDim.x);
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+      for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+
+    for (int grp = 0; grp < ngroups; grp++) {
+      if (!WRES && grp + 1 < ngroups) wfetch(grp + 1);
+      const int s0 = WRES ? 0 : grp * g.kg;
+      const int s1 = WRES ? g.nsteps : ((s0 + g.kg) < g.nsteps ? (s0 + g.kg) : g.nsteps);
+      const uint4* wbuf = sW + (WRES ? 0 : (grp & 1) * BN * g.wpitch);
+#pragma unroll 1
+      for (int s = (a.dbg & 2) ? s1 : s0; s < s1; s++) {
+        const int off = sOff[s * 4 + q];
+        const int u = (s - s0) * 4 + q;
+        uint4 wf[NR], xf[MR];
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++) wf[nf] = wbuf[(nf * 16 + li) * g.wpitch + u];
+#pragma unroll
+        for (int mf = 0; mf < MR; mf++) xf[mf] = *(const uint4*)(sPb + pixbase[mf] + off);
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf[nf], xf[mf], acc[mf][nf]);
+      }
+      if (!WRES) {
+        if (grp + 1 < ngroups) wstore((grp + 1) & 1);
+        ys_barrier_lds();
+      }
+    }
+    if (WRES) ys_barrier_lds();               // every wave finished reading the patch: it becomes the staging area
+
+    long orow[MR];
+    bool pv[MR];
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) {
+      const int oy = oy0 + pty[mf], ox = ox0 + ptx[mf];
+      pv[mf] = pty[mf] < g.TH && oy < a.Hout && ox < a.Wout;
+      orow[mf] = (long)b * a.out_bstride + (pv[mf] ? ((long)oy * a.Wout + ox) : 0);
+    }
+    char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 8);
+    if (!(a.dbg & 4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, sStat, (long)tile);
+  }
+}
+
+struct P2Plan { int ok, mr, nr, wres, gx, gy; size_t lds; P2Args g; };
+static P2Plan conv_p2_plan(const ConvArgs& a) {
+  P2Plan p{};
+  if (!(a.KH == 3 && a.KW == 3 && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.out_rh == 0 && a.pad_w_delta == 0)) return p;
+  if (a.Cin % 8) return p;
+  const int nfr = (a.Cout + 15) / 16;
+  const int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
+  const int bn = nr * 16;
+  const int cu = a.Cin / 8;
+  P2Args g{};
+  g.ppb = a.Cin * 2 + ((cu & 1) ? 32 : 16);
+  g.nsteps = (9 * a.Cin + 31) / 32;
+  const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
+  const int wres = wres_bytes <= 20 * 1024 ? 1 : 0;
+  g.kg = wres ? g.nsteps : 2;
+  if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
+  g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
+  const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
+  const size_t tab = ((size_t)g.nsteps * 16 + 15) / 16 * 16;
+  const size_t stat = (size_t)4 * bn * 2 * 4;
+  const size_t budget = 76 * 1024;           // two workgroups per CU
+  const int gy = ys_cdiv(a.Cout, bn);
+  // tile = (64*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed weights,
+  // output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large enough
+  double best = 1e30; bool best_full = false;
+  for (int mr = (nr <= 4 ? 4 : 2); mr >= 1; mr >>= 1) {
+    const int npx = 64 * mr;
+    const size_t stage = (size_t)4 * (16 * mr * (bn + 8) * 2 + 16 * mr * 8);
+    for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
+      int th = npx / tw; if (th > a.Hout) th = a.Hout;
+      const int ph = (th - 1) * a.SA + 3, pw = (tw - 1) * a.SA + 3;
+      size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
+      const size_t lds = tab + wbytes + pbytes + stat;
+      if (lds > budget || ph * pw * cu > P2_NPU * 256) continue;
+      const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
+      const long ntiles = (long)tx * ty * a.B;
+      const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * 9.0 * a.Cin) + 1.0 * npx * (a.Cin + bn) + 3000.0;
+      const double cost = (double)tx * ty * per_tile;
+      const bool full = ntiles * gy >= 512;
+      if ((full && !best_full) || (full == best_full && cost < best)) {
+        best = cost; best_full = full;
+        P2Args cur = g;
+        cur.TH = th; cur.TW = tw; cur.tiles_x = tx; cur.tiles_y = ty; cur.PH = ph; cur.PW = pw; cur.ntiles = (int)ntiles;
+        cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
+        p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy;
+      }
+    }
+  }
+  if (!p.ok) return p;
+  if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
+  const int per_cu = p.lds <= 50 * 1024 ? 3 : 2;
+  long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
+  if (gx > p.g.ntiles) gx = p.g.ntiles;
+  if (gx < 1) gx = 1;
+  p.gx = (int)gx;
+  return p;
+}
+
+template <int MR, int NR, int WRES>
+static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
+  static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
+  a.dbg = dbg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  char lab[192] = "";
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k3 s%d div1 cin%d cout%d M%d acc%d mr%d nr%d wres%d tile%dx%d grid%dx%d lds%d", a.SA, a.Cin, a.Cout, a.M, a.accumulate, MR, NR, WRES, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
+  YsKprofScope prof(st, "conv_igemm", lab);
+  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+  return YS_OK;
+}
+static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
+#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) return p.wres ? conv_p2_launch_t<M_, N_, 1>(st, a, p) : conv_p2_launch_t<M_, N_, 0>(st, a, p);
+  P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
+#undef P2
+  ys_set_error("conv p2: no kernel for MR=%d NR=%d", p.mr, p.nr);
+  return YS_ERR_UNSUPPORTED;
+}
+
 // host-side tile choice for the patch kernel: largest pixel tile (64*MR) whose patch fits PATCH_UNITS, shaped to
 // minimise (patch pixels loaded) + (idle tile pixels), keeping a few workgroups per CU
 struct TileChoice { int mr, th, tw, tx, ty; };
@@ -536,7 +932,11 @@ static int conv_pick_mr(int M, int cout) {
   return mr;
 }
 
-int ys_conv_grid_m(const ConvArgs& a) {
+int ys_conv_grid_m(const ConvArgs& a, int dtype) {
+  if (dtype == YS_BF16) {
+    const P2Plan p2 = conv_p2_plan(a);
+    if (p2.ok) return p2.g.ntiles;
+  }
   if (conv_use_patch(a)) {
     // tile shape does not depend on dtype-specific chunking; NR only enters through the workgroup-count heuristic
     const TileChoice t = conv3x3_pick_tile(a, conv3x3_plan(a, 8).nr);
@@ -599,7 +999,12 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
     ys_set_error("conv: Cin/ldc/coff (%d,%d,%d) must be multiples of %d", a.Cin, a.in_ldc, a.in_coff, epl);
     return YS_ERR_INVALID_ARG;
   }
-  if (dtype == YS_BF16) return conv_launch_dtype<bf16_t>(st, a);
+  if (dtype == YS_BF16) {
+    static const bool p2_off = getenv("YS_NO_P2") != nullptr;
+    const P2Plan p2 = conv_p2_plan(a);
+    if (p2.ok && !p2_off) return conv_p2_dispatch(st, a, p2);
+    return conv_launch_dtype<bf16_t>(st, a);
+  }
   return conv_launch_dtype<float>(st, a);
 }
 
@@ -753,23 +1158,37 @@ conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int cin_pad, int cin_real,
                     float* __restrict__ grad) {
   // grad[(row)*cin_real + ci] += sum_s partial[s][row*cin_pad + ci]   (drops padded input channels)
-  // 64 outputs x 4 split lanes per workgroup: the sum over splits is 4 interleaved chains combined in a fixed order
-  __shared__ float sred[4][64];
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + o;
-  float s = 0.f;
-  if (i < n)
-    for (int k = sl; k < splits; k += 4) s += partial[(long)k * n + i];
-  sred[sl][o] = s;
+  // 32 outputs x 16 split lanes per workgroup; every lane walks its splits (k = sl, sl+16, ...) with four loads in flight,
+  // and the 16 lane sums are combined in a fixed order -> deterministic
+  __shared__ float sred[16][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 48 < splits; k += 64) {
+      s0 += partial[(long)k * n + i];
+      s1 += partial[(long)(k + 16) * n + i];
+      s2 += partial[(long)(k + 32) * n + i];
+      s3 += partial[(long)(k + 48) * n + i];
+    }
+    for (; k < splits; k += 16) s0 += partial[(long)k * n + i];
+  }
+  sred[sl][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && i < n) {
     const long row = i / cin_pad;
     const int ci = (int)(i - row * cin_pad);
-    if (ci < cin_real) grad[row * cin_real + ci] += (sred[0][o] + sred[1][o]) + (sred[2][o] + sred[3][o]);
+    if (ci < cin_real) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; w++) t += sred[w][o];
+      grad[row * cin_real + ci] += t;
+    }
   }
 }
 
@@ -878,7 +1297,7 @@ conv_wgrad_tr_kernel(WgradArgs a) {
   int tile = blockIdx.x;
   if (tile < a.ntiles) fetch(tile);
   while (tile < a.ntiles) {
-    __syncthreads();                                    // every wave finished reading the previous tile
+    ys_barrier_lds();                                   // every wave finished reading the previous tile
 #pragma unroll
     for (int k = 0; k < ND; k++) {
       const int idx = tid + NT * k;
@@ -889,7 +1308,7 @@ conv_wgrad_tr_kernel(WgradArgs a) {
       const int idx = tid + NT * k;
       if (idx < npatch) { const int pix = idx / XV; *(uint4*)(sXb + (size_t)pix * a.pxb + (idx - pix * XV) * 16) = rx[k]; }
     }
-    __syncthreads();
+    ys_barrier_lds();
     int t = tile;
     const int txi = t % a.tiles_x; t /= a.tiles_x;
     const int tyi = t % a.tiles_y;
@@ -1123,7 +1542,7 @@ int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, i
     else wgrad_dispatch<float>(st, a, splits);
   }
   const long n = (long)a.Cout * a.KH * a.KW * a.Cin;
-  YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 64), 256, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
+  YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 32), 512, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
   return YS_OK;
 }
 

@@ -205,37 +205,59 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
     if (MODE == 0) {
       ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(mean + c, mu); ys_ldcoef<EPL>(rstd + c, rs);
     }
-    for (long row = r0 + rl; row < r1; row += RP) {
-      float g[EPL];
-      const long zb = row / rpb;
-      const long zrow = zb * bstride + (row - zb * rpb);   // dz rows may be strided per image (head outputs)
-      const uint4 gv = ys_ld16(dz + zrow * dz_ldc + dz_coff + c);
-      ys_unpack<T>(gv, g);
-      if (MODE == 0) {
-        float f[EPL];
-        ys_unpack<T>(ys_ld16(y + row * C + c), f);
-        if (rg) {
-          float o[EPL];
-          T* rp = rg + row * rg_ldc + rg_coff + c;
-          ys_unpack<T>(ys_ld16(rp), o);
+    // four rows per trip: all loads of a trip are issued before any arithmetic (memory-level parallelism; the SiLU
+    // derivative is ~100 VALU operations per 16-byte vector, so one row in flight per thread left HBM idle)
+    constexpr int U = 4;
+    const bool dense = rpb == rows;                      // no per-image row stride: skip the 64-bit division
+    for (long rowb = r0 + rl; rowb < r1; rowb += (long)RP * U) {
+      uint4 gv[U], fv[U], ov[U];
+      bool ok[U];
 #pragma unroll
-          for (int e = 0; e < EPL; e++) o[e] += g[e];
-          ys_st16(rp, ys_pack<T>(o));
+      for (int k = 0; k < U; k++) {
+        const long row = rowb + (long)k * RP;
+        ok[k] = row < r1;
+        gv[k] = ys_zero16(); fv[k] = ys_zero16(); ov[k] = ys_zero16();
+        if (ok[k]) {
+          long zrow = row;
+          if (!dense) { const long zb = row / rpb; zrow = zb * bstride + (row - zb * rpb); }   // dz rows strided per image (head outputs)
+          gv[k] = ys_ld16(dz + zrow * dz_ldc + dz_coff + c);
+          if (MODE == 0) {
+            fv[k] = ys_ld16(y + row * C + c);
+            if (rg) ov[k] = ys_ld16(rg + row * rg_ldc + rg_coff + c);
+          }
         }
+      }
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-          const float u = f[e] * sc[e] + sh[e];
-          const float du = act ? g[e] * ys_silu_grad(u) : g[e];
-          const float xh = (f[e] - mu[e]) * rs[e];
-          a1[e] += du;
-          a2[e] += du * xh;
+      for (int k = 0; k < U; k++) {
+        if (!ok[k]) continue;
+        const long row = rowb + (long)k * RP;
+        float g[EPL];
+        ys_unpack<T>(gv[k], g);
+        if (MODE == 0) {
+          float f[EPL];
+          ys_unpack<T>(fv[k], f);
+          if (rg) {
+            float o[EPL];
+            ys_unpack<T>(ov[k], o);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) o[e] += g[e];
+            ys_st16(rg + row * rg_ldc + rg_coff + c, ys_pack<T>(o));
+          }
+#pragma unroll
+          for (int e = 0; e < EPL; e++) {
+            const float u = f[e] * sc[e] + sh[e];
+            const float du = act ? g[e] * ys_silu_grad(u) : g[e];
+            const float xh = (f[e] - mu[e]) * rs[e];
+            a1[e] += du;
+            a2[e] += du * xh;
+          }
+        } else if (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < EPL; e++) { a1[e] += g[e]; a2[e] += g[e] * g[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; e++) a1[e] += g[e];
         }
-      } else if (MODE == 2) {
-#pragma unroll
-        for (int e = 0; e < EPL; e++) { a1[e] += g[e]; a2[e] += g[e] * g[e]; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPL; e++) a1[e] += g[e];
       }
     }
   }
@@ -256,7 +278,11 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
 static int reduce_blocks(long rows, int C, int epl) {
   const int cg = C / epl;
   const int rp = EW_THREADS / cg;
-  long nb = (rows + (long)rp * 8 - 1) / ((long)rp * 8);  // >= 8 passes per workgroup
+  // 4 row passes = one unrolled trip; prefer 16 passes per workgroup, but never fewer than ~1024 workgroups (4 per CU)
+  // while a workgroup still has a full trip of work
+  long passes = 16;
+  while (passes > 4 && (rows + (long)rp * passes - 1) / ((long)rp * passes) < 1024) passes >>= 1;
+  long nb = (rows + (long)rp * passes - 1) / ((long)rp * passes);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   return (int)nb;

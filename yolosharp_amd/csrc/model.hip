@@ -727,7 +727,7 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
     a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
     a.stats = m->stat_partial;
     YS_TRY(ys_conv_launch(st, m->dtype, a));
-    const int gm = ys_conv_grid_m(a);
+    const int gm = ys_conv_grid_m(a, m->dtype);
     YS_TRY(ys_bn_finalize_launch(st, m->stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
                                  m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
                                  chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));

@@ -75,7 +75,7 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
   a.vec_ok = 1; a.M = (int)M;
   const void* result = nullptr;
   if (has_bn && training) {
-    const int gm = ys_conv_grid_m(a);
+    const int gm = ys_conv_grid_m(a, dtype);
     YS_TRY(dstat.alloc((size_t)gm * 2 * Cout * 4));
     a.y = dy.p; a.stats = (float*)dstat.p;
     YS_TRY(ys_conv_launch(st, dtype, a));

@@ -261,4 +261,16 @@ __device__ inline void ys_lds_tr_wait(uint2& a, uint2& b) {
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (loads and stores share the counter
+// on gfx9-family parts), which would stall on the next tile's global prefetch at every barrier; this one waits for the
+// wave's own LDS operations and leaves global loads in flight.  Use only where no global data is exchanged inside the
+// workgroup across the barrier.
+__device__ inline void ys_barrier_lds() {
+#ifdef YS_EMU_BUILD
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

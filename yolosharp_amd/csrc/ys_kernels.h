@@ -46,7 +46,7 @@ struct WgradArgs {
 };
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
-int ys_conv_grid_m(const ConvArgs& a);
+int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
 int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad);
 int ys_weight_prep_launch(hipStream_t st, int dtype, const float* w, int Cout, int taps, int cin_real, int cin_pad,
