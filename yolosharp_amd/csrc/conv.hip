@@ -470,7 +470,7 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 // conv_epilogue the two phases keep few values live, which leaves the registers to the next tile's patch prefetch.
 template <int MR, int NR>
 __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const long (&orow)[MR], const bool (&pv)[MR],
-                                   int n0, char* stg, float* sStat, long stat_row) {
+                                   int n0, char* stg, float (&s1)[8], float (&s2)[8]) {
   typedef bf16_t T;
   constexpr int BN = NR * 16;
   constexpr int PITCH = (BN + 8) * 2;         // bytes per staged pixel row
@@ -478,7 +478,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   constexpr int VPP = BN / 8;                  // 16-byte vectors per pixel
   constexpr int PPI = 64 / VPP;                // pixels per wave iteration
   constexpr int NITER = (NPX + PPI - 1) / PPI;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
   long* rowtab = (long*)(stg + NPX * PITCH);
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
@@ -510,9 +510,6 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   const bool active = lane < PPI * VPP;
   const int c = n0 + cv * 8;
   const bool do_stats = a.stats != nullptr;
-  float s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; }
   char* yb = (char*)a.y;
   const char* rb = (const char*)a.res;
 #pragma unroll 2
@@ -548,33 +545,42 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     }
   }
   ys_wave_sync();
-  if (do_stats) {
+}
+
+// One statistics row per workgroup: the per-lane column sums gathered over all of its tiles are combined across the
+// lanes that share a channel vector, then across the 4 waves, in a fixed order.
+template <int NR>
+__device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8], float (&s2)[8], float* sStat, long stat_row) {
+  constexpr int BN = NR * 16;
+  constexpr int VPP = BN / 8;
+  constexpr int PPI = 64 / VPP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cv = lane % VPP;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      float x1 = s1[e], x2 = s2[e];
-      if ((VPP & (VPP - 1)) == 0) {
-        for (int msk = VPP; msk < 64; msk <<= 1) { x1 += __shfl_xor(x1, msk); x2 += __shfl_xor(x2, msk); }
-      } else {
-        float t1 = x1, t2 = x2;
-        for (int k = 1; k < PPI; k++) { t1 += __shfl(x1, (lane + k * VPP) & 63); t2 += __shfl(x2, (lane + k * VPP) & 63); }
-        x1 = t1; x2 = t2;
-      }
-      if (lane < VPP) {
-        sStat[((wave * BN) + cv * 8 + e) * 2 + 0] = x1;
-        sStat[((wave * BN) + cv * 8 + e) * 2 + 1] = x2;
-      }
+  for (int e = 0; e < 8; e++) {
+    float x1 = s1[e], x2 = s2[e];
+    if ((VPP & (VPP - 1)) == 0) {
+      for (int msk = VPP; msk < 64; msk <<= 1) { x1 += __shfl_xor(x1, msk); x2 += __shfl_xor(x2, msk); }
+    } else {
+      float t1 = x1, t2 = x2;
+      for (int k = 1; k < PPI; k++) { t1 += __shfl(x1, (lane + k * VPP) & 63); t2 += __shfl(x2, (lane + k * VPP) & 63); }
+      x1 = t1; x2 = t2;
     }
-    ys_barrier_lds();
-    if (tid < BN && n0 + tid < a.Cout) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int w = 0; w < 4; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
-      a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
-      a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
+    if (lane < VPP) {
+      sStat[((wave * BN) + cv * 8 + e) * 2 + 0] = x1;
+      sStat[((wave * BN) + cv * 8 + e) * 2 + 1] = x2;
     }
+  }
+  ys_barrier_lds();
+  if (tid < BN && n0 + tid < a.Cout) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < 4; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
+    a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
+    a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
   }
 }
 
-#define P2_NPU 12          // patch units (16 B) a thread keeps in flight: 12 x 256 x 16 B = 48 KB per workgroup
+#define P2_NPU 12          // max patch units (16 B) a thread keeps in flight: 12 x 256 x 16 B = 48 KB per workgroup (small layers: 6)
 struct P2Args {
   int TH, TW, tiles_x, tiles_y, ntiles, PH, PW;
   int ppb;       // patch pixel pitch (bytes)
@@ -584,8 +590,8 @@ struct P2Args {
   int off_w, off_p, off_stat;   // LDS byte offsets (offset table sits at 0)
 };
 
-template <int MR, int NR, int WRES>
-__global__ void __launch_bounds__(256, 2)   // >= 2 waves per SIMD: two workgroups per CU (matches the LDS budget)
+template <int MR, int NR, int WRES, int NPU>
+__global__ void __launch_bounds__(256, (NPU <= 6 ? 3 : 2))   // waves per SIMD = workgroups per CU the LDS budget allows
 conv_p2_kernel(ConvArgs a, P2Args g) {
   typedef bf16_t T;
   constexpr int BN = NR * 16;
@@ -635,92 +641,121 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
       sW[n * g.wpitch + u] = v;
     }
   }
-  const int ngroups = WRES ? 1 : (g.nsteps + g.kg - 1) / g.kg;
+  constexpr int KG = 2;                        // K-steps per streamed weight group
+  constexpr int GU = KG * 4;                   // 16-byte units per weight row and group
+  const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
   uint4 rw[NWU];
-  auto wfetch = [&](int grp) {                // global -> registers: weights of K-steps [grp*kg, grp*kg + kg)
-    const int gu = g.kg * 4;
+  auto wfetch = [&](int grp) {                // global -> registers: weights of K-steps [grp*KG, grp*KG + KG)
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
       const int idx = tid + 256 * k;
       uint4 v = ys_zero16();
-      if (idx < BN * gu) {
-        const int n = idx / gu, u = grp * gu + (idx - n * gu);
-        if (n0 + n < a.Cout && u * 8 < Ktot) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
+      if (idx < BN * GU) {
+        const int n = idx / GU, u = grp * GU + (idx - n * GU);
+        if (n0 + n < a.Cout && u * 8 < Ktot && !(a.dbg & 16)) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
       }
       rw[k] = v;
     }
   };
   auto wstore = [&](int buf) {
-    const int gu = g.kg * 4;
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
       const int idx = tid + 256 * k;
-      if (idx < BN * gu) { const int n = idx / gu; sW[(buf * BN + n) * g.wpitch + (idx - n * gu)] = rw[k]; }
+      if (idx < BN * GU) { const int n = idx / GU; sW[(buf * BN + n) * g.wpitch + (idx - n * GU)] = rw[k]; }
     }
   };
 
   // ---- patch of a tile: global -> registers (all loads back-to-back); the NEXT tile's patch is in flight while the
   // current one is consumed, so every resident workgroup always has a whole patch outstanding (HBM needs ~40 KB per CU
-  // in flight to reach its bandwidth)
-  uint4 rp[P2_NPU];
-  // per-thread patch unit descriptors (tile-independent): patch row (10 bits) | patch column (10) | channel unit (10);
-  // kept packed and re-opened per tile (the asm barrier stops the compiler from keeping 4 derived values per unit live)
-  unsigned pdesc[P2_NPU];
+  // in flight to reach its bandwidth).  Per patch unit a thread keeps two tile-independent words: the element offset from
+  // the tile's patch origin in global memory, and (row, column, LDS slot) packed -- so a tile costs an add, two compares
+  // and a shift per unit instead of divisions and multiplies.
+  uint4 rp[NPU];
+  unsigned pdesc[NPU];                      // patch row (9 bits) | patch column (10) | LDS offset / 16 (13)
+  int goff[NPU];                            // (row * Win + column) * in_ldc + unit * 8
+  {
+    int pix = tid / cu, u = tid - pix * cu;
+    int r = pix / g.PW, cc = pix - r * g.PW;
+    const int qs = 256 / cu, rs = 256 - qs * cu;         // idx += 256  ->  (pix, u) += (qs, rs) with carry
+    const int dr = qs / g.PW, dc = qs - dr * g.PW;
 #pragma unroll
-  for (int k = 0; k < P2_NPU; k++) {
-    const int idx = tid + 256 * k;
-    unsigned d = 0xffffffffu;
-    if (idx < npatch) {
-      const int pix = idx / cu, u = idx - pix * cu;
-      const int r = pix / g.PW, cc = pix - r * g.PW;
-      d = ((unsigned)r << 20) | ((unsigned)cc << 10) | (unsigned)u;
+    for (int k = 0; k < NPU; k++) {
+      unsigned d = 0xffffffffu;
+      int go = 0;
+      if (tid + 256 * k < npatch) {
+        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (unsigned)(((r * g.PW + cc) * g.ppb + u * 16) >> 4);
+        go = (r * a.Win + cc) * a.in_ldc + u * 8;
+      }
+      pdesc[k] = d; goff[k] = go;
+      u += rs; r += dr; cc += dc;
+      if (u >= cu) { u -= cu; cc++; }
+      if (cc >= g.PW) { cc -= g.PW; r++; }
+      if (cc >= g.PW) { cc -= g.PW; r++; }
     }
-    pdesc[k] = d;
   }
-  auto pfetch = [&](int tile) {
-    int t = tile;
-    const int txi = t % g.tiles_x; t /= g.tiles_x;
-    const int tyi = t % g.tiles_y;
-    const int b = t / g.tiles_y;
+  // tile coordinates advance incrementally by gridDim.x tiles (no per-tile divisions)
+  int stx, sty, sb;
+  {
+    const int G = gridDim.x;
+    stx = G % g.tiles_x; const int rem = G / g.tiles_x;
+    sty = rem % g.tiles_y; sb = rem / g.tiles_y;
+  }
+  auto advance = [&](int& txi, int& tyi, int& b) {
+    txi += stx; if (txi >= g.tiles_x) { txi -= g.tiles_x; tyi++; }
+    tyi += sty; if (tyi >= g.tiles_y) { tyi -= g.tiles_y; b++; }
+    b += sb;
+  };
+  auto pfetch = [&](int txi, int tyi, int b) {
     const int iy0 = tyi * g.TH * a.SA - a.PAD, ix0 = txi * g.TW * a.SA - a.PAD;
-    const char* xbb = xb + ((long)b * a.in_bstride * a.in_ldc + a.in_coff) * 2L;
+    const char* xt = xb + (((long)b * a.in_bstride + (long)iy0 * a.Win + ix0) * a.in_ldc + a.in_coff) * 2L;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + g.PH <= a.Hin && ix0 + g.PW <= a.Win;
 #pragma unroll
-    for (int k = 0; k < P2_NPU; k++) {
+    for (int k = 0; k < NPU; k++) {
       unsigned d = pdesc[k];
+      int go = goff[k];
 #ifndef YS_EMU_BUILD
-      asm volatile("" : "+v"(d));
+      asm volatile("" : "+v"(d), "+v"(go));
 #endif
       uint4 v = ys_zero16();
       if (d != 0xffffffffu) {
-        const int iy = iy0 + (int)(d >> 20), ix = ix0 + (int)((d >> 10) & 1023u);
-        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && !(a.dbg & 1))
-          v = ys_ld16(xbb + ((long)(iy * a.Win + ix) * a.in_ldc + (int)(d & 1023u) * 8) * 2L);
+        bool ok = true;
+        if (!interior) {
+          const int iy = iy0 + (int)(d >> 23), ix = ix0 + (int)((d >> 13) & 1023u);
+          ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        }
+        if (ok && !(a.dbg & 1)) v = ys_ld16(xt + (long)go * 2L);
       }
       rp[k] = v;
     }
   };
-  if ((int)blockIdx.x < g.ntiles) pfetch(blockIdx.x);
+  int txi, tyi, b;
+  {
+    int t = blockIdx.x;
+    txi = t % g.tiles_x; t /= g.tiles_x;
+    tyi = t % g.tiles_y; b = t / g.tiles_y;
+  }
+  int ntx = txi, nty = tyi, nb = b;
+  if ((int)blockIdx.x < g.ntiles) pfetch(txi, tyi, b);
+  float st1[8], st2[8];                        // BN statistics of this workgroup's tiles (per-lane column sums)
+#pragma unroll
+  for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-    int t = tile;
-    const int txi = t % g.tiles_x; t /= g.tiles_x;
-    const int tyi = t % g.tiles_y;
-    const int b = t / g.tiles_y;
     const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
     if (!WRES) wfetch(0);
 #pragma unroll
-    for (int k = 0; k < P2_NPU; k++) {
+    for (int k = 0; k < NPU; k++) {
       unsigned d = pdesc[k];
 #ifndef YS_EMU_BUILD
       asm volatile("" : "+v"(d));
 #endif
-      if (d != 0xffffffffu && !(a.dbg & 8))
-        *(uint4*)(sPb + ((int)(d >> 20) * g.PW + (int)((d >> 10) & 1023u)) * g.ppb + (int)(d & 1023u) * 16) = rp[k];
+      if (d != 0xffffffffu && !(a.dbg & 8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = rp[k];
     }
     if (!WRES) wstore(0);
     ys_barrier_lds();
-    if (tile + (int)gridDim.x < g.ntiles) pfetch(tile + gridDim.x);
+    advance(ntx, nty, nb);
+    if (tile + (int)gridDim.x < g.ntiles) pfetch(ntx, nty, nb);
 
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -730,8 +765,8 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
 
     for (int grp = 0; grp < ngroups; grp++) {
       if (!WRES && grp + 1 < ngroups) wfetch(grp + 1);
-      const int s0 = WRES ? 0 : grp * g.kg;
-      const int s1 = WRES ? g.nsteps : ((s0 + g.kg) < g.nsteps ? (s0 + g.kg) : g.nsteps);
+      const int s0 = WRES ? 0 : grp * KG;
+      const int s1 = WRES ? g.nsteps : ((s0 + KG) < g.nsteps ? (s0 + KG) : g.nsteps);
       const uint4* wbuf = sW + (WRES ? 0 : (grp & 1) * BN * g.wpitch);
 #pragma unroll 1
       for (int s = (a.dbg & 2) ? s1 : s0; s < s1; s++) {
@@ -763,11 +798,13 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
       orow[mf] = (long)b * a.out_bstride + (pv[mf] ? ((long)oy * a.Wout + ox) : 0);
     }
     char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 8);
-    if (!(a.dbg & 4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, sStat, (long)tile);
+    if (!(a.dbg & 4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
+    txi = ntx; tyi = nty; b = nb;
   }
+  if (a.stats) p2_stats_flush<NR>(a, n0, st1, st2, sStat, (long)blockIdx.x);
 }
 
-struct P2Plan { int ok, mr, nr, wres, gx, gy; size_t lds; P2Args g; };
+struct P2Plan { int ok, mr, nr, wres, npu, gx, gy; size_t lds; P2Args g; };
 static P2Plan conv_p2_plan(const ConvArgs& a) {
   P2Plan p{};
   if (!(a.KH == 3 && a.KW == 3 && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.out_rh == 0 && a.pad_w_delta == 0)) return p;
@@ -781,7 +818,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   g.nsteps = (9 * a.Cin + 31) / 32;
   const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
   const int wres = wres_bytes <= 20 * 1024 ? 1 : 0;
-  g.kg = wres ? g.nsteps : 2;
+  g.kg = wres ? g.nsteps : 2;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
   g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
@@ -812,12 +849,13 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         cur.TH = th; cur.TW = tw; cur.tiles_x = tx; cur.tiles_y = ty; cur.PH = ph; cur.PW = pw; cur.ntiles = (int)ntiles;
         cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
         p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy;
+        p.npu = ph * pw * cu <= 6 * 256 ? 6 : 12;
       }
     }
   }
   if (!p.ok) return p;
   if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
-  const int per_cu = p.lds <= 50 * 1024 ? 3 : 2;
+  const int per_cu = (p.lds <= 50 * 1024 && p.npu == 6) ? 3 : 2;
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
   if (gx < 1) gx = 1;
@@ -825,23 +863,25 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   return p;
 }
 
-template <int MR, int NR, int WRES>
+template <int MR, int NR, int WRES, int NPU>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
   a.dbg = dbg;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k3 s%d div1 cin%d cout%d M%d acc%d mr%d nr%d wres%d tile%dx%d grid%dx%d lds%d", a.SA, a.Cin, a.Cout, a.M, a.accumulate, MR, NR, WRES, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k3 s%d div1 cin%d cout%d M%d acc%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.SA, a.Cin, a.Cout, a.M, a.accumulate, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
-  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
   return YS_OK;
 }
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
-#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) return p.wres ? conv_p2_launch_t<M_, N_, 1>(st, a, p) : conv_p2_launch_t<M_, N_, 0>(st, a, p);
+#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { \
+    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12>(st, a, p); \
+    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12>(st, a, p); }
   P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
 #undef P2
   ys_set_error("conv p2: no kernel for MR=%d NR=%d", p.mr, p.nr);
@@ -935,7 +975,7 @@ static int conv_pick_mr(int M, int cout) {
 int ys_conv_grid_m(const ConvArgs& a, int dtype) {
   if (dtype == YS_BF16) {
     const P2Plan p2 = conv_p2_plan(a);
-    if (p2.ok) return p2.g.ntiles;
+    if (p2.ok) return p2.gx;   // one statistics row per (persistent) workgroup
   }
   if (conv_use_patch(a)) {
     // tile shape does not depend on dtype-specific chunking; NR only enters through the workgroup-count heuristic
