@@ -38,6 +38,20 @@ def synth_labels(B, nc, seed=1, kmax=16):
     return np.concatenate(bi), np.concatenate(cl), np.concatenate(bb)
 
 
+def synth_masks(bi, bb, B, mh, mw):
+    """Overlap-encoded instance masks [B, H/4, W/4] (YoloDataset.cs:265-267): each label's box-inscribed ellipse painted
+    with its 1-based per-image index, later labels on top."""
+    masks = np.zeros((B, mh, mw), np.float32)
+    yy, xx = np.meshgrid(np.arange(mh, dtype=np.float32) + 0.5, np.arange(mw, dtype=np.float32) + 0.5, indexing="ij")
+    per = [0] * B
+    for j in range(len(bi)):
+        b = int(bi[j]); per[b] += 1
+        cx, cy, w, h = bb[j] * np.array([mw, mh, mw, mh], np.float32)
+        inside = ((xx - cx) / max(w / 2, 1e-3)) ** 2 + ((yy - cy) / max(h / 2, 1e-3)) ** 2 <= 1.0
+        masks[b][inside] = per[b]
+    return masks
+
+
 def cpu_baseline(nc, H, W, sample_b=8):
     """Oracle (port) train step on the host cores: forward + loss + backward + AdamW, fp32."""
     import torch
@@ -67,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", default="n")
+    ap.add_argument("--family", type=int, default=8, choices=[8, 11], help="graph family (8 = YOLOv8, 11 = YOLOv11); default = BASELINE config 2")
+    ap.add_argument("--task", default="detect", choices=["detect", "segment"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
@@ -85,22 +101,27 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from yolosharp_amd import Engine
-    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    from yolosharp_amd.model import Yolov8, Yolov11, Yolov8Segment, Yolov11Segment, v8DetectionLoss, v8SegmentationLoss
     from yolosharp_amd import dist as ysd
     from yolosharp_amd.workload import step_work
 
     nc, H, W, B = 80, 640, 640, args.batch
     stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
     eng = Engine(local_rank, stream=stream)          # N>1: run on torch's stream so RCCL orders against our kernels
-    model = Yolov8(eng, nc=nc, size=args.size, height=H, width=W, max_batch=B, dtype=args.dtype)
+    seg = args.task == "segment"
+    Model = {(8, False): Yolov8, (11, False): Yolov11, (8, True): Yolov8Segment, (11, True): Yolov11Segment}[(args.family, seg)]
+    model = Model(eng, nc=nc, size=args.size, height=H, width=W, max_batch=B, dtype=args.dtype)
     model.init_weights(2)
     model.train()
-    crit = v8DetectionLoss(model)
+    crit = v8SegmentationLoss(model) if seg else v8DetectionLoss(model)
+    headline = args.family == 8 and not seg          # BASELINE.json metric/config (YOLOv8 detect)
     rng = np.random.default_rng(0 + rank)
     images = rng.random((B, 3, H, W), dtype=np.float32)
     bi, cl, bb = synth_labels(B, nc, seed=1 + rank)
     d_img = eng.to_device(images)
     d_lab = (eng.to_device(bi), eng.to_device(cl), eng.to_device(bb), len(bi))
+    if seg:
+        d_lab = d_lab + (eng.to_device(synth_masks(bi, bb, B, H // 4, W // 4)),)
     lr0 = round(0.002 * 5 / (4 + nc), 6)
     lrs = [lr0, lr0, lr0]
     gptr, gn = model.grad_buffer()
@@ -144,7 +165,12 @@ def main():
     out = None
     if rank == 0:
         es = 2 if args.dtype == "bf16" else 4
-        wk = step_work(args.size, nc, H, W, es)
+        if headline:
+            wk = step_work(args.size, nc, H, W, es)
+        else:   # SURVEY.md 8d totals for the other configurations (per image, bf16 bytes scaled by the element size)
+            tab = {(11, "m", "segment"): (1182e6, 339.3e9)}
+            tb, tf = tab.get((args.family, args.size, args.task), (0.0, 0.0))
+            wk = {"train_bytes": tb * es / 2, "train_flop": tf, "igemm_bytes": 0.0, "igemm_launches": 1}
         # ---- dominant kernel class, HIP events on the engine stream, untimed extra steps
         eng.kernel_profile(True)
         for _ in range(2):
@@ -162,21 +188,28 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the timed process)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            if tj["conv_igemm_class"]["config"] == f"YOLOv8{args.size} B={B} {H}x{W} {args.dtype}":
+            if headline and tj["conv_igemm_class"]["config"] == f"YOLOv8{args.size} B={B} {H}x{W} {args.dtype}":
                 traffic = tj["conv_igemm_class"]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
-        roofline = {"bound": "hbm", "kernel": "conv_igemm class = conv_igemm_kernel (1x1, stride-2) + conv3x3_tile_kernel (3x3 s1 fwd, all 3x3 dgrads): 125 forward+dgrad launches/step", "achieved": round(achieved, 1),
+        if not headline:   # no per-class byte table for this graph: report the whole step against the HBM roofline
+            achieved = wk["train_bytes"] * B / (ms * 1e-3) / 1e9
+            bytes_per_launch = wk["train_bytes"] * B
+        kdesc = ("conv_igemm class = every forward + dgrad convolution launch of the step: conv_p2_kernel (3x3 forward s1/s2 and "
+                 "stride-1 dgrad, whole-Cin LDS patch), conv_igemm_kernel (1x1), conv3x3_tile_kernel (stride-2 dgrads)") if headline else \
+                "whole training step (all kernels), algorithmic bytes from SURVEY.md 8d"
+        roofline = {"bound": "hbm", "kernel": kdesc, "achieved": round(achieved, 1),
                     "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "launches_per_step": n_ig // steps_prof, "avg_launch_ms": round(avg_ms, 5),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "class_ms_per_step": {"conv_igemm": round(ms_ig / steps_prof, 3), "conv_wgrad": round(ms_wg / steps_prof, 3)},
                     "step_algorithmic_GBps": round(wk["train_bytes"] * B / (ms * 1e-3) / 1e9, 1),
                     "step_TFLOPs": round(wk["train_flop"] * B / (ms * 1e-3) / 1e12, 2)}
-        out = {"metric": "train images/sec YOLOv8n 640x640 bs=64/GPU", "value": round(value, 2), "unit": "images/s",
+        gname = f"YOLOv{args.family}{args.size}" + ("-seg" if seg else "")
+        out = {"metric": f"train images/sec {gname} 640x640 bs={B}/GPU", "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"YOLOv8{args.size} detect train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, COCO-80 synthetic labels",
+               "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, COCO-80 synthetic labels" + (" + instance masks" if seg else ""),
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
         # ---- secondary metric: NMS boxes/s on [64, 84, 8400]

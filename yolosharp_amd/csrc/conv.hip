@@ -21,6 +21,8 @@
 #include "ys_internal.h"
 #include "ys_kernels.h"
 #include <cstdlib>
+#include <map>
+#include <vector>
 
 // ------------------------------------------------------------------ shared epilogue
 // Lane (li,q) holds acc[mf][nf][r] = D[channel n0+nf*16+4q+r][pixel mf*16+li].  Per pixel fragment the wave rounds its
@@ -549,7 +551,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 
 // One statistics row per workgroup: the per-lane column sums gathered over all of its tiles are combined across the
 // lanes that share a channel vector, then across the 4 waves, in a fixed order.
-template <int NR>
+template <int NR, int NW>
 __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8], float (&s2)[8], float* sStat, long stat_row) {
   constexpr int BN = NR * 16;
   constexpr int VPP = BN / 8;
@@ -574,7 +576,7 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
   ys_barrier_lds();
   if (tid < BN && n0 + tid < a.Cout) {
     float t1 = 0.f, t2 = 0.f;
-    for (int w = 0; w < 4; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
+    for (int w = 0; w < NW; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
     a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
     a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
   }
@@ -590,18 +592,19 @@ struct P2Args {
   int off_w, off_p, off_stat;   // LDS byte offsets (offset table sits at 0)
 };
 
-template <int MR, int NR, int WRES, int NPU>
-__global__ void __launch_bounds__(256, (NPU <= 6 ? 3 : 2))   // waves per SIMD = workgroups per CU the LDS budget allows
-conv_p2_kernel(ConvArgs a, P2Args g) {
+template <int MR, int NR, int WRES, int NPU, int NT>
+__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 ? 3 : 2)))   // waves per SIMD the LDS budget allows (512 threads: 2 workgroups x 2)
+conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
   constexpr int BN = NR * 16;
-  constexpr int NWU = WRES ? 1 : (BN * 2 * 4 + 255) / 256;     // streamed weight units per thread (kg = 2)
+  constexpr int NWV = NT / 64;
+  constexpr int NWU = WRES ? 1 : (BN * 2 * 4 + NT - 1) / NT;   // streamed weight units per thread (kg = 2)
   YS_DYN_LDS(lds);
   char* lb = (char*)lds;
   int* sOff = (int*)lb;                       // [nsteps][4]
   uint4* sW = (uint4*)(lb + g.off_w);         // WRES: [BN][wpitch]; else [2][BN][wpitch]
   char* sPb = lb + g.off_p;                   // [PH*PW][ppb]
-  float* sStat = (float*)(lb + g.off_stat);   // [4][BN][2]
+  float* sStat = (float*)(lb + g.off_stat);   // [NWV][BN][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.y * BN;
@@ -612,29 +615,20 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
   const int cu = a.Cin >> 3;                  // 16-byte units per patch pixel
   const int npatch = g.PH * g.PW * cu;
 
-  // ---- tile-independent tables
-  for (int e = tid; e < g.nsteps * 4; e += 256) {
-    const int k0 = (e >> 2) * 32 + (e & 3) * 8;
-    int off = 0;
-    if (k0 < Ktot) {
-      const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
-      const int kh = tap / a.KW, kw = tap - kh * a.KW;
-      off = (kh * g.PW + kw) * g.ppb + ch * 2;
-    }
-    sOff[e] = off;
-  }
+  // ---- tile-independent tables, computed once per layer geometry on the host (p2_tables): per-(K-step, quarter) patch
+  // offsets, per-thread pixel offsets, per-thread patch unit descriptors
+  for (int e = tid; e < g.nsteps * 4; e += NT) sOff[e] = tab[e];
+  const int* tpx = tab + g.nsteps * 4;
   int pixbase[MR], pty[MR], ptx[MR];
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
-    const int p = wave * (MR * 16) + mf * 16 + li;
-    int ty = p / g.TW, tx = p - ty * g.TW;
-    if (ty >= g.TH) { ty = g.TH; tx = 0; }    // idle lane of a ragged tile: marked by ty == TH, reads pixel (0,0)
-    pty[mf] = ty; ptx[mf] = tx;
-    pixbase[mf] = ty < g.TH ? ((ty * a.SA) * g.PW + tx * a.SA) * g.ppb : 0;
+    pixbase[mf] = tpx[(mf * 3 + 0) * NT + tid];
+    pty[mf] = tpx[(mf * 3 + 1) * NT + tid];
+    ptx[mf] = tpx[(mf * 3 + 2) * NT + tid];
   }
   if (WRES) {
     const int per_row = g.nsteps * 4;
-    for (int idx = tid; idx < BN * per_row; idx += 256) {
+    for (int idx = tid; idx < BN * per_row; idx += NT) {
       const int n = idx / per_row, u = idx - n * per_row;
       uint4 v = ys_zero16();
       if (n0 + n < a.Cout && u * 8 < Ktot) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
@@ -648,7 +642,7 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
   auto wfetch = [&](int grp) {                // global -> registers: weights of K-steps [grp*KG, grp*KG + KG)
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
-      const int idx = tid + 256 * k;
+      const int idx = tid + NT * k;
       uint4 v = ys_zero16();
       if (idx < BN * GU) {
         const int n = idx / GU, u = grp * GU + (idx - n * GU);
@@ -660,7 +654,7 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
   auto wstore = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
-      const int idx = tid + 256 * k;
+      const int idx = tid + NT * k;
       if (idx < BN * GU) { const int n = idx / GU; sW[(buf * BN + n) * g.wpitch + (idx - n * GU)] = rw[k]; }
     }
   };
@@ -674,23 +668,11 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
   unsigned pdesc[NPU];                      // patch row (9 bits) | patch column (10) | LDS offset / 16 (13)
   int goff[NPU];                            // (row * Win + column) * in_ldc + unit * 8
   {
-    int pix = tid / cu, u = tid - pix * cu;
-    int r = pix / g.PW, cc = pix - r * g.PW;
-    const int qs = 256 / cu, rs = 256 - qs * cu;         // idx += 256  ->  (pix, u) += (qs, rs) with carry
-    const int dr = qs / g.PW, dc = qs - dr * g.PW;
+    const int* tpd = tpx + MR * 3 * NT;
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
-      unsigned d = 0xffffffffu;
-      int go = 0;
-      if (tid + 256 * k < npatch) {
-        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (unsigned)(((r * g.PW + cc) * g.ppb + u * 16) >> 4);
-        go = (r * a.Win + cc) * a.in_ldc + u * 8;
-      }
-      pdesc[k] = d; goff[k] = go;
-      u += rs; r += dr; cc += dc;
-      if (u >= cu) { u -= cu; cc++; }
-      if (cc >= g.PW) { cc -= g.PW; r++; }
-      if (cc >= g.PW) { cc -= g.PW; r++; }
+      pdesc[k] = (unsigned)tpd[(2 * k + 0) * NT + tid];
+      goff[k] = tpd[(2 * k + 1) * NT + tid];
     }
   }
   // tile coordinates advance incrementally by gridDim.x tiles (no per-tile divisions)
@@ -801,10 +783,10 @@ conv_p2_kernel(ConvArgs a, P2Args g) {
     if (!(a.dbg & 4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
     txi = ntx; tyi = nty; b = nb;
   }
-  if (a.stats) p2_stats_flush<NR>(a, n0, st1, st2, sStat, (long)blockIdx.x);
+  if (a.stats) p2_stats_flush<NR, NWV>(a, n0, st1, st2, sStat, (long)blockIdx.x);
 }
 
-struct P2Plan { int ok, mr, nr, wres, npu, gx, gy; size_t lds; P2Args g; };
+struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
 static P2Plan conv_p2_plan(const ConvArgs& a) {
   P2Plan p{};
   if (!(a.KH == 3 && a.KW == 3 && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.out_rh == 0 && a.pad_w_delta == 0)) return p;
@@ -823,33 +805,39 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
   const size_t tab = ((size_t)g.nsteps * 16 + 15) / 16 * 16;
-  const size_t stat = (size_t)4 * bn * 2 * 4;
   const size_t budget = 76 * 1024;           // two workgroups per CU
   const int gy = ys_cdiv(a.Cout, bn);
-  // tile = (64*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed weights,
-  // output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large enough
+  // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
+  // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
+  // enough.  (512-thread workgroups -- 8 waves x 2 fragments, same LDS footprint -- were measured 13 % slower: the 128-register
+  // budget of 4 waves/SIMD spills for >= 48 output channels.)
   double best = 1e30; bool best_full = false;
-  for (int mr = (nr <= 4 ? 4 : 2); mr >= 1; mr >>= 1) {
-    const int npx = 64 * mr;
-    const size_t stage = (size_t)4 * (16 * mr * (bn + 8) * 2 + 16 * mr * 8);
-    for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
-      int th = npx / tw; if (th > a.Hout) th = a.Hout;
-      const int ph = (th - 1) * a.SA + 3, pw = (tw - 1) * a.SA + 3;
-      size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
-      const size_t lds = tab + wbytes + pbytes + stat;
-      if (lds > budget || ph * pw * cu > P2_NPU * 256) continue;
-      const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
-      const long ntiles = (long)tx * ty * a.B;
-      const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * 9.0 * a.Cin) + 1.0 * npx * (a.Cin + bn) + 3000.0;
-      const double cost = (double)tx * ty * per_tile;
-      const bool full = ntiles * gy >= 512;
-      if ((full && !best_full) || (full == best_full && cost < best)) {
-        best = cost; best_full = full;
-        P2Args cur = g;
-        cur.TH = th; cur.TW = tw; cur.tiles_x = tx; cur.tiles_y = ty; cur.PH = ph; cur.PW = pw; cur.ntiles = (int)ntiles;
-        cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
-        p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy;
-        p.npu = ph * pw * cu <= 6 * 256 ? 6 : 12;
+  for (int nt = 256; nt >= 256; nt >>= 1) {
+    const int nwv = nt / 64;
+    const size_t stat = (size_t)nwv * bn * 2 * 4;
+    const int npu_max = nt == 512 ? 6 : P2_NPU;
+    for (int mr = (nt == 512 ? 2 : (nr <= 4 ? 4 : 2)); mr >= 1; mr >>= 1) {
+      const int npx = 16 * nwv * mr;
+      const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 8);
+      for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
+        int th = npx / tw; if (th > a.Hout) th = a.Hout;
+        const int ph = (th - 1) * a.SA + 3, pw = (tw - 1) * a.SA + 3;
+        size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
+        const size_t lds = tab + wbytes + pbytes + stat;
+        if (lds > budget || ph * pw * cu > npu_max * nt) continue;
+        const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
+        const long ntiles = (long)tx * ty * a.B;
+        const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * 9.0 * a.Cin) + 1.0 * npx * (a.Cin + bn) + 3000.0;
+        const double cost = (double)tx * ty * per_tile;
+        const bool full = ntiles * gy >= 512;
+        if ((full && !best_full) || (full == best_full && cost < best)) {
+          best = cost; best_full = full;
+          P2Args cur = g;
+          cur.TH = th; cur.TW = tw; cur.tiles_x = tx; cur.tiles_y = ty; cur.PH = ph; cur.PW = pw; cur.ntiles = (int)ntiles;
+          cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
+          p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy; p.nt = nt;
+          p.npu = nt == 512 ? 6 : (ph * pw * cu <= 6 * 256 ? 6 : 12);
+        }
       }
     }
   }
@@ -863,28 +851,86 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   return p;
 }
 
-template <int MR, int NR, int WRES, int NPU>
+// Tile-independent index tables of a P2 launch (see conv_p2_kernel), built on the host once per layer geometry and cached
+// on the device for the life of the process (a few KB per distinct layer shape).
+static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
+  static std::map<std::vector<int>, int*> cache;
+  int dev = 0;
+  hipGetDevice(&dev);
+  const P2Args& g = p.g;
+  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.nsteps, p.mr, p.npu, p.nt};
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const int NT = p.nt;
+  const int cu = a.Cin / 8, Ktot = a.KH * a.KW * a.Cin, npatch = g.PH * g.PW * cu;
+  std::vector<int> h((size_t)g.nsteps * 4 + (size_t)p.mr * 3 * NT + (size_t)p.npu * 2 * NT, 0);
+  for (int e = 0; e < g.nsteps * 4; e++) {
+    const int k0 = (e >> 2) * 32 + (e & 3) * 8;
+    if (k0 < Ktot) {
+      const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      h[e] = (kh * g.PW + kw) * g.ppb + ch * 2;
+    }
+  }
+  int* tpx = h.data() + g.nsteps * 4;
+  for (int tid = 0; tid < NT; tid++) {
+    const int wave = tid >> 6, li = tid & 15;
+    for (int mf = 0; mf < p.mr; mf++) {
+      const int px = wave * (p.mr * 16) + mf * 16 + li;
+      int ty = px / g.TW, tx = px - ty * g.TW;
+      if (ty >= g.TH) { ty = g.TH; tx = 0; }    // idle lane of a ragged tile: marked by ty == TH, reads pixel (0,0)
+      tpx[(mf * 3 + 0) * NT + tid] = ty < g.TH ? ((ty * a.SA) * g.PW + tx * a.SA) * g.ppb : 0;
+      tpx[(mf * 3 + 1) * NT + tid] = ty;
+      tpx[(mf * 3 + 2) * NT + tid] = tx;
+    }
+  }
+  int* tpd = tpx + p.mr * 3 * NT;
+  for (int tid = 0; tid < NT; tid++)
+    for (int k = 0; k < p.npu; k++) {
+      const int idx = tid + NT * k;
+      unsigned d = 0xffffffffu; int go = 0;
+      if (idx < npatch) {
+        const int pix = idx / cu, u = idx - pix * cu;
+        const int r = pix / g.PW, cc = pix - r * g.PW;
+        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (unsigned)(((r * g.PW + cc) * g.ppb + u * 16) >> 4);
+        go = (r * a.Win + cc) * a.in_ldc + u * 8;
+      }
+      tpd[(2 * k + 0) * NT + tid] = (int)d;
+      tpd[(2 * k + 1) * NT + tid] = go;
+    }
+  int* dptr = nullptr;
+  if (hipMalloc(&dptr, h.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(dptr, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); return nullptr; }
+  cache[key] = dptr;
+  return dptr;
+}
+
+template <int MR, int NR, int WRES, int NPU, int NT>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
   a.dbg = dbg;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k3 s%d div1 cin%d cout%d M%d acc%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.SA, a.Cin, a.Cout, a.M, a.accumulate, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k3 s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.SA, a.Cin, a.Cout, a.M, a.accumulate, NT, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
-  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+  const int* tab = p2_tables(a, p);
+  if (!tab) { ys_set_error("conv p2: cannot allocate the index tables"); return YS_ERR_OOM; }
+  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU, NT>), dim3(p.gx, p.gy), NT, p.lds, st, a, p.g, tab);
   return YS_OK;
 }
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
+  {
 #define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { \
-    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12>(st, a, p); \
-    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12>(st, a, p); }
-  P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
+    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256>(st, a, p); \
+    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256>(st, a, p); }
+    P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
 #undef P2
-  ys_set_error("conv p2: no kernel for MR=%d NR=%d", p.mr, p.nr);
+  }
+  ys_set_error("conv p2: no kernel for NT=%d MR=%d NR=%d", p.nt, p.mr, p.nr);
   return YS_ERR_UNSUPPORTED;
 }
 
@@ -954,9 +1000,9 @@ static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
 }
 
 // Tile selection.  NR = output-channel fragments per workgroup (all of Cout when it fits, so activations are read
-// once); MR = pixel fragments per wave: as many as the accumulator budget allows (MR*NR <= 16) because every extra
-// fragment is one more independent 16-byte load in flight per lane, but small feature maps (20x20, 40x40 at the
-// deep end of the net) fall back to smaller MR so that the grid still covers the 256 CUs a few times.
+// once); MR = pixel fragments per wave: 2 (occupancy: three workgroups per CU overlap each other's load and
+// epilogue phases; larger MR measured slower), 1 on small feature maps (20x20, 40x40 at the deep end of the net)
+// so that the grid still covers the 256 CUs a few times.
 static int conv_pick_nr(int cout) {
   const int nfr = (cout + 15) / 16;
   if (nfr <= 6) return nfr;
@@ -967,7 +1013,7 @@ static int conv_pick_nr(int cout) {
 static int conv_pick_mr(int M, int cout) {
   const int nr = conv_pick_nr(cout);
   const int gy = ys_cdiv(cout, nr * 16);
-  int mr = nr == 1 ? 8 : nr == 2 ? 8 : nr <= 4 ? 4 : 2;
+  int mr = 2;   // measured: 2 fragments per wave (<= ~130 registers, 3 workgroups per CU) beats 4-8 fragments at 2 per CU
   while (mr > 1 && (long)ys_cdiv(M, 64 * mr) * gy < 768) mr >>= 1;
   return mr;
 }
