@@ -244,6 +244,7 @@ hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
@@ -259,5 +260,7 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
 hipError_t hipMemGetInfo(size_t* free_, size_t* total);
 #define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

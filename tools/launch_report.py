@@ -5,7 +5,7 @@ import re
 import sys
 
 
-def main(path, steps=2, top=40, cls=None):
+def main(path, steps=2, top=200, cls=None):
     rows = list(csv.DictReader(open(path)))
     agg = collections.OrderedDict()
     for r in rows:
@@ -16,10 +16,11 @@ def main(path, steps=2, top=40, cls=None):
         a[1] += float(r["us"])
     out = []
     for (c, l), (n, us) in agg.items():
-        m = re.search(r"k(\d) s(\d).*?cin(\d+) cout(\d+) M(\d+)", l)
+        m = re.search(r"k(\d+) s(\d).*?cin(\d+) cout(\d+) M(\d+)", l)
         k, s, cin, cout, M = map(int, m.groups())
+        taps = k * k if k < 10 else (k // 10) * (k % 10)      # "k21" = 2x1 taps (stride-2 dgrad phases)
         byt = M * (cin + cout) * 2
-        fl = 2.0 * M * cin * cout * k * k
+        fl = 2.0 * M * cin * cout * taps
         if c != "conv_wgrad":
             if s == 2 and "direct" in l and "div1" in l:
                 byt = M * (4 * cin + cout) * 2

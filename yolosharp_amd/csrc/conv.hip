@@ -777,7 +777,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     for (int mf = 0; mf < MR; mf++) {
       const int oy = oy0 + pty[mf], ox = ox0 + ptx[mf];
       pv[mf] = pty[mf] < g.TH && oy < a.Hout && ox < a.Wout;
-      orow[mf] = (long)b * a.out_bstride + (pv[mf] ? ((long)oy * a.Wout + ox) : 0);
+      orow[mf] = (long)b * a.out_bstride + (pv[mf] ? (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox)) : 0);
     }
     char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 8);
     if (!(a.dbg & 4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
@@ -789,7 +789,10 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
 static P2Plan conv_p2_plan(const ConvArgs& a) {
   P2Plan p{};
-  if (!(a.KH == 3 && a.KW == 3 && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.out_rh == 0 && a.pad_w_delta == 0)) return p;
+  // 3x3 forward / stride-1 dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided output-row map)
+  const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
+  const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
+  if (!((k3 || phase) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
   if (a.Cin % 8) return p;
   const int nfr = (a.Cout + 15) / 16;
   const int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
@@ -797,7 +800,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   const int cu = a.Cin / 8;
   P2Args g{};
   g.ppb = a.Cin * 2 + ((cu & 1) ? 32 : 16);
-  g.nsteps = (9 * a.Cin + 31) / 32;
+  const int taps = a.KH * a.KW;
+  g.nsteps = (taps * a.Cin + 31) / 32;
   const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
   const int wres = wres_bytes <= 20 * 1024 ? 1 : 0;
   g.kg = wres ? g.nsteps : 2;     // conv_p2_kernel::KG
@@ -821,13 +825,13 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
       const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 8);
       for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
         int th = npx / tw; if (th > a.Hout) th = a.Hout;
-        const int ph = (th - 1) * a.SA + 3, pw = (tw - 1) * a.SA + 3;
+        const int ph = (th - 1) * a.SA + a.KH, pw = (tw - 1) * a.SA + a.KW;
         size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
         const size_t lds = tab + wbytes + pbytes + stat;
         if (lds > budget || ph * pw * cu > npu_max * nt) continue;
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
         const long ntiles = (long)tx * ty * a.B;
-        const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * 9.0 * a.Cin) + 1.0 * npx * (a.Cin + bn) + 3000.0;
+        const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + 3000.0;
         const double cost = (double)tx * ty * per_tile;
         const bool full = ntiles * gy >= 512;
         if ((full && !best_full) || (full == best_full && cost < best)) {
@@ -915,7 +919,7 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
     attr_done = true;
   }
   char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k3 s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.SA, a.Cin, a.Cout, a.M, a.accumulate, NT, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k%d s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, NT, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
   const int* tab = p2_tables(a, p);
   if (!tab) { ys_set_error("conv p2: cannot allocate the index tables"); return YS_ERR_OOM; }
@@ -1079,6 +1083,33 @@ static int conv_launch_dtype(hipStream_t st, const ConvArgs& a) {
   return YS_ERR_UNSUPPORTED;
 }
 
+// ---- stride-2 3x3 dgrad as four phase convolutions (bf16).  dx[ih, iw] only receives the taps whose parity matches
+// (ih, iw): phase (a, b) = (ih & 1, iw & 1) is a stride-1 correlation of dy with KH_a x KW_b taps (1 if the parity is 0,
+// else 2: row offsets {0, +1} <-> kh = {2, 0}) written to the rows 2i+a / columns 2j+b of dx.  9/4 taps per output pixel
+// instead of 9 with 3/4 of them predicated off.  The dgrad weights of such a layer are laid out phase-major by the weight
+// prep: [phase][Cin_real][taps_p][Cout_pad], phases in the order (0,0) (0,1) (1,0) (1,1) -> tap offsets 0, 1, 3, 5.
+bool ys_conv_dgrad_uses_phases(int dtype, int k, int stride) { return dtype == YS_BF16 && k == 3 && stride == 2; }
+
+static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a) {
+  static const int toff[4] = {0, 1, 3, 5};
+  const int Hx = a.Hout, Wx = a.Wout;                     // dx grid (the layer's input)
+  for (int ph = 0; ph < 4; ph++) {
+    const int pa = ph >> 1, pb = ph & 1;
+    ConvArgs q = a;
+    q.KH = pa ? 2 : 1; q.KW = pb ? 2 : 1;
+    q.SA = 1; q.DIVS = 0; q.DIVM = 0; q.PAD = 0;
+    q.Hout = (Hx - pa + 1) / 2; q.Wout = (Wx - pb + 1) / 2;
+    if (q.Hout <= 0 || q.Wout <= 0) continue;
+    q.M = a.B * q.Hout * q.Wout;
+    q.w = (const char*)a.w + (size_t)toff[ph] * a.Cout * a.Cin * 2;   // [phase][Cout = layer Cin_real][taps_p][Cin = layer Cout_pad]
+    q.out_rh = 2 * Wx; q.out_rw = 2; q.out_r0 = (long)pa * Wx + pb;
+    const P2Plan p2 = conv_p2_plan(q);
+    if (p2.ok) { const int rc = conv_p2_dispatch(st, q, p2); if (rc != YS_OK) return rc; }
+    else { const int rc = conv_launch_dtype<bf16_t>(st, q); if (rc != YS_OK) return rc; }
+  }
+  return YS_OK;
+}
+
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   if (a.Cin % epl || a.in_ldc % epl || a.in_coff % epl) {
@@ -1087,6 +1118,7 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
   }
   if (dtype == YS_BF16) {
     static const bool p2_off = getenv("YS_NO_P2") != nullptr;
+    if (ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH) return conv_dgrad_s2_phases(st, a);
     const P2Plan p2 = conv_p2_plan(a);
     if (p2.ok && !p2_off) return conv_p2_dispatch(st, a, p2);
     return conv_launch_dtype<bf16_t>(st, a);
@@ -1638,7 +1670,7 @@ int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, i
 template <class T>
 __global__ void __launch_bounds__(256)
 weight_prep_kernel(const float* __restrict__ w, int Cout, int taps, int cin_real, int cin_pad, int cout_pad,
-                   T* __restrict__ wf, T* __restrict__ wd) {
+                   T* __restrict__ wf, T* __restrict__ wd, int phase) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nf = (long)Cout * taps * cin_pad;
   if (i < nf) {
@@ -1649,24 +1681,29 @@ weight_prep_kernel(const float* __restrict__ w, int Cout, int taps, int cin_real
   if (wd) {
     const long nd = (long)cin_real * taps * cout_pad;
     if (i < nd) {
-      const int co = (int)(i % cout_pad);
-      const long r = i / cout_pad;
-      const int tapf = (int)(r % taps);
-      const int ci = (int)(r / taps);
-      const int tap = taps - 1 - tapf;  // spatial flip of a square kernel
+      int co, ci, tap;
+      if (phase) {
+        ys_phase_wd_index(i, cin_real, cout_pad, ci, tap, co);
+      } else {
+        co = (int)(i % cout_pad);
+        const long r = i / cout_pad;
+        const int tapf = (int)(r % taps);
+        ci = (int)(r / taps);
+        tap = taps - 1 - tapf;  // spatial flip of a square kernel
+      }
       wd[i] = Elem<T>::from_f(co < Cout ? w[((long)co * taps + tap) * cin_real + ci] : 0.f);
     }
   }
 }
 
 int ys_weight_prep_launch(hipStream_t st, int dtype, const float* w, int Cout, int taps, int cin_real, int cin_pad,
-                          int cout_pad, void* wf, void* wd) {
+                          int cout_pad, void* wf, void* wd, int phase) {
   const long nf = (long)Cout * taps * cin_pad;
   const long nd = wd ? (long)cin_real * taps * cout_pad : 0;
   const long n = nf > nd ? nf : nd;
   if (dtype == YS_BF16)
-    YS_LAUNCH((weight_prep_kernel<bf16_t>), ys_cdiv(n, 256), 256, st, w, Cout, taps, cin_real, cin_pad, cout_pad, (bf16_t*)wf, (bf16_t*)wd);
+    YS_LAUNCH((weight_prep_kernel<bf16_t>), ys_cdiv(n, 256), 256, st, w, Cout, taps, cin_real, cin_pad, cout_pad, (bf16_t*)wf, (bf16_t*)wd, phase);
   else
-    YS_LAUNCH((weight_prep_kernel<float>), ys_cdiv(n, 256), 256, st, w, Cout, taps, cin_real, cin_pad, cout_pad, (float*)wf, (float*)wd);
+    YS_LAUNCH((weight_prep_kernel<float>), ys_cdiv(n, 256), 256, st, w, Cout, taps, cin_real, cin_pad, cout_pad, (float*)wf, (float*)wd, phase);
   return YS_OK;
 }

@@ -50,7 +50,7 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
   YS_CHECK_HIP(hipMemcpyAsync(dx.p, x_nchw, (size_t)B * Cin * H * W * 4, hipMemcpyHostToDevice, st));
   YS_CHECK_HIP(hipMemcpyAsync(dwm.p, wint.data(), wint.size() * 4, hipMemcpyHostToDevice, st));
   YS_TRY(ys_pack_input_launch(st, dtype, (const float*)dx.p, B, Cin, H, W, cpad, dxn.p));
-  YS_TRY(ys_weight_prep_launch(st, dtype, (const float*)dwm.p, Cout, taps, Cin, cpad, cout_ld, dwf.p, nullptr));
+  YS_TRY(ys_weight_prep_launch(st, dtype, (const float*)dwm.p, Cout, taps, Cin, cpad, cout_ld, dwf.p, nullptr, 0));
 
   // per-channel parameter block: gamma, beta, rmean, rvar, scale, shift, mean, rstd, bias, nbt
   YS_TRY(dpar.alloc((size_t)Cout * 10 * 4));
@@ -143,7 +143,7 @@ extern "C" int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, i
   YS_CHECK_HIP(hipMemcpyAsync(dwm.p, wint.data(), wint.size() * 4, hipMemcpyHostToDevice, st));
   YS_TRY(ys_pack_input_launch(st, dtype, (const float*)dx.p, B, Cin, H, W, cpad, dxn.p));
   YS_TRY(ys_pack_input_launch(st, dtype, (const float*)ddy.p, B, Cout, Ho, Wo, copad, ddyn.p));
-  YS_TRY(ys_weight_prep_launch(st, dtype, (const float*)dwm.p, Cout, taps, Cin, cpad, copad, dwf.p, dwd.p));
+  YS_TRY(ys_weight_prep_launch(st, dtype, (const float*)dwm.p, Cout, taps, Cin, cpad, copad, dwf.p, dwd.p, ys_conv_dgrad_uses_phases(dtype, k, stride) ? 1 : 0));
   WgradArgs wa{};
   wa.x = dxn.p; wa.dy = ddyn.p;
   wa.B = B; wa.Hin = H; wa.Win = W; wa.Cin = cpad; wa.Hout = Ho; wa.Wout = Wo; wa.Cout = Cout; wa.KH = wa.KW = k;

@@ -50,7 +50,27 @@ int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
 int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad);
 int ys_weight_prep_launch(hipStream_t st, int dtype, const float* w, int Cout, int taps, int cin_real, int cin_pad,
-                          int cout_pad, void* wf, void* wd);
+                          int cout_pad, void* wf, void* wd, int phase);
+// true when the dgrad of a (k, stride) layer runs as four phase convolutions and wants the phase-major dgrad weights
+bool ys_conv_dgrad_uses_phases(int dtype, int k, int stride);
+// element e of a phase-major dgrad weight block [phase][Cin_real][taps_p][Cout_pad] (3x3, stride 2) -> (ci, tap, co)
+__host__ __device__ inline void ys_phase_wd_index(long e, int cin_real, int cout_pad, int& ci, int& tap, int& co) {
+  const long blk = (long)cin_real * cout_pad;
+  const int ph = e < blk ? 0 : (e < 3 * blk ? 1 : (e < 5 * blk ? 2 : 3));
+  const long start = (ph == 0 ? 0 : (ph == 1 ? 1 : (ph == 2 ? 3 : 5))) * blk;
+  const int pa = ph >> 1, pb = ph & 1;
+  const int kwn = pb ? 2 : 1, tp_n = (pa ? 2 : 1) * kwn;
+  const long el = e - start;
+  co = (int)(el % cout_pad);
+  const long r = el / cout_pad;
+  const int tp = (int)(r % tp_n);
+  ci = (int)(r / tp_n);
+  const int khp = tp / kwn, kwp = tp - khp * kwn;
+  const int kh = pa == 0 ? 1 : (khp == 0 ? 2 : 0);
+  const int kw = pb == 0 ? 1 : (kwp == 0 ? 2 : 0);
+  tap = kh * 3 + kw;
+}
+
 
 // ---- elementwise.hip
 // NCHW fp32 -> NHWC T with channels zero-padded to cpad
