@@ -789,10 +789,13 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
 static P2Plan conv_p2_plan(const ConvArgs& a) {
   P2Plan p{};
-  // 3x3 forward / stride-1 dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided output-row map)
+  // 3x3 forward / stride-1 dgrad, 1x1 forward / dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided
+  // output-row map)
   const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
   const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
-  if (!((k3 || phase) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
+  // 1x1 layers use the same kernel (patch = tile, no halo): measured 4 % faster per step than the direct-fragment kernel
+  const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
+  if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
   if (a.Cin % 8) return p;
   const int nfr = (a.Cout + 15) / 16;
   const int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
@@ -809,8 +812,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
   const size_t tab = ((size_t)g.nsteps * 16 + 15) / 16 * 16;
-  const size_t budget = 76 * 1024;           // two workgroups per CU
   const int gy = ys_cdiv(a.Cout, bn);
+  for (size_t budget = 76 * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
   // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
   // enough.  (512-thread workgroups -- 8 waves x 2 fragments, same LDS footprint -- were measured 13 % slower: the 128-register
@@ -845,9 +848,10 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
       }
     }
   }
+  }
   if (!p.ok) return p;
   if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
-  const int per_cu = (p.lds <= 50 * 1024 && p.npu == 6) ? 3 : 2;
+  const int per_cu = (p.lds <= 50 * 1024 && p.npu == 6) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
   if (gx < 1) gx = 1;
