@@ -172,8 +172,9 @@ def main():
             tb, tf = tab.get((args.family, args.size, args.task), (0.0, 0.0))
             wk = {"train_bytes": tb * es / 2, "train_flop": tf, "igemm_bytes": 0.0, "igemm_launches": 1}
         # ---- dominant kernel class, HIP events on the engine stream, untimed extra steps
+        steps_prof = 2
         eng.kernel_profile(True)
-        for _ in range(2):
+        for _ in range(steps_prof):
             step()
         eng.synchronize()
         n_ig, ms_ig = eng.kernel_profile_read("conv_igemm")
@@ -181,8 +182,8 @@ def main():
         if args.dump_launches:
             eng.kernel_profile_dump(args.dump_launches)
         eng.kernel_profile(False)
-        steps_prof = 2
-        bytes_per_launch = wk["igemm_bytes"] * B / wk["igemm_launches"]
+        # class bytes of one step / launches actually made per step (a stride-2 dgrad runs as four phase launches)
+        bytes_per_launch = wk["igemm_bytes"] * B / max(n_ig / steps_prof, 1)
         avg_ms = ms_ig / max(n_ig, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
