@@ -213,6 +213,20 @@ def main():
                "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, COCO-80 synthetic labels" + (" + instance masks" if seg else ""),
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
+        # ---- secondary metric: inference images/s = eval forward (BN folded into the conv epilogues) + Detect decode
+        model.eval()
+        for _ in range(3):
+            model.forward_device(d_img, B)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        n_inf = 10
+        for _ in range(n_inf):
+            model.forward_device(d_img, B)
+        eng.synchronize()
+        t_inf = (time.perf_counter() - t1) / n_inf
+        out["infer"] = {"images_per_s": round(B / t_inf, 1), "ms_per_batch": round(t_inf * 1e3, 3), "batch": B,
+                        "what": "eval forward + decode to pred [B,4+nc(+nm),A], inputs resident in HBM"}
+        model.train()
         # ---- secondary metric: NMS boxes/s on [64, 84, 8400]
         if not args.no_nms:
             prng = np.random.default_rng(3)

@@ -490,11 +490,11 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
-      if (a.scale || a.shift) {
+      if (!a.scale && a.shift) {             // plain conv bias (heads): added to the fp32 accumulators
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int cc = (c + r) < a.Cout ? (c + r) : 0;
-          v[r] = v[r] * (a.scale ? a.scale[cc] : 1.0f) + (a.shift ? a.shift[cc] : 0.0f);
+          v[r] += a.shift[cc];
           if (a.act) v[r] = ys_silu(v[r]);
         }
       }
@@ -512,6 +512,16 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   const bool active = lane < PPI * VPP;
   const int c = n0 + cv * 8;
   const bool do_stats = a.stats != nullptr;
+  // eval-mode BatchNorm folded into the conv (Convs.cs:48 with running statistics): applied on the wide path to the
+  // bf16-rounded conv output -- the same value the training path normalises -- with the lane's 8 coefficients loaded once
+  const bool bn_eval = a.scale != nullptr;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
+  if (bn_eval && active && c < a.Cout) {     // coefficient arrays are padded to a multiple of 4 floats; Cout % 8 == 0 for BN convs
+    ys_ldcoef<8>(a.scale + c, sc);
+    if (a.shift) ys_ldcoef<8>(a.shift + c, sh);
+  }
   char* yb = (char*)a.y;
   const char* rb = (const char*)a.res;
 #pragma unroll 2
@@ -526,6 +536,11 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
         if (do_stats) {
 #pragma unroll
           for (int e = 0; e < 8; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+        }
+        if (bn_eval) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { f[e] = f[e] * sc[e] + sh[e]; if (a.act) f[e] = ys_silu(f[e]); if (c + e >= a.Cout) f[e] = 0.f; }
+          if (!(rb || a.accumulate)) val = ys_pack<T>(f);
         }
         T* yp = (T*)(yb + (row * a.out_ldc + a.out_coff + c) * 2L);
         if (rb || a.accumulate) {
