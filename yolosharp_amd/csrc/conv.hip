@@ -828,6 +828,10 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
   const size_t tab = ((size_t)g.nsteps * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
+  // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed
+  // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
+  static const int maxcin3 = getenv("YS_P2_MAXCIN3") ? atoi(getenv("YS_P2_MAXCIN3")) : 255;
+  if (k3 && a.SA == 1 && a.Cin > maxcin3) return p;
   for (size_t budget = 76 * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
   // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
