@@ -690,10 +690,17 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       goff[k] = tpd[(2 * k + 1) * NT + tid];
     }
   }
-  // tile coordinates advance incrementally by gridDim.x tiles (no per-tile divisions)
+  // Tile order.  Workgroup i runs on XCD i % 8 (round-robin dispatch); when the grid is a multiple of 8 each XCD walks its own
+  // contiguous eighth of the tile list, so the tiles resident on an XCD at any time are spatial neighbours and their shared
+  // halo rows hit that XCD's L2.  Otherwise plain interleaving.  Tile coordinates advance incrementally (no per-tile divisions).
+  const bool xcd_order = (gridDim.x & 7) == 0 && !(a.dbg & 32);
+  const int t_per_xcd = (g.ntiles + 7) >> 3;
+  const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_end = xcd_order ? (((int)(blockIdx.x & 7) + 1) * t_per_xcd < g.ntiles ? ((int)(blockIdx.x & 7) + 1) * t_per_xcd : g.ntiles) : g.ntiles;
   int stx, sty, sb;
   {
-    const int G = gridDim.x;
+    const int G = t_step;
     stx = G % g.tiles_x; const int rem = G / g.tiles_x;
     sty = rem % g.tiles_y; sb = rem / g.tiles_y;
   }
@@ -727,17 +734,17 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   };
   int txi, tyi, b;
   {
-    int t = blockIdx.x;
+    int t = t_first;
     txi = t % g.tiles_x; t /= g.tiles_x;
     tyi = t % g.tiles_y; b = t / g.tiles_y;
   }
   int ntx = txi, nty = tyi, nb = b;
-  if ((int)blockIdx.x < g.ntiles) pfetch(txi, tyi, b);
+  if (t_first < t_end) pfetch(txi, tyi, b);
   float st1[8], st2[8];                        // BN statistics of this workgroup's tiles (per-lane column sums)
 #pragma unroll
   for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
 
-  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+  for (int tile = t_first; tile < t_end; tile += t_step) {
     const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
     if (!WRES) wfetch(0);
@@ -752,7 +759,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     if (!WRES) wstore(0);
     ys_barrier_lds();
     advance(ntx, nty, nb);
-    if (tile + (int)gridDim.x < g.ntiles) pfetch(ntx, nty, nb);
+    if (tile + t_step < t_end) pfetch(ntx, nty, nb);
 
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -821,7 +828,10 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   const int taps = a.KH * a.KW;
   g.nsteps = (taps * a.Cin + 31) / 32;
   const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
-  const int wres = wres_bytes <= 20 * 1024 ? 1 : 0;
+  // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
+  // workgroup per CU); YS_P2_WRESMAX overrides for experiments
+  static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 40 * 1024;
+  const int wres = wres_bytes <= wresmax ? 1 : 0;
   g.kg = wres ? g.nsteps : 2;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
   g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
@@ -832,7 +842,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
   static const int maxcin3 = getenv("YS_P2_MAXCIN3") ? atoi(getenv("YS_P2_MAXCIN3")) : 255;
   if (k3 && a.SA == 1 && a.Cin > maxcin3) return p;
-  for (size_t budget = 76 * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
+  for (size_t budget = (wres && wres_bytes > 40 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
   // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
   // enough.  (512-thread workgroups -- 8 waves x 2 fragments, same LDS footprint -- were measured 13 % slower: the 128-register
