@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="skip the eval-forward secondary metric (profiling runs)")
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (class,label,us) of the profiled conv launches (triage)")
     args = ap.parse_args()
 
@@ -215,16 +216,16 @@ def main():
                "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
         # ---- secondary metric: inference images/s = eval forward (BN folded into the conv epilogues) + Detect decode
         model.eval()
-        for _ in range(3):
+        for _ in range(0 if args.no_infer else 3):
             model.forward_device(d_img, B)
         eng.synchronize()
         t1 = time.perf_counter()
         n_inf = 10
-        for _ in range(n_inf):
+        for _ in range(0 if args.no_infer else n_inf):
             model.forward_device(d_img, B)
         eng.synchronize()
         t_inf = (time.perf_counter() - t1) / n_inf
-        out["infer"] = {"images_per_s": round(B / t_inf, 1), "ms_per_batch": round(t_inf * 1e3, 3), "batch": B,
+        out["infer"] = None if args.no_infer else {"images_per_s": round(B / t_inf, 1), "ms_per_batch": round(t_inf * 1e3, 3), "batch": B,
                         "what": "eval forward + decode to pred [B,4+nc(+nm),A], inputs resident in HBM"}
         model.train()
         # ---- secondary metric: NMS boxes/s on [64, 84, 8400]

@@ -597,6 +597,9 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
   }
 }
 
+#ifndef P2_KG
+#define P2_KG 2            // K-steps (32 K each) per streamed weight group
+#endif
 #define P2_NPU 12          // max patch units (16 B) a thread keeps in flight: 12 x 256 x 16 B = 48 KB per workgroup (small layers: 6)
 struct P2Args {
   int TH, TW, tiles_x, tiles_y, ntiles, PH, PW;
@@ -611,9 +614,10 @@ template <int MR, int NR, int WRES, int NPU, int NT>
 __global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 ? 3 : 2)))   // waves per SIMD the LDS budget allows (512 threads: 2 workgroups x 2)
 conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
+  if (a.dbg & 64) return;                     // ablation: launch + dispatch cost only
   constexpr int BN = NR * 16;
   constexpr int NWV = NT / 64;
-  constexpr int NWU = WRES ? 1 : (BN * 2 * 4 + NT - 1) / NT;   // streamed weight units per thread (kg = 2)
+  constexpr int NWU = WRES ? 1 : (BN * P2_KG * 4 + NT - 1) / NT;   // streamed weight units per thread
   YS_DYN_LDS(lds);
   char* lb = (char*)lds;
   int* sOff = (int*)lb;                       // [nsteps][4]
@@ -650,7 +654,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       sW[n * g.wpitch + u] = v;
     }
   }
-  constexpr int KG = 2;                        // K-steps per streamed weight group
+  constexpr int KG = P2_KG;                    // K-steps per streamed weight group
   constexpr int GU = KG * 4;                   // 16-byte units per weight row and group
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
   uint4 rw[NWU];
@@ -832,7 +836,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   // workgroup per CU); YS_P2_WRESMAX overrides for experiments
   static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 40 * 1024;
   const int wres = wres_bytes <= wresmax ? 1 : 0;
-  g.kg = wres ? g.nsteps : 2;     // conv_p2_kernel::KG
+  g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
   g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;

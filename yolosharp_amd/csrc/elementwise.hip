@@ -646,51 +646,100 @@ int ys_fill_launch(hipStream_t st, float* p, long n, float v) {
 // ------------------------------------------------------------------ Detect._inference decode
 // pred[b, 0:4, a] = dist2bbox(DFL(boxes), anchors, xywh) * stride ; pred[b, 4:4+nc, a] = sigmoid(scores)
 // (Head.cs:204-223; DFL = softmax over reg_max bins, expectation with weights 0..reg_max-1, Block.cs:40-45)
+#define DEC_ANCH 64     // anchors per workgroup
 template <class T>
 __global__ void __launch_bounds__(EW_THREADS)
 detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ ps, int ld_ps, int B, int A, int nc,
                      int reg_max, int nl, int o0, int o1, int o2, int w0, int w1, int w2, int s0, int s1, int s2,
                      float* __restrict__ pred, int pred_C) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * A) return;
-  const int a = (int)(i % A);
-  const long b = i / A;
-  int lo = o0, lw = w0, ls = s0;
-  if (nl > 1 && a >= o1) { lo = o1; lw = w1; ls = s1; }
-  if (nl > 2 && a >= o2) { lo = o2; lw = w2; ls = s2; }
-  const int cell = a - lo;
-  const float ax = (float)(cell % lw) + 0.5f, ay = (float)(cell / lw) + 0.5f;
-  const T* row = pd + i * ld_pd;
-  float d[4];
-  for (int s = 0; s < 4; s++) {
-    float mx = -INFINITY;
-    for (int j = 0; j < reg_max; j++) mx = fmaxf(mx, Elem<T>::to_f(row[s * reg_max + j]));
-    float se = 0.f, sw = 0.f;
-    for (int j = 0; j < reg_max; j++) {
-      const float e = __expf(Elem<T>::to_f(row[s * reg_max + j]) - mx);
-      se += e;
-      sw += e * (float)j;
+  // One workgroup decodes DEC_ANCH consecutive rows of the [B*A][ld] head outputs: the rows are staged in LDS with
+  // coalesced 16-byte loads, (anchor, side) threads take the DFL expectation, and the class probabilities are written
+  // channel-major so that consecutive lanes store consecutive anchors of pred[b][c][:].
+  constexpr int EPL = Elem<T>::EPL;
+  YS_DYN_LDS(lds);
+  const int nb = 4 * reg_max;                       // box logits per anchor
+  const int pb = nb + 1, pc = nc | 1;               // odd LDS pitches (floats): conflict-free column reads
+  float* sB = (float*)lds;                          // [DEC_ANCH][pb]
+  float* sC = sB + DEC_ANCH * pb;                   // [DEC_ANCH][pc]
+  float* sD = sC + DEC_ANCH * pc;                   // [DEC_ANCH][4]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * DEC_ANCH;
+  const long rows = (long)B * A;
+  const int ub = (nb + EPL - 1) / EPL, uc = (nc + EPL - 1) / EPL;
+  for (int idx = tid; idx < DEC_ANCH * ub; idx += EW_THREADS) {
+    const int r = idx / ub, u = idx - r * ub;
+    if (r0 + r < rows) {
+      float f[EPL];
+      ys_unpack<T>(ys_ld16(pd + (r0 + r) * ld_pd + u * EPL), f);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) if (u * EPL + e < nb) sB[r * pb + u * EPL + e] = f[e];
     }
-    d[s] = sw / se;
   }
-  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
-  float* o = pred + b * (long)pred_C * A + a;
-  const float st = (float)ls;
-  o[0] = (x1 + x2) / 2.0f * st;
-  o[(long)A] = (y1 + y2) / 2.0f * st;
-  o[2 * (long)A] = (x2 - x1) * st;
-  o[3 * (long)A] = (y2 - y1) * st;
-  const T* srow = ps + i * ld_ps;
-  for (int c = 0; c < nc; c++) o[(long)(4 + c) * A] = ys_sigmoid(Elem<T>::to_f(srow[c]));
+  for (int idx = tid; idx < DEC_ANCH * uc; idx += EW_THREADS) {
+    const int r = idx / uc, u = idx - r * uc;
+    if (r0 + r < rows) {
+      float f[EPL];
+      ys_unpack<T>(ys_ld16(ps + (r0 + r) * ld_ps + u * EPL), f);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) if (u * EPL + e < nc) sC[r * pc + u * EPL + e] = f[e];
+    }
+  }
+  __syncthreads();
+  {   // DFL expectation: thread = (anchor, side)
+    const int r = tid >> 2, sd = tid & 3;
+    if (r < DEC_ANCH && r0 + r < rows) {
+      const float* row = sB + r * pb + sd * reg_max;
+      float mx = -INFINITY;
+      for (int j = 0; j < reg_max; j++) mx = fmaxf(mx, row[j]);
+      float se = 0.f, sw = 0.f;
+      for (int j = 0; j < reg_max; j++) {
+        const float e = __expf(row[j] - mx);
+        se += e;
+        sw += e * (float)j;
+      }
+      sD[r * 4 + sd] = sw / se;
+    }
+  }
+  __syncthreads();
+  if (tid < DEC_ANCH && r0 + tid < rows) {
+    const long i = r0 + tid;
+    const int a = (int)(i % A);
+    const long b = i / A;
+    int lo = o0, lw = w0, ls = s0;
+    if (nl > 1 && a >= o1) { lo = o1; lw = w1; ls = s1; }
+    if (nl > 2 && a >= o2) { lo = o2; lw = w2; ls = s2; }
+    const int cell = a - lo;
+    const float ax = (float)(cell % lw) + 0.5f, ay = (float)(cell / lw) + 0.5f;
+    const float* d = sD + tid * 4;
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    float* o = pred + b * (long)pred_C * A + a;
+    const float st = (float)ls;
+    o[0] = (x1 + x2) / 2.0f * st;
+    o[(long)A] = (y1 + y2) / 2.0f * st;
+    o[2 * (long)A] = (x2 - x1) * st;
+    o[3 * (long)A] = (y2 - y1) * st;
+  }
+  {   // class probabilities: lane = anchor, the 4 waves stride over the classes
+    const int r = tid & (DEC_ANCH - 1);
+    if (r0 + r < rows) {
+      const long i = r0 + r;
+      const int a = (int)(i % A);
+      const long b = i / A;
+      float* o = pred + b * (long)pred_C * A + a;
+      for (int c = tid / DEC_ANCH; c < nc; c += EW_THREADS / DEC_ANCH) o[(long)(4 + c) * A] = ys_sigmoid(sC[r * pc + c]);
+    }
+  }
 }
 int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
                             int nc, int reg_max, int nl, const int* lo, const int* lw, const int* ls, float* pred, int pred_C) {
   const long n = (long)B * A;
   const int o1 = nl > 1 ? lo[1] : 0, o2 = nl > 2 ? lo[2] : 0, w1 = nl > 1 ? lw[1] : 1, w2 = nl > 2 ? lw[2] : 1;
   const int s1 = nl > 1 ? ls[1] : 1, s2 = nl > 2 ? ls[2] : 1;
+  const size_t lds_bytes = (size_t)DEC_ANCH * ((4 * reg_max + 1) + (nc | 1) + 4) * 4;
+  if (lds_bytes > 60 * 1024 || DEC_ANCH * 4 > EW_THREADS) { ys_set_error("detect decode: nc=%d reg_max=%d too large", nc, reg_max); return YS_ERR_UNSUPPORTED; }
   if (dtype == YS_BF16)
-    YS_LAUNCH((detect_decode_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
+    YS_LAUNCH_LDS((detect_decode_kernel<bf16_t>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
   else
-    YS_LAUNCH((detect_decode_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
+    YS_LAUNCH_LDS((detect_decode_kernel<float>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
   return YS_OK;
 }
