@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--no-infer", action="store_true", help="skip the eval-forward secondary metric (profiling runs)")
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) code path even with WORLD_SIZE=1 (self-test)")
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (class,label,us) of the profiled conv launches (triage)")
     args = ap.parse_args()
 
@@ -94,7 +95,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -131,15 +132,18 @@ def main():
         flat = ysd.device_view(gptr.value, gn, dev)
         sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())])
 
+    def local_step():
+        model.forward_device(d_img, B)
+        crit.forward_device(*d_lab)
+        model.backward()
+        model.adamw_step(lrs)
+        model.zero_grad()
+
     def step():
         if sync is not None:
             ysd.train_step_dp(model, crit, sync, d_img, B, d_lab, lrs)
         else:
-            model.forward_device(d_img, B)
-            crit.forward_device(*d_lab)
-            model.backward()
-            model.adamw_step(lrs)
-            model.zero_grad()
+            local_step()
 
     def barrier():
         if distributed:
@@ -176,7 +180,7 @@ def main():
         steps_prof = 2
         eng.kernel_profile(True)
         for _ in range(steps_prof):
-            step()
+            local_step()        # rank 0 only: no collective may be issued here (the other ranks are already at the final barrier)
         eng.synchronize()
         n_ig, ms_ig = eng.kernel_profile_read("conv_igemm")
         n_wg, ms_wg = eng.kernel_profile_read("conv_wgrad")
