@@ -153,6 +153,17 @@ YS_API int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int batch, in
                           float conf_thres, float iou_thres, int max_det, int nc, int max_nms, int max_wh,
                           float* out_rows, int64_t* out_keep, int32_t* out_count);
 
+/* Validation, per-image part of Detector.Val (Models/Detector.cs:103-120), batched on the device:
+ * GT boxes = bboxes[batch_idx == b] * (W,H,W,H) -> xyxy (Utils/Ops.cs:68-81); iou = Metrics.box_iou(gt, pred[:,0:4])
+ * (Utils/Metrics.cs:16-34); correct = match_predictions(pred[:,5], cls, iou) (Models/YoloBaseTaskModel.cs:377-446) for the
+ * IoU thresholds linspace(0.5, 0.95, 10).  rows [B,max_det,row_stride] / count [B] are ys_nms_batched outputs;
+ * correct: uint8 [B, max_det, 10].  `on_device` applies to rows, count, the label arrays and correct. */
+YS_API int ys_val_match_batched(ys_ctx* ctx, const float* rows, const int32_t* count, int on_device, int batch, int max_det,
+                                int row_stride, const float* batch_idx, const float* cls, const float* bboxes, int n_labels,
+                                float img_w, float img_h, uint8_t* correct);
+/* Metrics.box_iou (Utils/Metrics.cs:16-34): iou [n, m] of xyxy boxes, fp32, eps as given (reference default 1e-7). */
+YS_API int ys_box_iou(ys_ctx* ctx, const float* box1, int n, const float* box2, int m, float eps, int on_device, float* iou);
+
 /* Ops.process_mask (Utils/Ops.cs:462-489), used by Segmenter post-processing (Models/Segmenter.cs:131-160 region):
  * masks = masks_in[n,nm] @ protos[nm,mh,mw], cropped to boxes (xyxy, image pixels) scaled to the mask grid,
  * optionally bilinearly upsampled (align_corners = false) to (ih, iw), thresholded > 0.

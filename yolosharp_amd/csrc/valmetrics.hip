@@ -1,0 +1,175 @@
+// valmetrics.hip -- the per-image part of Detector.Val (Models/Detector.cs:103-120) on the device:
+//   GT boxes = bboxes[batch_idx == b] * (W, H, W, H) -> xyxy          (Ops.xywh2xyxy, Utils/Ops.cs:68-81)
+//   iou      = Metrics.box_iou(gt, pred[:, 0:4])                       (Utils/Metrics.cs:16-34, eps 1e-7)
+//   correct  = match_predictions(pred[:, 5], cls, iou)                 (Models/YoloBaseTaskModel.cs:377-446)
+// The reference walks images on the host and de-duplicates matches with per-element .item() loops
+// (GetUniqueByColumn, :422-444); here one workgroup owns an image and nothing leaves the device.
+//
+// match_predictions, restated.  For a threshold t the reference takes all (label, detection) pairs with
+// iou * (class match) >= t, orders them by IoU descending, keeps the FIRST pair of every detection (result ordered by
+// detection index, since torch.unique sorts), then the first pair of every label in THAT order.  Hence:
+//   best(d)  = the class-matching label with the largest IoU for detection d (independent of t),
+//   label l is credited to the smallest d with best(d) == l and iou(best(d), d) >= t,   correct[d][t] = 1 for those d.
+// Equal IoUs are ordered by the sort implementation upstream (unpinned); here the lower label index wins.
+// Compiled with -ffp-contract=off: the IoU arithmetic is the reference's operation order in plain fp32.
+#include "ys_internal.h"
+#include "ys_kernels.h"
+
+#define VM_THREADS 256
+#define VM_NT 10          // IoU thresholds linspace(0.5, 0.95, 10)
+
+struct VmThr { float t[VM_NT]; };
+
+__device__ inline float vm_iou(float a1x, float a1y, float a2x, float a2y, float b1x, float b1y, float b2x, float b2y, float eps) {
+  // inter = (min(a2, b2) - max(a1, b1)).clamp(0).prod ; iou = inter / (area1 + area2 - inter + eps)
+  float iw = fminf(a2x, b2x) - fmaxf(a1x, b1x);
+  float ih = fminf(a2y, b2y) - fmaxf(a1y, b1y);
+  iw = iw < 0.f ? 0.f : iw;
+  ih = ih < 0.f ? 0.f : ih;
+  const float inter = iw * ih;
+  const float area1 = (a2x - a1x) * (a2y - a1y), area2 = (b2x - b1x) * (b2y - b1y);
+  return inter / (area1 + area2 - inter + eps);
+}
+
+__global__ void __launch_bounds__(VM_THREADS)
+box_iou_kernel(const float* __restrict__ b1, int n, const float* __restrict__ b2, int m, float eps, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * m) return;
+  const int r = (int)(i / m), c = (int)(i - (long)r * m);
+  out[i] = vm_iou(b1[4 * r], b1[4 * r + 1], b1[4 * r + 2], b1[4 * r + 3], b2[4 * c], b2[4 * c + 1], b2[4 * c + 2], b2[4 * c + 3], eps);
+}
+
+// one workgroup per image
+__global__ void __launch_bounds__(VM_THREADS)
+val_match_kernel(const float* __restrict__ rows, const int* __restrict__ count, int max_det, int row_stride,
+                 const float* __restrict__ batch_idx, const float* __restrict__ cls, const float* __restrict__ bboxes, int n_labels,
+                 float img_w, float img_h, VmThr thr, int lcap, int* __restrict__ ws_lab /*[B][lcap]*/,
+                 float* __restrict__ ws_best /*[B][max_det][2]*/, unsigned char* __restrict__ correct /*[B][max_det][10]*/, int* __restrict__ overflow) {
+  __shared__ int s_nl;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int* lab = ws_lab + (long)b * lcap;
+  float* best = ws_best + (long)b * max_det * 2;
+  unsigned char* cor = correct + (long)b * max_det * VM_NT;
+  const int D = count[b] < max_det ? count[b] : max_det;
+  for (int i = tid; i < max_det * VM_NT; i += VM_THREADS) cor[i] = 0;
+  // labels of this image, in collate order (boolean-mask indexing keeps the order, Detector.cs:110-112)
+  if (tid == 0) {
+    int k = 0;
+    for (int j = 0; j < n_labels; j++)
+      if ((int)batch_idx[j] == b) { if (k < lcap) lab[k] = j; k++; }
+    if (k > lcap) { atomicMax(overflow, k); k = lcap; }
+    s_nl = k;
+  }
+  __syncthreads();
+  const int L = s_nl;
+  // best class-matching label per detection
+  for (int d = tid; d < D; d += VM_THREADS) {
+    const float* pr = rows + ((long)b * max_det + d) * row_stride;
+    const float px1 = pr[0], py1 = pr[1], px2 = pr[2], py2 = pr[3], pc = pr[5];
+    float bi = -1.f; int bl = -1;
+    for (int k = 0; k < L; k++) {
+      const int j = lab[k];
+      if (cls[j] != pc) continue;
+      const float cx = bboxes[4 * j] * img_w, cy = bboxes[4 * j + 1] * img_h, w = bboxes[4 * j + 2] * img_w, h = bboxes[4 * j + 3] * img_h;
+      const float iou = vm_iou(cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, px1, py1, px2, py2, 1e-7f);
+      if (iou > bi) { bi = iou; bl = k; }
+    }
+    best[2 * d] = bi;
+    best[2 * d + 1] = (float)bl;
+  }
+  __syncthreads();
+  // every (label, threshold): the first detection that chose this label and clears the threshold
+  for (int e = tid; e < L * VM_NT; e += VM_THREADS) {
+    const int k = e / VM_NT, ti = e - k * VM_NT;
+    const float t = thr.t[ti];
+    for (int d = 0; d < D; d++)
+      if ((int)best[2 * d + 1] == k && best[2 * d] >= t) { cor[d * VM_NT + ti] = 1; break; }
+  }
+}
+
+// torch.linspace(0.5, 0.95, 10) in fp32 (ATen: step = (end-start)/(steps-1); first half start + step*i, second half
+// end - step*(steps-1-i))
+static VmThr vm_thresholds() {
+  VmThr t;
+  const float start = 0.5f, end = 0.95f;
+  const float step = (end - start) / (float)(VM_NT - 1);
+  for (int i = 0; i < VM_NT; i++) t.t[i] = i < VM_NT / 2 ? start + step * (float)i : end - step * (float)(VM_NT - 1 - i);
+  return t;
+}
+
+extern "C" {
+
+int ys_box_iou(ys_ctx* ctx, const float* box1, int n, const float* box2, int m, float eps, int on_device, float* iou) {
+  YS_REQUIRE(ctx && iou && n >= 0 && m >= 0, "ys_box_iou: bad argument");
+  if ((long)n * m == 0) return YS_OK;
+  YS_REQUIRE(box1 && box2, "ys_box_iou: null boxes");
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (on_device) {
+    YS_LAUNCH(box_iou_kernel, ys_cdiv((long)n * m, VM_THREADS), VM_THREADS, st, box1, n, box2, m, eps, iou);
+    return YS_OK;
+  }
+  float *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+  YS_CHECK_HIP(hipMalloc(&d1, (size_t)n * 16));
+  YS_CHECK_HIP(hipMalloc(&d2, (size_t)m * 16));
+  YS_CHECK_HIP(hipMalloc(&d3, (size_t)n * m * 4));
+  hipMemcpyAsync(d1, box1, (size_t)n * 16, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d2, box2, (size_t)m * 16, hipMemcpyHostToDevice, st);
+  YS_LAUNCH(box_iou_kernel, ys_cdiv((long)n * m, VM_THREADS), VM_THREADS, st, (const float*)d1, n, (const float*)d2, m, eps, d3);
+  hipMemcpyAsync(iou, d3, (size_t)n * m * 4, hipMemcpyDeviceToHost, st);
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(d1); hipFree(d2); hipFree(d3);
+  if (e != hipSuccess) { ys_set_error("ys_box_iou: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
+  return YS_OK;
+}
+
+int ys_val_match_batched(ys_ctx* ctx, const float* rows, const int32_t* count, int on_device, int batch, int max_det, int row_stride,
+                         const float* batch_idx, const float* cls, const float* bboxes, int n_labels, float img_w, float img_h,
+                         uint8_t* correct) {
+  YS_REQUIRE(ctx && rows && count && correct, "ys_val_match_batched: null argument");
+  YS_REQUIRE(batch > 0 && max_det > 0 && row_stride >= 6 && n_labels >= 0, "ys_val_match_batched: bad shape");
+  YS_REQUIRE(n_labels == 0 || (batch_idx && cls && bboxes), "ys_val_match_batched: null label arrays");
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int lcap = n_labels > 0 ? n_labels : 1;          // an image can hold all labels of the batch
+  const size_t nrow = (size_t)batch * max_det * row_stride, ncor = (size_t)batch * max_det * VM_NT;
+  const float *d_rows = rows, *d_bi = batch_idx, *d_cl = cls, *d_bb = bboxes;
+  const int* d_cnt = count;
+  unsigned char* d_cor = correct;
+  std::vector<void*> tmp;
+  auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
+  int* d_lab = (int*)dalloc((size_t)batch * lcap * 4);
+  float* d_best = (float*)dalloc((size_t)batch * max_det * 8);
+  int* d_ovf = (int*)dalloc(4);
+  bool ok = d_lab && d_best && d_ovf;
+  if (ok && !on_device) {
+    float* a = (float*)dalloc(nrow * 4); int* c = (int*)dalloc((size_t)batch * 4);
+    float* b1 = (float*)dalloc((size_t)lcap * 4); float* b2 = (float*)dalloc((size_t)lcap * 4); float* b3 = (float*)dalloc((size_t)lcap * 16);
+    unsigned char* co = (unsigned char*)dalloc(ncor);
+    ok = a && c && b1 && b2 && b3 && co;
+    if (ok) {
+      hipMemcpyAsync(a, rows, nrow * 4, hipMemcpyHostToDevice, st);
+      hipMemcpyAsync(c, count, (size_t)batch * 4, hipMemcpyHostToDevice, st);
+      if (n_labels > 0) {
+        hipMemcpyAsync(b1, batch_idx, (size_t)n_labels * 4, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(b2, cls, (size_t)n_labels * 4, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(b3, bboxes, (size_t)n_labels * 16, hipMemcpyHostToDevice, st);
+      }
+      d_rows = a; d_cnt = c; d_bi = b1; d_cl = b2; d_bb = b3; d_cor = co;
+    }
+  }
+  int rc = YS_OK;
+  if (!ok) { ys_set_error("ys_val_match_batched: out of device memory"); rc = YS_ERR_OOM; }
+  if (rc == YS_OK) {
+    hipMemsetAsync(d_ovf, 0, 4, st);
+    YS_LAUNCH(val_match_kernel, batch, VM_THREADS, st, d_rows, d_cnt, max_det, row_stride, d_bi, d_cl, d_bb, n_labels, img_w, img_h,
+              vm_thresholds(), lcap, d_lab, d_best, d_cor, d_ovf);
+    if (!on_device) hipMemcpyAsync(correct, d_cor, ncor, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipStreamSynchronize(st);      // the scratch buffers are released below
+    if (e != hipSuccess) { ys_set_error("ys_val_match_batched: %s", hipGetErrorString(e)); rc = YS_ERR_HIP; }
+  }
+  for (void* p : tmp) hipFree(p);
+  return rc;
+}
+
+}  // extern "C"

@@ -89,6 +89,29 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_memcpy_d2h(self.ctx, _ptr(out), p, out.nbytes))
         return out
 
+    # ---- validation (Detector.cs:103-120): box_iou + match_predictions per image, batched on the device
+    def box_iou(self, box1, box2, eps=1e-7):
+        """Metrics.box_iou (Metrics.cs:16-34): xyxy [n,4] x [m,4] -> [n,m] fp32."""
+        b1 = np.ascontiguousarray(box1, np.float32).reshape(-1, 4)
+        b2 = np.ascontiguousarray(box2, np.float32).reshape(-1, 4)
+        out = np.zeros((b1.shape[0], b2.shape[0]), np.float32)
+        _lib.check(self.lib, self.lib.ys_box_iou(self.ctx, _ptr(b1), b1.shape[0], _ptr(b2), b2.shape[0], eps, 0, _ptr(out)))
+        return out
+
+    def val_match(self, rows, count, batch, img_w, img_h):
+        """rows [B,max_det,6+extra] / count [B]: the padded NMS outputs (x1,y1,x2,y2,conf,cls,...); batch = collate dict
+        (batch_idx, cls, bboxes normalised cxcywh).  Returns a list of bool [count[b], 10] (match_predictions per image)."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        count = np.ascontiguousarray(count, np.int32)
+        B, max_det, stride = rows.shape
+        bi = np.ascontiguousarray(np.asarray(batch["batch_idx"], np.float32).reshape(-1))
+        cl = np.ascontiguousarray(np.asarray(batch["cls"], np.float32).reshape(-1))
+        bb = np.ascontiguousarray(np.asarray(batch["bboxes"], np.float32).reshape(-1, 4))
+        cor = np.zeros((B, max_det, 10), np.uint8)
+        _lib.check(self.lib, self.lib.ys_val_match_batched(self.ctx, _ptr(rows), _ptr(count), 0, B, max_det, stride, _ptr(bi), _ptr(cl),
+                                                           _ptr(bb), bi.shape[0], float(img_w), float(img_h), _ptr(cor)))
+        return [cor[b, :count[b]].astype(bool) for b in range(B)]
+
     # ---- Ops.process_mask (Ops.cs:462-489)
     def process_mask(self, protos, masks_in, bboxes, shape, upsample=False, cpu_crop_branch=False):
         """protos [nm,mh,mw], masks_in [n,nm], bboxes [n,4] xyxy (image pixels), shape=(ih,iw) -> bool [n,oh,ow]."""
