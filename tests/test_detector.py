@@ -1,0 +1,43 @@
+"""Detector.ImagePredict / Val host mirror (Models/Detector.cs:26-154) end to end on the engine vs the oracle pieces."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BACKENDS
+from oracle import yolo_oracle as O
+from test_model import make_ref
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_predict_and_val(backend, engine):
+    from yolosharp_amd.detector import Detector, pad_to_32
+    from yolosharp_amd.model import Yolov8
+    from yolosharp_amd import metrics as M
+    nc, H, W, B = 80, 32, 32, 2
+    ref = make_ref(nc=nc)
+    m = Yolov8(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    det = Detector(m)
+    # ---- ImagePredict: 20x29 image -> padded with 114 to 32x32 (Detector.cs:33-41)
+    img = (torch.rand(3, 20, 29, generator=torch.Generator().manual_seed(0)) * 255).floor()
+    x = pad_to_32(img.numpy())
+    assert x.shape == (3, 32, 32) and x[0, 31, 31] == np.float32(114.0 / 255.0) and x[1, 10, 10] == np.float32(img[1, 10, 10] / 255.0)
+    res = det.ImagePredict(img.numpy(), predict_threshold=0.001, iou_threshold=0.7)
+    ref.eval()
+    with torch.no_grad():
+        rinf, _ = ref(torch.from_numpy(x)[None])
+    p = rinf["boxes"].numpy().copy()
+    rows, _ = engine.non_max_suppression(p, 0.001, 0.7)          # NMS itself is pinned bit-exactly in test_nms.py
+    assert len(res) > 0 and abs(len(res) - len(rows[0])) <= max(2, len(rows[0]) // 10)
+    assert all(isinstance(r.CenterX, int) and 0 <= r.ClassID < nc for r in res)
+    # ---- Val: loss items + (P, R, mAP50, mAP50-95) through the device matching; running statistics are left alone
+    g = torch.Generator().manual_seed(4)
+    tb = O.synthetic_batch(B, H, W, nc, seed=20, kmax=4)
+    d = {k: v.numpy() for k, v in tb.items()}
+    d["images"] = torch.rand(B, 3, H, W, generator=g).numpy()
+    bn_before = m.state_dict()["model.0.bn.running_mean"].copy()
+    loss_items, (P, R, m50, m5095) = det.Val([d], conf_thres=0.001)
+    assert loss_items.shape == (3,) and np.all(np.isfinite(loss_items))
+    assert 0.0 <= m5095 <= m50 <= 1.0 and 0.0 <= P <= 1.0
+    assert np.array_equal(bn_before, m.state_dict()["model.0.bn.running_mean"])
+    m.close()

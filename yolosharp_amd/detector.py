@@ -1,0 +1,80 @@
+"""Host mirror of Models/Detector.cs on the engine: ImagePredict (:26-72) and Val (:76-154).
+
+Everything per image / per anchor runs on the device (eval forward + decode, NMS, box_iou + match_predictions); only the
+epoch-level ap_per_class (small) and the reference's integer truncation of the results stay on the host.  The model must have
+been created with (height, width) = the padded image size: the reference pads bottom/right with 114 to a multiple of 32
+before dividing by 255 (Detector.cs:35-41), this does the same."""
+import numpy as np
+
+from . import metrics as M
+from .model import AMPWrapper, v8DetectionLoss
+
+
+class YoloResult:
+    """Types/YoloResult: integer box (truncated like Detector.cs:52-68)."""
+    __slots__ = ("ClassID", "Score", "CenterX", "CenterY", "Width", "Height")
+
+    def __init__(self, row):
+        x, y = int(row[0]), int(row[1])
+        rw, rh = int(row[2]) - x, int(row[3]) - y
+        self.ClassID, self.Score = int(row[5]), float(row[4])
+        self.CenterX, self.CenterY, self.Width, self.Height = x + rw // 2, y + rh // 2, rw, rh
+
+    def __repr__(self):
+        return f"YoloResult(cls={self.ClassID}, score={self.Score:.3f}, cx={self.CenterX}, cy={self.CenterY}, w={self.Width}, h={self.Height})"
+
+
+def pad_to_32(image_chw_u8):
+    """Detector.cs:33-41: zero-pad mode with value 114 on the bottom / right to a multiple of 32, then / 255."""
+    c, h, w = image_chw_u8.shape
+    ph, pw = (32 - h % 32) % 32, (32 - w % 32) % 32
+    out = np.full((c, h + ph, w + pw), 114.0, np.float32)
+    out[:, :h, :w] = image_chw_u8
+    return out / np.float32(255.0)
+
+
+class Detector:
+    def __init__(self, model):
+        self.model, self.engine = model, model.engine
+        self.amp = AMPWrapper(model)
+
+    def ImagePredict(self, image_chw_u8, predict_threshold=0.25, iou_threshold=0.5):
+        """image: uint8 / float [3,H,W] in 0..255 (RGB).  Returns a list of YoloResult."""
+        x = pad_to_32(np.asarray(image_chw_u8, np.float32))[None]
+        assert x.shape[2:] == (self.model.height, self.model.width), "create the model with the padded image size"
+        inference, _ = self.amp.Evaluate(x)
+        output, _ = self.engine.non_max_suppression(inference["boxes"], predict_threshold, iou_threshold)
+        return [YoloResult(r) for r in output[0]]
+
+    def Val(self, batches, conf_thres=0.1, iou_thres=0.7, max_det=300):
+        """batches: iterable of dicts (images [B,3,H,W] in [0,1], batch_idx, cls, bboxes).  Returns
+        (mean loss items, (P, R, mAP50, mAP50-95)) like Detector.Val (:76-154)."""
+        crit = v8DetectionLoss(self.model)
+        tps, confs, pcls, tcls = [], [], [], []
+        loss_sum, count = None, 0
+        for data in batches:
+            images = np.ascontiguousarray(data["images"], np.float32)
+            B = images.shape[0]
+            # the reference evaluates the loss on the eval-mode preds (Detector.cs:96-97); the engine's criterion needs a
+            # training-mode forward, so the loss pass is separate (running statistics are restored afterwards)
+            sd = {k: v for k, v in self.model.state_dict().items() if "running" in k or "num_batches" in k}
+            self.model.train(); self.model.forward(images, fetch=False)
+            _, items = crit.forward(None, data)
+            self.model.load_state_dict(sd, strict=False)
+            loss_sum = items if loss_sum is None else loss_sum + items
+            inference, _ = self.amp.Evaluate(images)
+            pred = inference["boxes"]
+            nc = self.model.nc
+            rows = np.zeros((B, max_det, pred.shape[1] - nc + 2), np.float32)
+            output, _ = self.engine.non_max_suppression(pred, conf_thres, iou_thres, max_det=max_det, nc=nc)
+            cnt = np.array([len(o) for o in output], np.int32)
+            for b, o in enumerate(output):
+                rows[b, :len(o)] = o
+            correct = self.engine.val_match(rows, cnt, data, images.shape[3], images.shape[2])
+            bi = np.asarray(data["batch_idx"]).reshape(-1)
+            for b in range(B):
+                tps.append(correct[b]); confs.append(rows[b, :cnt[b], 4]); pcls.append(rows[b, :cnt[b], 5])
+                tcls.append(np.asarray(data["cls"], np.float32).reshape(-1)[bi == b])
+            count += B
+        stats = M.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls))
+        return loss_sum, M.val_summary(stats)
