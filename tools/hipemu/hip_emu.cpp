@@ -4,6 +4,34 @@
 #include <chrono>
 #include <mutex>
 
+#if EMU_FAST_SWITCH
+asm(R"(
+    .text
+    .globl emu_switch
+    .type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_switch,.-emu_switch
+)");
+#define EMU_SWAP(from, to) emu_switch(&(from), &(to))
+#else
+#define EMU_SWAP(from, to) swapcontext(&(from), &(to))
+#endif
+
 namespace emu {
 
 static thread_local Block* g_blk = nullptr;
@@ -11,7 +39,7 @@ Block& blk() { return *g_blk; }
 
 void yield() {
   Block& b = *g_blk;
-  swapcontext(&b.cur->ctx, &b.sched);
+  EMU_SWAP(b.cur->ctx, b.sched);
 }
 
 static void trampoline() {
@@ -22,7 +50,7 @@ static void trampoline() {
   t->done = true;
   b2.alive--;
   b2.waves[t->lin >> 6].alive--;
-  swapcontext(&t->ctx, &b2.sched);  // never resumed
+  EMU_SWAP(t->ctx, b2.sched);  // never resumed
 }
 
 void barrier() {
@@ -58,11 +86,22 @@ static void run_block(Block& b) {
     t.tid.z = i / (b.bdim.x * b.bdim.y);
     t.done = false;
     t.par = 0;
+#if EMU_FAST_SWITCH
+    {   // initial frame: six callee-saved register slots, then the entry point as the return address of emu_switch
+      uintptr_t top = ((uintptr_t)(b.stacks.data() + (size_t)(i + 1) * b.stack_size)) & ~(uintptr_t)15;
+      void** sp = (void**)top;
+      *--sp = nullptr;                      // fake return address of trampoline (it never returns)
+      *--sp = (void*)trampoline;
+      for (int r = 0; r < 6; r++) *--sp = nullptr;
+      t.ctx.sp = sp;
+    }
+#else
     getcontext(&t.ctx);
     t.ctx.uc_stack.ss_sp = b.stacks.data() + (size_t)i * b.stack_size;
     t.ctx.uc_stack.ss_size = b.stack_size;
     t.ctx.uc_link = nullptr;
     makecontext(&t.ctx, (void (*)())trampoline, 0);
+#endif
   }
   long sweeps = 0;
   while (b.alive > 0) {
@@ -70,7 +109,7 @@ static void run_block(Block& b) {
       Thread& t = b.th[i];
       if (t.done) continue;
       b.cur = &t;
-      swapcontext(&b.sched, &t.ctx);
+      EMU_SWAP(b.sched, t.ctx);
     }
     if (++sweeps > 200000000L) { fprintf(stderr, "hipemu: deadlock suspected\n"); abort(); }
   }

@@ -14,6 +14,16 @@
 // waves behave like hardware.
 #pragma once
 #include <ucontext.h>
+
+// Coroutine switch.  glibc's swapcontext saves / restores the signal mask with a system call on every switch, which
+// dominated the interpreter's run time; on x86-64 a 14-instruction switch of the callee-saved registers replaces it.
+#if defined(__x86_64__)
+#define EMU_FAST_SWITCH 1
+struct emu_ctx { void* sp; };
+extern "C" void emu_switch(emu_ctx* from, emu_ctx* to);
+#else
+#define EMU_FAST_SWITCH 0
+#endif
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -50,7 +60,11 @@ static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 namespace emu {
 
 struct Thread {
+#if EMU_FAST_SWITCH
+  emu_ctx ctx;
+#else
   ucontext_t ctx;
+#endif
   dim3 tid;
   int lin;      // linear thread id in block
   bool done;
@@ -70,7 +84,11 @@ struct Block {
   std::vector<Thread> th;
   std::vector<Wave> waves;
   Thread* cur;
+#if EMU_FAST_SWITCH
+  emu_ctx sched;
+#else
   ucontext_t sched;
+#endif
   int alive;
   int bar_arrived;
   int bar_gen;

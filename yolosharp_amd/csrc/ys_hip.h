@@ -173,6 +173,31 @@ template <> __device__ inline f32x4 ys_mma<bf16_t>(const uint4& a, const uint4& 
   return mfma_16x16x32_bf16(a, b, c);
 }
 template <> __device__ inline f32x4 ys_mma<float>(const uint4& a, const uint4& b, f32x4 c) {
+#ifdef YS_EMU_BUILD
+  // interpreter only: the four chained 16x16x4 MFMAs below as ONE wave rendezvous (same fma order, bit-identical) --
+  // the rendezvous, not the arithmetic, dominates the CPU test suite's run time
+  struct Dep { uint4 a, b; } dep{a, b};
+  f32x4 d = c;
+  const int l = emu::lane();
+  emu::wave_collective(&dep, sizeof(dep), [&](unsigned char (*slot)[128]) {
+    const int j = l & 15;
+    for (int r = 0; r < 4; r++) {
+      const int i = 4 * (l >> 4) + r;
+      float acc = d[r];
+      for (int t = 0; t < 4; t++)
+        for (int k = 0; k < 4; k++) {
+          Dep da, db;
+          memcpy(&da, slot[i + 16 * k], sizeof(Dep));
+          memcpy(&db, slot[j + 16 * k], sizeof(Dep));
+          const unsigned* pa = (const unsigned*)&da.a;
+          const unsigned* pb = (const unsigned*)&db.b;
+          acc = fmaf(ys_u2f(pa[t]), ys_u2f(pb[t]), acc);
+        }
+      d[r] = acc;
+    }
+  });
+  return d;
+#endif
   c = mfma_16x16x4_f32(ys_u2f(a.x), ys_u2f(b.x), c);
   c = mfma_16x16x4_f32(ys_u2f(a.y), ys_u2f(b.y), c);
   c = mfma_16x16x4_f32(ys_u2f(a.z), ys_u2f(b.z), c);
