@@ -505,7 +505,10 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
       pk.y = ys_pack_bf16x2(v[2], v[3]);
       *(uint2*)(stg + (mf * 16 + li) * PITCH + (nf * 16 + 4 * q) * 2) = pk;
     }
-    if (q == 0) rowtab[mf * 16 + li] = pv[mf] ? orow[mf] : -1L;
+    if (q == 0) {
+      rowtab[mf * 16 + li] = pv[mf] ? (orow[mf] * a.out_ldc + a.out_coff) * 2L : -1L;   // byte offset of the pixel row
+      rowtab[NPX + mf * 16 + li] = orow[mf];                                              // row index (residual view)
+    }
   }
   ys_wave_sync();
   const int cv = lane % VPP, pl = lane / VPP;
@@ -528,8 +531,8 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   for (int it = 0; it < NITER; it++) {
     const int px = it * PPI + pl;
     if (active && px < NPX && c < a.Cout) {
-      const long row = rowtab[px];
-      if (row >= 0) {
+      const long rofs = rowtab[px];
+      if (rofs >= 0) {
         uint4 val = *(const uint4*)(stg + px * PITCH + cv * 16);
         float f[8];
         ys_unpack<T>(val, f);
@@ -542,10 +545,11 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
           for (int e = 0; e < 8; e++) { f[e] = f[e] * sc[e] + sh[e]; if (a.act) f[e] = ys_silu(f[e]); if (c + e >= a.Cout) f[e] = 0.f; }
           if (!(rb || a.accumulate)) val = ys_pack<T>(f);
         }
-        T* yp = (T*)(yb + (row * a.out_ldc + a.out_coff + c) * 2L);
+        T* yp = (T*)(yb + rofs + c * 2);
         if (rb || a.accumulate) {
           float gq[8];
           if (rb) {
+            const long row = rowtab[NPX + px];                                    // eval-only path (Bottleneck shortcut)
             ys_unpack<T>(ys_ld16(rb + (row * a.res_ldc + a.res_coff + c) * 2L), gq);
 #pragma unroll
             for (int e = 0; e < 8; e++) f[e] += gq[e];
@@ -597,6 +601,12 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
   }
 }
 
+// ablation switches (YS_DBG bits) cost scalar checks in the hot loops: compiled in only for triage builds (-DYS_P2_ABLATE)
+#ifdef YS_P2_ABLATE
+#define P2_DBG(bit) ((a.dbg & (bit)) != 0)
+#else
+#define P2_DBG(bit) false
+#endif
 #ifndef P2_KG
 #define P2_KG 2            // K-steps (32 K each) per streamed weight group
 #endif
@@ -614,7 +624,7 @@ template <int MR, int NR, int WRES, int NPU, int NT>
 __global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 ? 3 : 2)))   // waves per SIMD the LDS budget allows (512 threads: 2 workgroups x 2)
 conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
-  if (a.dbg & 64) return;                     // ablation: launch + dispatch cost only
+  if (P2_DBG(64)) return;                     // ablation: launch + dispatch cost only
   constexpr int BN = NR * 16;
   constexpr int NWV = NT / 64;
   constexpr int NWU = WRES ? 1 : (BN * P2_KG * 4 + NT - 1) / NT;   // streamed weight units per thread
@@ -658,15 +668,22 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   constexpr int GU = KG * 4;                   // 16-byte units per weight row and group
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
   uint4 rw[NWU];
+  // this thread's (row, unit-in-group) of the streamed weight tile never changes: keep the row pointers, step by group
+  const char* wrow[NWU];
+  int wun[NWU];
+#pragma unroll
+  for (int k = 0; k < NWU; k++) {
+    const int idx = tid + NT * k;
+    const int n = idx / GU;
+    wun[k] = (idx < BN * GU && n0 + n < a.Cout) ? idx - n * GU : -1;
+    wrow[k] = wb + ((long)(n0 + (wun[k] >= 0 ? n : 0)) * Ktot) * 2L;
+  }
   auto wfetch = [&](int grp) {                // global -> registers: weights of K-steps [grp*KG, grp*KG + KG)
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
-      const int idx = tid + NT * k;
       uint4 v = ys_zero16();
-      if (idx < BN * GU) {
-        const int n = idx / GU, u = grp * GU + (idx - n * GU);
-        if (n0 + n < a.Cout && u * 8 < Ktot && !(a.dbg & 16)) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
-      }
+      const int u = grp * GU + wun[k];
+      if (wun[k] >= 0 && u * 8 < Ktot && !P2_DBG(16)) v = ys_ld16(wrow[k] + u * 16);
       rw[k] = v;
     }
   };
@@ -697,7 +714,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   // Tile order.  Workgroup i runs on XCD i % 8 (round-robin dispatch); when the grid is a multiple of 8 each XCD walks its own
   // contiguous eighth of the tile list, so the tiles resident on an XCD at any time are spatial neighbours and their shared
   // halo rows hit that XCD's L2.  Otherwise plain interleaving.  Tile coordinates advance incrementally (no per-tile divisions).
-  const bool xcd_order = (gridDim.x & 7) == 0 && !(a.dbg & 32);
+  const bool xcd_order = (gridDim.x & 7) == 0 && !P2_DBG(32);
   const int t_per_xcd = (g.ntiles + 7) >> 3;
   const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
   const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -731,7 +748,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
           const int iy = iy0 + (int)(d >> 23), ix = ix0 + (int)((d >> 13) & 1023u);
           ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         }
-        if (ok && !(a.dbg & 1)) v = ys_ld16(xt + (long)go * 2L);
+        if (ok && !P2_DBG(1)) v = ys_ld16(xt + (long)go * 2L);
       }
       rp[k] = v;
     }
@@ -758,7 +775,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #ifndef YS_EMU_BUILD
       asm volatile("" : "+v"(d));
 #endif
-      if (d != 0xffffffffu && !(a.dbg & 8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = rp[k];
+      if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = rp[k];
     }
     if (!WRES) wstore(0);
     ys_barrier_lds();
@@ -777,7 +794,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       const int s1 = WRES ? g.nsteps : ((s0 + KG) < g.nsteps ? (s0 + KG) : g.nsteps);
       const uint4* wbuf = sW + (WRES ? 0 : (grp & 1) * BN * g.wpitch);
 #pragma unroll 1
-      for (int s = (a.dbg & 2) ? s1 : s0; s < s1; s++) {
+      for (int s = P2_DBG(2) ? s1 : s0; s < s1; s++) {
         const int off = sOff[s * 4 + q];
         const int u = (s - s0) * 4 + q;
         uint4 wf[NR], xf[MR];
@@ -805,8 +822,8 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       pv[mf] = pty[mf] < g.TH && oy < a.Hout && ox < a.Wout;
       orow[mf] = (long)b * a.out_bstride + (pv[mf] ? (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox)) : 0);
     }
-    char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 8);
-    if (!(a.dbg & 4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
+    char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 16);
+    if (!P2_DBG(4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
     txi = ntx; tyi = nty; b = nb;
   }
   if (a.stats) p2_stats_flush<NR, NWV>(a, n0, st1, st2, sStat, (long)blockIdx.x);
@@ -858,7 +875,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     const int npu_max = nt == 512 ? 6 : P2_NPU;
     for (int mr = (nt == 512 ? 2 : (nr <= 4 ? 4 : 2)); mr >= 1; mr >>= 1) {
       const int npx = 16 * nwv * mr;
-      const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 8);
+      const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 16);
       for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
         int th = npx / tw; if (th > a.Hout) th = a.Hout;
         const int ph = (th - 1) * a.SA + a.KH, pw = (tw - 1) * a.SA + a.KW;
