@@ -761,6 +761,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   }
   int ntx = txi, nty = tyi, nb = b;
   if (t_first < t_end) pfetch(txi, tyi, b);
+  if (P2_DBG(128)) return;                     // ablation: prologue only (tables, resident weights, first patch fetch)
   float st1[8], st2[8];                        // BN statistics of this workgroup's tiles (per-lane column sums)
 #pragma unroll
   for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
