@@ -137,6 +137,21 @@ YS_API int ys_model_zero_grad(ys_model* m);
 YS_API int ys_model_grad_buffer(ys_model* m, float** dptr, int64_t* count);
 YS_API int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count);
 
+/* ---- data-parallel exchange (the reference has no multi-GPU path of its own) ------------------------------
+ * One process (and one ys_ctx) per GPU; gradients of a step are SUM-all-reduced over RCCL / xGMI before AdamW.
+ * ys_dist_unique_id: rank 0 creates the 128-byte RCCL id and ships it to the other ranks by any host channel.
+ * ys_dist_init: joins the communicator (collective).  ys_dist_allreduce_grads(m, seg): asynchronous SUM all-reduce of a
+ * backward segment's gradient range (seg < 0: the whole buffer) on a communication stream ordered after the engine stream.
+ * ys_dist_wait: the engine stream waits for the outstanding all-reduces.  ys_model_backward_allreduce = the three backward
+ * segments with each finished segment's all-reduce overlapped with the next (the loop bench.py runs through torch.distributed).
+ * RCCL is dlopen'ed on first use; single-GPU processes never load it. */
+YS_API int ys_dist_unique_id(void* id128);
+YS_API int ys_dist_init(ys_ctx* ctx, int rank, int world, const void* id128);
+YS_API int ys_dist_destroy(ys_ctx* ctx);
+YS_API int ys_dist_allreduce_grads(ys_model* m, int segment);
+YS_API int ys_dist_wait(ys_model* m);
+YS_API int ys_model_backward_allreduce(ys_model* m);
+
 /* torch.optim.AdamW.step (built YoloBaseTaskModel.cs:144-153, stepped Amp.cs:355-356,371-372):
  * decoupled weight decay, bias-corrected.  Parameter groups follow the reference's name rule:
  * group 0 = names containing "bias", 1 = "weight" (non-BN), 2 = "bn" weights.  lr comes from the host

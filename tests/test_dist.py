@@ -90,3 +90,44 @@ def test_segment_ranges_cover_flat_buffer(emu_lib_path):
     for (o1, c1), (o2, _) in zip(ranges, ranges[1:]):
         assert o1 + c1 == o2
     m.close()
+
+
+def test_c_abi_dist_needs_device_build():
+    """The interpreter build has no RCCL: the C-level exchange must refuse loudly, never silently skip the all-reduce."""
+    import ctypes as C
+    from yolosharp_amd import _lib, build
+    lib = _lib.load(build.build_emu())
+    buf = (C.c_ubyte * 128)()
+    assert lib.ys_dist_unique_id(buf) == 4 and b"interpreter" in lib.ys_last_error()
+
+
+@pytest.mark.gpu
+def test_c_abi_rccl_world1():
+    """ys_dist_* on a real GPU with a one-rank communicator: the overlapped segmented backward + all-reduce reproduces the
+    plain backward bit for bit (SUM over one rank), AdamW runs behind ys_dist_wait, and misuse is reported."""
+    from yolosharp_amd import Engine, YsError
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    eng = Engine(0)
+    B, H, W, nc = 4, 128, 128, 80
+    x = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
+    sys.path.insert(0, ROOT)
+    from oracle import yolo_oracle as O
+    batch = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=1, kmax=5).items()}
+    m = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="bf16")
+    m.init_weights(3); m.train()
+    m.forward(x, fetch=False); v8DetectionLoss(m)(None, batch)
+    with pytest.raises(YsError):
+        m.backward_allreduce()                       # no communicator yet
+    m.zero_grad(); m.backward()
+    ref = m.grads()
+    eng.dist_init(0, 1, eng.dist_unique_id())
+    with pytest.raises(YsError):
+        eng.dist_init(0, 1, eng.dist_unique_id())    # one communicator per context
+    m.forward(x, fetch=False); v8DetectionLoss(m)(None, batch)
+    m.zero_grad(); m.backward_allreduce()
+    got = m.grads()
+    assert all(np.array_equal(ref[k], got[k]) for k in ref)
+    m.adamw_step([1e-3] * 3); m.zero_grad()
+    eng.synchronize()
+    eng.dist_destroy()
+    m.close()

@@ -62,6 +62,12 @@ PROTOTYPES = {
     "ys_model_zero_grad": (C.c_int, [C.c_void_p]),
     "ys_model_grad_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
     "ys_model_param_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
+    "ys_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "ys_dist_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ys_dist_destroy": (C.c_int, [C.c_void_p]),
+    "ys_dist_allreduce_grads": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_dist_wait": (C.c_int, [C.c_void_p]),
+    "ys_model_backward_allreduce": (C.c_int, [C.c_void_p]),
     "ys_optim_adamw_step": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "ys_nms_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -127,6 +127,7 @@ int ys_ctx_destroy(ys_ctx* ctx) {
   if (!ctx) return YS_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  ys_dist_destroy(ctx);
   if (ctx->nms_ws) hipFree(ctx->nms_ws);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);

@@ -1077,6 +1077,9 @@ int ys_model_destroy(ys_model* m) {
   return YS_OK;
 }
 
+}  // extern "C"
+ys_ctx* ys_model_ctx(ys_model* m) { return m->ctx; }   // for dist.hip
+extern "C" {
 int ys_model_num_tensors(ys_model* m) { return m ? (int)m->tensors.size() : 0; }
 int ys_model_num_anchors(ys_model* m) { return m ? m->A : 0; }
 int64_t ys_model_num_params(ys_model* m) { return m ? (int64_t)m->n_params : 0; }

@@ -44,6 +44,9 @@ struct ys_ctx {
   // scratch for per-operator entry points
   std::map<std::string, float> last_ms;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // data-parallel state (dist.hip): RCCL communicator, its stream, hand-over events
+  void* dist_comm = nullptr; int dist_rank = 0, dist_world = 1;
+  hipStream_t dist_stream = nullptr; hipEvent_t dist_ready = nullptr, dist_done = nullptr; bool dist_pending = false;
 };
 
 // simple RAII-free timing helper: records events on the ctx stream when profiling is on

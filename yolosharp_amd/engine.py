@@ -89,6 +89,19 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_memcpy_d2h(self.ctx, _ptr(out), p, out.nbytes))
         return out
 
+    # ---- data-parallel exchange through the C ABI (RCCL inside the library; bench.py uses torch.distributed instead)
+    def dist_unique_id(self):
+        buf = (C.c_ubyte * 128)()
+        _lib.check(self.lib, self.lib.ys_dist_unique_id(buf))
+        return bytes(buf)
+
+    def dist_init(self, rank, world, unique_id):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _lib.check(self.lib, self.lib.ys_dist_init(self.ctx, rank, world, buf))
+
+    def dist_destroy(self):
+        _lib.check(self.lib, self.lib.ys_dist_destroy(self.ctx))
+
     # ---- validation (Detector.cs:103-120): box_iou + match_predictions per image, batched on the device
     def box_iou(self, box1, box2, eps=1e-7):
         """Metrics.box_iou (Metrics.cs:16-34): xyxy [n,4] x [m,4] -> [n,m] fp32."""

@@ -160,6 +160,11 @@ class Yolov8:
         _lib.check(self.lib, self.lib.ys_model_segment_grad_range(self.handle, seg, C.byref(o), C.byref(c)))
         return o.value, c.value
 
+    def backward_allreduce(self):
+        """Segmented backward with the RCCL SUM all-reduce of each finished segment overlapped with the next (needs
+        Engine.dist_init); ends with the engine stream ordered after the last all-reduce."""
+        _lib.check(self.lib, self.lib.ys_model_backward_allreduce(self.handle))
+
     def zero_grad(self):
         _lib.check(self.lib, self.lib.ys_model_zero_grad(self.handle))
 
