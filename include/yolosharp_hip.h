@@ -93,6 +93,9 @@ YS_API int64_t ys_model_num_params(ys_model* m);
  * training: Detect returns preds only (Head.cs:89-106): "boxes" [B,4*reg_max,A], "scores" [B,nc,A].
  * eval: additionally Detect._inference (Head.cs:204-223): "pred" [B,4+nc,A] (xywh*stride, sigmoid). */
 YS_API int ys_model_forward(ys_model* m, const float* images, int on_device, int batch);
+/* Predict-side input path (Models/Detector.cs:31-41): uint8 RGB planes [B,3,h,w] (0..255) are padded on the bottom / right
+ * with 114 up to the model's (height, width), divided by 255 and packed on the device; then the forward above. */
+YS_API int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int batch, int h, int w);
 /* Copy an output to a host fp32 array in the reference layout: key = "boxes" | "scores" | "pred";
  * Segment models (Head.cs:283-313) add "mask_coefficient" [B,nm,A] and "proto" [B,nm,H/4,W/4], and their eval
  * "pred" is [B,4+nc+nm,A] (raw mask coefficients appended).  "dboxes" | "dscores" | "dmask_coefficient" | "dproto"

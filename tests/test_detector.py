@@ -23,6 +23,11 @@ def test_predict_and_val(backend, engine):
     x = pad_to_32(img.numpy())
     assert x.shape == (3, 32, 32) and x[0, 31, 31] == np.float32(114.0 / 255.0) and x[1, 10, 10] == np.float32(img[1, 10, 10] / 255.0)
     res = det.ImagePredict(img.numpy(), predict_threshold=0.001, iou_threshold=0.7)
+    # the device-side uint8 input path (pad 114, / 255, pack) feeds the network the same tensor
+    m.eval()
+    inf_u8, _ = m.forward_u8(img.numpy().astype(np.uint8)[None])
+    inf_f, _ = m.forward(x[None])
+    assert np.array_equal(inf_u8["boxes"], inf_f["boxes"])
     ref.eval()
     with torch.no_grad():
         rinf, _ = ref(torch.from_numpy(x)[None])

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "ys_model_num_anchors": (C.c_int, [C.c_void_p]),
     "ys_model_num_params": (C.c_int64, [C.c_void_p]),
     "ys_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "ys_model_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ys_model_get_output": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "ys_model_pred_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ys_loss_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

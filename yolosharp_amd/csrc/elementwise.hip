@@ -11,21 +11,40 @@
 #define EW_THREADS 256
 
 // ------------------------------------------------------------------ input pack / unpack
-template <class T>
+// one thread per pixel: C planar reads (coalesced across threads), one packed row of cpad channels written with 16-byte stores
+template <class T, class SRC>
 __global__ void __launch_bounds__(EW_THREADS)
-pack_input_kernel(const float* __restrict__ x, int B, int C, long HW, int cpad, T* __restrict__ y) {
+pack_input_kernel(const SRC* __restrict__ x, int B, int C, int h, int w, int H, int W, int cpad, float div, float padv,
+                  T* __restrict__ y) {
+  constexpr int EPL = Elem<T>::EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long HW = (long)H * W;
   if (i >= (long)B * HW) return;
   const long b = i / HW, p = i - b * HW;
-  for (int c = 0; c < cpad; c++) {
-    const float v = c < C ? x[(b * C + c) * HW + p] : 0.f;
-    y[i * cpad + c] = Elem<T>::from_f(v);
+  const int py = (int)(p / W), px = (int)(p - (long)py * W);
+  const bool in = py < h && px < w;                       // bottom / right padding (Detector.cs:33-41)
+  for (int c0 = 0; c0 < cpad; c0 += EPL) {
+    float f[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      const int c = c0 + e;
+      f[e] = c < C ? (in ? (float)x[((b * C + c) * h + py) * (long)w + px] / div : padv) : 0.f;
+    }
+    ys_st16(y + i * cpad + c0, ys_pack<T>(f));
   }
 }
 int ys_pack_input_launch(hipStream_t st, int dtype, const float* x, int B, int C, int H, int W, int cpad, void* y) {
   const long n = (long)B * H * W;
-  if (dtype == YS_BF16) YS_LAUNCH((pack_input_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, (long)H * W, cpad, (bf16_t*)y);
-  else YS_LAUNCH((pack_input_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, (long)H * W, cpad, (float*)y);
+  if (dtype == YS_BF16) YS_LAUNCH((pack_input_kernel<bf16_t, float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, H, W, H, W, cpad, 1.0f, 0.0f, (bf16_t*)y);
+  else YS_LAUNCH((pack_input_kernel<float, float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, H, W, H, W, cpad, 1.0f, 0.0f, (float*)y);
+  return YS_OK;
+}
+// uint8 [B,C,h,w] (0..255) -> NHWC T [B,H,W,cpad]: value / 255, bottom / right padding with 114 / 255 (Detector.cs:33-41)
+int ys_pack_input_u8_launch(hipStream_t st, int dtype, const unsigned char* x, int B, int C, int h, int w, int H, int W, int cpad, void* y) {
+  const long n = (long)B * H * W;
+  const float s = 255.0f, pv = 114.0f / 255.0f;        // true division like the reference's `/ 255.0f`
+  if (dtype == YS_BF16) YS_LAUNCH((pack_input_kernel<bf16_t, unsigned char>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, h, w, H, W, cpad, s, pv, (bf16_t*)y);
+  else YS_LAUNCH((pack_input_kernel<float, unsigned char>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, h, w, H, W, cpad, s, pv, (float*)y);
   return YS_OK;
 }
 

@@ -1218,6 +1218,27 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
   return YS_OK;
 }
 
+// Predict-side input path (Models/Detector.cs:31-41): uint8 RGB planes [B,3,h,w] -> zero-pad mode with value 114 on the bottom /
+// right up to the model's (H, W) -> / 255 -> the NHWC input buffer, in one kernel (no fp32 image is materialised).
+int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int batch, int h, int w) {
+  YS_REQUIRE(m && images, "ys_model_forward_u8: null argument");
+  YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_forward_u8: batch %d outside (0, %d]", batch, m->maxB);
+  YS_REQUIRE(h > 0 && w > 0 && h <= m->d.height && w <= m->d.width, "ys_model_forward_u8: image %dx%d does not fit the model's %dx%d", h, w, m->d.height, m->d.width);
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const unsigned char* src = images;
+  if (!on_device) {
+    YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, images, (size_t)batch * 3 * h * w, hipMemcpyHostToDevice, st));
+    src = (const unsigned char*)m->img_dev;
+  }
+  YsTimer timer(m->ctx, "forward");
+  m->B = batch;
+  YS_TRY(ys_pack_input_u8_launch(st, m->dtype, src, batch, 3, h, w, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
+  YS_TRY(forward_impl(m, batch));
+  m->have_fwd = true; m->have_loss = false; m->have_seg_loss = false;
+  return YS_OK;
+}
+
 int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count) {
   YS_REQUIRE(m && key && host, "ys_model_get_output: null argument");
   YS_REQUIRE(m->have_fwd, "ys_model_get_output: no forward has run");

@@ -129,6 +129,17 @@ class Yolov8:
 
     __call__ = forward
 
+    def forward_u8(self, images_u8):
+        """uint8 [B,3,h,w] (0..255, h <= height, w <= width): padded with 114, / 255 and packed on the device (Detector.cs:31-41),
+        then the eval / train forward.  Returns like forward()."""
+        x = np.ascontiguousarray(images_u8, np.uint8)
+        B, c, h, w = x.shape
+        assert c == 3
+        _lib.check(self.lib, self.lib.ys_model_forward_u8(self.handle, _ptr(x), 0, B, h, w))
+        self._batch = B
+        preds = {"boxes": self.get_output("boxes"), "scores": self.get_output("scores")}
+        return (None, preds) if self.training else ({"boxes": self.get_output("pred")}, preds)
+
     def get_output(self, key):
         B = self._batch
         C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc + self.NM, "dboxes": 4 * self.reg_max,
