@@ -46,3 +46,31 @@ def test_predict_and_val(backend, engine):
     assert 0.0 <= m5095 <= m50 <= 1.0 and 0.0 <= P <= 1.0
     assert np.array_equal(bn_before, m.state_dict()["model.0.bn.running_mean"])
     m.close()
+
+
+@pytest.mark.gpu
+def test_segmenter_predict_gpu():
+    """Segmenter.ImagePredict (Segmenter.cs:28-84) on the device path vs the oracle pieces on the same NMS rows."""
+    from yolosharp_amd import Engine
+    from yolosharp_amd.detector import Segmenter, pad_to_32
+    from yolosharp_amd.model import Yolov8Segment
+    from test_segment import make_ref
+    eng = Engine(0)
+    nc, H, W = 80, 128, 160
+    ref = make_ref(8, nc, "n")
+    m = Yolov8Segment(eng, nc=nc, size="n", height=H, width=W, max_batch=1, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    img = (torch.rand(3, 117, 150, generator=torch.Generator().manual_seed(1)) * 255).floor()
+    res = Segmenter(m).ImagePredict(img.numpy(), predict_threshold=0.01, iou_threshold=0.7)
+    assert len(res) > 0
+    ref.eval()
+    with torch.no_grad():
+        rinf, _ = ref(torch.from_numpy(pad_to_32(img.numpy()))[None])
+    rows, _ = eng.non_max_suppression(rinf["boxes"].numpy().copy(), 0.01, 0.7, nc=nc)
+    rows = torch.from_numpy(rows[0])
+    rmasks = O.process_mask(rinf["proto"][0], rows[:, 6:], rows[:, :4].clone(), (H, W), upsample=True).numpy().astype(bool)[:, :117, :150]
+    n = min(len(res), rmasks.shape[0])
+    assert abs(len(res) - rmasks.shape[0]) <= max(2, rmasks.shape[0] // 10)
+    agree = np.mean([np.mean(res[i][1] == rmasks[i]) for i in range(n)])
+    assert agree > 0.98 and res[0][1].shape == (117, 150)
+    m.close()

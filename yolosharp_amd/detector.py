@@ -33,6 +33,14 @@ def pad_to_32(image_chw_u8):
     return out / np.float32(255.0)
 
 
+def clip_boxes(boxes, shape):
+    """Ops.clip_boxes: xyxy clipped to (h, w)."""
+    b = boxes.copy()
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 0, shape[1])
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 0, shape[0])
+    return b
+
+
 class Detector:
     def __init__(self, model):
         self.model, self.engine = model, model.engine
@@ -78,3 +86,28 @@ class Detector:
             count += B
         stats = M.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls))
         return loss_sum, M.val_summary(stats)
+
+
+class Segmenter(Detector):
+    """Models/Segmenter.cs:28-84: ImagePredict with instance masks -- eval forward (pred carries the 32 mask coefficients
+    per anchor), NMS (the coefficients ride along as extra columns), Ops.process_mask on the device with upsample=True, boxes
+    clipped to the original image and masks cropped to it (the padded region is bottom / right, so the resize of
+    Segmenter.cs:56-57 is an identity crop here)."""
+
+    def ImagePredict(self, image_chw_u8, predict_threshold=0.25, iou_threshold=0.5):
+        img = np.asarray(image_chw_u8)
+        h, w = img.shape[1:]
+        self.model.eval()
+        inference, preds = self.model.forward_u8(np.ascontiguousarray(img, np.uint8)[None])
+        proto = self.model.get_output("proto")[0]
+        output, _ = self.engine.non_max_suppression(inference["boxes"], predict_threshold, iou_threshold, nc=self.model.nc)
+        rows = output[0]
+        results = []
+        if len(rows):
+            masks = self.engine.process_mask(proto, rows[:, 6:], rows[:, :4], (self.model.height, self.model.width), upsample=True)
+            rows[:, :4] = clip_boxes(rows[:, :4], (h, w))
+            masks = masks[:, :h, :w]
+            for r, mk in zip(rows, masks):
+                res = YoloResult(r)
+                results.append((res, mk))
+        return results
