@@ -57,7 +57,15 @@ template <> struct Elem<float> {
 template <> struct Elem<bf16_t> {
   static constexpr int EPL = 8;
   __host__ __device__ static inline float to_f(bf16_t x) { return bf16_bits_to_f32(x.v); }
-  __host__ __device__ static inline bf16_t from_f(float x) { bf16_t r; r.v = f32_to_bf16_bits(x); return r; }
+  __host__ __device__ static inline bf16_t from_f(float x) {
+    bf16_t r;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(YS_EMU_BUILD)
+    r.v = __builtin_bit_cast(unsigned short, (__bf16)x);          // v_cvt_pk_bf16_f32
+#else
+    r.v = f32_to_bf16_bits(x);
+#endif
+    return r;
+  }
 };
 
 // unpack / pack one 16-byte vector of T to floats
@@ -75,8 +83,17 @@ template <class T> __device__ inline uint4 ys_pack(const float* f);
 template <> __device__ inline uint4 ys_pack<float>(const float* f) {
   return make_uint4(ys_f2u(f[0]), ys_f2u(f[1]), ys_f2u(f[2]), ys_f2u(f[3]));
 }
+// two floats -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddled form costs ~8
+// VALU instructions per element, i.e. ~64 per stored 16-byte vector in every bf16-writing kernel)
 __device__ inline unsigned ys_pack_bf16x2(float lo, float hi) {
+#ifdef YS_EMU_BUILD
   return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+#else
+  typedef __bf16 ys_bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float ys_f32x2_t __attribute__((ext_vector_type(2)));
+  ys_f32x2_t v; v[0] = lo; v[1] = hi;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ys_bf16x2_t));
+#endif
 }
 template <> __device__ inline uint4 ys_pack<bf16_t>(const float* f) {
   return make_uint4(ys_pack_bf16x2(f[0], f[1]), ys_pack_bf16x2(f[2], f[3]),
@@ -205,8 +222,17 @@ template <> __device__ inline f32x4 ys_mma<float>(const uint4& a, const uint4& b
   return c;
 }
 
-__device__ inline float ys_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ inline float ys_silu(float x) { return x / (1.0f + __expf(-x)); }
+// 1 / d with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the IEEE division sequence (~10 VALU instructions): the BN /
+// SiLU passes are VALU-bound on exactly this; the error is far inside the 1e-3 parity budget
+__device__ inline float ys_rcp(float d) {
+#ifdef YS_EMU_BUILD
+  return 1.0f / d;
+#else
+  return __builtin_amdgcn_rcpf(d);
+#endif
+}
+__device__ inline float ys_sigmoid(float x) { return ys_rcp(1.0f + __expf(-x)); }
+__device__ inline float ys_silu(float x) { return x * ys_rcp(1.0f + __expf(-x)); }
 // d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))
 __device__ inline float ys_silu_grad(float x) { float s = ys_sigmoid(x); return s * (1.0f + x * (1.0f - s)); }
 
