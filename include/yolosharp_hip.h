@@ -203,6 +203,48 @@ YS_API int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, int C
                        const float* w_oihw, int Cout, int k, int stride, const float* dy_nchw,
                        float* dx_nchw, float* dw_oihw);
 
+/* ---- per-block entry points: a TorchSharp-free body for the reference's block modules, one stateful handle per
+ *      module instance (SURVEY 8b "ys_c2f_fwd/bwd, ys_c3k2_fwd/bwd, ys_sppf_fwd/bwd, ys_proto_fwd/bwd").  The handle IS a
+ *      ys_model: ys_model_num_tensors / tensor_info / set_tensor / get_tensor / get_grad / init_weights / set_training /
+ *      zero_grad / optim_adamw_step / destroy all apply, with the module-relative state_dict names TorchSharp gives a
+ *      standalone module ("cv1.conv.weight", "m.0.cv2.bn.running_var", "upsample.bias", ...).
+ *        YS_BLOCK_CONV        Convs.Conv        (Convs.cs:36-62)    c1->c2, k in {1,3}, s in {1,2}, act
+ *        YS_BLOCK_BOTTLENECK  Block.Bottleneck  (Block.cs:572-608)  c1 == c2, 3x3/3x3, hidden int(c2*e), shortcut
+ *        YS_BLOCK_C2F         Block.C2f         (Block.cs:371-399)  n Bottlenecks (e = 1.0), shortcut
+ *        YS_BLOCK_C3K2        Block.C3k2        (Block.cs:623-662)  n x (C3k(c,c,2) if c3k else Bottleneck(c,c)), e, shortcut = true
+ *        YS_BLOCK_SPPF        Block.SPPF        (Block.cs:236-285)  c1 == c2
+ *        YS_BLOCK_C2PSA       Block.C2PSA       (Block.cs:664-810)  c1 == c2, (c1/2) % 64 == 0, n PSABlocks
+ *        YS_BLOCK_PROTO       Block.Proto       (Block.cs:51-84)    c1 -> n (= c_, hidden) -> c2 masks, output 2H x 2W
+ *      Channel counts (c1, c2 and every hidden width) must be multiples of 4 (f32) / 8 (bf16): the widths the YOLO graphs use. */
+typedef enum ys_block_kind {
+  YS_BLOCK_CONV = 0, YS_BLOCK_BOTTLENECK = 1, YS_BLOCK_C2F = 2, YS_BLOCK_C3K2 = 3, YS_BLOCK_SPPF = 4, YS_BLOCK_C2PSA = 5,
+  YS_BLOCK_PROTO = 6
+} ys_block_kind;
+
+typedef struct ys_block_desc {
+  int32_t kind;       /* ys_block_kind */
+  int32_t c1, c2;     /* input / output channels */
+  int32_t n;          /* repeats (C2f, C3k2, C2PSA); hidden width c_ (Proto) */
+  int32_t shortcut;   /* Bottleneck / C2f */
+  int32_t c3k;        /* C3k2: use C3k inner blocks */
+  float e;            /* expansion (Bottleneck, C3k2); 0 = the module's default (0.5) */
+  int32_t k, s, act;  /* Conv */
+  int32_t height;     /* input H */
+  int32_t width;      /* input W */
+  int32_t max_batch;
+  int32_t dtype;      /* ys_dtype */
+} ys_block_desc;
+
+YS_API int ys_block_create(ys_ctx* ctx, const ys_block_desc* desc, ys_model** out);
+/* output geometry of the block: [c, h, w] */
+YS_API int ys_block_output_shape(ys_model* block, int32_t shape_chw[3]);
+/* y = module.forward(x): x fp32 NCHW [batch,c1,H,W], y fp32 NCHW [batch,c2,Ho,Wo]; host arrays (on_device = 0) or device
+ * pointers (1).  Training mode uses batch statistics and updates the running ones, exactly like the full model. */
+YS_API int ys_block_forward(ys_model* block, const float* x_nchw, int on_device, int batch, float* y_nchw);
+/* autograd of the last training-mode forward: given dy (shape of y) accumulates parameter gradients (read with
+ * ys_model_get_grad) and writes dx (shape of x; may be NULL). */
+YS_API int ys_block_backward(ys_model* block, const float* dy_nchw, int on_device, float* dx_nchw);
+
 /* device memory helpers for hosts without a HIP binding of their own */
 YS_API int ys_device_malloc(ys_ctx* ctx, size_t bytes, void** dptr);
 YS_API int ys_device_free(ys_ctx* ctx, void* dptr);

@@ -22,6 +22,12 @@ class ModelDesc(C.Structure):
                 ("max_batch", C.c_int32), ("dtype", C.c_int32), ("max_labels", C.c_int32)]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32), ("n", C.c_int32), ("shortcut", C.c_int32),
+                ("c3k", C.c_int32), ("e", C.c_float), ("k", C.c_int32), ("s", C.c_int32), ("act", C.c_int32),
+                ("height", C.c_int32), ("width", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/yolosharp_hip.h
 PROTOTYPES = {
     "ys_last_error": (C.c_char_p, []),
@@ -77,6 +83,10 @@ PROTOTYPES = {
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_conv_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                              C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ys_block_create": (C.c_int, [C.c_void_p, C.POINTER(BlockDesc), C.POINTER(C.c_void_p)]),
+    "ys_block_output_shape": (C.c_int, [C.c_void_p, c_i32_p]),
+    "ys_block_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ys_block_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ys_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ys_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ys_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -86,6 +86,7 @@ struct ys_model {
   int n_items = 3; bool have_seg_loss = false;
   int dfl_after_conv = -1;   // the DFL weight registers right after Detect's cv2/cv3 (Head.cs:52-56), before Segment's proto/cv4
   int in_buf = -1, pd_buf = -1, ps_buf = -1;
+  bool is_block = false; int blk_out = -1, blk_c1 = 3, blk_c2 = 0;   // standalone block handle (ys_block_create)
   int ld_pd = 0, ld_ps = 0;
   // flat fp32 parameter state
   long n_params = 0;
@@ -288,6 +289,21 @@ void add_sppf(ys_model* m, const std::string& name, View xin, View xout, int c1,
   add_conv_reg(m, name + ".cv2", View{catS, 0, 4 * c_}, xout, 4 * c_, c1, 1, 1, true, true, H, W, seg);
 }
 
+// Proto (Block.cs:51-84): cv1 3x3 -> ConvTranspose2d(2,2,bias) -> cv2 3x3 -> cv3 1x1; field / registration order cv1, cv2, cv3,
+// upsample (:53-56).  Returns the output buffer [2H][2W][pad(nm)].
+int add_proto(ys_model* m, const std::string& name, View in, int c1, int npr, int nm, int H, int W, int seg) {
+  const int ld = (nm + m->epl - 1) / m->epl * m->epl;
+  const int pa = new_buf(m, H, W, npr), pu = new_buf(m, 2 * H, 2 * W, npr), pb = new_buf(m, 2 * H, 2 * W, npr);
+  const int out = new_buf(m, 2 * H, 2 * W, ld);
+  const int p1 = add_conv(m, name + ".cv1", in, View{pa, 0, npr}, c1, npr, 3, 1, true, true, H, W, seg);
+  const int pup = add_conv(m, name + ".upsample", View{pa, 0, npr}, View{pu, 0, npr}, npr, npr, 1, 1, false, false, H, W, seg);
+  m->convs[pup].ct = true; m->convs[pup].Hout = 2 * H; m->convs[pup].Wout = 2 * W;
+  const int p2 = add_conv(m, name + ".cv2", View{pu, 0, npr}, View{pb, 0, npr}, npr, npr, 3, 1, true, true, 2 * H, 2 * W, seg);
+  const int p3 = add_conv(m, name + ".cv3", View{pb, 0, npr}, View{out, 0, nm}, npr, nm, 1, 1, true, true, 2 * H, 2 * W, seg);
+  m->reg.push_back(p1); m->reg.push_back(p2); m->reg.push_back(p3); m->reg.push_back(pup);
+  return out;
+}
+
 // Detect (Head.cs:35-53): c2 = max(16, ch0/4, 4*reg_max), c3 = max(ch0, min(nc,100)); strides fixed {8,16,32} (:43).
 // legacy=false (v11, Head.cs:50): each 3x3 Conv of the cls tower becomes DWConv3x3(x->x) + Conv1x1(x->c3).
 int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch, const int* hh, const int* ww, bool legacy, int seg) {
@@ -333,15 +349,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
     m->ld_mc = (nm + m->epl - 1) / m->epl * m->epl;
     m->ld_pr = m->ld_mc;
     m->mh = 2 * hh[0]; m->mw = 2 * ww[0];
-    // Proto (Block.cs:51-84); field/registration order cv1, cv2, cv3, upsample (:53-56)
-    const int pa = new_buf(m, hh[0], ww[0], npr), pu = new_buf(m, m->mh, m->mw, npr), pb = new_buf(m, m->mh, m->mw, npr);
-    m->pr_buf = new_buf(m, m->mh, m->mw, m->ld_pr);
-    const int p1 = add_conv(m, hp + ".proto.cv1", View{pv[0], 0, ch[0]}, View{pa, 0, npr}, ch[0], npr, 3, 1, true, true, hh[0], ww[0], seg);
-    const int pup = add_conv(m, hp + ".proto.upsample", View{pa, 0, npr}, View{pu, 0, npr}, npr, npr, 1, 1, false, false, hh[0], ww[0], seg);
-    m->convs[pup].ct = true; m->convs[pup].Hout = m->mh; m->convs[pup].Wout = m->mw;
-    const int p2 = add_conv(m, hp + ".proto.cv2", View{pu, 0, npr}, View{pb, 0, npr}, npr, npr, 3, 1, true, true, m->mh, m->mw, seg);
-    const int p3 = add_conv(m, hp + ".proto.cv3", View{pb, 0, npr}, View{m->pr_buf, 0, nm}, npr, nm, 1, 1, true, true, m->mh, m->mw, seg);
-    m->reg.push_back(p1); m->reg.push_back(p2); m->reg.push_back(p3); m->reg.push_back(pup);
+    m->pr_buf = add_proto(m, hp + ".proto", View{pv[0], 0, ch[0]}, ch[0], npr, nm, hh[0], ww[0], seg);
     m->mc_buf = new_buf(m, 1, m->A, m->ld_mc);
     for (int i = 0; i < 3; i++) {
       const std::string tp = hp + ".cv4." + std::to_string(i);
@@ -463,6 +471,75 @@ int build_v11_detect(ys_model* m) {
   const int hh[3] = {H8, H16, H32}, ww[3] = {W8, W16, W32};
   const int pv[3] = {b16, b19, b22};
   return add_detect(m, "model.23", pv, ch, hh, ww, false, SH);
+}
+
+// Standalone block graph (ys_block_create): input buffer -> one module -> output buffer.  Modules are built with the
+// prefix "block" and the tensor names are made module-relative afterwards (layout_block_names).
+int build_block(ys_model* m, const ys_block_desc& bd) {
+  const int epl = m->epl, H = bd.height, W = bd.width, c1 = bd.c1, c2 = bd.c2;
+  auto bad = [&](int v, const char* what) {
+    if (v > 0 && v % epl == 0) return false;
+    ys_set_error("ys_block_create: %s = %d must be a positive multiple of %d for this dtype", what, v, epl);
+    return true;
+  };
+  if (bad(c1, "c1") || bad(c2, "c2")) return YS_ERR_UNSUPPORTED;
+  const float e = bd.e > 0.f ? bd.e : 0.5f;
+  m->in_buf = new_buf(m, H, W, c1);
+  const View vin{m->in_buf, 0, c1};
+  int Ho = H, Wo = W;
+  if (bd.kind == YS_BLOCK_CONV) {
+    if ((bd.k != 1 && bd.k != 3) || (bd.s != 1 && bd.s != 2)) { ys_set_error("ys_block_create: Conv k=%d s=%d unsupported (k in {1,3}, s in {1,2})", bd.k, bd.s); return YS_ERR_UNSUPPORTED; }
+    const int p = bd.k / 2;
+    Ho = (H + 2 * p - bd.k) / bd.s + 1; Wo = (W + 2 * p - bd.k) / bd.s + 1;
+  } else if (bd.kind == YS_BLOCK_PROTO) {
+    Ho = 2 * H; Wo = 2 * W;
+  }
+  m->blk_out = new_buf(m, Ho, Wo, c2);
+  const View vout{m->blk_out, 0, c2};
+  const std::string nm = "block";
+  switch (bd.kind) {
+    case YS_BLOCK_CONV:
+      add_conv_reg(m, nm, vin, vout, c1, c2, bd.k, bd.s, true, bd.act != 0, H, W, 0);
+      break;
+    case YS_BLOCK_BOTTLENECK: {
+      if (c1 != c2) { ys_set_error("ys_block_create: Bottleneck needs c1 == c2 (the graphs' only use)"); return YS_ERR_UNSUPPORTED; }
+      if (bad((int)(c2 * e), "Bottleneck hidden width")) return YS_ERR_UNSUPPORTED;
+      auto pr = add_bottleneck(m, nm, vin, vout, c2, e, bd.shortcut != 0, H, W, 0);
+      m->reg.push_back(pr.first); m->reg.push_back(pr.second);
+      break;
+    }
+    case YS_BLOCK_C2F:
+      if (bd.n < 1 || bad((int)(c2 * 0.5f), "C2f hidden width")) { if (bd.n < 1) ys_set_error("ys_block_create: n = %d", bd.n); return YS_ERR_UNSUPPORTED; }
+      add_c2f(m, nm, vin, vout, c1, c2, bd.n, bd.shortcut != 0, H, W, 0);
+      break;
+    case YS_BLOCK_C3K2: {
+      const int c = (int)(c2 * e);
+      if (bd.n < 1) { ys_set_error("ys_block_create: n = %d", bd.n); return YS_ERR_UNSUPPORTED; }
+      if (bad(c, "C3k2 hidden width") || bad((int)(c * 0.5f), "C3k2 inner hidden width")) return YS_ERR_UNSUPPORTED;
+      add_c3k2(m, nm, vin, vout, c1, c2, bd.n, bd.c3k != 0, e, H, W, 0);
+      break;
+    }
+    case YS_BLOCK_SPPF:
+      if (c1 != c2) { ys_set_error("ys_block_create: SPPF needs c1 == c2 (the graphs' only use)"); return YS_ERR_UNSUPPORTED; }
+      if (bad(c1 / 2, "SPPF hidden width")) return YS_ERR_UNSUPPORTED;
+      add_sppf(m, nm, vin, vout, c1, H, W, 0);
+      break;
+    case YS_BLOCK_C2PSA:
+      if (c1 != c2 || (c1 / 2) % 64 || bd.n < 1) { ys_set_error("ys_block_create: C2PSA needs c1 == c2, (c1/2) %% 64 == 0 and n >= 1"); return YS_ERR_UNSUPPORTED; }
+      add_c2psa(m, nm, vin, vout, c1, bd.n, H, W, 0);
+      break;
+    case YS_BLOCK_PROTO: {
+      if (bad(bd.n, "Proto hidden width (n)")) return YS_ERR_UNSUPPORTED;
+      // add_proto allocates its own output buffer: use it as the block output
+      m->bufs.pop_back();
+      m->blk_out = add_proto(m, nm, vin, c1, bd.n, c2, H, W, 0);
+      break;
+    }
+    default:
+      ys_set_error("ys_block_create: unknown block kind %d", bd.kind);
+      return YS_ERR_INVALID_ARG;
+  }
+  return YS_OK;
 }
 
 // ---- parameter layout: [segment][group] contiguous ranges; group rule of YoloBaseTaskModel.cs:144-151 made disjoint:
@@ -652,9 +729,10 @@ int allocate(ys_model* m) {
   m->n_wgp = wgp;
   YS_TRY(dev_alloc(m, (void**)&m->wg_partial, (size_t)wgp * 4));
   const ys_model_desc& d = m->d;
-  YS_TRY(dev_alloc(m, (void**)&m->img_dev, (size_t)B * 3 * d.height * d.width * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->img_dev, (size_t)B * std::max(3, m->blk_c1) * d.height * d.width * 4));
   YS_TRY(dev_alloc(m, (void**)&m->pred, (size_t)B * (4 + d.nc + m->nm) * m->A * 4));
   m->n_out_stage = std::max((long)B * m->A * std::max(std::max(m->ld_pd, m->ld_ps), 4 + d.nc + m->nm), (long)B * m->mh * m->mw * std::max(m->ld_pr, 1));
+  if (m->is_block) { const Buf& ob = m->bufs[m->blk_out]; m->n_out_stage = std::max(m->n_out_stage, (long)B * ob.rows_per_b * ob.ldc); }
   if (m->segment) {
     YS_TRY(dev_alloc(m, (void**)&m->masks_dev, (size_t)B * m->mh * m->mw * 4));
     YS_TRY(dev_alloc(m, (void**)&m->seg_cnt, (size_t)B * 4));
@@ -800,7 +878,7 @@ int forward_impl(ys_model* m, int B) {
       YS_TRY(ys_copy_view_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, (long)B * op.H * op.W, op.in.C, ob.act, ob.ldc, op.out.coff, 0));
     }
   }
-  if (!m->training) {
+  if (!m->training && m->pd_buf >= 0) {
     YS_TRY(ys_detect_decode_launch(st, m->dtype, m->bufs[m->pd_buf].act, m->ld_pd, m->bufs[m->ps_buf].act, m->ld_ps, B, m->A,
                                    m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred, 4 + m->d.nc + m->nm));
     if (m->segment)   // Segment._inference: cat(preds, mask_coefficient) (Head.cs:309-313), raw coefficients
@@ -1009,6 +1087,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
 
 void reset_grad_state(ys_model* m) {
   for (auto& b : m->bufs) std::fill(b.gw.begin(), b.gw.end(), 0);
+  if (m->is_block) { std::fill(m->bufs[m->blk_out].gw.begin(), m->bufs[m->blk_out].gw.end(), 1); return; }   // the caller's dy
   // the loss wrote the head gradients
   std::fill(m->bufs[m->pd_buf].gw.begin(), m->bufs[m->pd_buf].gw.end(), 1);
   std::fill(m->bufs[m->ps_buf].gw.begin(), m->bufs[m->ps_buf].gw.end(), 1);
@@ -1202,6 +1281,7 @@ int ys_model_set_training(ys_model* m, int training) {
 
 int ys_model_forward(ys_model* m, const float* images, int on_device, int batch) {
   YS_REQUIRE(m && images, "ys_model_forward: null argument");
+  YS_REQUIRE(!m->is_block, "ys_model_forward: this handle is a block (use ys_block_forward / ys_block_backward)");
   YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_forward: batch %d outside (0, %d]", batch, m->maxB);
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
@@ -1222,6 +1302,7 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
 // right up to the model's (H, W) -> / 255 -> the NHWC input buffer, in one kernel (no fp32 image is materialised).
 int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int batch, int h, int w) {
   YS_REQUIRE(m && images, "ys_model_forward_u8: null argument");
+  YS_REQUIRE(!m->is_block, "ys_model_forward_u8: this handle is a block (use ys_block_forward / ys_block_backward)");
   YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_forward_u8: batch %d outside (0, %d]", batch, m->maxB);
   YS_REQUIRE(h > 0 && w > 0 && h <= m->d.height && w <= m->d.width, "ys_model_forward_u8: image %dx%d does not fit the model's %dx%d", h, w, m->d.height, m->d.width);
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -1241,6 +1322,7 @@ int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int b
 
 int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count) {
   YS_REQUIRE(m && key && host, "ys_model_get_output: null argument");
+  YS_REQUIRE(!m->is_block, "ys_model_get_output: this handle is a block (use ys_block_forward / ys_block_backward)");
   YS_REQUIRE(m->have_fwd, "ys_model_get_output: no forward has run");
   hipStream_t st = m->ctx->stream;
   const int B = m->B;
@@ -1296,7 +1378,7 @@ int ys_model_pred_device(ys_model* m, float** dptr) {
 
 int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device) {
   YS_REQUIRE(m, "null model");
-  YS_REQUIRE(m->have_fwd && m->training, "ys_loss_detect: needs a training-mode forward first");
+  YS_REQUIRE(!m->is_block && m->have_fwd && m->training, "ys_loss_detect: needs a training-mode forward of a full model first");
   YS_REQUIRE(n >= 0 && n <= m->max_labels, "ys_loss_detect: %d labels exceed capacity %d (max_labels per image %d)", n, m->max_labels, m->gcap);
   YS_REQUIRE(n == 0 || (batch_idx && cls && bboxes), "ys_loss_detect: null label arrays");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -1435,6 +1517,80 @@ int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, flo
     }
   m->weights_dirty = true; m->eval_coeffs_dirty = true;
   YS_CHECK_HIP(hipGetLastError());
+  return YS_OK;
+}
+
+
+// ------------------------------------------------------------------ standalone blocks (include/yolosharp_hip.h "per-block entry points")
+int ys_block_create(ys_ctx* ctx, const ys_block_desc* bd, ys_model** out) {
+  YS_REQUIRE(ctx && bd && out, "ys_block_create: null argument");
+  YS_REQUIRE(bd->dtype == YS_F32 || bd->dtype == YS_BF16, "ys_block_create: dtype %d unsupported", bd->dtype);
+  YS_REQUIRE(bd->height > 0 && bd->width > 0 && bd->max_batch > 0, "ys_block_create: geometry %dx%d batch %d", bd->height, bd->width, bd->max_batch);
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  ys_model* m = new ys_model();
+  m->ctx = ctx; m->dtype = bd->dtype; m->epl = bd->dtype == YS_BF16 ? 8 : 4; m->es = bd->dtype == YS_BF16 ? 2 : 4;
+  m->maxB = bd->max_batch; m->is_block = true; m->blk_c1 = bd->c1; m->blk_c2 = bd->c2; m->A = 0; m->nl = 0;
+  m->d = ys_model_desc{}; m->d.height = bd->height; m->d.width = bd->width; m->d.max_batch = bd->max_batch; m->d.dtype = bd->dtype;
+  m->d.reg_max = 1; m->d.max_labels = 1;
+  int st = build_block(m, *bd);
+  if (st == YS_OK) st = layout_params(m);
+  if (st == YS_OK) {
+    for (auto& t : m->tensors) if (t.name.compare(0, 6, "block.") == 0) t.name.erase(0, 6);   // module-relative names
+    st = allocate(m);
+  }
+  if (st == YS_OK) st = ys_model_init_weights(m, 0);
+  if (st != YS_OK) { ys_model_destroy(m); return st; }
+  *out = m;
+  return YS_OK;
+}
+
+int ys_block_output_shape(ys_model* m, int32_t shape_chw[3]) {
+  YS_REQUIRE(m && m->is_block && shape_chw, "ys_block_output_shape: not a block handle");
+  const Buf& ob = m->bufs[m->blk_out];
+  shape_chw[0] = m->blk_c2; shape_chw[1] = ob.H; shape_chw[2] = ob.W;
+  return YS_OK;
+}
+
+int ys_block_forward(ys_model* m, const float* x, int on_device, int batch, float* y) {
+  YS_REQUIRE(m && m->is_block && x && y, "ys_block_forward: null argument or not a block handle");
+  YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_block_forward: batch %d outside (0, %d]", batch, m->maxB);
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[m->in_buf];
+  const Buf& ob = m->bufs[m->blk_out];
+  const size_t nx = (size_t)batch * m->blk_c1 * ib.rows_per_b, ny = (size_t)batch * m->blk_c2 * ob.rows_per_b;
+  const float* src = x;
+  if (!on_device) { YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, x, nx * 4, hipMemcpyHostToDevice, st)); src = m->img_dev; }
+  m->B = batch;
+  YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, m->blk_c1, ib.H, ib.W, ib.ldc, ib.act));
+  YS_TRY(forward_impl(m, batch));
+  m->have_fwd = m->training;   // only a training-mode forward keeps what backward needs (pre-BN outputs, batch statistics)
+  float* dst = on_device ? y : m->out_stage;
+  YS_TRY(ys_unpack_nchw_launch(st, m->dtype, ob.act, ob.ldc, 0, batch, m->blk_c2, ob.rows_per_b, dst));
+  if (!on_device) { YS_CHECK_HIP(hipMemcpyAsync(y, m->out_stage, ny * 4, hipMemcpyDeviceToHost, st)); YS_CHECK_HIP(hipStreamSynchronize(st)); }
+  return YS_OK;
+}
+
+int ys_block_backward(ys_model* m, const float* dy, int on_device, float* dx) {
+  YS_REQUIRE(m && m->is_block && dy, "ys_block_backward: null argument or not a block handle");
+  YS_REQUIRE(m->have_fwd && m->training, "ys_block_backward: needs a training-mode ys_block_forward first");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const int B = m->B;
+  const Buf& ib = m->bufs[m->in_buf];
+  const Buf& ob = m->bufs[m->blk_out];
+  const size_t nx = (size_t)B * m->blk_c1 * ib.rows_per_b, ny = (size_t)B * m->blk_c2 * ob.rows_per_b;
+  const float* src = dy;
+  if (!on_device) { YS_CHECK_HIP(hipMemcpyAsync(m->out_stage, dy, ny * 4, hipMemcpyHostToDevice, st)); src = m->out_stage; }
+  YS_TRY(ys_pack_input_launch(st, m->dtype, src, B, m->blk_c2, ob.H, ob.W, ob.ldc, ob.grad));
+  reset_grad_state(m);
+  YS_TRY(backward_range(m, 0, 2));
+  if (dx) {
+    float* dst = on_device ? dx : m->img_dev;
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, ib.grad, ib.ldc, 0, B, m->blk_c1, ib.rows_per_b, dst));
+    if (!on_device) YS_CHECK_HIP(hipMemcpyAsync(dx, m->img_dev, nx * 4, hipMemcpyDeviceToHost, st));
+  }
+  YS_CHECK_HIP(hipStreamSynchronize(st));
   return YS_OK;
 }
 
