@@ -182,6 +182,16 @@ YS_API int ys_val_match_batched(ys_ctx* ctx, const float* rows, const int32_t* c
 /* Metrics.box_iou (Utils/Metrics.cs:16-34): iou [n, m] of xyxy boxes, fp32, eps as given (reference default 1e-7). */
 YS_API int ys_box_iou(ys_ctx* ctx, const float* box1, int n, const float* box2, int m, float eps, int on_device, float* iou);
 
+/* Metrics.mask_iou (Utils/Metrics.cs:120-125) as Segmenter.Val uses it (Models/Segmenter.cs:131-143): mask1[k] = (gt_ids == k+1),
+ * k < nl, from the image's overlap-encoded instance-id map [npix] (fp32 ids, YoloDataset.cs:265-267); mask2 = pred_masks uint8
+ * [n, npix] (ys_process_mask output) -> iou fp32 [nl, n].  Bit-exact: the reference's float matmul of 0/1 masks is an integer count. */
+YS_API int ys_mask_iou(ys_ctx* ctx, const float* gt_ids, int nl, const uint8_t* pred_masks, int n, int npix, float eps,
+                       int on_device, float* iou);
+/* match_predictions (Models/YoloBaseTaskModel.cs:377-446) on a caller-supplied IoU matrix [nl, n] (box, mask, OBB or keypoint
+ * IoU alike): correct uint8 [n, 10] for the thresholds linspace(0.5, 0.95, 10). */
+YS_API int ys_match_predictions(ys_ctx* ctx, const float* pred_cls, int n, const float* true_cls, int nl, const float* iou,
+                                int on_device, uint8_t* correct);
+
 /* Ops.process_mask (Utils/Ops.cs:462-489), used by Segmenter post-processing (Models/Segmenter.cs:131-160 region):
  * masks = masks_in[n,nm] @ protos[nm,mh,mw], cropped to boxes (xyxy, image pixels) scaled to the mask grid,
  * optionally bilinearly upsampled (align_corners = false) to (ih, iw), thresholded > 0.

@@ -74,3 +74,49 @@ def test_segmenter_predict_gpu():
     agree = np.mean([np.mean(res[i][1] == rmasks[i]) for i in range(n)])
     assert agree > 0.98 and res[0][1].shape == (117, 150)
     m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_segmenter_val(backend, engine):
+    """Segmenter.Val (Segmenter.cs:85-185) through the device pieces vs the same loop on the oracle's pieces (process_mask at
+    proto resolution with un-rescaled boxes, box_iou + mask_iou -> match_predictions -> ap_per_class twice)."""
+    from yolosharp_amd.detector import Segmenter
+    from yolosharp_amd.model import Yolov8Segment
+    from yolosharp_amd import metrics as M
+    from test_segment import make_ref
+    nc, H, W, B = 80, 64, 64, 2
+    ref = make_ref(8, nc, "n")
+    m = Yolov8Segment(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    tb = O.synthetic_batch(B, H, W, nc, seed=21, kmax=4)
+    tb["masks"] = O.synthetic_masks(tb, B, H // 4, W // 4)
+    d = {k: v.numpy() for k, v in tb.items()}
+    d["images"] = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(4)).numpy()
+    before = m.state_dict()
+    loss_items, box, mask = Segmenter(m).Val([d], conf_thres=0.001)
+    after = m.state_dict()
+    assert all(np.array_equal(before[k], after[k]) for k in before if "running" in k)
+    assert loss_items.shape == (5,) and np.all(np.isfinite(loss_items))
+    # the oracle's pieces on the engine's own NMS rows (NMS, forward and process_mask are pinned in their own tests)
+    m.eval()
+    inference, _ = m.forward(d["images"])
+    proto = torch.from_numpy(m.get_output("proto"))
+    output, _ = engine.non_max_suppression(inference["boxes"], 0.001, 0.7, nc=nc)
+    tps, tpms, confs, pcls, tcls = [], [], [], [], []
+    for b, rows in enumerate(output):
+        rows = torch.from_numpy(rows)
+        sel = tb["batch_idx"].view(-1) == b
+        tcl = tb["cls"].view(-1)[sel]
+        nl = int(sel.sum())
+        masks = O.process_mask(proto[b], rows[:, 6:], rows[:, :4].clone(), (W // 4, H // 4))
+        gt = O.xywh2xyxy(tb["bboxes"][sel] * torch.tensor([W, H, W, H], dtype=torch.float32))
+        tps.append(O.match_predictions(rows[:, 5], tcl, O.box_iou(gt, rows[:, :4])).numpy())
+        bm = (tb["masks"][b].view(1, H // 4, W // 4) == torch.arange(1, nl + 1).view(nl, 1, 1)).float()
+        tpms.append(O.match_predictions(rows[:, 5], tcl, O.mask_iou(bm.flatten(1), masks.flatten(1).float())).numpy())
+        confs.append(rows[:, 4].numpy()); pcls.append(rows[:, 5].numpy()); tcls.append(tcl.numpy())
+    conf, pc, tc = np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls)
+    assert len(conf) > 0
+    rbox = M.val_summary(M.ap_per_class(np.concatenate(tps), conf, pc, tc))
+    rmask = M.val_summary(M.ap_per_class(np.concatenate(tpms), conf, pc, tc))
+    assert np.allclose(box, rbox, atol=1e-6) and np.allclose(mask, rmask, atol=1e-6), (box, rbox, mask, rmask)
+    m.close()

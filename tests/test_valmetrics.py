@@ -123,3 +123,66 @@ def test_ap_per_class_host(seed):
     tc = torch.arange(6).float()
     perfect = M.ap_per_class(np.ones((6, 10), bool), np.linspace(0.9, 0.4, 6, dtype=np.float32), tc.numpy(), tc.numpy())
     assert np.allclose(perfect["ap"], 0.99, atol=1e-6) and np.allclose(perfect["r"], 1.0, atol=1e-6)
+
+
+def _mask_scene(seed, nl, n, mh, mw):
+    """An overlap-encoded id map (YoloDataset.cs:265-267) with nl instances and n predicted 0/1 masks: jittered copies of
+    the instances (so IoUs span 0..1), an exact copy (IoU 1), an empty mask and a full mask."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(mh, mw)
+    boxes = []
+    for k in range(nl):
+        x0, y0 = int(torch.randint(0, mw - 8, (1,), generator=g)), int(torch.randint(0, mh - 8, (1,), generator=g))
+        w, h = int(torch.randint(4, mw // 2, (1,), generator=g)), int(torch.randint(4, mh // 2, (1,), generator=g))
+        ids[y0:y0 + h, x0:x0 + w] = k + 1          # later instances overwrite earlier ones (overlap encoding)
+        boxes.append((x0, y0, w, h))
+    pm = torch.zeros(n, mh, mw)
+    for j in range(n):
+        if j == 0 and nl:
+            pm[0] = (ids == 1).float()
+        elif j == 1:
+            pass                                   # empty prediction: union may be 0 -> 0 / eps
+        elif j == 2:
+            pm[2] = 1.0
+        elif nl:
+            x0, y0, w, h = boxes[j % nl]
+            dx, dy = int(torch.randint(-3, 4, (1,), generator=g)), int(torch.randint(-3, 4, (1,), generator=g))
+            pm[j, max(0, y0 + dy):y0 + dy + h, max(0, x0 + dx):x0 + dx + w] = 1.0
+        else:
+            pm[j] = (torch.rand(mh, mw, generator=g) > 0.5).float()
+    return ids, pm
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("nl,n,mh,mw", [(5, 12, 40, 48), (1, 3, 16, 16), (0, 4, 16, 16), (7, 0, 16, 16), (300, 5, 32, 32)])
+def test_mask_iou_exact(backend, engine, nl, n, mh, mw):
+    """Metrics.mask_iou (Metrics.cs:120-125) on Segmenter.Val's operands (Segmenter.cs:131-143): bit-exact vs the oracle matmul."""
+    ids, pm = _mask_scene(nl + n, nl, n, mh, mw)
+    got = engine.mask_iou(ids.numpy(), nl, pm.numpy())
+    index = torch.arange(1, nl + 1).view(nl, 1, 1)
+    gt = (ids[None] == index).float()
+    ref = O.mask_iou(gt.flatten(1), pm.flatten(1)).numpy() if nl and n else np.zeros((nl, n), np.float32)
+    assert got.shape == (nl, n) and got.dtype == np.float32
+    assert np.array_equal(got, ref)
+    if nl and n:
+        assert np.all(got[:, 1] == 0)
+        if gt[0].sum() > 0:                      # (instance 1 may be fully overwritten by later ones)
+            assert got[0, 0] == pytest.approx(1.0, abs=1e-6)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_match_predictions_on_mask_iou(backend, engine, seed):
+    """Segmenter.cs:142-143: tp_m = match_predictions(pred_classes, true_classes, mask_iou(...)) -- exact vs the oracle,
+    including images without labels / without detections."""
+    g = torch.Generator().manual_seed(100 + seed)
+    nl, n = [(6, 20), (3, 7), (0, 5), (4, 0)][seed]
+    ids, pm = _mask_scene(seed, nl, n, 40, 40)
+    tcls = torch.randint(0, 3, (nl,), generator=g).float()
+    pcls = torch.tensor([float(tcls[j % nl]) if nl and j % 4 else float(torch.randint(0, 3, (1,), generator=g)) for j in range(n)])
+    miou = engine.mask_iou(ids.numpy(), nl, pm.numpy())
+    got = engine.match_predictions(pcls.numpy(), tcls.numpy(), miou)
+    ref = O.match_predictions(pcls, tcls, torch.from_numpy(miou)).numpy()
+    assert got.shape == (n, 10) and np.array_equal(got, ref.astype(bool)), (got.astype(int), ref.astype(int))
+    if seed == 0:
+        assert got.sum() > 0

@@ -83,6 +83,8 @@ PROTOTYPES = {
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_conv_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                              C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ys_mask_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "ys_match_predictions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ys_block_create": (C.c_int, [C.c_void_p, C.POINTER(BlockDesc), C.POINTER(C.c_void_p)]),
     "ys_block_output_shape": (C.c_int, [C.c_void_p, c_i32_p]),
     "ys_block_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

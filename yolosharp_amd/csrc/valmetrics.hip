@@ -87,6 +87,69 @@ val_match_kernel(const float* __restrict__ rows, const int* __restrict__ count, 
   }
 }
 
+// Metrics.mask_iou (Utils/Metrics.cs:120-125) as Segmenter.Val calls it (Models/Segmenter.cs:131-143): mask1[k] = (gt_ids == k + 1)
+// from the overlap-encoded id map, mask2[j] = the 0/1 masks of Ops.process_mask.  The reference's float matmul of 0/1 values is
+// an exact integer count (npix < 2^24), so  iou = inter / ((area1 + area2 - inter) + eps)  is reproduced bit for bit.
+// One workgroup per predicted mask; LDS histograms over the label ids (dynamic LDS: 2 * nl ints).
+__global__ void __launch_bounds__(VM_THREADS)
+mask_iou_kernel(const float* __restrict__ gt_ids, int nl, const unsigned char* __restrict__ pm, int n, int npix, float eps,
+                float* __restrict__ iou /*[nl][n]*/) {
+  YS_DYN_LDS(lds);
+  int* s_hist = (int*)lds;                 // [0, nl): |mask1[k]|, [nl, 2 nl): |mask1[k] & mask2[j]|
+  __shared__ int s_area2;
+  const int j = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 2 * nl; i += VM_THREADS) s_hist[i] = 0;
+  if (tid == 0) s_area2 = 0;
+  __syncthreads();
+  const unsigned char* m2 = pm + (long)j * npix;
+  int a2 = 0;
+  for (int p = tid; p < npix; p += VM_THREADS) {
+    const float idf = gt_ids[p];
+    const int id = (int)idf;
+    const bool lab = id >= 1 && id <= nl && (float)id == idf;       // (batch_mask == index) is an exact float comparison
+    const bool on = m2[p] != 0;
+    if (on) a2++;
+    if (lab) {
+      atomicAdd(&s_hist[id - 1], 1);
+      if (on) atomicAdd(&s_hist[nl + id - 1], 1);
+    }
+  }
+  atomicAdd(&s_area2, a2);
+  __syncthreads();
+  for (int k = tid; k < nl; k += VM_THREADS) {
+    const float inter = (float)s_hist[nl + k];
+    const float uni = ((float)s_hist[k] + (float)s_area2) - inter;
+    iou[(long)k * n + j] = inter / (uni + eps);
+  }
+}
+
+// match_predictions (Models/YoloBaseTaskModel.cs:377-446) on a caller-supplied IoU matrix [L][D]; same restatement as
+// val_match_kernel above (one workgroup).
+__global__ void __launch_bounds__(VM_THREADS)
+match_iou_kernel(const float* __restrict__ pred_cls, int D, const float* __restrict__ true_cls, int L, const float* __restrict__ iou,
+                 VmThr thr, float* __restrict__ best /*[D][2]*/, unsigned char* __restrict__ cor /*[D][10]*/) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < D * VM_NT; i += VM_THREADS) cor[i] = 0;
+  for (int d = tid; d < D; d += VM_THREADS) {
+    const float pc = pred_cls[d];
+    float bi = -1.f; int bl = -1;
+    for (int k = 0; k < L; k++) {
+      if (true_cls[k] != pc) continue;
+      const float v = iou[(long)k * D + d];
+      if (v > bi) { bi = v; bl = k; }
+    }
+    best[2 * d] = bi;
+    best[2 * d + 1] = (float)bl;
+  }
+  __syncthreads();
+  for (int e = tid; e < L * VM_NT; e += VM_THREADS) {
+    const int k = e / VM_NT, ti = e - k * VM_NT;
+    const float t = thr.t[ti];
+    for (int d = 0; d < D; d++)
+      if ((int)best[2 * d + 1] == k && best[2 * d] >= t) { cor[d * VM_NT + ti] = 1; break; }
+  }
+}
+
 // torch.linspace(0.5, 0.95, 10) in fp32 (ATen: step = (end-start)/(steps-1); first half start + step*i, second half
 // end - step*(steps-1-i))
 static VmThr vm_thresholds() {
@@ -120,6 +183,65 @@ int ys_box_iou(ys_ctx* ctx, const float* box1, int n, const float* box2, int m, 
   hipError_t e = hipStreamSynchronize(st);
   hipFree(d1); hipFree(d2); hipFree(d3);
   if (e != hipSuccess) { ys_set_error("ys_box_iou: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
+  return YS_OK;
+}
+
+// scratch + staging helper for the small validation calls: device pointers are used as they are, host arrays are staged
+namespace {
+struct VmStage {
+  hipStream_t st; bool on_device; std::vector<void*> tmp; bool ok = true;
+  VmStage(hipStream_t s, int od) : st(s), on_device(od != 0) {}
+  ~VmStage() { for (void* p : tmp) hipFree(p); }
+  void* alloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) { ok = false; return nullptr; } tmp.push_back(p); return p; }
+  const void* in(const void* host, size_t bytes) {
+    if (on_device || !host) return host;
+    void* d = alloc(bytes);
+    if (d && bytes) hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st);
+    return d;
+  }
+  void* out(void* host, size_t bytes) { return on_device ? host : alloc(bytes); }
+};
+}  // namespace
+
+int ys_mask_iou(ys_ctx* ctx, const float* gt_ids, int nl, const uint8_t* pred_masks, int n, int npix, float eps, int on_device, float* iou) {
+  YS_REQUIRE(ctx && iou && nl >= 0 && n >= 0 && npix > 0, "ys_mask_iou: bad argument");
+  if ((long)nl * n == 0) return YS_OK;
+  YS_REQUIRE(gt_ids && pred_masks, "ys_mask_iou: null masks");
+  YS_REQUIRE(npix < (1 << 24), "ys_mask_iou: %d pixels exceed the exact-integer range of the fp32 reference", npix);
+  YS_REQUIRE(nl <= 8192, "ys_mask_iou: %d labels exceed the LDS histogram capacity (8192)", nl);
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  VmStage sg(st, on_device);
+  const float* d_ids = (const float*)sg.in(gt_ids, (size_t)npix * 4);
+  const unsigned char* d_pm = (const unsigned char*)sg.in(pred_masks, (size_t)n * npix);
+  float* d_iou = (float*)sg.out(iou, (size_t)nl * n * 4);
+  if (!sg.ok) { ys_set_error("ys_mask_iou: out of device memory"); return YS_ERR_OOM; }
+  YS_LAUNCH_LDS(mask_iou_kernel, n, VM_THREADS, (size_t)2 * nl * sizeof(int) + 16, st, d_ids, nl, d_pm, n, npix, eps, d_iou);
+  YS_CHECK_HIP(hipGetLastError());
+  if (!on_device) {
+    hipMemcpyAsync(iou, d_iou, (size_t)nl * n * 4, hipMemcpyDeviceToHost, st);
+    YS_CHECK_HIP(hipStreamSynchronize(st));
+  }
+  return YS_OK;
+}
+
+int ys_match_predictions(ys_ctx* ctx, const float* pred_cls, int n, const float* true_cls, int nl, const float* iou, int on_device,
+                         uint8_t* correct) {
+  YS_REQUIRE(ctx && n >= 0 && nl >= 0, "ys_match_predictions: bad argument");
+  if (n == 0) return YS_OK;
+  YS_REQUIRE(pred_cls && correct && (nl == 0 || (true_cls && iou)), "ys_match_predictions: null argument");
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  VmStage sg(st, on_device);
+  const float* d_pc = (const float*)sg.in(pred_cls, (size_t)n * 4);
+  const float* d_tc = (const float*)sg.in(true_cls, (size_t)nl * 4);
+  const float* d_iou = (const float*)sg.in(iou, (size_t)nl * n * 4);
+  unsigned char* d_cor = (unsigned char*)sg.out(correct, (size_t)n * VM_NT);
+  float* d_best = (float*)sg.alloc((size_t)n * 8);
+  if (!sg.ok) { ys_set_error("ys_match_predictions: out of device memory"); return YS_ERR_OOM; }
+  YS_LAUNCH(match_iou_kernel, 1, VM_THREADS, st, d_pc, n, d_tc, nl, d_iou, vm_thresholds(), d_best, d_cor);
+  if (!on_device) hipMemcpyAsync(correct, d_cor, (size_t)n * VM_NT, hipMemcpyDeviceToHost, st);
+  YS_CHECK_HIP(hipStreamSynchronize(st));      // the scratch buffers are released on return
   return YS_OK;
 }
 

@@ -111,3 +111,49 @@ class Segmenter(Detector):
                 res = YoloResult(r)
                 results.append((res, mk))
         return results
+
+    def Val(self, batches, conf_thres=0.01, iou_thres=0.7, max_det=300):
+        """Models/Segmenter.cs:85-185: per batch eval forward + loss, NMS (conf 0.01, IoU 0.7), and per image
+        process_mask at the prototype resolution (:126 passes the proto size as `shape`, so the boxes are NOT rescaled -- kept),
+        box IoU matching and mask IoU matching (Metrics.mask_iou on the overlap-encoded `masks`, :131-143) -- all on the device;
+        the two epoch-level ap_per_class reductions stay on the host.  batches: dicts with images [B,3,H,W] in [0,1], batch_idx,
+        cls, bboxes, masks [B,H/4,W/4].  Returns (summed loss items [5], box (P,R,mAP50,mAP50-95), mask (P,R,mAP50,mAP50-95))."""
+        from .model import v8SegmentationLoss
+        crit = v8SegmentationLoss(self.model)
+        tps, tpms, confs, pcls, tcls = [], [], [], [], []
+        loss_sum = None
+        nc = self.model.nc
+        for data in batches:
+            if np.asarray(data["batch_idx"]).size < 1:          # Segmenter.cs:105-108
+                continue
+            images = np.ascontiguousarray(data["images"], np.float32)
+            B, _, H, W = images.shape
+            sd = {k: v for k, v in self.model.state_dict().items() if "running" in k or "num_batches" in k}
+            self.model.train(); self.model.forward(images, fetch=False)
+            _, items = crit.forward(None, data)
+            self.model.load_state_dict(sd, strict=False)
+            loss_sum = items if loss_sum is None else loss_sum + items
+            inference, _ = self.amp.Evaluate(images)
+            proto = self.model.get_output("proto")
+            mh, mw = proto.shape[2:]
+            output, _ = self.engine.non_max_suppression(inference["boxes"], conf_thres, iou_thres, max_det=max_det, nc=nc)
+            bi = np.asarray(data["batch_idx"], np.float32).reshape(-1)
+            cl = np.asarray(data["cls"], np.float32).reshape(-1)
+            bb = np.asarray(data["bboxes"], np.float32).reshape(-1, 4)
+            gm = np.asarray(data["masks"], np.float32).reshape(B, mh, mw)
+            for b, rows in enumerate(output):
+                sel = bi == b
+                true_cls = cl[sel]
+                nl = int(sel.sum())
+                masks = self.engine.process_mask(proto[b], rows[:, 6:], rows[:, :4], (mw, mh)) if len(rows) else np.zeros((0, mh, mw), bool)
+                gt = bb[sel] * np.array([W, H, W, H], np.float32)
+                gt_xyxy = np.concatenate((gt[:, :2] - gt[:, 2:] / 2, gt[:, :2] + gt[:, 2:] / 2), 1).astype(np.float32)
+                iou = self.engine.box_iou(gt_xyxy, rows[:, :4])
+                tps.append(self.engine.match_predictions(rows[:, 5], true_cls, iou))
+                miou = self.engine.mask_iou(gm[b], nl, masks)
+                tpms.append(self.engine.match_predictions(rows[:, 5], true_cls, miou))
+                confs.append(rows[:, 4]); pcls.append(rows[:, 5]); tcls.append(true_cls)
+        conf, pc, tc = np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls)
+        box = M.val_summary(M.ap_per_class(np.concatenate(tps), conf, pc, tc))
+        mask = M.val_summary(M.ap_per_class(np.concatenate(tpms), conf, pc, tc))
+        return loss_sum, box, mask

@@ -125,6 +125,23 @@ class Engine:
                                                            _ptr(bb), bi.shape[0], float(img_w), float(img_h), _ptr(cor)))
         return [cor[b, :count[b]].astype(bool) for b in range(B)]
 
+    def mask_iou(self, gt_ids, nl, pred_masks, eps=1e-7):
+        """Metrics.mask_iou (Metrics.cs:120-125) on (gt_ids == k+1), k < nl, vs pred_masks bool/uint8 [n, h, w] -> [nl, n] fp32."""
+        ids = np.ascontiguousarray(gt_ids, np.float32).reshape(-1)
+        pm = np.ascontiguousarray(np.asarray(pred_masks).astype(np.uint8)).reshape(-1, ids.shape[0]) if len(pred_masks) else np.zeros((0, ids.shape[0]), np.uint8)
+        out = np.zeros((nl, pm.shape[0]), np.float32)
+        _lib.check(self.lib, self.lib.ys_mask_iou(self.ctx, _ptr(ids), nl, _ptr(pm), pm.shape[0], ids.shape[0], eps, 0, _ptr(out)))
+        return out
+
+    def match_predictions(self, pred_classes, true_classes, iou):
+        """YoloBaseTaskModel.match_predictions (:377-446): iou [nl, n] -> bool [n, 10]."""
+        pc = np.ascontiguousarray(pred_classes, np.float32).reshape(-1)
+        tc = np.ascontiguousarray(true_classes, np.float32).reshape(-1)
+        iou = np.ascontiguousarray(iou, np.float32).reshape(tc.shape[0], pc.shape[0])
+        cor = np.zeros((pc.shape[0], 10), np.uint8)
+        _lib.check(self.lib, self.lib.ys_match_predictions(self.ctx, _ptr(pc), pc.shape[0], _ptr(tc), tc.shape[0], _ptr(iou), 0, _ptr(cor)))
+        return cor.astype(bool)
+
     # ---- Ops.process_mask (Ops.cs:462-489)
     def process_mask(self, protos, masks_in, bboxes, shape, upsample=False, cpu_crop_branch=False):
         """protos [nm,mh,mw], masks_in [n,nm], bboxes [n,4] xyxy (image pixels), shape=(ih,iw) -> bool [n,oh,ow]."""
