@@ -199,14 +199,18 @@ int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, 
 // ------------------------------------------------------------------ per-channel reductions over rows
 // thread t owns channel vector cv = t % CG and row lane t / CG; workgroup blk owns a contiguous row range.
 // MODE 0: BN backward (sum du, sum du*xhat), optional res_grad += dz.   MODE 1: plain column sum.
-template <class T, int MODE>
+#ifndef CR_U
+#define CR_U 2
+#endif
+template <class T, int MODE, bool RG = false, bool ACT = false>
 __global__ void __launch_bounds__(EW_THREADS)
 chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                    const float* __restrict__ rstd, int act, T* __restrict__ rg, int rg_ldc, int rg_coff,
                    float* __restrict__ partial, long rpb, long bstride) {
   constexpr int EPL = Elem<T>::EPL;
-  __shared__ float sAcc[EW_THREADS][EPL * 2];
+  constexpr int NV = MODE == 1 ? EPL : 2 * EPL;          // running sums per thread
+  __shared__ float sAcc[NV][EW_THREADS];                 // [value][thread]: conflict-free for consecutive threads
   const int CG = C / EPL;
   const int RP = EW_THREADS / CG;  // rows per pass
   const int tid = threadIdx.x;
@@ -220,42 +224,45 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
 #pragma unroll
   for (int e = 0; e < EPL; e++) { a1[e] = 0.f; a2[e] = 0.f; }
   if (rl < RP) {
-    float sc[EPL], sh[EPL], mu[EPL], rs[EPL];
-    if (MODE == 0) {
-      ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(mean + c, mu); ys_ldcoef<EPL>(rstd + c, rs);
-    }
-    // four rows per trip: all loads of a trip are issued before any arithmetic (memory-level parallelism; the SiLU
-    // derivative is ~100 VALU operations per 16-byte vector, so one row in flight per thread left HBM idle)
-    constexpr int U = 4;
-    const bool dense = rpb == rows;                      // no per-image row stride: skip the 64-bit division
-    for (long rowb = r0 + rl; rowb < r1; rowb += (long)RP * U) {
-      uint4 gv[U], fv[U], ov[U];
-      bool ok[U];
+    // the second BN-backward sum is accumulated against the raw conv output (sum du*y); chan_finalize turns it into
+    // sum du*xhat = rstd * (sum du*y - mean * sum du) in double.  Keeping mean / rstd out of the loop saves 16 VGPRs per
+    // thread (occupancy 3 -> 5 waves per SIMD), which is what this latency-bound pass needs.
+    float sc[EPL], sh[EPL];
+    if (MODE == 0) { ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); }
+    // Software-pipelined over trips of U rows: the loads of trip t+1 are issued before the arithmetic of trip t.  The SiLU
+    // derivative is ~18 VALU issue slots per element, i.e. about as long as the HBM latency of a trip; without the
+    // prefetch every wave of a SIMD alternates in step between "all waiting" and "all computing" and the two never overlap.
+    constexpr int U = CR_U;
+    const bool dense = MODE != 1 || rpb == rows;         // no per-image row stride (always for the BN passes): skip the 64-bit division
+    const long step = (long)RP * U;
+    auto issue = [&](long rowb, uint4 (&gv)[U], uint4 (&fv)[U], uint4 (&ov)[U]) {
 #pragma unroll
       for (int k = 0; k < U; k++) {
-        const long row = rowb + (long)k * RP;
-        ok[k] = row < r1;
-        gv[k] = ys_zero16(); fv[k] = ys_zero16(); ov[k] = ys_zero16();
-        if (ok[k]) {
-          long zrow = row;
-          if (!dense) { const long zb = row / rpb; zrow = zb * bstride + (row - zb * rpb); }   // dz rows strided per image (head outputs)
-          gv[k] = ys_ld16(dz + zrow * dz_ldc + dz_coff + c);
-          if (MODE == 0) {
-            fv[k] = ys_ld16(y + row * C + c);
-            if (rg) ov[k] = ys_ld16(rg + row * rg_ldc + rg_coff + c);
-          }
-        }
+        // rows past the end are clamped to the last row and ignored by consume(): loads inside exec-masked branches make the
+        // compiler fall back to s_waitcnt vmcnt(0) at the join, which would wait for the prefetch as well
+        long row = rowb + (long)k * RP;
+        row = row < r1 ? row : r1 - 1;
+        long zrow = row;
+        if (!dense) { const long zb = row / rpb; zrow = zb * bstride + (row - zb * rpb); }   // dz rows strided per image (head outputs)
+        gv[k] = ys_ld16(dz + zrow * dz_ldc + dz_coff + c);
+        if (MODE == 0) {
+          fv[k] = ys_ld16(y + row * C + c);
+          if (RG) ov[k] = ys_ld16(rg + row * rg_ldc + rg_coff + c);
+        } else { fv[k] = ys_zero16(); }
+        if (!RG) ov[k] = ys_zero16();
       }
+    };
+    auto consume = [&](long rowb, const uint4 (&gv)[U], const uint4 (&fv)[U], const uint4 (&ov)[U]) {
 #pragma unroll
       for (int k = 0; k < U; k++) {
-        if (!ok[k]) continue;
         const long row = rowb + (long)k * RP;
+        if (row >= r1) continue;
         float g[EPL];
         ys_unpack<T>(gv[k], g);
         if (MODE == 0) {
           float f[EPL];
           ys_unpack<T>(fv[k], f);
-          if (rg) {
+          if (RG) {
             float o[EPL];
             ys_unpack<T>(ov[k], o);
 #pragma unroll
@@ -265,10 +272,9 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
 #pragma unroll
           for (int e = 0; e < EPL; e++) {
             const float u = f[e] * sc[e] + sh[e];
-            const float du = act ? g[e] * ys_silu_grad(u) : g[e];
-            const float xh = (f[e] - mu[e]) * rs[e];
-            a1[e] += du;
-            a2[e] += du * xh;
+            const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];   // compile-time: a run-time flag here splits the unrolled
+            a1[e] += du;                                            // elements into basic blocks and serialises the exp/rcp chains
+            a2[e] += du * f[e];
           }
         } else if (MODE == 2) {
 #pragma unroll
@@ -278,18 +284,42 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
           for (int e = 0; e < EPL; e++) a1[e] += g[e];
         }
       }
+    };
+    uint4 gA[U], fA[U], oA[U], gB[U], fB[U], oB[U];
+    long rowb = r0 + rl;
+    if (rowb < r1) {
+      issue(rowb, gA, fA, oA);
+      while (true) {                                     // two trips per iteration: the buffers alternate without dynamic indexing
+        issue(rowb + step, gB, fB, oB);                  // (unconditional: past the end it re-reads the last row)
+        consume(rowb, gA, fA, oA);
+        rowb += step;
+        if (rowb >= r1) break;
+        issue(rowb + step, gA, fA, oA);
+        consume(rowb, gB, fB, oB);
+        rowb += step;
+        if (rowb >= r1) break;
+      }
     }
   }
+  // workgroup reduction over the RP row lanes: pairwise halving with every thread taking part (the previous form -- CG threads
+  // each walking RP rows -- was a serial chain of up to 2048 LDS reads per workgroup for the 16-channel layers)
 #pragma unroll
-  for (int e = 0; e < EPL; e++) { sAcc[tid][e] = a1[e]; sAcc[tid][EPL + e] = a2[e]; }
+  for (int e = 0; e < EPL; e++) { sAcc[e][tid] = a1[e]; if (MODE != 1) sAcc[EPL + e][tid] = a2[e]; }
   __syncthreads();
+  for (int n = RP; n > 1;) {
+    const int half = (n + 1) >> 1;
+    if (rl + half < n) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) sAcc[v][tid] += sAcc[v][tid + half * CG];
+    }
+    __syncthreads();
+    n = half;
+  }
   if (tid < CG) {
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int k = 0; k < RP; k++) { t1 += sAcc[k * CG + tid][e]; t2 += sAcc[k * CG + tid][EPL + e]; }
-      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = t1;
-      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = t2;
+      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = sAcc[e][tid];
+      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = MODE != 1 ? sAcc[(MODE != 1 ? EPL : 0) + e][tid] : 0.f;
     }
   }
 }
@@ -315,10 +345,20 @@ int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ld
   if (C % epl || C / epl > EW_THREADS) { ys_set_error("bn_bwd: unsupported channel count %d", C); return YS_ERR_UNSUPPORTED; }
   const int nb = reduce_blocks(rows, C, epl);
   *nblk_out = nb;
-  if (dtype == YS_BF16)
-    YS_LAUNCH((chan_reduce_kernel<bf16_t, 0>), nb, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, mean, rstd, act, (bf16_t*)res_grad, rg_ldc, rg_coff, partial, rows, rows);
-  else
-    YS_LAUNCH((chan_reduce_kernel<float, 0>), nb, EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, mean, rstd, act, (float*)res_grad, rg_ldc, rg_coff, partial, rows, rows);
+#define CR_LAUNCH(TT, RGF, ACTF) \
+  YS_LAUNCH((chan_reduce_kernel<TT, 0, RGF, ACTF>), nb, EW_THREADS, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, scale, shift, mean, rstd, act, (TT*)res_grad, rg_ldc, rg_coff, partial, rows, rows)
+  const int variant = (dtype == YS_BF16 ? 4 : 0) | (res_grad ? 2 : 0) | (act ? 1 : 0);
+  switch (variant) {
+    case 0: CR_LAUNCH(float, false, false); break;
+    case 1: CR_LAUNCH(float, false, true); break;
+    case 2: CR_LAUNCH(float, true, false); break;
+    case 3: CR_LAUNCH(float, true, true); break;
+    case 4: CR_LAUNCH(bf16_t, false, false); break;
+    case 5: CR_LAUNCH(bf16_t, false, true); break;
+    case 6: CR_LAUNCH(bf16_t, true, false); break;
+    default: CR_LAUNCH(bf16_t, true, true); break;
+  }
+#undef CR_LAUNCH
   return YS_OK;
 }
 
@@ -352,11 +392,12 @@ chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double 
   if (MODE == 0) s2 = block_sum_d(s2, sbuf);
   if (threadIdx.x == 0) {
     if (MODE == 0) {
+      const float sc = scale[c], mu = mean[c], rs = rstd[c];
+      s2 = (double)rs * (s2 - (double)mu * s1);   // sum(du * xhat) from sum(du * y) (chan_reduce_kernel)
       g0[c] += (float)s2;  // dgamma = sum(du * xhat)
       g1[c] += (float)s1;  // dbeta  = sum(du)
       // dy = gamma*rstd*(du - m1 - xhat*m2) = scale*du - k2 - y*k3  (m1 = mean(du), m2 = mean(du*xhat))
       const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
-      const float sc = scale[c], mu = mean[c], rs = rstd[c];
       c1[c] = sc * (m1 - mu * rs * m2);   // k2
       c2[c] = sc * rs * m2;               // k3
     } else {
