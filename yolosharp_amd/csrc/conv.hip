@@ -730,10 +730,14 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     tyi += sty; if (tyi >= g.tiles_y) { tyi -= g.tiles_y; b++; }
     b += sb;
   };
-  auto pfetch = [&](int txi, int tyi, int b) {
+  // Every unit issues its load unconditionally -- units that are unused or fall into the zero padding read a harmless valid
+  // address and are zeroed from the returned bit mask when the patch is written to LDS.  Loads inside exec-masked branches make
+  // the compiler lose count of what is in flight and fall back to s_waitcnt vmcnt(0) BEFORE the MFMA loop, i.e. no overlap.
+  const long safe_off = (long)a.in_coff * 2L;
+  auto pfetch = [&](int txi, int tyi, int b) -> unsigned {
     const int iy0 = tyi * g.TH * a.SA - a.PAD, ix0 = txi * g.TW * a.SA - a.PAD;
-    const char* xt = xb + (((long)b * a.in_bstride + (long)iy0 * a.Win + ix0) * a.in_ldc + a.in_coff) * 2L;
-    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + g.PH <= a.Hin && ix0 + g.PW <= a.Win;
+    const long toff = (((long)b * a.in_bstride + (long)iy0 * a.Win + ix0) * a.in_ldc + a.in_coff) * 2L;
+    unsigned okm = 0;
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       unsigned d = pdesc[k];
@@ -741,17 +745,15 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #ifndef YS_EMU_BUILD
       asm volatile("" : "+v"(d), "+v"(go));
 #endif
-      uint4 v = ys_zero16();
-      if (d != 0xffffffffu) {
-        bool ok = true;
-        if (!interior) {
-          const int iy = iy0 + (int)(d >> 23), ix = ix0 + (int)((d >> 13) & 1023u);
-          ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-        }
-        if (ok && !P2_DBG(1)) v = ys_ld16(xt + (long)go * 2L);
-      }
-      rp[k] = v;
+      // branch-free validity (bitwise, not short-circuit): unit in use, row and column inside the image
+      const unsigned iy = (unsigned)(iy0 + (int)(d >> 23)), ix = (unsigned)(ix0 + (int)((d >> 13) & 1023u));
+      const bool ok = (bool)((int)(d != 0xffffffffu) & (int)(iy < (unsigned)a.Hin) & (int)(ix < (unsigned)a.Win) & (int)!P2_DBG(1));
+      long off = toff + (long)go * 2L;
+      off = ok ? off : safe_off;
+      rp[k] = ys_ld16(xb + off);
+      okm |= (unsigned)ok << k;
     }
+    return okm;
   };
   int txi, tyi, b;
   {
@@ -760,7 +762,8 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     tyi = t % g.tiles_y; b = t / g.tiles_y;
   }
   int ntx = txi, nty = tyi, nb = b;
-  if (t_first < t_end) pfetch(txi, tyi, b);
+  unsigned okm_next = 0;
+  if (t_first < t_end) okm_next = pfetch(txi, tyi, b);
   if (P2_DBG(128)) return;                     // ablation: prologue only (tables, resident weights, first patch fetch)
   float st1[8], st2[8];                        // BN statistics of this workgroup's tiles (per-lane column sums)
 #pragma unroll
@@ -776,12 +779,15 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #ifndef YS_EMU_BUILD
       asm volatile("" : "+v"(d));
 #endif
-      if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = rp[k];
+      if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = ((okm_next >> k) & 1u) ? rp[k] : ys_zero16();
     }
     if (!WRES) wstore(0);
     ys_barrier_lds();
     advance(ntx, nty, nb);
-    if (tile + t_step < t_end) pfetch(ntx, nty, nb);
+    // everything older (the patch just consumed, the previous epilogue's conditional loads / stores) has already been waited
+    // for above; saying so explicitly resets the compiler's "may still be in flight" state for the accumulator registers
+    YS_WAIT_VM0();
+    if (tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
 
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -794,6 +800,8 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       const int s0 = WRES ? 0 : grp * KG;
       const int s1 = WRES ? g.nsteps : ((s0 + KG) < g.nsteps ? (s0 + KG) : g.nsteps);
       const uint4* wbuf = sW + (WRES ? 0 : (grp & 1) * BN * g.wpitch);
+      // (reading the operand fragments of step s+1 during the MFMAs of step s -- two register sets -- was measured neutral:
+      //  12.95 -> 13.00 ms/step; the other waves of the SIMD already cover the LDS round trips)
 #pragma unroll 1
       for (int s = P2_DBG(2) ? s1 : s0; s < s1; s++) {
         const int off = sOff[s * 4 + q];
@@ -842,17 +850,24 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
   if (a.Cin % 8) return p;
   const int nfr = (a.Cout + 15) / 16;
-  const int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
-  const int bn = nr * 16;
+  int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
   const int cu = a.Cin / 8;
   P2Args g{};
   g.ppb = a.Cin * 2 + ((cu & 1) ? 32 : 16);
   const int taps = a.KH * a.KW;
   g.nsteps = (taps * a.Cin + 31) / 32;
-  const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
   // workgroup per CU); YS_P2_WRESMAX overrides for experiments
   static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 40 * 1024;
+  // Streamed weights cost one L2 round trip per K-group on the critical path of every tile.  When half the output channels
+  // would make the weight set resident, split the channels over two workgroup columns instead (the patch is then read
+  // twice, from L2).
+  static const int nrsplit = getenv("YS_P2_NRSPLIT") ? atoi(getenv("YS_P2_NRSPLIT")) : 1;   // measured 13.00 -> 12.86 ms/step
+  if (nrsplit && (size_t)nr * 16 * ((g.nsteps * 4) | 1) * 16 > wresmax && nr % 2 == 0 &&
+      (size_t)(nr / 2) * 16 * ((g.nsteps * 4) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
+    nr /= 2;
+  const int bn = nr * 16;
+  const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
   const int wres = wres_bytes <= wresmax ? 1 : 0;
   g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;

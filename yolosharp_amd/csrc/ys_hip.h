@@ -22,6 +22,14 @@
   hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__)
 #endif
 
+// s_waitcnt vmcnt(0) as a real instruction the compiler's wait-count bookkeeping sees (gfx9 encoding: vmcnt = 0, expcnt = 7,
+// lgkmcnt = 15 -> 0x0F70); nothing to do in the interpreter
+#ifdef YS_EMU_BUILD
+#define YS_WAIT_VM0() ((void)0)
+#else
+#define YS_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
+
 // launch with dynamic LDS; YS_DYN_LDS(name) declares the dynamic region inside a kernel as `uint4* name`
 #ifdef YS_EMU_BUILD
 #define YS_LAUNCH_LDS(KERNEL, GRID, BLOCK, LDS_BYTES, STREAM, ...) \
