@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", default="n")
+    ap.add_argument("--imgsz", type=int, default=640, help="square input size (BASELINE configs: 640; config 5 shape: 1280)")
     ap.add_argument("--family", type=int, default=8, choices=[8, 11], help="graph family (8 = YOLOv8, 11 = YOLOv11); default = BASELINE config 2")
     ap.add_argument("--task", default="detect", choices=["detect", "segment"])
     ap.add_argument("--dtype", default="bf16")
@@ -107,7 +108,7 @@ def main():
     from yolosharp_amd import dist as ysd
     from yolosharp_amd.workload import step_work
 
-    nc, H, W, B = 80, 640, 640, args.batch
+    nc, H, W, B = 80, args.imgsz, args.imgsz, args.batch
     stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
     eng = Engine(local_rank, stream=stream)          # N>1: run on torch's stream so RCCL orders against our kernels
     seg = args.task == "segment"
@@ -212,7 +213,7 @@ def main():
                     "step_algorithmic_GBps": round(wk["train_bytes"] * B / (ms * 1e-3) / 1e9, 1),
                     "step_TFLOPs": round(wk["train_flop"] * B / (ms * 1e-3) / 1e12, 2)}
         gname = f"YOLOv{args.family}{args.size}" + ("-seg" if seg else "")
-        out = {"metric": f"train images/sec {gname} 640x640 bs={B}/GPU", "value": round(value, 2), "unit": "images/s",
+        out = {"metric": f"train images/sec {gname} {W}x{H} bs={B}/GPU", "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, COCO-80 synthetic labels" + (" + instance masks" if seg else ""),

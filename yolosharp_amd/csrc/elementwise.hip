@@ -7,6 +7,7 @@
 // All tensors are [rows][ldc] views with a channel offset; one thread moves 16 bytes (8 bf16 / 4 f32).
 #include "ys_internal.h"
 #include "ys_kernels.h"
+#include <cstdlib>
 
 #define EW_THREADS 256
 
@@ -327,12 +328,15 @@ chan_reduce_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* _
 static int reduce_blocks(long rows, int C, int epl) {
   const int cg = C / epl;
   const int rp = EW_THREADS / cg;
-  // 4 row passes = one unrolled trip; prefer 16 passes per workgroup, but never fewer than ~1024 workgroups (4 per CU)
-  // while a workgroup still has a full trip of work
+  // prefer 16 row passes per workgroup, but keep >= 512 workgroups (2 per CU) while a workgroup still has a few trips of
+  // work; at most 768 (3 per CU, one resident round at 4-5 waves per SIMD): more partial rows only lengthen the finalize
+  // kernel and add a ragged second round (measured: 2048 -> 12.86, 1024 -> 12.77, 768/512 -> 12.75 ms/step)
+  static const long maxnb = getenv("YS_CR_MAXNB") ? atol(getenv("YS_CR_MAXNB")) : 768;
+  static const long minnb = getenv("YS_CR_MINNB") ? atol(getenv("YS_CR_MINNB")) : 512;
   long passes = 16;
-  while (passes > 4 && (rows + (long)rp * passes - 1) / ((long)rp * passes) < 1024) passes >>= 1;
+  while (passes > 4 && (rows + (long)rp * passes - 1) / ((long)rp * passes) < minnb) passes >>= 1;
   long nb = (rows + (long)rp * passes - 1) / ((long)rp * passes);
-  if (nb > 2048) nb = 2048;
+  if (nb > maxnb) nb = maxnb;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
