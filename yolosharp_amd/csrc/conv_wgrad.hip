@@ -163,6 +163,14 @@ wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int c
   __shared__ float sred[16][32];
   const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long i = (long)blockIdx.x * 32 + o;
+  // the read-modify-write of grad is issued up front so its latency overlaps the partial loads (it was a second dependent
+  // round trip at the tail of a ~5 us kernel)
+  float gprev = 0.f; long gidx = -1;
+  if (sl == 0 && i < n) {
+    const long row = i / cin_pad;
+    const int ci = (int)(i - row * cin_pad);
+    if (ci < cin_real) { gidx = row * cin_real + ci; gprev = grad[gidx]; }
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int k = sl;
@@ -176,15 +184,11 @@ wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int c
   }
   sred[sl][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (sl == 0 && i < n) {
-    const long row = i / cin_pad;
-    const int ci = (int)(i - row * cin_pad);
-    if (ci < cin_real) {
-      float t = 0.f;
+  if (gidx >= 0) {
+    float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 16; w++) t += sred[w][o];
-      grad[row * cin_real + ci] += t;
-    }
+    for (int w = 0; w < 16; w++) t += sred[w][o];
+    grad[gidx] = gprev + t;
   }
 }
 

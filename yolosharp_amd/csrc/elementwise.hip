@@ -89,17 +89,18 @@ int ys_unpack_nchw_strided_launch(hipStream_t st, int dtype, const void* x, int 
 }
 
 // ------------------------------------------------------------------ block reduction helper (double)
-__device__ inline double block_sum_d(double v, double* sbuf) {
-  const int tid = threadIdx.x;
-  sbuf[tid] = v;
+// two sums at once: wave shuffles, then one LDS exchange of the EW_THREADS/64 wave totals combined in a fixed order (the LDS
+// tree above costs 9 barriers per value -- most of a ~5 us finalize kernel)
+__device__ inline void block_sum2_d(double& a, double& b, double* sbuf) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if (lane == 0) { sbuf[2 * wave] = a; sbuf[2 * wave + 1] = b; }
   __syncthreads();
-  for (int s = EW_THREADS / 2; s > 0; s >>= 1) {
-    if (tid < s) sbuf[tid] += sbuf[tid + s];
-    __syncthreads();
-  }
-  const double r = sbuf[0];
-  __syncthreads();
-  return r;
+  double ta = 0.0, tb = 0.0;
+#pragma unroll
+  for (int w = 0; w < EW_THREADS / 64; w++) { ta += sbuf[2 * w]; tb += sbuf[2 * w + 1]; }
+  a = ta; b = tb;
 }
 
 // ------------------------------------------------------------------ BN forward finalize
@@ -111,28 +112,30 @@ bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double co
                    float* __restrict__ shift, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
   __shared__ double sbuf[EW_THREADS];
   const int c = blockIdx.x;
+  // per-channel operands of the tail are fetched first: their latency overlaps the partial loads instead of forming a second
+  // dependent round trip after the reduction
+  float g = 0.f, bt = 0.f, rm0 = 0.f, rv0 = 0.f, nbt0 = 0.f;
+  if (threadIdx.x == 0) { g = gamma[c]; bt = beta[c]; rm0 = run_mean[c]; rv0 = run_var[c]; if (c == 0 && nbt) nbt0 = nbt[0]; }
   double s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < nblk; k += EW_THREADS) {
     s1 += (double)partial[((long)k * 2 + 0) * C + c];
     s2 += (double)partial[((long)k * 2 + 1) * C + c];
   }
-  s1 = block_sum_d(s1, sbuf);
-  s2 = block_sum_d(s2, sbuf);
+  block_sum2_d(s1, s2, sbuf);
   if (threadIdx.x == 0) {
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;  // biased (torch BatchNorm2d training normalisation)
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma[c], bt = beta[c];
     scale[c] = g * rstd;
     shift[c] = bt - (float)mean * g * rstd;
     mean_o[c] = (float)mean;
     rstd_o[c] = rstd;
     // running stats: momentum 0.03, unbiased variance (Convs.cs:41-42,48)
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
-    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
-    if (c == 0 && nbt) nbt[0] += 1.0f;
+    run_mean[c] = (1.0f - momentum) * rm0 + momentum * (float)mean;
+    run_var[c] = (1.0f - momentum) * rv0 + momentum * (float)unb;
+    if (c == 0 && nbt) nbt[0] = nbt0 + 1.0f;
   }
 }
 int ys_bn_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, const float* gamma,
@@ -387,25 +390,28 @@ chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double 
                      const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd) {
   __shared__ double sbuf[EW_THREADS];
   const int c = blockIdx.x;
+  float sc = 0.f, mu = 0.f, rs = 0.f, g0p = 0.f, g1p = 0.f;   // tail operands first (see bn_finalize_kernel)
+  if (threadIdx.x == 0) {
+    g0p = g0[c];
+    if (MODE == 0) { sc = scale[c]; mu = mean[c]; rs = rstd[c]; g1p = g1[c]; }
+  }
   double s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < nblk; k += EW_THREADS) {
     s1 += (double)partial[((long)k * 2 + 0) * C + c];
     if (MODE == 0) s2 += (double)partial[((long)k * 2 + 1) * C + c];
   }
-  s1 = block_sum_d(s1, sbuf);
-  if (MODE == 0) s2 = block_sum_d(s2, sbuf);
+  block_sum2_d(s1, s2, sbuf);
   if (threadIdx.x == 0) {
     if (MODE == 0) {
-      const float sc = scale[c], mu = mean[c], rs = rstd[c];
       s2 = (double)rs * (s2 - (double)mu * s1);   // sum(du * xhat) from sum(du * y) (chan_reduce_kernel)
-      g0[c] += (float)s2;  // dgamma = sum(du * xhat)
-      g1[c] += (float)s1;  // dbeta  = sum(du)
+      g0[c] = g0p + (float)s2;  // dgamma += sum(du * xhat)
+      g1[c] = g1p + (float)s1;  // dbeta  += sum(du)
       // dy = gamma*rstd*(du - m1 - xhat*m2) = scale*du - k2 - y*k3  (m1 = mean(du), m2 = mean(du*xhat))
       const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
       c1[c] = sc * (m1 - mu * rs * m2);   // k2
       c2[c] = sc * rs * m2;               // k3
     } else {
-      g0[c] += (float)s1;
+      g0[c] = g0p + (float)s1;
     }
   }
 }
