@@ -20,8 +20,10 @@
 // (SA = 1, DIV = stride, PAD = k-1-k/2, spatially flipped + transposed weights).
 #include "ys_internal.h"
 #include "ys_kernels.h"
+#include <atomic>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 // ------------------------------------------------------------------ shared epilogue
@@ -862,6 +864,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   // Streamed weights cost one L2 round trip per K-group on the critical path of every tile.  When half the output channels
   // would make the weight set resident, split the channels over two workgroup columns instead (the patch is then read
   // twice, from L2).
+  static const double tileconst = getenv("YS_P2_TILECONST") ? atof(getenv("YS_P2_TILECONST")) : 3000.0;
   static const int nrsplit = getenv("YS_P2_NRSPLIT") ? atoi(getenv("YS_P2_NRSPLIT")) : 1;   // measured 13.00 -> 12.86 ms/step
   if (nrsplit && (size_t)nr * 16 * ((g.nsteps * 4) | 1) * 16 > wresmax && nr % 2 == 0 &&
       (size_t)(nr / 2) * 16 * ((g.nsteps * 4) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
@@ -900,7 +903,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         if (lds > budget || ph * pw * cu > npu_max * nt) continue;
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
         const long ntiles = (long)tx * ty * a.B;
-        const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + 3000.0;
+        const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + tileconst;
         const double cost = (double)tx * ty * per_tile;
         const bool full = ntiles * gy >= 512;
         if ((full && !best_full) || (full == best_full && cost < best)) {
@@ -929,6 +932,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
 // on the device for the life of the process (a few KB per distinct layer shape).
 static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   static std::map<std::vector<int>, int*> cache;
+  static std::mutex cache_mu;                   // distinct ys_ctx may launch from different threads
+  std::lock_guard<std::mutex> lock(cache_mu);
   int dev = 0;
   hipGetDevice(&dev);
   const P2Args& g = p.g;
@@ -983,10 +988,12 @@ template <int MR, int NR, int WRES, int NPU, int NT>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
   a.dbg = dbg;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
     hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[192] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k%d s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, NT, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
@@ -1115,10 +1122,12 @@ static int conv3x3_launch_t(hipStream_t st, ConvArgs a, const TileChoice& t, con
   const int per_cu = p.lds_bytes <= 76 * 1024 ? 2 : 1;
   int gx = (256 * per_cu + gy - 1) / gy;
   if (gx > ntiles) gx = ntiles;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
     hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, MR, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[160] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "patch k3 s%d div%d cin%d cout%d M%d acc%d mr%d nr%d tile%dx%d grid%dx%d lds%d", a.SA, a.DIVM + 1, a.Cin, a.Cout, a.M, a.accumulate, MR, NR, a.TH, a.TW, gx, gy, (int)p.lds_bytes);

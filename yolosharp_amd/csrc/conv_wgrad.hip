@@ -2,6 +2,7 @@
 // the fixed-order split reduction, and the weight-shadow preparation kernels.
 #include "ys_internal.h"
 #include "ys_kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 // ===================================================================================== wgrad
@@ -456,10 +457,12 @@ static void wgrad_tr_launch_t(hipStream_t st, WgradArgs a, const WgPlan& p) {
   a.TH = p.th; a.TWS = p.tws; a.tiles_x = p.tx; a.tiles_y = p.ty; a.ntiles = p.tx * p.ty * a.B;
   a.PH = p.ph; a.PW = p.pw; a.pdb = p.pdb; a.pxb = p.pxb;
   const int gy = ys_cdiv(a.Cout, MRA * 16) * ys_cdiv(a.Cin, NRB * 16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
     hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<MRA, NRB, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[160] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "wgrad_tr k%d s%d cin%d cout%d M%d tile%dx%d grid%dx%d lds%d", a.KH, a.stride, a.Cin, a.Cout, a.M, p.th, 1 << p.tws, p.gx, gy, (int)p.lds);
