@@ -96,12 +96,18 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
   for (int i = tid; i < a.B; i += LS_THREADS) a.gt_count[i] = 0;
   for (int i = tid; i < a.B * a.gcap; i += LS_THREADS) { a.pos_align[i] = 0u; a.pos_ov[i] = 0u; }
   if (tid < 8) a.scalars[tid] = 0.f;
+  // image index of every label staged in LDS: the rank loop below is O(n^2) and was a chain of global loads (57 us for 544 labels)
+  constexpr int SB = 4096;
+  __shared__ short s_b[SB];
+  const bool staged = a.n_labels <= SB;
+  if (staged) for (int i = tid; i < a.n_labels; i += LS_THREADS) { const int bb = (int)a.batch_idx[i]; s_b[i] = (short)(bb < -1 || bb > 32766 ? -1 : bb); }
   __syncthreads();
   for (int i = tid; i < a.n_labels; i += LS_THREADS) {
     const int b = (int)a.batch_idx[i];
     if (b < 0 || b >= a.B) continue;
     int slot = 0;  // rank among labels of the same image, in order of appearance
-    for (int j = 0; j < i; j++) slot += ((int)a.batch_idx[j] == b) ? 1 : 0;
+    if (staged) { for (int j = 0; j < i; j++) slot += ((int)s_b[j] == b) ? 1 : 0; }
+    else { for (int j = 0; j < i; j++) slot += ((int)a.batch_idx[j] == b) ? 1 : 0; }
     atomicAdd(&a.gt_count[b], 1);
     if (slot >= a.gcap) continue;  // capacity exceeded (count is clamped below)
     const float sw = (float)a.W, shh = (float)a.H;
@@ -119,9 +125,10 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
 
 // ------------------------------------------------------------------ K1: bbox_decode (Loss.cs:398-409)
 // four consecutive lanes own one anchor (one side each): 32-byte contiguous logit reads instead of a 128-byte stride per lane
-template <class T>
+template <class T, int RR>     // RR = reg_max when it is 16 (row of 16 bins as 16-byte vector loads, unrolled), 0 = run-time
 __global__ void __launch_bounds__(LS_THREADS)
 loss_decode_kernel(LossArgs a) {
+  constexpr int EPL = Elem<T>::EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.A * 4;
   const bool inb = i < total;
@@ -130,13 +137,20 @@ loss_decode_kernel(LossArgs a) {
   const int lane = threadIdx.x & 63;
   float d = 0.f;
   if (inb) {
-    const T* lr = (const T*)a.pd + row * a.ld_pd + s * a.reg_max;
-    float mx = -INFINITY;
-    for (int j = 0; j < a.reg_max; j++) mx = fmaxf(mx, Elem<T>::to_f(lr[j]));
-    float se = 0.f, sw = 0.f;
-    for (int j = 0; j < a.reg_max; j++) {
-      const float e = __expf(Elem<T>::to_f(lr[j]) - mx);
-      se += e; sw += e * (float)j;
+    const int R = RR ? RR : a.reg_max;
+    const T* lr = (const T*)a.pd + row * a.ld_pd + s * R;
+    float mx = -INFINITY, se = 0.f, sw = 0.f;
+    if (RR) {
+      float x[RR ? RR : 1];
+#pragma unroll
+      for (int v = 0; v < RR / EPL; v++) ys_unpack<T>(ys_ld16(lr + v * EPL), x + v * EPL);
+#pragma unroll
+      for (int j = 0; j < RR; j++) mx = fmaxf(mx, x[j]);
+#pragma unroll
+      for (int j = 0; j < RR; j++) { const float e = __expf(x[j] - mx); se += e; sw += e * (float)j; }
+    } else {
+      for (int j = 0; j < R; j++) mx = fmaxf(mx, Elem<T>::to_f(lr[j]));
+      for (int j = 0; j < R; j++) { const float e = __expf(Elem<T>::to_f(lr[j]) - mx); se += e; sw += e * (float)j; }
     }
     d = sw / se;
   }
@@ -297,22 +311,33 @@ tal_targets_kernel(LossArgs a, float* partial) {
 //                                                   mode 1: adds columns 1..3 into scalars[5..7]
 __global__ void __launch_bounds__(LS_THREADS)
 loss_sum_kernel(const float* __restrict__ partial, int nblk, float* scalars, int mode) {
-  __shared__ double sbuf[LS_THREADS];
-  const int tid = threadIdx.x;
-  for (int col = 0; col < 4; col++) {
-    double s = 0.0;
-    for (int k = tid; k < nblk; k += LS_THREADS) s += (double)partial[(long)k * 4 + col];
-    sbuf[tid] = s;
-    __syncthreads();
-    for (int st = LS_THREADS / 2; st > 0; st >>= 1) {
-      if (tid < st) sbuf[tid] += sbuf[tid + st];
-      __syncthreads();
-    }
-    if (tid == 0) {
-      if (mode == 0 && col == 0) scalars[0] = (float)(sbuf[0] > 1.0 ? sbuf[0] : 1.0);  // Loss.cs:444
-      if (mode == 1 && col > 0) scalars[4 + col] += (float)sbuf[0];
-    }
-    __syncthreads();
+  // one pass over the [nblk][4] partial rows (16-byte loads, four independent rows in flight per thread), double accumulators,
+  // wave shuffles and a fixed-order combine of the wave totals -- deterministic
+  __shared__ double sbuf[LS_THREADS / 64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const float4* rows = (const float4*)partial;
+  int k = tid;
+  for (; k + 3 * LS_THREADS < nblk; k += 4 * LS_THREADS) {
+    const float4 r0 = rows[k], r1 = rows[k + LS_THREADS], r2 = rows[k + 2 * LS_THREADS], r3 = rows[k + 3 * LS_THREADS];
+    s[0] += ((double)r0.x + (double)r1.x) + ((double)r2.x + (double)r3.x);
+    s[1] += ((double)r0.y + (double)r1.y) + ((double)r2.y + (double)r3.y);
+    s[2] += ((double)r0.z + (double)r1.z) + ((double)r2.z + (double)r3.z);
+    s[3] += ((double)r0.w + (double)r1.w) + ((double)r2.w + (double)r3.w);
+  }
+  for (; k < nblk; k += LS_THREADS) { const float4 r = rows[k]; s[0] += r.x; s[1] += r.y; s[2] += r.z; s[3] += r.w; }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[c] += __shfl_down(s[c], off);
+  }
+  if (lane == 0) { sbuf[wave][0] = s[0]; sbuf[wave][1] = s[1]; sbuf[wave][2] = s[2]; sbuf[wave][3] = s[3]; }
+  __syncthreads();
+  if (tid == 0) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int w = 0; w < LS_THREADS / 64; w++) for (int c = 0; c < 4; c++) t[c] += sbuf[w][c];
+    if (mode == 0) scalars[0] = (float)(t[0] > 1.0 ? t[0] : 1.0);  // Loss.cs:444
+    if (mode == 1) for (int c = 1; c < 4; c++) scalars[4 + c] += (float)t[c];
   }
 }
 
@@ -367,38 +392,50 @@ loss_cls_kernel(LossArgs a, float* partial) {
 
 // ------------------------------------------------------------------ K6: CIoU + DFL loss + gradient (Loss.cs:134-166)
 // four consecutive lanes own one anchor (one side l,t,r,b each)
-template <class T>
+// RR = reg_max when it is the usual 16 (compile-time: the 16 bins stay in registers, rows move as 16-byte vectors), 0 = run-time.
+// Only foreground anchors (a few per cent) need the softmax at all; every other row just receives a zero gradient.
+template <class T, int RR>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_box_kernel(LossArgs a, float* partial) {
+  constexpr int EPL = Elem<T>::EPL;
+  constexpr int RM = RR ? RR : 32;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.A * 4;
   const bool inb = i < total;
   const long row = inb ? i >> 2 : 0;
   const int s = (int)(i & 3);
   const int lane = threadIdx.x & 63;
-  const int R = a.reg_max;
+  const int R = RR ? RR : a.reg_max;
   const int g = inb ? a.fg_gt[row] : -1;
-  const int b = (int)(row / a.A), ai = (int)(row % a.A);
-  float p[32];
+  float p[RM], xl[RM], gl[RM];
   float dist = 0.f, lse = 0.f;
   const T* lrow = (const T*)a.pd + row * a.ld_pd + s * R;
-  float xl[32];
-  if (inb) {
+#pragma unroll
+  for (int j = 0; j < RM; j++) gl[j] = 0.f;
+  if (g >= 0) {
+    if (RR) {
+#pragma unroll
+      for (int v = 0; v < RM / EPL; v++) ys_unpack<T>(ys_ld16(lrow + v * EPL), xl + v * EPL);
+    } else {
+      for (int j = 0; j < R; j++) xl[j] = Elem<T>::to_f(lrow[j]);
+    }
     float mx = -INFINITY;
-    for (int j = 0; j < R; j++) { xl[j] = Elem<T>::to_f(lrow[j]); mx = fmaxf(mx, xl[j]); }
+#pragma unroll
+    for (int j = 0; j < RM; j++) if (j < R) mx = fmaxf(mx, xl[j]);
     float se = 0.f;
-    for (int j = 0; j < R; j++) { p[j] = __expf(xl[j] - mx); se += p[j]; }
+#pragma unroll
+    for (int j = 0; j < RM; j++) if (j < R) { p[j] = __expf(xl[j] - mx); se += p[j]; }
     const float inv = 1.0f / se;
-    for (int j = 0; j < R; j++) { p[j] *= inv; dist += p[j] * (float)j; }
+#pragma unroll
+    for (int j = 0; j < RM; j++) if (j < R) { p[j] *= inv; dist += p[j] * (float)j; }
     lse = mx + __logf(se);
   }
-  // the four side distances of this anchor
+  // the four side distances of this anchor (all four lanes of an anchor share g, so they take the branch above together)
   const int base = lane & ~3;
   const float d0 = __shfl(dist, base + 0), d1 = __shfl(dist, base + 1), d2 = __shfl(dist, base + 2), d3 = __shfl(dist, base + 3);
   float l_iou = 0.f, l_dfl = 0.f;
-  float gl[32];
-  for (int j = 0; j < R; j++) gl[j] = 0.f;
   if (g >= 0) {
+    const int b = (int)(row / a.A), ai = (int)(row - (long)b * a.A);
     const AnchorInfo an = anchor_of(a, ai);
     const float w = a.tnorm[row];                      // weight = target_scores.sum(-1) (Loss.cs:138)
     const float tss = a.scalars[0];
@@ -411,7 +448,8 @@ loss_box_kernel(LossArgs a, float* partial) {
     if (s == 0) l_iou = (1.0f - ci.v) * w;
     // d(total)/d(dist_s): loss_box*B = hyp_box*B/tss * sum((1-ciou)*w); x1 = ax - l, y1 = ay - t, x2 = ax + r, y2 = ay + b
     const float gbox = a.hyp_box * (float)a.B / tss * w;
-    const float gd = (s < 2) ? (gbox * ci.g[s]) : (-gbox * ci.g[s]);   // -(dciou/dx1)*(-1) = +g ; -(dciou/dx2)*(+1) = -g
+    const float cg = (s == 0) ? ci.g[0] : (s == 1) ? ci.g[1] : (s == 2) ? ci.g[2] : ci.g[3];
+    const float gd = (s < 2) ? (gbox * cg) : (-gbox * cg);   // -(dciou/dx1)*(-1) = +g ; -(dciou/dx2)*(+1) = -g
     // DFL (Loss.cs:104-118, Tal.cs:365-379): target ltrb clamped to [0, reg_max-1-0.01]
     float t = (s == 0) ? (an.ax - tb[0]) : (s == 1) ? (an.ay - tb[1]) : (s == 2) ? (tb[2] - an.ax) : (tb[3] - an.ay);
     const float tmax = (float)(R - 1) - 0.01f;
@@ -419,18 +457,29 @@ loss_box_kernel(LossArgs a, float* partial) {
     const int tl = (int)t;
     const int tr = tl + 1;
     const float wl = (float)tr - t, wr = 1.0f - wl;
-    const float ce_l = lse - xl[tl], ce_r = lse - xl[tr];
+    float x_l = 0.f, x_r = 0.f;                         // xl[tl], xl[tr] without dynamic register indexing
+#pragma unroll
+    for (int j = 0; j < RM; j++) { x_l = (j == tl) ? xl[j] : x_l; x_r = (j == tr) ? xl[j] : x_r; }
+    const float ce_l = lse - x_l, ce_r = lse - x_r;
     l_dfl = (ce_l * wl + ce_r * wr) * 0.25f * w;        // mean over the 4 sides, x weight
     const float gdfl = a.hyp_dfl * (float)a.B / tss * w * 0.25f;
-    for (int j = 0; j < R; j++) {
-      float gj = gd * p[j] * ((float)j - dist);          // through softmax expectation
-      gj += gdfl * (p[j] - (j == tl ? wl : 0.f) - (j == tr ? wr : 0.f));
-      gl[j] = gj;
+#pragma unroll
+    for (int j = 0; j < RM; j++) {
+      if (j < R) {
+        float gj = gd * p[j] * ((float)j - dist);          // through softmax expectation
+        gj += gdfl * (p[j] - (j == tl ? wl : 0.f) - (j == tr ? wr : 0.f));
+        gl[j] = gj;
+      }
     }
   }
   if (inb) {
     T* drow = (T*)a.dpd + row * a.ld_pd + s * R;
-    for (int j = 0; j < R; j++) drow[j] = Elem<T>::from_f(gl[j]);
+    if (RR) {
+#pragma unroll
+      for (int v = 0; v < RM / EPL; v++) ys_st16(drow + v * EPL, ys_pack<T>(gl + v * EPL));
+    } else {
+      for (int j = 0; j < R; j++) drow[j] = Elem<T>::from_f(gl[j]);
+    }
   }
   block_partial4(0.f, 0.f, l_iou, l_dfl, partial + (long)blockIdx.x * 4);
 }
@@ -471,14 +520,16 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   float* part_c = part_t + (size_t)nb_a * 4;
   float* part_b = part_c + (size_t)nb_c * 4;
   YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
-  YS_LAUNCH((loss_decode_kernel<T>), nb_b, LS_THREADS, st, a);
+  if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b, LS_THREADS, st, a);
+  else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b, LS_THREADS, st, a);
   YS_LAUNCH((tal_metrics_kernel<T>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
   YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);
   YS_LAUNCH((loss_cls_kernel<T>), nb_c, LS_THREADS, st, a, part_c);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_c, nb_c, a.scalars, 1);
-  YS_LAUNCH((loss_box_kernel<T>), nb_b, LS_THREADS, st, a, part_b);
+  if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16>), nb_b, LS_THREADS, st, a, part_b);
+  else YS_LAUNCH((loss_box_kernel<T, 0>), nb_b, LS_THREADS, st, a, part_b);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_b, nb_b, a.scalars, 1);
   YS_LAUNCH(loss_items_kernel, 1, 64, st, a);
   return YS_OK;
