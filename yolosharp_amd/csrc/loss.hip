@@ -216,10 +216,13 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   for (int k = 0; k < a.topk; k++) {
     float bv = -1.f;
     int bi = 0x7fffffff;
+    // unconditional loads (a `continue` in front of the load made every iteration wait for its own L2 round trip: ~20 us per
+    // round); a thread visits its anchors in increasing order, so a strict '>' keeps the lowest index among equals
+#pragma unroll 8
     for (int ai = tid; ai < a.A; ai += LS_THREADS) {
-      if (s_taken[ai >> 5] & (1u << (ai & 31))) continue;
-      const float v = alr[ai];
-      if (v > bv || (v == bv && ai < bi)) { bv = v; bi = ai; }
+      float v = alr[ai];
+      v = (s_taken[ai >> 5] & (1u << (ai & 31))) ? -2.f : v;
+      if (v > bv) { bv = v; bi = ai; }
     }
     for (int m = 32; m >= 1; m >>= 1) {
       const float ov_ = __shfl_xor(bv, m);
