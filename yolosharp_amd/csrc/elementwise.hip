@@ -163,17 +163,20 @@ int ys_bn_eval_coeffs_launch(hipStream_t st, int C, const float* gamma, const fl
 }
 
 // ------------------------------------------------------------------ BN + act apply (training forward, pass 2)
-template <class T>
+// ACT is a template parameter: a run-time flag inside the unrolled element loop splits it into basic blocks (see chan_reduce);
+// rows * CG < 2^31 (every graph here) takes 32-bit index arithmetic instead of a ~80-instruction 64-bit division.
+template <class T, bool ACT>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_act_apply_kernel(const T* __restrict__ y, long rows, int C, const float* __restrict__ scale,
-                    const float* __restrict__ shift, int act, const T* __restrict__ res, int res_ldc, int res_coff,
-                    T* __restrict__ z, int z_ldc, int z_coff) {
+                    const float* __restrict__ shift, const T* __restrict__ res, int res_ldc, int res_coff,
+                    T* __restrict__ z, int z_ldc, int z_coff, int small) {
   constexpr int EPL = Elem<T>::EPL;
   const int CG = C / EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * CG) return;
-  const long row = i / CG;
-  const int c = (int)(i - row * CG) * EPL;
+  long row; int c;
+  if (small) { const unsigned iu = (unsigned)i, r = iu / (unsigned)CG; row = r; c = (int)(iu - r * (unsigned)CG) * EPL; }
+  else { row = i / CG; c = (int)(i - row * CG) * EPL; }
   float f[EPL], r[EPL], sc[EPL], sh[EPL];
   ys_unpack<T>(ys_ld16(y + row * C + c), f);
   if (res) ys_unpack<T>(ys_ld16(res + row * res_ldc + res_coff + c), r);
@@ -182,7 +185,7 @@ bn_act_apply_kernel(const T* __restrict__ y, long rows, int C, const float* __re
 #pragma unroll
   for (int e = 0; e < EPL; e++) {
     float u = f[e] * sc[e] + sh[e];
-    if (act) u = ys_silu(u);
+    if (ACT) u = ys_silu(u);
     if (res) u += r[e];
     f[e] = u;
   }
@@ -193,10 +196,11 @@ int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, 
                            int z_ldc, int z_coff) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
-  if (dtype == YS_BF16)
-    YS_LAUNCH((bn_act_apply_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)y, rows, C, scale, shift, act, (const bf16_t*)res, res_ldc, res_coff, (bf16_t*)z, z_ldc, z_coff);
-  else
-    YS_LAUNCH((bn_act_apply_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)y, rows, C, scale, shift, act, (const float*)res, res_ldc, res_coff, (float*)z, z_ldc, z_coff);
+  const int small = n < (1L << 31) ? 1 : 0;
+#define BA_LAUNCH(TT, AF) YS_LAUNCH((bn_act_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)y, rows, C, scale, shift, (const TT*)res, res_ldc, res_coff, (TT*)z, z_ldc, z_coff, small)
+  if (dtype == YS_BF16) { if (act) BA_LAUNCH(bf16_t, true); else BA_LAUNCH(bf16_t, false); }
+  else { if (act) BA_LAUNCH(float, true); else BA_LAUNCH(float, false); }
+#undef BA_LAUNCH
   return YS_OK;
 }
 
@@ -436,17 +440,18 @@ int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff
   return YS_OK;
 }
 
-template <class T>
+template <class T, bool ACT>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k2,
-                    const float* __restrict__ k3, int act, T* __restrict__ dy) {
+                    const float* __restrict__ k3, T* __restrict__ dy, int small) {
   constexpr int EPL = Elem<T>::EPL;
   const int CG = C / EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * CG) return;
-  const long row = i / CG;
-  const int c = (int)(i - row * CG) * EPL;
+  long row; int c;
+  if (small) { const unsigned iu = (unsigned)i, r = iu / (unsigned)CG; row = r; c = (int)(iu - r * (unsigned)CG) * EPL; }
+  else { row = i / CG; c = (int)(i - row * CG) * EPL; }
   float g[EPL], f[EPL], sc[EPL], sh[EPL], a2[EPL], a3[EPL];
   ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
   ys_unpack<T>(ys_ld16(y + row * C + c), f);
@@ -454,7 +459,7 @@ bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* 
 #pragma unroll
   for (int e = 0; e < EPL; e++) {
     const float u = f[e] * sc[e] + sh[e];
-    const float du = act ? g[e] * ys_silu_grad(u) : g[e];
+    const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];
     f[e] = sc[e] * du - a2[e] - f[e] * a3[e];
   }
   ys_st16(dy + row * C + c, ys_pack<T>(f));
@@ -463,10 +468,11 @@ int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc
                            int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
-  if (dtype == YS_BF16)
-    YS_LAUNCH((bn_bwd_apply_kernel<bf16_t>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, k2, k3, act, (bf16_t*)dy);
-  else
-    YS_LAUNCH((bn_bwd_apply_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)dz, dz_ldc, dz_coff, (const float*)y, rows, C, scale, shift, k2, k3, act, (float*)dy);
+  const int small = n < (1L << 31) ? 1 : 0;
+#define BB_LAUNCH(TT, AF) YS_LAUNCH((bn_bwd_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, scale, shift, k2, k3, (TT*)dy, small)
+  if (dtype == YS_BF16) { if (act) BB_LAUNCH(bf16_t, true); else BB_LAUNCH(bf16_t, false); }
+  else { if (act) BB_LAUNCH(float, true); else BB_LAUNCH(float, false); }
+#undef BB_LAUNCH
   return YS_OK;
 }
 
@@ -700,6 +706,33 @@ int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v
                     float beta2, float eps, float wd, float bc1, float bc2) {
   if (n <= 0) return YS_OK;
   YS_LAUNCH(adamw_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
+  return YS_OK;
+}
+
+// All parameter groups in one launch: the flat parameter vector is a few contiguous [offset, count) ranges (segment x group,
+// model.hip layout_params), each with its own learning rate.
+__global__ void __launch_bounds__(EW_THREADS)
+adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                    AdamwRanges rg, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float lr = 0.f; bool hit = false;
+#pragma unroll
+  for (int k = 0; k < YS_ADAMW_MAX_RANGES; k++)
+    if (k < rg.n && i >= rg.off[k] && i < rg.off[k] + rg.count[k]) { lr = rg.lr[k]; hit = true; }
+  if (!hit) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+  const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+}
+int ys_adamw_ranges_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, const AdamwRanges& rg,
+                           float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+  if (n <= 0 || rg.n <= 0) return YS_OK;
+  YS_LAUNCH(adamw_ranges_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, g, m, v, n, rg, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
   return YS_OK;
 }
 

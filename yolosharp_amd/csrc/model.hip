@@ -1508,13 +1508,15 @@ int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, flo
   YsTimer timer(m->ctx, "optim");
   m->step += 1;
   const float bc1 = 1.0f - powf(beta1, (float)m->step), bc2 = 1.0f - powf(beta2, (float)m->step);
+  AdamwRanges rg{};                          // one launch for the 3 segments x 3 groups (was nine ~5 us launches)
   for (int seg = 0; seg < 3; seg++)
     for (int g = 0; g < 3; g++) {
       const auto r = m->seg_group[seg][g];
-      const float lr = lr_per_group[g < ngroups ? g : ngroups - 1];
-      YS_TRY(ys_adamw_launch(m->ctx->stream, m->params + r.off, m->grads + r.off, m->adam_m + r.off, m->adam_v + r.off, r.count, lr,
-                             beta1, beta2, eps, wd, bc1, bc2));
+      if (r.count <= 0) continue;
+      rg.off[rg.n] = r.off; rg.count[rg.n] = r.count; rg.lr[rg.n] = lr_per_group[g < ngroups ? g : ngroups - 1];
+      rg.n++;
     }
+  YS_TRY(ys_adamw_ranges_launch(m->ctx->stream, m->params, m->grads, m->adam_m, m->adam_v, m->n_params, rg, beta1, beta2, eps, wd, bc1, bc2));
   m->weights_dirty = true; m->eval_coeffs_dirty = true;
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;

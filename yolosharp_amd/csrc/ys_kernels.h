@@ -119,6 +119,10 @@ int ys_upsample2x_bwd_launch(hipStream_t st, int dtype, const void* dy, int dy_l
 int ys_copy_view_launch(hipStream_t st, int dtype, const void* src, int s_ldc, int s_coff, long rows, int C, void* dst,
                         int d_ldc, int d_coff, int accumulate);
 // AdamW over a flat range
+#define YS_ADAMW_MAX_RANGES 9
+struct AdamwRanges { int n; long off[YS_ADAMW_MAX_RANGES]; long count[YS_ADAMW_MAX_RANGES]; float lr[YS_ADAMW_MAX_RANGES]; };
+int ys_adamw_ranges_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, const AdamwRanges& rg,
+                           float beta1, float beta2, float eps, float wd, float bc1, float bc2);
 int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                     float beta2, float eps, float wd, float bc1, float bc2);
 int ys_fill_launch(hipStream_t st, float* p, long n, float v);
