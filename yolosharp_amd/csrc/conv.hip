@@ -497,7 +497,10 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
         for (int r = 0; r < 4; r++) {
           const int cc = (c + r) < a.Cout ? (c + r) : 0;
           v[r] += a.shift[cc];
-          if (a.act) v[r] = ys_silu(v[r]);
+        }
+        if (a.act) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = ys_silu(v[r]);
         }
       }
 #pragma unroll
@@ -544,7 +547,13 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
         }
         if (bn_eval) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) { f[e] = f[e] * sc[e] + sh[e]; if (a.act) f[e] = ys_silu(f[e]); if (c + e >= a.Cout) f[e] = 0.f; }
+          for (int e = 0; e < 8; e++) f[e] = f[e] * sc[e] + sh[e];
+          if (a.act) {                        // one uniform branch around the unrolled loop, not one per element
+#pragma unroll
+            for (int e = 0; e < 8; e++) f[e] = ys_silu(f[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) if (c + e >= a.Cout) f[e] = 0.f;
           if (!(rb || a.accumulate)) val = ys_pack<T>(f);
         }
         T* yp = (T*)(yb + rofs + c * 2);
