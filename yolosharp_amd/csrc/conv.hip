@@ -214,20 +214,29 @@ conv_igemm_kernel(ConvArgs a) {
       px[mf] = xb + (pix * a.in_ldc + a.in_coff) * (long)sizeof(T);
     }
   };
-  auto load_step = [&](uint4* xf, int s) {
+  // Loads are issued unconditionally (padding pixels point at pixel 0, a channel tail re-reads channel 0) and masked when the
+  // fragment is consumed: a load under an exec mask makes the compiler wait with vmcnt(0) BEFORE the MFMAs of the current step,
+  // which serialises the one-step-ahead prefetch with the arithmetic it is meant to hide behind.
+  auto load_step = [&](uint4* xf, int s) -> unsigned {
     const int c = (4 * s + q) * EPL;
+    const bool cok = c < a.Cin;
+    const long cb = (long)(cok ? c : 0) * (long)sizeof(T);
+    unsigned okm = 0;
 #pragma unroll
     for (int mf = 0; mf < MR; mf++) {
-      xf[mf] = ys_zero16();
-      if (pvt[mf] && c < a.Cin) xf[mf] = ys_ld16(px[mf] + (long)c * (long)sizeof(T));
+      xf[mf] = ys_ld16(px[mf] + cb);
+      okm |= (pvt[mf] && cok) ? (1u << mf) : 0u;
     }
+    return okm;
   };
   uint4 xc[MR], xn[MR];
-#pragma unroll
-  for (int mf = 0; mf < MR; mf++) xn[mf] = ys_zero16();
   int ltap = 0, ls = 0, lkh = 0, lkw = 0;   // position of the NEXT load
   set_tap(0, 0);
-  load_step(xc, 0);
+  {
+    const unsigned m0k = load_step(xc, 0);
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) if (!((m0k >> mf) & 1u)) xc[mf] = ys_zero16();
+  }
   int lt = 0;                                // k-step index inside the staged weight group
   for (int t = 0; t < total; t++) {
     // advance the load position and prefetch step t+1
@@ -237,7 +246,7 @@ conv_igemm_kernel(ConvArgs a) {
       if (lkw == a.KW) { lkw = 0; lkh++; }
       if (ltap < taps) set_tap(lkh, lkw);
     }
-    if (t + 1 < total) load_step(xn, ls);
+    const unsigned nmask = load_step(xn, ls);   // (past the last step: a harmless re-read)
     if (lt == 0) {
       // stage the weights of k-steps [t, t+GSTEPS) for this workgroup's BN output channels
       __syncthreads();
@@ -263,7 +272,7 @@ conv_igemm_kernel(ConvArgs a) {
       for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf, xc[mf], acc[mf][nf]);
     }
 #pragma unroll
-    for (int mf = 0; mf < MR; mf++) xc[mf] = xn[mf];
+    for (int mf = 0; mf < MR; mf++) xc[mf] = ((nmask >> mf) & 1u) ? xn[mf] : ys_zero16();
     lt++;
     if (lt == GSTEPS) lt = 0;
   }
