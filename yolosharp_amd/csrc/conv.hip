@@ -341,7 +341,11 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
     }
   }
 
+  // All loads of a fetch are issued unconditionally (clamped to a valid address) and masked when the registers are written to
+  // LDS: loads under exec masks make the compiler wait for them with vmcnt(0) before the MFMAs they are meant to overlap.
   uint4 rp[NPU], rw[NWU];
+  unsigned pmask = 0, wmask = 0;
+  const long safe_x = (long)a.in_coff * (long)sizeof(T);
   auto fetch = [&](int tile, int chunk) {
     int t = tile;
     const int txi = t % a.tiles_x; t /= a.tiles_x;
@@ -353,32 +357,33 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
     const int PH = iy_hi - iy_lo + 1, PW = ix_hi - ix_lo + 1;
     const int npatch = PH * PW * 4;
     const int c0 = chunk * 4 * EPL;
+    pmask = 0;
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       const int idx = tid + C3_THREADS * k;
-      uint4 v = ys_zero16();
-      if (idx < npatch) {
-        const int pix = idx >> 2, u = idx & 3;
-        const int r = pix / PW, cc = pix - r * PW;
-        const int iy = iy_lo + r, ix = ix_lo + cc;
-        const int ch = c0 + u * EPL;
-        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && ch < a.Cin && !(a.dbg & 1))
-          v = ys_ld16(xb + ((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) + a.in_coff + ch) * (long)sizeof(T));
-      }
-      rp[k] = v;
+      const int pix = idx >> 2, u = idx & 3;
+      const int r = pix / PW, cc = pix - r * PW;
+      const int iy = iy_lo + r, ix = ix_lo + cc;
+      const int ch = c0 + u * EPL;
+      const bool ok = (bool)((int)(idx < npatch) & (int)((unsigned)iy < (unsigned)a.Hin) & (int)((unsigned)ix < (unsigned)a.Win) &
+                             (int)(ch < a.Cin) & (int)!(a.dbg & 1));
+      long off = ((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) + a.in_coff + ch) * (long)sizeof(T);
+      off = ok ? off : safe_x;
+      rp[k] = ys_ld16(xb + off);
+      pmask |= (unsigned)ok << k;
     }
     if (!wres) {
+      wmask = 0;
 #pragma unroll
       for (int k = 0; k < NWU; k++) {
         const int idx = tid + C3_THREADS * k;
-        uint4 v = ys_zero16();
-        if (idx < BN * 36) {
-          const int n = idx / 36, tu = idx - n * 36;
-          const int ch = c0 + (tu & 3) * EPL;
-          if (n0 + n < a.Cout && ch < a.Cin)
-            v = ys_ld16(wb + ((long)(n0 + n) * Ktot + (long)(tu >> 2) * a.Cin + ch) * (long)sizeof(T));
-        }
-        rw[k] = v;
+        const int n = idx / 36, tu = idx - n * 36;
+        const int ch = c0 + (tu & 3) * EPL;
+        const bool ok = (bool)((int)(idx < BN * 36) & (int)(n0 + n < a.Cout) & (int)(ch < a.Cin));
+        long off = ((long)(n0 + n) * Ktot + (long)(tu >> 2) * a.Cin + ch) * (long)sizeof(T);
+        off = ok ? off : 0;
+        rw[k] = ys_ld16(wb + off);
+        wmask |= (unsigned)ok << k;
       }
     }
   };
@@ -395,20 +400,23 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       const int idx = tid + C3_THREADS * k;
-      if (idx < PATCH_DATA) sP[(idx >> 2) * PP + (idx & 3)] = rp[k];
+      if (idx < PATCH_DATA) sP[(idx >> 2) * PP + (idx & 3)] = ((pmask >> k) & 1u) ? rp[k] : ys_zero16();
     }
     if (!wres) {
 #pragma unroll
       for (int k = 0; k < NWU; k++) {
         const int idx = tid + C3_THREADS * k;
-        if (idx < BN * 36) { const int n = idx / 36; sW[n * wpitch + (idx - n * 36)] = rw[k]; }
+        if (idx < BN * 36) { const int n = idx / 36; sW[n * wpitch + (idx - n * 36)] = ((wmask >> k) & 1u) ? rw[k] : ys_zero16(); }
       }
     }
     __syncthreads();
-    // ---- prefetch the next (tile, chunk)
+    // ---- prefetch the next (tile, chunk); past the end it re-fetches the current one (unconditional, see above)
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
-    if (ntile < ntiles) fetch(ntile, nchunk);
+    {
+      const bool more = ntile < ntiles;
+      fetch(more ? ntile : tile, more ? nchunk : chunk);
+    }
     // ---- compute this chunk from LDS
     if (chunk == 0) {
       int t = tile;
