@@ -97,6 +97,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or args.force_dist
+    if rank != 0:   # only rank 0 owns stdout (one JSON line); library chatter of the other ranks must not follow it in the merged stream
+        try:
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        except Exception:
+            pass
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -261,7 +266,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(nc, H, W)
         else:
             out["cpu_baseline"] = None
+        # the JSON line must be the LAST line of rank 0's stdout: libraries (RCCL prints "Librccl path : ..." through C stdio,
+        # block-buffered when piped) would otherwise land after it at exit.  Flush C stdio first, print, then close fd 1.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
+        try:
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        except Exception:
+            pass
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
