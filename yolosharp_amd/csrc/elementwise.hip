@@ -21,21 +21,65 @@ pack_input_kernel(const SRC* __restrict__ x, int B, int C, int h, int w, int H, 
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long HW = (long)H * W;
   if (i >= (long)B * HW) return;
-  const long b = i / HW, p = i - b * HW;
-  const int py = (int)(p / W), px = (int)(p - (long)py * W);
+  long b; int py, px;
+  if ((long)B * HW < (1L << 31)) {                        // 32-bit index arithmetic (two 64-bit divisions are ~160 VALU instructions)
+    const unsigned iu = (unsigned)i, hw = (unsigned)HW, bu = iu / hw, pu = iu - bu * hw;
+    b = bu; py = (int)(pu / (unsigned)W); px = (int)(pu - (unsigned)py * (unsigned)W);
+  } else {
+    b = i / HW; const long p = i - b * HW;
+    py = (int)(p / W); px = (int)(p - (long)py * W);
+  }
   const bool in = py < h && px < w;                       // bottom / right padding (Detector.cs:33-41)
+  const bool unit = div == 1.0f;                          // fp32 images in [0,1]: no division at all
   for (int c0 = 0; c0 < cpad; c0 += EPL) {
     float f[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
       const int c = c0 + e;
-      f[e] = c < C ? (in ? (float)x[((b * C + c) * h + py) * (long)w + px] / div : padv) : 0.f;
+      float v = 0.f;
+      if (c < C) {
+        v = padv;
+        if (in) { const float r = (float)x[((b * C + c) * h + py) * (long)w + px]; v = unit ? r : r / div; }
+      }
+      f[e] = v;
     }
     ys_st16(y + i * cpad + c0, ys_pack<T>(f));
   }
 }
+// fp32 image planes, C <= EPL (one 16-byte vector per pixel), W % 4 == 0: four consecutive pixels per thread -- 16-byte plane loads,
+// 64 contiguous bytes written
+template <class T>
+__global__ void __launch_bounds__(EW_THREADS)
+pack_input4_kernel(const float* __restrict__ x, long npix4, int C, long HW, T* __restrict__ y) {
+  constexpr int EPL = Elem<T>::EPL;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // group of 4 pixels
+  if (i >= npix4) return;
+  const long pix = i * 4;
+  const long b = pix / HW, p = pix - b * HW;
+  float4 pl[EPL];
+#pragma unroll
+  for (int c = 0; c < EPL; c++) pl[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < EPL; c++)
+    if (c < C) pl[c] = *(const float4*)(x + (b * C + c) * HW + p);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float f[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; c++) f[c] = k == 0 ? pl[c].x : k == 1 ? pl[c].y : k == 2 ? pl[c].z : pl[c].w;
+    ys_st16(y + (pix + k) * EPL, ys_pack<T>(f));
+  }
+}
+
 int ys_pack_input_launch(hipStream_t st, int dtype, const float* x, int B, int C, int H, int W, int cpad, void* y) {
   const long n = (long)B * H * W;
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  if (cpad == epl && C <= epl && C <= 4 && W % 4 == 0 && ((size_t)x & 15) == 0) {   // the model's image input
+    const long n4 = n / 4;
+    if (dtype == YS_BF16) YS_LAUNCH((pack_input4_kernel<bf16_t>), ys_cdiv(n4, EW_THREADS), EW_THREADS, st, x, n4, C, (long)H * W, (bf16_t*)y);
+    else YS_LAUNCH((pack_input4_kernel<float>), ys_cdiv(n4, EW_THREADS), EW_THREADS, st, x, n4, C, (long)H * W, (float*)y);
+    return YS_OK;
+  }
   if (dtype == YS_BF16) YS_LAUNCH((pack_input_kernel<bf16_t, float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, H, W, H, W, cpad, 1.0f, 0.0f, (bf16_t*)y);
   else YS_LAUNCH((pack_input_kernel<float, float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, x, B, C, H, W, H, W, cpad, 1.0f, 0.0f, (float*)y);
   return YS_OK;
