@@ -1110,15 +1110,18 @@ static void conv_launch_t(hipStream_t st, const ConvArgs& a) {
 // once); MR = pixel fragments per wave: 2 (occupancy: three workgroups per CU overlap each other's load and
 // epilogue phases; larger MR measured slower), 1 on small feature maps (20x20, 40x40 at the deep end of the net)
 // so that the grid still covers the 256 CUs a few times.
-static int conv_pick_nr(int cout) {
+static int conv_pick_nr(int cout, int M = 1 << 30) {
   const int nfr = (cout + 15) / 16;
   if (nfr <= 6) return nfr;
+  // small feature maps: narrower column tiles give the chip more workgroups (Cin = 128 -> 256 stride-2 layer at 20x20: 119 -> 83 us)
+  static const int smallm = getenv("YS_IG_SMALLM") ? atoi(getenv("YS_IG_SMALLM")) : 30000;
+  if (M <= smallm && nfr % 4 == 0) return 4;
   if (nfr % 8 == 0 || nfr > 10) return 8;
   if (nfr % 5 == 0) return 5;
   return 4;
 }
 static int conv_pick_mr(int M, int cout) {
-  const int nr = conv_pick_nr(cout);
+  const int nr = conv_pick_nr(cout, M);
   const int gy = ys_cdiv(cout, nr * 16);
   int mr = 2;   // measured: 2 fragments per wave (<= ~130 registers, 3 workgroups per CU) beats 4-8 fragments at 2 per CU
   while (mr > 1 && (long)ys_cdiv(M, 64 * mr) * gy < 768) mr >>= 1;
@@ -1174,7 +1177,7 @@ static int conv_launch_dtype(hipStream_t st, const ConvArgs& a) {
     ys_set_error("conv3x3: no kernel for tile MR=%d NR=%d", t.mr, p.nr);
     return YS_ERR_UNSUPPORTED;
   }
-  const int nr = conv_pick_nr(a.Cout), mr = conv_pick_mr(a.M, a.Cout);
+  const int nr = conv_pick_nr(a.Cout, a.M), mr = conv_pick_mr(a.M, a.Cout);
 #define CV(M_, N_) if (mr == M_ && nr == N_) { conv_launch_t<T, M_, N_>(st, a); return YS_OK; }
   CV(1, 1) CV(2, 1) CV(4, 1) CV(8, 1)
   CV(1, 2) CV(2, 2) CV(4, 2) CV(8, 2)
