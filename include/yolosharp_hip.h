@@ -67,7 +67,9 @@ typedef struct ys_model_desc {
   int32_t width;      /* input W (multiple of 32) */
   int32_t max_batch;  /* capacity; forward may use any B <= max_batch */
   int32_t dtype;      /* ys_dtype: YS_F32 = parity path, YS_BF16 = performance path */
-  int32_t max_labels; /* capacity of ground-truth rows per batch for the loss (0 = default 64*max_batch) */
+  int32_t max_labels; /* initial capacity of ground-truth rows PER IMAGE for the loss (0 = 64).  Not a limit: host-label loss calls
+                         grow the workspace to the batch's largest per-image count (the reference pads to counts.max(),
+                         Utils/Loss.cs:363-390); device-label callers reserve with ys_model_reserve_labels */
 } ys_model_desc;
 
 YS_API int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out);
@@ -101,18 +103,32 @@ YS_API int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device
  * "pred" is [B,4+nc+nm,A] (raw mask coefficients appended).  "dboxes" | "dscores" | "dmask_coefficient" | "dproto"
  * return the loss gradients w.r.t. those outputs after a loss call. */
 YS_API int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count);
+/* The criterion's `preds` argument supplied by the caller (Utils/Loss.cs:411 `forward(preds, batch)`): host fp32 head outputs in the
+ * reference layout -- boxes [B,4*reg_max,A], scores [B,nc,A], and for Segment models mask_coefficient [B,nm,A] + proto
+ * [B,nm,H/4,W/4] (NULL otherwise) -- become the engine's head buffers, as if a forward had produced them.  ys_loss_detect /
+ * ys_loss_segment and the "dboxes" / "dscores" / "dmask_coefficient" / "dproto" outputs then work on them; ys_model_backward
+ * is refused (there is no graph state behind such preds). */
+YS_API int ys_model_set_preds(ys_model* m, int batch, const float* boxes, const float* scores,
+                              const float* mask_coefficient, const float* proto);
 /* Device pointer of the eval prediction [B,4+nc,A] fp32 (input of ys_nms_batched). */
 YS_API int ys_model_pred_device(ys_model* m, float** dptr);
 
 /* v8DetectionLoss.forward (Utils/Loss.cs:411-484) + TaskAlignedAssigner (Utils/Tal.cs:13-258)
  * + BboxLoss/DFLoss (Loss.cs:94-167) + bbox_iou CIoU (Utils/Metrics.cs:36-111), and d(sum(loss*B))/d(preds).
  * Labels use the collate contract (Data/YoloDataLoader.cs:18-44): batch_idx[n], cls[n], bboxes[n,4]
- * normalised cxcywh, all fp32.  Asynchronous: results stay on the device until ys_loss_read. */
+ * normalised cxcywh, all fp32.  Asynchronous: results stay on the device until ys_loss_read.
+ * Works after a training-mode forward (the step's criterion, Amp.cs:338-348) and after an eval-mode forward (the validation loss
+ * on the eval preds, Models/Detector.cs:94-97); only ys_model_backward needs the training-mode forward.
+ * Label capacity: with host labels the padded ground-truth workspace grows to the batch's largest per-image label count, like
+ * the reference's counts.max() (Loss.cs:376-380).  With device labels (no host sync) an image holding more labels than the
+ * workspace makes ys_loss_read* return YS_ERR_INVALID_ARG -- never a silently truncated assignment; reserve first. */
 YS_API int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
                           int n_labels, int on_device);
 /* loss_items[3] = (box, cls, dfl) un-multiplied (the reference's loss_detach), *loss_sum = sum(items)*B
  * (the scalar the reference calls backward() on, Amp.cs:340).  Synchronises the stream. */
 YS_API int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum);
+/* Grow the per-image ground-truth capacity of the loss workspace ahead of device-label calls (no-op when already large enough). */
+YS_API int ys_model_reserve_labels(ys_model* m, int per_image);
 
 /* v8SegmentationLoss.forward (Utils/Loss.cs:688-863) for task = YS_SEGMENT models: the detection terms and
  * assignment above, then calculate_segmentation_loss / single_mask_loss (:794-863) with Ops.crop_mask

@@ -41,8 +41,13 @@ def test_predict_and_val(backend, engine):
     d = {k: v.numpy() for k, v in tb.items()}
     d["images"] = torch.rand(B, 3, H, W, generator=g).numpy()
     bn_before = m.state_dict()["model.0.bn.running_mean"].copy()
-    loss_items, (P, R, m50, m5095) = det.Val([d], conf_thres=0.001)
-    assert loss_items.shape == (3,) and np.all(np.isfinite(loss_items))
+    empty = {"images": d["images"], "batch_idx": np.zeros(0, np.float32), "cls": np.zeros(0, np.float32), "bboxes": np.zeros((0, 4), np.float32)}
+    loss_items, (P, R, m50, m5095) = det.Val([empty, d], conf_thres=0.001)      # an empty batch is skipped (Detector.cs:91-94)
+    # the validation loss is the criterion on the EVAL-mode preds (running statistics), Detector.cs:95-97
+    with torch.no_grad():
+        _, rpreds = ref(torch.from_numpy(d["images"]))
+        _, ritems = O.v8DetectionLoss(nc)(rpreds, tb)
+    assert loss_items.shape == (3,) and np.allclose(loss_items, ritems.numpy(), rtol=1e-3, atol=1e-5), (loss_items, ritems)
     assert 0.0 <= m5095 <= m50 <= 1.0 and 0.0 <= P <= 1.0
     assert np.array_equal(bn_before, m.state_dict()["model.0.bn.running_mean"])
     m.close()

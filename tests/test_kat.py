@@ -1,0 +1,129 @@
+"""Independent known-answer tests (the oracle was parity-unpinned).
+
+tests/kat_ref.py is a SECOND restatement of the cited C# -- scalar fp64 Python, explicit loops, finite-difference gradients --
+that shares nothing with oracle/yolo_oracle.py (no torch, no autograd).  tests/golden/kat_loss.json holds its answers for a
+hand-built case (tests/golden/make_kat.py).  Here both the ATen oracle AND the HIP kernels are checked against those answers:
+CIoU, DFL incl. both clamps, TAL (double-claimed anchor, zero-metric ties, tiny-box inflation, padded GT row), the three loss
+items, d(loss)/d(boxes, scores), and BatchNorm's batch / running statistics (momentum 0.03, unbiased running_var)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import kat_ref as K
+from conftest import BACKENDS
+from oracle import yolo_oracle as O
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_loss.json")))
+
+
+def _case():
+    k = KAT
+    return (np.array(k["boxes"], np.float64), np.array(k["scores"], np.float64),
+            {"batch_idx": np.array(k["batch_idx"], np.float32), "cls": np.array(k["cls"], np.float32),
+             "bboxes": np.array(k["bboxes"], np.float32)})
+
+
+def test_kat_file_reproduces():
+    """The committed answers are what kat_ref computes today (the fixture did not drift from its generator)."""
+    k = KAT
+    items, total, tg = K.detection_loss(k["boxes"], k["scores"], k["batch_idx"], k["cls"], k["bboxes"], k["H"], k["W"], k["nc"])
+    assert np.allclose(items, k["items"], rtol=1e-12) and abs(total - k["total"]) < 1e-9
+    assert [[bool(v) for v in t[0]] for t in tg] == k["fg"] and [t[1] for t in tg] == k["gt_idx"]
+    for (b1, b2, want) in k["ciou_pairs"]:
+        assert abs(K.ciou(b1, b2) - want) < 1e-14
+    # closed-form spot checks of the independent restatement itself
+    assert abs(K.ciou((1, 1, 3, 3), (1, 1, 3, 3)) - (4.0 / (4.0 + 1e-7))) < 1e-12            # identical boxes: iou = 4/(4+eps), no penalty
+    iou = 9.0 / (16 + 16 - 9 + 1e-7)                                                          # (0,0,4,4) vs (1,1,5,5): v = 0
+    assert abs(K.ciou((0, 0, 4, 4), (1, 1, 5, 5)) - (iou - 2.0 / (50 + 1e-7))) < 1e-12
+    lg = k["dfl_logits"]
+    ls = K.log_softmax(lg)
+    assert abs(K.dfl(lg, 7.3) - (-(ls[7] * 0.7 + ls[8] * 0.3))) < 1e-9
+    assert abs(K.dfl(lg, 20.0) - K.dfl(lg, 14.99)) < 1e-15 and abs(K.dfl(lg, 14.99) - (-(ls[14] * 0.01 + ls[15] * 0.99))) < 1e-9
+    assert abs(K.dfl(lg, 0.0) + ls[0]) < 1e-12
+
+
+def test_oracle_matches_kat():
+    """ATen-CPU oracle vs the independent fp64 answers: scalar CIoU / DFL, assignment, loss items, autograd vs finite differences."""
+    k = KAT
+    for (b1, b2, want) in k["ciou_pairs"]:
+        got = float(O.bbox_iou_ciou(torch.tensor([b1], dtype=torch.float64), torch.tensor([b2], dtype=torch.float64)))
+        assert abs(got - want) < 1e-9, (b1, b2, got, want)
+    lg = torch.tensor(k["dfl_logits"], dtype=torch.float64)
+    for t, want in k["dfl_cases"]:
+        tt = torch.tensor([t], dtype=torch.float64).clamp(0, 16 - 1 - 0.01)                  # Loss.cs:108
+        tl = tt.long(); wl = (tl + 1) - tt
+        got = float(torch.nn.functional.cross_entropy(lg[None], tl) * wl + torch.nn.functional.cross_entropy(lg[None], tl + 1) * (1 - wl))
+        assert abs(got - want) < 1e-9, (t, got, want)
+    bx, sc, batch = _case()
+    B, nc = k["B"], k["nc"]
+    for dt, tol in ((torch.float64, 1e-7), (torch.float32, 2e-4)):
+        boxes = torch.tensor(bx, dtype=dt, requires_grad=True)
+        scores = torch.tensor(sc, dtype=dt, requires_grad=True)
+        feats = [torch.zeros(B, 1, k["H"] // s, k["W"] // s, dtype=dt) for s in (8, 16, 32)]
+        tb = {kk: torch.from_numpy(v) for kk, v in batch.items()}
+        loss, items, tg = O.v8DetectionLoss(nc)({"boxes": boxes, "scores": scores, "feats": feats}, tb, return_targets=True)
+        assert np.allclose(items.detach().numpy(), k["items"], rtol=tol, atol=tol), (dt, items, k["items"])
+        assert tg["fg_mask"].tolist() == k["fg"]
+        fg = np.array(k["fg"])
+        assert np.array_equal(tg["target_gt_idx"].numpy()[fg], np.array(k["gt_idx"])[fg])
+        assert np.allclose(tg["target_scores"].detach().numpy(), np.array(k["target_scores"]), rtol=tol * 10, atol=tol)
+        loss.sum().backward()
+        for got, want in ((boxes.grad, k["dboxes"]), (scores.grad, k["dscores"])):
+            want = np.array(want)
+            assert np.abs(got.numpy() - want).max() <= max(tol * 50, 2e-5) * np.abs(want).max(), dt
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_engine_loss_matches_kat(backend, engine):
+    """HIP v8DetectionLoss on caller-supplied preds (ys_model_set_preds) vs the independent answers: items within 1e-3
+    (north star), d(sum(loss)*B)/d(boxes), d(scores) within 1e-3 of the gradient's max."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    k = KAT
+    bx, sc, batch = _case()
+    m = Yolov8(engine, nc=k["nc"], size="n", height=k["H"], width=k["W"], max_batch=k["B"], dtype="f32")
+    assert m.A == bx.shape[2]
+    m.set_preds({"boxes": bx, "scores": sc})
+    loss, items = v8DetectionLoss(m)(None, batch)
+    assert np.allclose(items, k["items"], rtol=1e-3, atol=1e-5), (items, k["items"])
+    assert np.allclose(loss.sum(), k["total"], rtol=1e-3)
+    for key, want in (("dboxes", k["dboxes"]), ("dscores", k["dscores"])):
+        want = np.array(want)
+        got = m.get_output(key)
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (key, np.abs(got - want).max(), np.abs(want).max())
+    from yolosharp_amd import YsError
+    with pytest.raises(YsError):
+        m.backward()                                       # no graph state behind caller-supplied preds
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_bn_silu_matches_kat(backend, engine):
+    """Conv unit (1x1 conv + BatchNorm(eps 1e-3, momentum 0.03) + SiLU, Convs.cs:36-62) in training mode: outputs, running_mean
+    and the UNBIASED running_var against the fp64 loops; same check for the oracle module."""
+    from yolosharp_amd import blocks
+    bn = KAT["bn"]
+    Cc, B, Hh, Ww = 4, 2, 4, 4
+    x = np.array(bn["x"], np.float32).reshape(B, Hh, Ww, Cc).transpose(0, 3, 1, 2).copy()     # NHWC rows -> NCHW
+    want = np.array(bn["out"]).reshape(B, Hh, Ww, Cc).transpose(0, 3, 1, 2)
+    sd = {"conv.weight": np.array(bn["w"], np.float32).reshape(Cc, Cc, 1, 1), "bn.weight": np.array(bn["gamma"], np.float32),
+          "bn.bias": np.array(bn["beta"], np.float32), "bn.running_mean": np.array(bn["running_mean"], np.float32),
+          "bn.running_var": np.array(bn["running_var"], np.float32), "bn.num_batches_tracked": np.zeros(1, np.float32)}
+    ref = O.Conv(Cc, Cc, 1, 1).train()
+    ref.load_state_dict({kk: torch.from_numpy(v).reshape(()).long() if "num_batches" in kk else torch.from_numpy(v) for kk, v in sd.items()})
+    ry = ref(torch.from_numpy(x)).detach().numpy()
+    assert np.abs(ry - want).max() < 1e-5
+    assert np.allclose(ref.bn.running_mean.numpy(), bn["new_running_mean"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(ref.bn.running_var.numpy(), bn["new_running_var"], rtol=1e-5)
+    blk = blocks.Conv(engine, Cc, Cc, 1, 1, True, height=Hh, width=Ww, max_batch=B, dtype="f32")
+    blk.load_state_dict(sd)
+    blk.train()
+    y = blk.forward(x)
+    assert np.abs(y - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+    after = blk.state_dict()
+    assert np.allclose(after["bn.running_mean"], bn["new_running_mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(after["bn.running_var"], bn["new_running_var"], rtol=1e-4)
+    assert after["bn.num_batches_tracked"][0] == 1
+    blk.close()

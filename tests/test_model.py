@@ -142,6 +142,55 @@ def test_loss_edge_cases(backend, engine):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_crowded_image_more_labels_than_initial_capacity(backend, engine):
+    """The reference pads every image to the batch's largest label count, whatever it is (Loss.cs:363-390; mosaic batches
+    exceed 64 per image).  Host labels grow the engine's workspace; device labels past the capacity are REFUSED, never truncated."""
+    from yolosharp_amd import YsError
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    B, H, W, nc = 2, 64, 64, 80
+    ref = make_ref(seed=5)
+    m = Yolov8(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32", max_labels=8)
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(6))
+    rng = np.random.default_rng(7)
+    n0, n1 = 71, 3                                            # image 0 carries 71 labels (> 64 and > the initial 8)
+    wh = rng.uniform(0.08, 0.5, (n0 + n1, 2)); c = wh / 2 + rng.uniform(0, 1, (n0 + n1, 2)) * (1 - wh)
+    batch = {"batch_idx": torch.tensor([0.0] * n0 + [1.0] * n1), "cls": torch.from_numpy(rng.integers(0, nc, n0 + n1).astype(np.float32)),
+             "bboxes": torch.from_numpy(np.concatenate([c, wh], 1).astype(np.float32))}
+    nb = {k: v.numpy() for k, v in batch.items()}
+    m.train(); ref.train()
+    m.forward(x.numpy(), fetch=False)
+    _, rpreds = ref(x)
+    rloss, ritems = O.v8DetectionLoss(nc)(rpreds, batch)
+    crit = v8DetectionLoss(m)
+    loss, items = crit(None, nb)                               # host labels: workspace grows to 71 -> 80
+    assert np.allclose(items, ritems.numpy(), rtol=1e-3, atol=1e-5), (items, ritems)
+    rloss.sum().backward()
+    m.zero_grad(); m.backward()
+    g = m.grads()
+    for name in ("model.22.cv3.0.2.bias", "model.22.cv2.1.2.weight", "model.0.conv.weight"):
+        r = dict(ref.named_parameters())[name].grad.numpy()
+        assert np.abs(g[name] - r).max() <= 2e-3 * np.abs(r).max() + 1e-7, name
+    # device-resident labels: no host sync can size the workspace -> the first synchronising read refuses the truncated result
+    m2 = Yolov8(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32", max_labels=8)
+    m2.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    m2.train(); m2.forward(x.numpy(), fetch=False)
+    d = [engine.to_device(nb[k]) for k in ("batch_idx", "cls", "bboxes")]
+    crit2 = v8DetectionLoss(m2)
+    crit2.forward_device(d[0], d[1], d[2], n0 + n1)
+    with pytest.raises(YsError) as ei:
+        crit2.read()
+    assert ei.value.status == 1 and "71" in str(ei.value)
+    m2.reserve_labels(71)
+    m2.forward(x.numpy(), fetch=False)
+    crit2.forward_device(d[0], d[1], d[2], n0 + n1)
+    assert np.allclose(crit2.read()[1], ritems.numpy(), rtol=1e-3, atol=1e-5)
+    for p in d:
+        engine.free(p)
+    m.close(); m2.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_bf16_path_tracks_f32(backend, engine):
     """bf16 is the performance mode: validated against the fp32 oracle within bf16 rounding (eval logits ~1%)."""
     B, H, W, nc = 2, 64, 64, 80

@@ -2,8 +2,9 @@
 
 The product library is yolosharp_amd/libyolosharp_hip.so (hipcc, gfx950).  There is NO CPU
 fallback: if the library is missing, or no HIP device is present when a context is created,
-loading/creation fails loudly.  Tests may point YS_LIB_PATH at the test-only interpreter build
-(tools/hipemu/libyolosharp_emu.so) to exercise the kernel sources without a GPU.
+loading/creation fails loudly.  Tests pass the path of the test-only interpreter build
+(tools/hipemu/libyolosharp_emu.so) EXPLICITLY to exercise the kernel sources without a GPU; no environment
+variable can redirect the default loader.
 """
 import ctypes as C
 import os
@@ -87,6 +88,8 @@ PROTOTYPES = {
     "ys_match_predictions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ys_block_create": (C.c_int, [C.c_void_p, C.POINTER(BlockDesc), C.POINTER(C.c_void_p)]),
     "ys_block_output_shape": (C.c_int, [C.c_void_p, c_i32_p]),
+    "ys_model_set_preds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ys_model_reserve_labels": (C.c_int, [C.c_void_p, C.c_int]),
     "ys_block_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_block_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ys_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -113,7 +116,7 @@ _cache = {}
 
 
 def load(path=None):
-    path = path or os.environ.get("YS_LIB_PATH") or DEFAULT_LIB
+    path = path or DEFAULT_LIB   # explicit argument only: no environment override can point the product loader elsewhere
     path = os.path.abspath(path)
     if path in _cache:
         return _cache[path]

@@ -119,6 +119,15 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
     gt_valid[(long)b * a.gcap + slot] = (gb[0] + gb[1] + gb[2] + gb[3]) > 0.0f ? 1 : 0;  // Loss.cs:431
   }
   __syncthreads();
+  // The reference pads to the batch's true per-image maximum (Loss.cs:363-390); a fixed-capacity workspace must never drop
+  // labels silently: the largest per-image count is recorded (scalars[15]) and ys_loss_read* / ys_model_backward refuse the
+  // result when it exceeds gcap (host-label calls grow the workspace up front, so only device-label callers can see this).
+  if (tid == 0) {
+    int mx = 0;
+    for (int i = 0; i < a.B; i++) mx = a.gt_count[i] > mx ? a.gt_count[i] : mx;
+    a.scalars[15] = (float)mx;
+  }
+  __syncthreads();
   for (int i = tid; i < a.B; i += LS_THREADS)
     if (a.gt_count[i] > a.gcap) a.gt_count[i] = a.gcap;
 }

@@ -123,6 +123,7 @@ struct ys_model {
   float *ov = nullptr, *align = nullptr; unsigned char* mpos = nullptr; unsigned *pos_align = nullptr, *pos_ov = nullptr;
   int* fg_gt = nullptr; float* tnorm = nullptr; float* loss_partial = nullptr; float* scalars = nullptr;
   bool have_fwd = false, have_loss = false;
+  bool fwd_training = false;   // the last forward kept what backward needs (training-mode BN statistics, pre-BN outputs)
   std::vector<void*> allocs;
 };
 
@@ -644,6 +645,38 @@ inline char* view_ptr(ys_model* m, void* base, const Buf& b, long row0) { return
 
 float* chan_ptr(ys_model* m, const ConvL& c, int which) { return m->chan + c.ch_off + (long)which * ((c.cout + 3) / 4 * 4); }
 
+void dev_free_tracked(ys_model* m, void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < m->allocs.size(); i++) if (m->allocs[i] == p) { m->allocs.erase(m->allocs.begin() + i); break; }
+  hipFree(p);
+}
+
+// Ground-truth workspace for `gcap` labels PER IMAGE (the reference pads every image to the batch's largest label count,
+// Loss.cs:363-390, without a cap): raw label staging, padded GT arrays and the [B][gcap][A] assignment matrices.
+int alloc_label_ws(ys_model* m, int gcap) {
+  const int B = m->maxB;
+  void* old[] = {m->lab_bidx, m->lab_cls, m->lab_box, m->gt_count, m->gt_box, m->gt_cls, m->ov, m->align, m->mpos, m->pos_align, m->pos_ov};
+  if (m->lab_bidx) YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+  for (void* p : old) dev_free_tracked(m, p);
+  m->lab_bidx = m->lab_cls = m->lab_box = nullptr; m->gt_count = nullptr; m->gt_box = nullptr; m->gt_cls = nullptr;
+  m->ov = m->align = nullptr; m->mpos = nullptr; m->pos_align = m->pos_ov = nullptr;
+  m->gcap = gcap;
+  m->max_labels = gcap * B;
+  const size_t GA = (size_t)B * gcap * m->A;
+  YS_TRY(dev_alloc(m, (void**)&m->lab_bidx, (size_t)m->max_labels * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->lab_cls, (size_t)m->max_labels * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->lab_box, (size_t)m->max_labels * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_count, (size_t)B * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_box, (size_t)B * gcap * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_cls, (size_t)B * gcap * 8));   // gt_cls + gt_valid
+  YS_TRY(dev_alloc(m, (void**)&m->ov, GA * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->align, GA * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->mpos, GA));
+  YS_TRY(dev_alloc(m, (void**)&m->pos_align, (size_t)B * gcap * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->pos_ov, (size_t)B * gcap * 4));
+  return YS_OK;
+}
+
 int allocate(ys_model* m) {
   const int B = m->maxB;
   hipStream_t st = m->ctx->stream; (void)st;
@@ -742,22 +775,9 @@ int allocate(ys_model* m) {
     YS_TRY(dev_alloc(m, (void**)&m->seg_part, (size_t)B * m->A * 4));
   }
   YS_TRY(dev_alloc(m, (void**)&m->out_stage, (size_t)m->n_out_stage * 4));
-  // loss workspace
-  m->gcap = d.max_labels > 0 ? d.max_labels : 64;
-  m->max_labels = m->gcap * B;
-  const size_t GA = (size_t)B * m->gcap * m->A;
-  YS_TRY(dev_alloc(m, (void**)&m->lab_bidx, (size_t)m->max_labels * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->lab_cls, (size_t)m->max_labels * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->lab_box, (size_t)m->max_labels * 16));
-  YS_TRY(dev_alloc(m, (void**)&m->gt_count, (size_t)B * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->gt_box, (size_t)B * m->gcap * 16));
-  YS_TRY(dev_alloc(m, (void**)&m->gt_cls, (size_t)B * m->gcap * 8));   // gt_cls + gt_valid
+  // loss workspace (label-capacity dependent part: alloc_label_ws; grown on demand by ys_loss_detect / ys_model_reserve_labels)
+  YS_TRY(alloc_label_ws(m, d.max_labels > 0 ? d.max_labels : 64));
   YS_TRY(dev_alloc(m, (void**)&m->pbox, (size_t)B * m->A * 16));
-  YS_TRY(dev_alloc(m, (void**)&m->ov, GA * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->align, GA * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->mpos, GA));
-  YS_TRY(dev_alloc(m, (void**)&m->pos_align, (size_t)B * m->gcap * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->pos_ov, (size_t)B * m->gcap * 4));
   YS_TRY(dev_alloc(m, (void**)&m->fg_gt, (size_t)B * m->A * 4));
   YS_TRY(dev_alloc(m, (void**)&m->tnorm, (size_t)B * m->A * 4));
   YS_TRY(dev_alloc(m, (void**)&m->loss_partial, ys_loss_partial_floats(B, m->A) * 4));
@@ -1294,7 +1314,7 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
   m->B = batch;
   YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, 3, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
-  m->have_fwd = true; m->have_loss = false; m->have_seg_loss = false;
+  m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;
   return YS_OK;
 }
 
@@ -1316,7 +1336,7 @@ int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int b
   m->B = batch;
   YS_TRY(ys_pack_input_u8_launch(st, m->dtype, src, batch, 3, h, w, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
-  m->have_fwd = true; m->have_loss = false; m->have_seg_loss = false;
+  m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;
   return YS_OK;
 }
 
@@ -1370,21 +1390,63 @@ int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count)
   return YS_OK;
 }
 
+// The criterion's `preds` argument supplied by the caller (Loss.cs:411 `forward(preds, batch)`): head outputs in the reference layout
+// -- boxes [B, 4*reg_max, A], scores [B, nc, A] and, for Segment models, mask_coefficient [B, nm, A] and proto [B, nm, H/4, W/4] --
+// are packed into the engine's head buffers as if a forward had produced them.  ys_loss_detect / ys_loss_segment and the
+// "dboxes" / "dscores" / ... gradient outputs then work on them; ys_model_backward is refused (no graph state behind these preds).
+int ys_model_set_preds(ys_model* m, int batch, const float* boxes, const float* scores, const float* mask_coefficient, const float* proto) {
+  YS_REQUIRE(m && !m->is_block && boxes && scores, "ys_model_set_preds: null argument or block handle");
+  YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_set_preds: batch %d outside (0, %d]", batch, m->maxB);
+  YS_REQUIRE(!m->segment || (mask_coefficient && proto), "ys_model_set_preds: a Segment model needs mask_coefficient and proto");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  struct Item { const float* src; int buf; int C; long rows; } items[4] = {
+    {boxes, m->pd_buf, 4 * m->d.reg_max, m->A}, {scores, m->ps_buf, m->d.nc, m->A},
+    {m->segment ? mask_coefficient : nullptr, m->mc_buf, m->nm, m->A}, {m->segment ? proto : nullptr, m->pr_buf, m->nm, (long)m->mh * m->mw}};
+  for (const Item& it : items) {
+    if (!it.src) continue;
+    const Buf& b = m->bufs[it.buf];
+    const size_t cnt = (size_t)batch * it.C * it.rows;
+    YS_REQUIRE((long)cnt <= m->n_out_stage, "ys_model_set_preds: staging buffer too small");
+    YS_CHECK_HIP(hipMemcpyAsync(m->out_stage, it.src, cnt * 4, hipMemcpyHostToDevice, st));
+    YS_TRY(ys_pack_input_launch(st, m->dtype, m->out_stage, batch, it.C, 1, (int)it.rows, b.ldc, b.act));
+    YS_CHECK_HIP(hipStreamSynchronize(st));   // out_stage is reused by the next item
+  }
+  m->B = batch; m->have_fwd = true; m->fwd_training = false; m->have_loss = false; m->have_seg_loss = false;
+  return YS_OK;
+}
+
 int ys_model_pred_device(ys_model* m, float** dptr) {
   YS_REQUIRE(m && dptr, "null argument");
   *dptr = m->pred;
   return YS_OK;
 }
 
+int ys_model_reserve_labels(ys_model* m, int per_image) {
+  YS_REQUIRE(m && !m->is_block, "ys_model_reserve_labels: needs a full model");
+  YS_REQUIRE(per_image > 0, "ys_model_reserve_labels: per_image = %d", per_image);
+  if (per_image <= m->gcap) return YS_OK;
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  m->have_loss = false; m->have_seg_loss = false;
+  return alloc_label_ws(m, (per_image + 15) / 16 * 16);
+}
+
 int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device) {
   YS_REQUIRE(m, "null model");
-  YS_REQUIRE(!m->is_block && m->have_fwd && m->training, "ys_loss_detect: needs a training-mode forward of a full model first");
-  YS_REQUIRE(n >= 0 && n <= m->max_labels, "ys_loss_detect: %d labels exceed capacity %d (max_labels per image %d)", n, m->max_labels, m->gcap);
+  // Training forward -> the criterion feeds backward (Amp.cs:338-348).  Eval forward -> validation loss on the eval-mode preds
+  // (Detector.cs:94-97): the head logits are produced in both modes; only backward needs the training-mode state.
+  YS_REQUIRE(!m->is_block && m->have_fwd, "ys_loss_detect: needs a forward of a full model first");
+  YS_REQUIRE(n >= 0, "ys_loss_detect: n_labels = %d", n);
   YS_REQUIRE(n == 0 || (batch_idx && cls && bboxes), "ys_loss_detect: null label arrays");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   const float *bi = batch_idx, *cl = cls, *bb = bboxes;
   if (!on_device && n > 0) {
+    // host labels: size the padded GT workspace from the batch itself, like the reference's counts.max() (Loss.cs:376-380)
+    std::vector<int> cnt(m->B, 0);
+    int mx = 0;
+    for (int i = 0; i < n; i++) { const int b = (int)batch_idx[i]; if (b >= 0 && b < m->B) mx = std::max(mx, ++cnt[b]); }
+    if (mx > m->gcap) YS_TRY(alloc_label_ws(m, (mx + 15) / 16 * 16));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_bidx, batch_idx, (size_t)n * 4, hipMemcpyHostToDevice, st));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_cls, cls, (size_t)n * 4, hipMemcpyHostToDevice, st));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_box, bboxes, (size_t)n * 16, hipMemcpyHostToDevice, st));
@@ -1432,6 +1494,17 @@ int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls, const
   return YS_OK;
 }
 
+// device-resident labels cannot size the workspace without a host sync: the prep kernel records the batch's largest per-image
+// label count and the first synchronising read refuses a truncated assignment instead of returning it
+static int check_label_overflow(ys_model* m, float max_count) {
+  if ((int)max_count <= m->gcap) return YS_OK;
+  m->have_loss = false; m->have_seg_loss = false;
+  ys_set_error("loss: an image of this batch has %d labels but the workspace holds %d per image (the reference pads to the batch maximum, "
+               "Loss.cs:363-390): call ys_model_reserve_labels(model, %d) or pass max_labels at creation, then repeat the step",
+               (int)max_count, m->gcap, (int)max_count);
+  return YS_ERR_INVALID_ARG;
+}
+
 // loss items in the reference's order: detect [box, cls, dfl] (Loss.cs:414); segment [box, seg, cls, dfl, semseg] (Loss.cs:719)
 int ys_loss_read_items(ys_model* m, float* items, int n_items, float* loss_sum) {
   YS_REQUIRE(m && m->have_loss, "ys_loss_read_items: no loss has run");
@@ -1439,6 +1512,7 @@ int ys_loss_read_items(ys_model* m, float* items, int n_items, float* loss_sum) 
   float h[16];
   YS_CHECK_HIP(hipMemcpyAsync(h, m->scalars, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
   YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+  YS_TRY(check_label_overflow(m, h[15]));
   if (m->segment) {
     YS_REQUIRE(m->have_seg_loss, "ys_loss_read_items: the Segment model needs ys_loss_segment");
     items[0] = h[1]; items[1] = h[8]; items[2] = h[2]; items[3] = h[3]; items[4] = 0.f;
@@ -1451,9 +1525,10 @@ int ys_loss_read_items(ys_model* m, float* items, int n_items, float* loss_sum) 
 
 int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum) {
   YS_REQUIRE(m && m->have_loss, "ys_loss_read: no loss has run");
-  float h[8];
+  float h[16];
   YS_CHECK_HIP(hipMemcpyAsync(h, m->scalars, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
   YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+  YS_TRY(check_label_overflow(m, h[15]));
   if (loss_items) { loss_items[0] = h[1]; loss_items[1] = h[2]; loss_items[2] = h[3]; }
   if (loss_sum) *loss_sum = h[4];
   return YS_OK;
@@ -1463,6 +1538,7 @@ int ys_model_backward_segments(ys_model* m) { (void)m; return 3; }
 
 int ys_model_backward_segment(ys_model* m, int seg) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
+  YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
   YS_REQUIRE(seg >= 0 && seg < 3, "ys_model_backward_segment: segment %d out of range", seg);
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   if (seg == 0) reset_grad_state(m);
@@ -1471,6 +1547,7 @@ int ys_model_backward_segment(ys_model* m, int seg) {
 
 int ys_model_backward(ys_model* m) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
+  YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
   YS_REQUIRE(!m->segment || m->have_seg_loss, "ys_model_backward: the Segment model needs ys_loss_segment (mask gradients)");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   YsTimer timer(m->ctx, "backward");

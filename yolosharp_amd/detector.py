@@ -61,16 +61,14 @@ class Detector:
         tps, confs, pcls, tcls = [], [], [], []
         loss_sum, count = None, 0
         for data in batches:
+            if np.asarray(data["batch_idx"]).size < 1:          # Detector.cs:91-94
+                continue
             images = np.ascontiguousarray(data["images"], np.float32)
             B = images.shape[0]
-            # the reference evaluates the loss on the eval-mode preds (Detector.cs:96-97); the engine's criterion needs a
-            # training-mode forward, so the loss pass is separate (running statistics are restored afterwards)
-            sd = {k: v for k, v in self.model.state_dict().items() if "running" in k or "num_batches" in k}
-            self.model.train(); self.model.forward(images, fetch=False)
-            _, items = crit.forward(None, data)
-            self.model.load_state_dict(sd, strict=False)
-            loss_sum = items if loss_sum is None else loss_sum + items
+            # eval forward, then the criterion on the eval-mode preds (Detector.cs:95-97): one forward serves loss and NMS
             inference, _ = self.amp.Evaluate(images)
+            _, items = crit.forward(None, data)
+            loss_sum = items if loss_sum is None else loss_sum + items
             pred = inference["boxes"]
             nc = self.model.nc
             rows = np.zeros((B, max_det, pred.shape[1] - nc + 2), np.float32)
@@ -84,6 +82,8 @@ class Detector:
                 tps.append(correct[b]); confs.append(rows[b, :cnt[b], 4]); pcls.append(rows[b, :cnt[b], 5])
                 tcls.append(np.asarray(data["cls"], np.float32).reshape(-1)[bi == b])
             count += B
+        if not tps:
+            return np.zeros(3, np.float32), (0.0, 0.0, 0.0, 0.0)
         stats = M.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls))
         return loss_sum, M.val_summary(stats)
 
@@ -128,12 +128,9 @@ class Segmenter(Detector):
                 continue
             images = np.ascontiguousarray(data["images"], np.float32)
             B, _, H, W = images.shape
-            sd = {k: v for k, v in self.model.state_dict().items() if "running" in k or "num_batches" in k}
-            self.model.train(); self.model.forward(images, fetch=False)
+            inference, _ = self.amp.Evaluate(images)                # Segmenter.cs:110-112: eval preds feed loss and NMS
             _, items = crit.forward(None, data)
-            self.model.load_state_dict(sd, strict=False)
             loss_sum = items if loss_sum is None else loss_sum + items
-            inference, _ = self.amp.Evaluate(images)
             proto = self.model.get_output("proto")
             mh, mw = proto.shape[2:]
             output, _ = self.engine.non_max_suppression(inference["boxes"], conf_thres, iou_thres, max_det=max_det, nc=nc)

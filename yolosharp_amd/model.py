@@ -151,6 +151,21 @@ class Yolov8:
         _lib.check(self.lib, self.lib.ys_model_get_output(self.handle, key.encode(), _ptr(a), a.size))
         return a
 
+    def set_preds(self, preds):
+        """The criterion's `preds` supplied by the caller (Loss.cs:411): {"boxes": [B,4*reg_max,A], "scores": [B,nc,A]} (+
+        "mask_coefficient" [B,nm,A], "proto" [B,nm,H/4,W/4] for Segment models) become the head outputs the loss reads."""
+        bx = np.ascontiguousarray(preds["boxes"], np.float32)
+        sc = np.ascontiguousarray(preds["scores"], np.float32)
+        B = bx.shape[0]
+        assert bx.shape == (B, 4 * self.reg_max, self.A) and sc.shape == (B, self.nc, self.A), (bx.shape, sc.shape)
+        mc = np.ascontiguousarray(preds["mask_coefficient"], np.float32) if self.NM else None
+        pr = np.ascontiguousarray(preds["proto"], np.float32) if self.NM else None
+        _lib.check(self.lib, self.lib.ys_model_set_preds(self.handle, B, _ptr(bx), _ptr(sc), _ptr(mc), _ptr(pr)))
+        self._batch = B
+
+    def reserve_labels(self, per_image):
+        _lib.check(self.lib, self.lib.ys_model_reserve_labels(self.handle, int(per_image)))
+
     def pred_device(self):
         p = C.c_void_p()
         _lib.check(self.lib, self.lib.ys_model_pred_device(self.handle, C.byref(p)))

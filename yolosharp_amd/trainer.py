@@ -80,15 +80,19 @@ class Trainer:
         self.best_fitness = -float("inf")
 
     def train_epoch(self, batches, epoch):
-        items_sum, n = None, 0
-        for i, data in enumerate(batches):
+        """TrainEpoch (:291-356): returns the SUM of the per-step loss items like the reference (zeros when no step ran).  The
+        warm-up index i only advances on batches that trained: the reference's `continue` on an empty batch skips its i++."""
+        items_sum, i = None, 0
+        for data in batches:
             self.amp.lrs = self.sched.begin_iteration(epoch, i)
             if np.asarray(data["batch_idx"]).size < 1:                            # :322-325
                 continue
             _, items = self.amp.TrainStep(np.ascontiguousarray(data["images"], np.float32), data, self.crit)
             items_sum = items if items_sum is None else items_sum + items
-            n += 1
-        return items_sum / max(n, 1)
+            i += 1
+        self.steps_run = i
+        n_items = 5 if isinstance(self.crit, v8SegmentationLoss) else 3
+        return items_sum if items_sum is not None else np.zeros(n_items, np.float32)
 
     def fit(self, train_batches, val_batches=None):
         """train_batches / val_batches: callables returning an iterable of batches for an epoch.  Returns the history."""
