@@ -1,0 +1,208 @@
+"""BASELINE.json configurations exercised on the MI355X (VERDICT r1 'configs_untested'):
+
+  C1  YOLOv8n detect, single-image inference on Assets/bus.jpg (eval forward + decode + NMS), 640x480 and padded 640x640
+  C3  YOLOv8s detect, 640x640: f32 parity at B=2, bf16 properties at the per-GPU shape B=32
+  C4  YOLOv11m-seg, 640x640: f32 parity at B=1, bf16 training step at B=32
+  C5  YOLOv8x detect, 1280x1280 (the fp8 configuration's graph and shape): f32 parity at B=1, bf16 tracking at B=2
+
+Full-size runs check size-independent properties (finite loss, bf16 tracks f32, determinism); parity proper is against the
+ATen-CPU oracle on the GPU box's host cores at batch sizes it finishes in seconds.  NMS indices are compared bit-exactly with
+the C oracle (oracle/nms_ref.c) on the engine's own predictions, as in smoke()."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo_oracle as O
+from test_model import make_ref, relerr
+from test_nms import oracle_nms
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from yolosharp_amd import Engine
+    e = Engine(0)
+    assert e.is_device_build
+    return e
+
+
+def _bus():
+    from PIL import Image
+    im = np.asarray(Image.open(os.path.join(HERE, "golden", "bus_480x640.jpg")).convert("RGB"), np.uint8)
+    assert im.shape == (640, 480, 3)
+    return np.ascontiguousarray(im.transpose(2, 0, 1))            # [3, 640, 480]
+
+
+@pytest.mark.parametrize("canvas", [(640, 480), (640, 640)])
+def test_c1_bus_predict(eng, oracle_lib, canvas):
+    """Detector.ImagePredict (Detector.cs:26-72) on bus.jpg: uint8 -> pad 114 -> /255 -> eval forward -> decode -> NMS(0.3, 0.5)."""
+    from yolosharp_amd.detector import Detector
+    from yolosharp_amd.model import Yolov8
+    H, W = canvas
+    nc = 80
+    img = _bus()
+    ref = make_ref(nc=nc, seed=11).eval()
+    m = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=1, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    m.eval()
+    assert m.A == (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32)
+    inf, _ = m.forward_u8(img[None])                               # device-side pad/scale (bottom/right 114 when W = 640)
+    x = np.full((1, 3, H, W), 114.0, np.float32)
+    x[0, :, :640, :480] = img
+    x /= np.float32(255.0)
+    with torch.no_grad():
+        rinf, _ = ref(torch.from_numpy(x))
+    assert relerr(inf["boxes"], rinf["boxes"]) < 1e-3
+    # NMS at the demo's thresholds (Program.cs:36-37) and at validation's: bit-exact vs the C oracle on the same tensor
+    for conf, iou in ((0.3, 0.5), (0.001, 0.7)):
+        ref_p, ref_rows, ref_keep = oracle_nms(oracle_lib, inf["boxes"], conf, iou)
+        mine = inf["boxes"].copy()
+        out, keepi = eng.non_max_suppression(mine, conf, iou)
+        assert np.array_equal(mine, ref_p) and np.array_equal(keepi[0], ref_keep[0]) and np.array_equal(out[0], ref_rows[0])
+    assert len(keepi[0]) > 0
+    # bf16 performance path on the same image: same detections up to near-threshold flips
+    mb = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=1, dtype="bf16")
+    mb.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    mb.eval()
+    infb, _ = mb.forward_u8(img[None])
+    assert relerr(infb["boxes"], rinf["boxes"]) < 2e-2
+    if W == 480:
+        res = Detector(m).ImagePredict(img.astype(np.float32), 0.001, 0.7)
+        assert len(res) == len(keepi[0])
+    m.close(); mb.close()
+
+
+def _detect_parity_f32(eng, size, B, H, W, seed, tol_fwd=1e-3, tol_grad=2e-3, grad_names=None):
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    nc = 80
+    ref = make_ref(nc=nc, size=size, seed=seed)
+    m = Yolov8(eng, nc=nc, size=size, height=H, width=W, max_batch=B, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(seed + 1))
+    batch = O.synthetic_batch(B, H, W, nc, seed=seed + 2)
+    m.train(); ref.train()
+    _, preds = m.forward(x.numpy())
+    _, rpreds = ref(x)
+    assert relerr(preds["boxes"], rpreds["boxes"]) < tol_fwd and relerr(preds["scores"], rpreds["scores"]) < tol_fwd
+    loss, items = v8DetectionLoss(m)(None, {k: v.numpy() for k, v in batch.items()})
+    rloss, ritems = O.v8DetectionLoss(nc)(rpreds, batch)
+    assert np.allclose(items, ritems.numpy(), rtol=1e-3, atol=1e-5), (items, ritems)
+    rloss.sum().backward()
+    m.zero_grad(); m.backward()
+    grads = m.grads()
+    named = dict(ref.named_parameters())
+    gscale = max(float(p.grad.abs().max()) for p in named.values() if p.grad is not None)
+    worst = 0.0
+    for name in (grad_names or [n for n, p in named.items() if p.grad is not None]):
+        r = named[name].grad.numpy()
+        worst = max(worst, np.abs(grads[name] - r).max() / (np.abs(r).max() + 1e-3 * gscale))
+    assert worst < tol_grad, worst
+    m.close()
+    return ritems.numpy()
+
+
+def test_c3_v8s_f32_parity(eng):
+    _detect_parity_f32(eng, "s", 2, 640, 640, seed=21)
+
+
+def test_c3_v8s_bf16_per_gpu_shape(eng):
+    """B=32 per GPU (global 256 over 8 GPUs): bf16 loss tracks the f32 engine, the step is deterministic, AdamW lowers the loss."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    B, H, W, nc = 32, 640, 640, 80
+    x = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
+    batch = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=1).items()}
+    res = {}
+    for dt in ("bf16", "f32"):
+        m = Yolov8(eng, nc=nc, size="s", height=H, width=W, max_batch=B, dtype=dt)
+        m.init_weights(5); m.train()
+        m.forward(x, fetch=False); _, items = v8DetectionLoss(m)(None, batch); m.zero_grad(); m.backward()
+        g1 = m.grads()
+        if dt == "bf16":
+            m.forward(x, fetch=False); v8DetectionLoss(m)(None, batch); m.zero_grad(); m.backward()
+            g2 = m.grads()
+            assert all(np.array_equal(g1[k], g2[k]) for k in g1), "step is not deterministic"
+            l0 = items.sum()
+            for _ in range(3):
+                m.adamw_step([1e-3] * 3); m.zero_grad()
+                m.forward(x, fetch=False); _, it = v8DetectionLoss(m)(None, batch); m.backward()
+            assert np.isfinite(it).all() and it.sum() < l0
+        res[dt] = (items, g1)
+        m.close()
+    assert np.allclose(res["bf16"][0], res["f32"][0], rtol=3e-2), (res["bf16"][0], res["f32"][0])
+    ga, gb = res["bf16"][1], res["f32"][1]
+    num = sum(float((ga[k].ravel() * gb[k].ravel()).sum()) for k in ga)
+    den = np.sqrt(sum(float((ga[k] ** 2).sum()) for k in ga) * sum(float((gb[k] ** 2).sum()) for k in gb))
+    assert num / den > 0.98, num / den
+
+
+def test_c4_v11m_seg_f32_parity(eng):
+    from test_segment import _segment_parity
+    _segment_parity(eng, 11, "m", 1, 640, 640, 1e-3, 3e-3)
+
+
+def test_c4_v11m_seg_bf16_train_step(eng):
+    """BASELINE config 4 at full size: YOLOv11m-seg, B=32, bf16: five finite loss items that track the f32 engine at B=4,
+    and a training step that lowers the loss."""
+    from yolosharp_amd.model import Yolov11Segment, v8SegmentationLoss
+    H, W, nc = 640, 640, 80
+    items = {}
+    for dt, B in (("bf16", 32), ("bf16", 4), ("f32", 4)):
+        x = np.random.default_rng(9).random((B, 3, H, W), dtype=np.float32)
+        tb = O.synthetic_batch(B, H, W, nc, seed=3, kmax=6)
+        tb["masks"] = O.synthetic_masks(tb, B, H // 4, W // 4)
+        nb = {k: v.numpy() for k, v in tb.items()}
+        m = Yolov11Segment(eng, nc=nc, size="m", height=H, width=W, max_batch=B, dtype=dt)
+        m.init_weights(6); m.train()
+        crit = v8SegmentationLoss(m)
+        m.forward(x, fetch=False); _, it = crit(None, nb); m.zero_grad(); m.backward()
+        assert it.shape == (5,) and np.isfinite(it).all()
+        items[(dt, B)] = it
+        if B == 32:
+            l0 = it.sum()
+            for _ in range(2):
+                m.adamw_step([1e-3] * 3); m.zero_grad()
+                m.forward(x, fetch=False); _, it2 = crit(None, nb); m.backward()
+            assert np.isfinite(it2).all() and it2.sum() < l0, (it2, l0)
+        m.close()
+    a, b = items[("bf16", 4)], items[("f32", 4)]
+    assert np.allclose(a[[0, 2, 3]], b[[0, 2, 3]], rtol=5e-2), (a, b)        # box, cls, dfl
+    assert abs(a[1] - b[1]) <= 0.15 * abs(b[1]) + 1e-3, (a, b)              # seg term: unweighted sum over fg anchors (Appendix C)
+
+
+def test_c5_v8x_1280_f32_parity(eng):
+    """The config-5 graph (YOLOv8x, 1280x1280, A = 33600) on the f32 parity path, B=1: logits, loss and head / stem gradients."""
+    _detect_parity_f32(eng, "x", 1, 1280, 1280, seed=31, tol_grad=3e-3,
+                       grad_names=["model.22.cv3.0.2.bias", "model.22.cv2.2.1.conv.weight", "model.21.cv2.conv.weight", "model.12.cv1.bn.weight",
+                                   "model.9.cv2.conv.weight", "model.4.m.2.cv1.conv.weight", "model.1.conv.weight", "model.0.conv.weight"])
+
+
+def test_c5_v8x_1280_bf16_tracks_oracle(eng):
+    """Same graph / shape in bf16 (the storage type the fp8 path falls back to per layer), B=2, against the fp32 oracle."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    B, H, W, nc = 2, 1280, 1280, 80
+    ref = make_ref(nc=nc, size="x", seed=41)
+    m = Yolov8(eng, nc=nc, size="x", height=H, width=W, max_batch=B, dtype="bf16")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(42))
+    batch = O.synthetic_batch(B, H, W, nc, seed=43)
+    m.train(); ref.train()
+    _, preds = m.forward(x.numpy())
+    with torch.no_grad():
+        _, rpreds = ref(x)
+        _, ritems = O.v8DetectionLoss(nc)(rpreds, batch)
+    # Random-init, train-mode BatchNorm amplifies storage rounding layer by layer (measured on this graph: relative L2 distance
+    # of the logits 0.26 and correlation 0.963 for v8x, 0.10 / 0.995 for v8n, tools/dev/v8x_bf16_diag.py; each Conv unit alone is
+    # within bf16 output rounding, tools/dev/wide_conv_check.py) -- so "tracks" is stated on correlation and on the loss items.
+    for key in ("boxes", "scores"):
+        a, b = preds[key].ravel(), rpreds[key].numpy().ravel()
+        assert np.linalg.norm(a - b) <= 0.35 * np.linalg.norm(b), key
+        assert np.corrcoef(a[::53], b[::53])[0, 1] > 0.94, key
+    _, items = v8DetectionLoss(m)(None, {k: v.numpy() for k, v in batch.items()})
+    assert np.allclose(items, ritems.numpy(), rtol=5e-2), (items, ritems)
+    m.zero_grad(); m.backward(); m.adamw_step([1e-4] * 3)
+    m.close()

@@ -105,6 +105,25 @@ def build_oracle(verbose=False):
     return LIB_ORACLE
 
 
+def build_abi_smoke(verbose=False):
+    """tests/c/abi_smoke.c (plain C consumer of include/yolosharp_hip.h) linked against the product library and against the
+    test-only interpreter build: build/abi_smoke_dev, build/abi_smoke_emu."""
+    src = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
+    hdr = os.path.join(ROOT, "include", "yolosharp_hip.h")
+    os.makedirs(BUILD, exist_ok=True)
+    outs = []
+    for tag, lib in (("dev", LIB_DEVICE), ("emu", LIB_EMU)):
+        exe = os.path.join(BUILD, "abi_smoke_" + tag)
+        if os.path.exists(lib) and _newer(exe, [src, hdr, lib]):
+            d, n = os.path.dirname(lib), os.path.basename(lib)[3:-3]
+            _run(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                  "-L", d, "-l" + n, "-lm", "-Wl,-rpath,$ORIGIN/" + os.path.relpath(d, BUILD), "-Wl,--allow-shlib-undefined"])
+        outs.append(exe)
+        if verbose:
+            print("built", exe)
+    return outs
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["device", "emu", "oracle"]
     if "device" in what:
@@ -113,3 +132,5 @@ if __name__ == "__main__":
         build_emu(True)
     if "oracle" in what:
         build_oracle(True)
+    if "abi" in what or len(sys.argv) == 1:
+        build_abi_smoke(True)
