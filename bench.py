@@ -77,8 +77,8 @@ def cpu_baseline(nc, H, W, sample_b=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)     # >= 50 timed steps after 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", default="n")
     ap.add_argument("--imgsz", type=int, default=640, help="square input size (BASELINE configs: 640; config 5 shape: 1280)")
@@ -116,6 +116,8 @@ def main():
     nc, H, W, B = 80, args.imgsz, args.imgsz, args.batch
     stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
     eng = Engine(local_rank, stream=stream)          # N>1: run on torch's stream so RCCL orders against our kernels
+    if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
+        raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
     seg = args.task == "segment"
     Model = {(8, False): Yolov8, (11, False): Yolov11, (8, True): Yolov8Segment, (11, True): Yolov11Segment}[(args.family, seg)]
     model = Model(eng, nc=nc, size=args.size, height=H, width=W, max_batch=B, dtype=args.dtype)

@@ -177,6 +177,12 @@ YS_API int ys_model_backward_allreduce(ys_model* m);
  * (warm-up / LambdaLR stay in C#, YoloBaseTaskModel.cs:306-319). */
 YS_API int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups,
                                float beta1, float beta2, float eps, float weight_decay);
+/* Parameter-group construction.  mode 0 (default): the name rule above made DISJOINT.  mode 1: the reference's three groups exactly
+ * as written (YoloBaseTaskModel.cs:144-151: Contains("bias") | Contains("weight") | Contains("bn")), in which every BatchNorm
+ * weight / bias is listed twice: TorchSharp keys optimizer state by parameter, so such a parameter receives two consecutive AdamW
+ * updates per step() from one shared state -- first with its first group's learning rate, then with the bn group's, its step
+ * counter advancing by two.  Choose before the first optimizer step. */
+YS_API int ys_optim_set_param_groups(ys_model* m, int mode);
 
 /* Ops.non_max_suppression (Utils/Ops.cs:239-371) incl. torchvision.ops.nms (:357).
  * pred: [B, C=4+nc+extra, A] fp32 xywh + class probabilities; boxes are converted to xyxy IN PLACE

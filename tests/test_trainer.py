@@ -63,3 +63,77 @@ def test_trainer_two_epochs_gpu(tmp_path):
     sd, code = weights_bin.read_bin(os.path.join(str(tmp_path), "weights", "last.bin"))
     assert code == weights_bin.FLOAT32 and "model.22.dfl.conv.weight" in sd
     m.close()
+
+
+def test_empty_batches_do_not_advance_the_warmup_index():
+    """TrainEpoch's `continue` on an empty batch skips its i++ (YoloBaseTaskModel.cs:322-325,349); the epoch returns the SUM of
+    the per-step loss items, and zeros when no step ran."""
+    class FakeAmp:
+        def __init__(self):
+            self.seen = []
+            self.lrs = None
+
+        def TrainStep(self, images, data, crit):
+            self.seen.append(list(self.lrs))
+            return np.ones(3, np.float32), np.array([1.0, 2.0, 3.0], np.float32)
+
+    tr = T.Trainer.__new__(T.Trainer)
+    tr.amp, tr.crit = FakeAmp(), object()
+    tr.sched = T.LrSchedule(nc=80, epochs=10, nb=4, lrf=0.01)
+    full = {"batch_idx": np.zeros(2, np.float32), "images": np.zeros((1, 3, 32, 32), np.float32)}
+    empty = {"batch_idx": np.zeros(0, np.float32), "images": np.zeros((1, 3, 32, 32), np.float32)}
+    out = tr.train_epoch([full, empty, empty, full], epoch=1)
+    assert np.array_equal(out, np.array([2.0, 4.0, 6.0], np.float32)) and tr.steps_run == 2
+    ref = T.LrSchedule(nc=80, epochs=10, nb=4, lrf=0.01)
+    assert tr.amp.seen == [ref.begin_iteration(1, 0), ref.begin_iteration(1, 1)]      # second trained batch is i = 1, not 3
+    assert np.array_equal(tr.train_epoch([empty, empty], epoch=2), np.zeros(3, np.float32))
+
+
+def test_reference_param_groups_step_bn_twice(emu_lib_path):
+    """param_groups = "reference": the optimizer groups exactly as written in YoloBaseTaskModel.cs:144-151 (every BatchNorm
+    weight / bias listed in two groups, one shared AdamW state) against the oracle's literal group loop, two optimizer steps
+    with distinct per-group learning rates; the default disjoint mode differs from it only on BatchNorm parameters."""
+    import torch
+    from oracle import yolo_oracle as O
+    from yolosharp_amd import Engine
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    from test_model import make_ref
+    eng = Engine(lib_path=emu_lib_path)
+    B, H, W, nc = 2, 32, 32, 80
+    ref = make_ref(seed=9).train()
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1))
+    batch = O.synthetic_batch(B, H, W, nc, seed=2, kmax=3)
+    nb = {k: v.numpy() for k, v in batch.items()}
+    lrs = [3e-3, 1e-3, 2e-3]
+    models = {}
+    for mode in ("reference", "disjoint"):
+        m = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
+        m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+        m.set_param_groups(mode)
+        models[mode] = m
+    params = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    state = {}
+    for step in range(2):
+        for m in models.values():
+            m.train(); m.forward(x.numpy(), fetch=False); v8DetectionLoss(m)(None, nb); m.zero_grad(); m.backward()
+        grads = {k: torch.from_numpy(v) for k, v in models["reference"].grads().items()}     # same gradients feed both optimizers
+        O.adamw_step_reference_groups(params, grads, state, lrs)
+        for m in models.values():
+            m.adamw_step(lrs)
+        if step == 0:      # keep the two engines on the same weights for the second step's gradients
+            models["disjoint"].load_state_dict({k: v for k, v in models["reference"].state_dict().items() if "running" not in k and "num_batches" not in k}, strict=False)
+        got = models["reference"].state_dict()
+        for name, p in params.items():
+            if name not in grads:
+                continue
+            g = grads[name].numpy()
+            big = np.abs(g) > 1e-2 * np.abs(g).max()          # elements whose Adam direction is not rounding noise
+            d = np.abs(got[name] - p.numpy())
+            assert d[big].max(initial=0.0) <= 5e-6 + 2e-4 * np.abs(p.numpy()).max(), (step, name, d[big].max())
+        assert state["model.0.bn.weight"][2] == 2 * (step + 1) and state["model.0.conv.weight"][2] == step + 1
+    a, b = models["reference"].state_dict(), models["disjoint"].state_dict()
+    assert np.abs(a["model.0.bn.weight"] - b["model.0.bn.weight"]).max() > 1e-4          # two updates vs one
+    with pytest.raises(Exception):
+        models["reference"].set_param_groups("disjoint")                                   # not after the optimizer has stepped
+    for m in models.values():
+        m.close()

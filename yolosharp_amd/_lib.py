@@ -90,6 +90,7 @@ PROTOTYPES = {
     "ys_block_output_shape": (C.c_int, [C.c_void_p, c_i32_p]),
     "ys_model_set_preds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ys_model_reserve_labels": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_optim_set_param_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "ys_block_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_block_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ys_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

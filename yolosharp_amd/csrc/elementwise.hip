@@ -757,7 +757,7 @@ int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v
 // model.hip layout_params), each with its own learning rate.
 __global__ void __launch_bounds__(EW_THREADS)
 adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                    AdamwRanges rg, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+                    AdamwRanges rg, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, AdamwDup dup) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float lr = 0.f; bool hit = false;
@@ -766,17 +766,31 @@ adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
     if (k < rg.n && i >= rg.off[k] && i < rg.off[k] + rg.count[k]) { lr = rg.lr[k]; hit = true; }
   if (!hit) return;
   const float gi = g[i];
+  // "reference" parameter groups (YoloBaseTaskModel.cs:144-151 as written): a BatchNorm parameter sits in two groups that share
+  // one optimizer state, so one optimizer.step() applies two consecutive AdamW updates with the same gradient -- the second with
+  // the bn group's learning rate -- and its step counter advances by two (bias corrections of steps 2t-1 and 2t)
+  const bool twice = dup.mask != nullptr && dup.mask[i] != 0;
+  const float b1 = twice ? dup.bc1_first : bc1, b2s = twice ? dup.bc2s_first : bc2_sqrt;
   float pi = p[i] * (1.0f - lr * wd);
-  const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
-  const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  pi -= (lr / bc1) * (mi / denom);
+  float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+  float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+  float denom = sqrtf(vi) / b2s + eps;
+  pi -= (lr / b1) * (mi / denom);
+  if (twice) {
+    pi *= (1.0f - dup.lr_second * wd);
+    mi = mi + (gi - mi) * (1.0f - beta1);
+    vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+    denom = sqrtf(vi) / dup.bc2s_second + eps;
+    pi -= (dup.lr_second / dup.bc1_second) * (mi / denom);
+  }
   p[i] = pi; m[i] = mi; v[i] = vi;
 }
 int ys_adamw_ranges_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, const AdamwRanges& rg,
-                           float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+                           float beta1, float beta2, float eps, float wd, float bc1, float bc2, const AdamwDup* dup) {
   if (n <= 0 || rg.n <= 0) return YS_OK;
-  YS_LAUNCH(adamw_ranges_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, g, m, v, n, rg, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
+  AdamwDup d{};
+  if (dup) d = *dup;
+  YS_LAUNCH(adamw_ranges_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, g, m, v, n, rg, beta1, beta2, eps, wd, bc1, sqrtf(bc2), d);
   return YS_OK;
 }
 

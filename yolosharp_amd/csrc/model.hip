@@ -96,6 +96,8 @@ struct ys_model {
   struct Range { long off, count; };
   Range seg_group[3][3];                         // [segment][adamw group]
   long step = 0;
+  int group_mode = 0;                            // 0 = disjoint groups, 1 = the reference's overlapping groups as written
+  unsigned char* bn_mask = nullptr;              // [n_params] 1 = BatchNorm weight / bias (listed twice in the reference's groups)
   // T weights
   void *wf_all = nullptr, *wd_all = nullptr; long n_wf = 0, n_wd = 0;
   PrepDesc* prep_dev = nullptr; int n_prep = 0; long prep_nf = 0, prep_nd = 0;
@@ -1579,6 +1581,27 @@ int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count) {
   return YS_OK;
 }
 
+// Parameter-group construction of the optimizer.  mode 0 (default): three DISJOINT groups (bias | conv weight | bn weight).
+// mode 1: the reference's groups exactly as written (YoloBaseTaskModel.cs:144-151) -- name.Contains("bias") | Contains("weight") |
+// Contains("bn") -- in which every BatchNorm weight and bias is listed twice; TorchSharp keys the optimizer state by parameter, so
+// such a parameter receives two AdamW updates per step() from one shared state.  Must be chosen before the
+// first optimizer step.
+int ys_optim_set_param_groups(ys_model* m, int mode) {
+  YS_REQUIRE(m && (mode == 0 || mode == 1), "ys_optim_set_param_groups: mode %d", mode);
+  YS_REQUIRE(m->step == 0 || mode == m->group_mode, "ys_optim_set_param_groups: the optimizer has already stepped");
+  if (mode == 1 && !m->bn_mask) {
+    YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+    std::vector<unsigned char> h((size_t)m->n_params, 0);
+    for (const auto& c : m->convs)
+      if (c.bn) for (int i = 0; i < c.cout; i++) { h[c.g_off + i] = 1; h[c.b_off + i] = 1; }
+    YS_TRY(dev_alloc(m, (void**)&m->bn_mask, h.size(), false));
+    YS_CHECK_HIP(hipMemcpyAsync(m->bn_mask, h.data(), h.size(), hipMemcpyHostToDevice, m->ctx->stream));
+    YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+  }
+  m->group_mode = mode;
+  return YS_OK;
+}
+
 int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, float beta1, float beta2, float eps, float wd) {
   YS_REQUIRE(m && lr_per_group && ngroups >= 1, "ys_optim_adamw_step: bad argument");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -1586,14 +1609,24 @@ int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, flo
   m->step += 1;
   const float bc1 = 1.0f - powf(beta1, (float)m->step), bc2 = 1.0f - powf(beta2, (float)m->step);
   AdamwRanges rg{};                          // one launch for the 3 segments x 3 groups (was nine ~5 us launches)
+  auto lr_of = [&](int g) { return lr_per_group[g < ngroups ? g : ngroups - 1]; };
   for (int seg = 0; seg < 3; seg++)
     for (int g = 0; g < 3; g++) {
       const auto r = m->seg_group[seg][g];
       if (r.count <= 0) continue;
-      rg.off[rg.n] = r.off; rg.count[rg.n] = r.count; rg.lr[rg.n] = lr_per_group[g < ngroups ? g : ngroups - 1];
+      // reference mode: bn.weight is met first in the "weight" group (lr of group 1), then again in the "bn" group
+      rg.off[rg.n] = r.off; rg.count[rg.n] = r.count; rg.lr[rg.n] = lr_of(m->group_mode == 1 && g == 2 ? 1 : g);
       rg.n++;
     }
-  YS_TRY(ys_adamw_ranges_launch(m->ctx->stream, m->params, m->grads, m->adam_m, m->adam_v, m->n_params, rg, beta1, beta2, eps, wd, bc1, bc2));
+  AdamwDup dup{};
+  if (m->group_mode == 1) {
+    const double s1 = 2.0 * (double)m->step - 1.0, s2 = 2.0 * (double)m->step;
+    dup.mask = m->bn_mask; dup.lr_second = lr_of(2);
+    dup.bc1_first = (float)(1.0 - pow((double)beta1, s1)); dup.bc2s_first = sqrtf((float)(1.0 - pow((double)beta2, s1)));
+    dup.bc1_second = (float)(1.0 - pow((double)beta1, s2)); dup.bc2s_second = sqrtf((float)(1.0 - pow((double)beta2, s2)));
+  }
+  YS_TRY(ys_adamw_ranges_launch(m->ctx->stream, m->params, m->grads, m->adam_m, m->adam_v, m->n_params, rg, beta1, beta2, eps, wd, bc1, bc2,
+                                m->group_mode == 1 ? &dup : nullptr));
   m->weights_dirty = true; m->eval_coeffs_dirty = true;
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;

@@ -121,8 +121,10 @@ int ys_copy_view_launch(hipStream_t st, int dtype, const void* src, int s_ldc, i
 // AdamW over a flat range
 #define YS_ADAMW_MAX_RANGES 9
 struct AdamwRanges { int n; long off[YS_ADAMW_MAX_RANGES]; long count[YS_ADAMW_MAX_RANGES]; float lr[YS_ADAMW_MAX_RANGES]; };
+// parameters listed in two optimizer groups (mask[i] != 0): a second update with lr_second; bias corrections of the two step indices
+struct AdamwDup { const unsigned char* mask; float lr_second, bc1_first, bc2s_first, bc1_second, bc2s_second; };
 int ys_adamw_ranges_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, const AdamwRanges& rg,
-                           float beta1, float beta2, float eps, float wd, float bc1, float bc2);
+                           float beta1, float beta2, float eps, float wd, float bc1, float bc2, const AdamwDup* dup = nullptr);
 int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                     float beta2, float eps, float wd, float bc1, float bc2);
 int ys_fill_launch(hipStream_t st, float* p, long n, float v);

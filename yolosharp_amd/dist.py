@@ -23,6 +23,12 @@ def device_view(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
+def host_view(ptr, n):
+    """The same view for the test-only interpreter build, whose "device" memory is host memory (gloo tests on CPU)."""
+    import ctypes
+    return torch.frombuffer((ctypes.c_float * int(n)).from_address(int(ptr)), dtype=torch.float32)
+
+
 class GradSync:
     def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None):
         """flat_grads: 1-D fp32 tensor aliasing the gradient buffer; segment_ranges: [(offset, count)] per backward segment."""

@@ -204,6 +204,11 @@ class Yolov8:
         _lib.check(self.lib, self.lib.ys_model_param_buffer(self.handle, C.byref(p), C.byref(n)))
         return p, n.value
 
+    def set_param_groups(self, mode="disjoint"):
+        """"disjoint" (default) or "reference" = the overlapping groups of YoloBaseTaskModel.cs:144-151 as written (BatchNorm
+        parameters are stepped twice per optimizer step from one shared state)."""
+        _lib.check(self.lib, self.lib.ys_optim_set_param_groups(self.handle, {"disjoint": 0, "reference": 1}[mode]))
+
     def adamw_step(self, lrs, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4):
         arr = (C.c_float * len(lrs))(*lrs)
         _lib.check(self.lib, self.lib.ys_optim_adamw_step(self.handle, arr, len(lrs), beta1, beta2, eps, weight_decay))
@@ -306,8 +311,10 @@ class AMPWrapper:
     half-precision branch never updates weights (SURVEY.md 5 'AMP quirk'); here bf16 keeps fp32 master weights inside
     the engine and the update is applied in every dtype."""
 
-    def __init__(self, model: Yolov8, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4):
+    def __init__(self, model: Yolov8, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4, param_groups="disjoint"):
         self.model = model
+        if param_groups != "disjoint":
+            model.set_param_groups(param_groups)
         lr0 = round(0.002 * 5 / (4 + model.nc), 6) if lr is None else lr     # YoloBaseTaskModel.cs:142
         self.lrs = [lr0, lr0, lr0]                                            # ParamGroups[i].LearningRate
         self.betas, self.eps, self.wd = betas, eps, weight_decay
