@@ -52,28 +52,31 @@ def _run(cmd):
     return r.stdout
 
 
-def build_device(verbose=False):
+def build_device(verbose=False, variant="dev", defines=(), out=None):
+    """variant "dev" is the product.  Triage variants (e.g. build_device(variant="tl", defines=["-DYS_P2_TIMELINE"],
+    out="build/libyolosharp_hip_tl.so")) compile the same sources with extra defines into their own object directory."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(os.path.join(BUILD, "dev"), exist_ok=True)
+    os.makedirs(os.path.join(BUILD, variant), exist_ok=True)
     hdrs = _headers()
+    lib = out or LIB_DEVICE
     objs, jobs = [], []
     for s in _sources():
         src = os.path.join(CSRC, s)
-        obj = os.path.join(BUILD, "dev", s + ".o")
+        obj = os.path.join(BUILD, variant, s + ".o")
         objs.append(obj)
         if _newer(obj, [src] + hdrs):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                   "-fno-strict-aliasing", "-Wno-unused-result", "-I", CSRC, "-c", src, "-o", obj]
+                   "-fno-strict-aliasing", "-Wno-unused-result", "-I", CSRC, "-c", src, "-o", obj] + list(defines)
             if s in NO_CONTRACT:
                 cmd.insert(4, "-ffp-contract=off")
             jobs.append(cmd)
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(_run, jobs))
-    if jobs or _newer(LIB_DEVICE, objs):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_DEVICE] + objs)
+    if jobs or _newer(lib, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     if verbose:
-        print("built", LIB_DEVICE, "(%d TU recompiled)" % len(jobs))
-    return LIB_DEVICE
+        print("built", lib, "(%d TU recompiled)" % len(jobs))
+    return lib
 
 
 def build_emu(verbose=False):
@@ -132,5 +135,7 @@ if __name__ == "__main__":
         build_emu(True)
     if "oracle" in what:
         build_oracle(True)
+    if "timeline" in what:
+        build_device(True, variant="tl", defines=["-DYS_P2_TIMELINE"], out=os.path.join(BUILD, "libyolosharp_hip_tl.so"))
     if "abi" in what or len(sys.argv) == 1:
         build_abi_smoke(True)

@@ -596,36 +596,32 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   ys_wave_sync();
 }
 
-// One statistics row per workgroup: the per-lane column sums gathered over all of its tiles are combined across the
-// lanes that share a channel vector, then across the 4 waves, in a fixed order.
+// One statistics row per workgroup: the per-lane column sums gathered over all of its tiles go through LDS ([16][NT] floats in
+// the patch region, lane-contiguous -> conflict-free) and one thread per (sum, channel) adds its NW * PPI entries in a fixed
+// order.  (The earlier form -- 16 values x log2(64 / VPP) rounds of cross-lane shuffles per lane -- was a 4-5 thousand cycle
+// chain of dependent ds_bpermutes at the end of every forward launch.)
 template <int NR, int NW>
-__device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8], float (&s2)[8], float* sStat, long stat_row) {
+__device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8], float (&s2)[8], float* scr, long stat_row) {
   constexpr int BN = NR * 16;
   constexpr int VPP = BN / 8;
   constexpr int PPI = 64 / VPP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cv = lane % VPP;
+  constexpr int NT = NW * 64;
+  const int tid = threadIdx.x;
+  ys_barrier_lds();                           // the last tile's epilogue staging (same LDS region) is consumed
 #pragma unroll
-  for (int e = 0; e < 8; e++) {
-    float x1 = s1[e], x2 = s2[e];
-    if ((VPP & (VPP - 1)) == 0) {
-      for (int msk = VPP; msk < 64; msk <<= 1) { x1 += __shfl_xor(x1, msk); x2 += __shfl_xor(x2, msk); }
-    } else {
-      float t1 = x1, t2 = x2;
-      for (int k = 1; k < PPI; k++) { t1 += __shfl(x1, (lane + k * VPP) & 63); t2 += __shfl(x2, (lane + k * VPP) & 63); }
-      x1 = t1; x2 = t2;
-    }
-    if (lane < VPP) {
-      sStat[((wave * BN) + cv * 8 + e) * 2 + 0] = x1;
-      sStat[((wave * BN) + cv * 8 + e) * 2 + 1] = x2;
-    }
-  }
+  for (int e = 0; e < 8; e++) { scr[e * NT + tid] = s1[e]; scr[(8 + e) * NT + tid] = s2[e]; }
   ys_barrier_lds();
-  if (tid < BN && n0 + tid < a.Cout) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int w = 0; w < NW; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
-    a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
-    a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
+  for (int o = tid; o < 2 * BN; o += NT) {
+    const int which = o / BN, c = o - which * BN;
+    const int cv = c >> 3, e = c & 7;
+    const float* col = scr + (which * 8 + e) * NT + cv;
+    float t = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < NW * PPI; k++) {      // lanes cv, cv + VPP, ... of wave 0, then wave 1, ...: lane index = (k / PPI) * 64 + (k % PPI) * VPP
+      const int w = k / PPI, j = k - w * PPI;
+      t += col[w * 64 + j * VPP];
+    }
+    if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
   }
 }
 
@@ -639,22 +635,43 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
 #define P2_KG 2            // K-steps (32 K each) per streamed weight group
 #endif
 #define P2_NPU 12          // max patch units (16 B) a thread keeps in flight: 12 x 256 x 16 B = 48 KB per workgroup (small layers: 6)
+// K-steps per register group of the pipelined K loop: enough MFMAs per group (>= 8) to cover an LDS round trip
+// G K-steps share one LDS wait: about 16 MFMAs per group, so that a group's MFMA time matches the LDS round trip the SIMD's other
+// waves have to cover -- bounded by the fragment registers a group keeps live, 4 * G * (MR + NR): <= 64 in the 256-register
+// variants, <= 32 in the `tight` ones (compiled for three waves per SIMD, 168 registers).  G is 1, 2 or 4 (one table read).
+__host__ __device__ constexpr int p2_reg_group(int mr, int nr, bool tight = false) {
+  const int want = mr * nr >= 10 ? 1 : (mr * nr >= 6 ? 2 : 4);
+  const int cap = (tight ? 8 : 16) / (mr + nr);
+  const int g = want < cap ? want : cap;
+  return g >= 4 ? 4 : (g >= 2 ? 2 : 1);
+}
 struct P2Args {
   int TH, TW, tiles_x, tiles_y, ntiles, PH, PW;
   int ppb;       // patch pixel pitch (bytes)
   int wpitch;    // weight row pitch in LDS (16-byte units)
   int nsteps;    // K-steps (32 K each) = ceil(KH*KW*Cin / 32)
+  int nsp;       // row length of the q-major offset table [4][nsp]: nsteps rounded up to 4, plus slack for the pipelined over-read
   int kg;        // K-steps per streamed weight group
   int off_w, off_p, off_stat;   // LDS byte offsets (offset table sits at 0)
 };
 
 template <int MR, int NR, int WRES, int NPU, int NT>
-__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 ? 3 : 2)))   // waves per SIMD the LDS budget allows (512 threads: 2 workgroups x 2)
+__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD   // waves per SIMD the LDS budget allows (512 threads: 2 workgroups x 2)
 conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
   if (P2_DBG(64)) return;                     // ablation: launch + dispatch cost only
   constexpr int BN = NR * 16;
   constexpr int NWV = NT / 64;
+#ifdef YS_P2_TIMELINE
+  // s_memtime stamps of wave 0 / lane 0 of every 37th workgroup: [slot 0] entry, [1] prologue issued, then per tile
+  // (top, patch in LDS, MFMA loop done, epilogue done), last = exit.  64 slots per recorded workgroup.
+  int tl_n = 0;
+  unsigned long long* tl_p = (a.tl && (blockIdx.x % 37) == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? a.tl + (blockIdx.x / 37) * 64 : nullptr;
+#define TL_STAMP() do { if (tl_p && tl_n < 63) tl_p[1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TL_STAMP() ((void)0)
+#endif
+  TL_STAMP();
   constexpr int NWU = WRES ? 1 : (BN * P2_KG * 4 + NT - 1) / NT;   // streamed weight units per thread
   YS_DYN_LDS(lds);
   char* lb = (char*)lds;
@@ -672,10 +689,11 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   const int cu = a.Cin >> 3;                  // 16-byte units per patch pixel
   const int npatch = g.PH * g.PW * cu;
 
-  // ---- tile-independent tables, computed once per layer geometry on the host (p2_tables): per-(K-step, quarter) patch
-  // offsets, per-thread pixel offsets, per-thread patch unit descriptors
-  for (int e = tid; e < g.nsteps * 4; e += NT) sOff[e] = tab[e];
-  const int* tpx = tab + g.nsteps * 4;
+  // ---- tile-independent tables, computed once per layer geometry on the host (p2_tables): per-(quarter, K-step) patch
+  // offsets (q-major so that a lane fetches the offsets of consecutive K-steps with one LDS read), per-thread pixel offsets,
+  // per-thread patch unit descriptors
+  for (int e = tid; e < g.nsp * 4; e += NT) sOff[e] = tab[e];
+  const int* tpx = tab + g.nsp * 4;
   int pixbase[MR], pty[MR], ptx[MR];
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
@@ -683,19 +701,13 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     pty[mf] = tpx[(mf * 3 + 1) * NT + tid];
     ptx[mf] = tpx[(mf * 3 + 2) * NT + tid];
   }
-  if (WRES) {
-    const int per_row = g.nsteps * 4;
-    for (int idx = tid; idx < BN * per_row; idx += NT) {
-      const int n = idx / per_row, u = idx - n * per_row;
-      uint4 v = ys_zero16();
-      if (n0 + n < a.Cout && u * 8 < Ktot) v = ys_ld16(wb + ((long)(n0 + n) * Ktot + u * 8) * 2L);
-      sW[n * g.wpitch + u] = v;
-    }
-  }
   constexpr int KG = P2_KG;                    // K-steps per streamed weight group
   constexpr int GU = KG * 4;                   // 16-byte units per weight row and group
+  constexpr bool TIGHT = NT == 256 && NPU <= 6 && MR * NR <= 8;                           // 168-register variants
+  constexpr int G0 = p2_reg_group(MR, NR, TIGHT);
+  constexpr int G = (WRES || G0 < KG) ? G0 : KG;   // K-steps per register group of the K loop
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
-  uint4 rw[NWU];
+  uint4 rwA[NWU];
   // this thread's (row, unit-in-group) of the streamed weight tile never changes: keep the row pointers, step by group
   const char* wrow[NWU];
   int wun[NWU];
@@ -706,16 +718,16 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     wun[k] = (idx < BN * GU && n0 + n < a.Cout) ? idx - n * GU : -1;
     wrow[k] = wb + ((long)(n0 + (wun[k] >= 0 ? n : 0)) * Ktot) * 2L;
   }
-  auto wfetch = [&](int grp) {                // global -> registers: weights of K-steps [grp*KG, grp*KG + KG)
+  auto wfetch = [&](uint4 (&rw)[NWU], int grp) {   // global -> registers: weights of K-steps [grp*KG, grp*KG + KG); unconditional loads
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
-      uint4 v = ys_zero16();
       const int u = grp * GU + wun[k];
-      if (wun[k] >= 0 && u * 8 < Ktot && !P2_DBG(16)) v = ys_ld16(wrow[k] + u * 16);
-      rw[k] = v;
+      const bool ok = (bool)((int)(wun[k] >= 0) & (int)(u * 8 < Ktot) & (int)!P2_DBG(16));
+      rw[k] = ys_ld16(wrow[k] + (ok ? u * 16 : 0));
+      if (!ok) rw[k] = ys_zero16();
     }
   };
-  auto wstore = [&](int buf) {
+  auto wstore = [&](const uint4 (&rw)[NWU], int buf) {
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
       const int idx = tid + NT * k;
@@ -791,7 +803,32 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   }
   int ntx = txi, nty = tyi, nb = b;
   unsigned okm_next = 0;
-  if (t_first < t_end) okm_next = pfetch(txi, tyi, b);
+  if (t_first < t_end) okm_next = pfetch(txi, tyi, b);   // the first patch is in flight while the weights are staged
+  if (WRES) {
+    // resident weights: rows padded with zeros to a multiple of 4 K-steps (the pipelined K loop runs whole register groups).
+    // Loads are issued eight at a time before the first LDS store: the one-load-one-store form was a chain of dependent L2
+    // round trips (measured 6-9 thousand cycles of prologue per workgroup for a 36 KB weight set).
+    const int per_row = ((g.nsteps + 3) & ~3) * 4;
+    const int total = BN * per_row;
+    constexpr int UB = 8;
+    for (int base = tid; base < total; base += NT * UB) {
+      uint4 v[UB];
+      int dst[UB];
+#pragma unroll
+      for (int k = 0; k < UB; k++) {
+        const int idx = base + k * NT;
+        const int n = idx / per_row, u = idx - n * per_row;
+        const bool ok = (bool)((int)(idx < total) & (int)(n0 + n < a.Cout) & (int)(u * 8 < Ktot));
+        const long off = ok ? ((long)(n0 + n) * Ktot + u * 8) * 2L : 0L;
+        v[k] = ys_ld16(wb + off);
+        if (!ok) v[k] = ys_zero16();
+        dst[k] = idx < total ? n * g.wpitch + u : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < UB; k++) if (dst[k] >= 0) sW[dst[k]] = v[k];
+    }
+  }
+  TL_STAMP();
   if (P2_DBG(128)) return;                     // ablation: prologue only (tables, resident weights, first patch fetch)
   float st1[8], st2[8];                        // BN statistics of this workgroup's tiles (per-lane column sums)
 #pragma unroll
@@ -799,8 +836,9 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 
   for (int tile = t_first; tile < t_end; tile += t_step) {
     const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
+    TL_STAMP();
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
-    if (!WRES) wfetch(0);
+    if (!WRES) wfetch(rwA, 0);
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       unsigned d = pdesc[k];
@@ -809,8 +847,9 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #endif
       if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = ((okm_next >> k) & 1u) ? rp[k] : ys_zero16();
     }
-    if (!WRES) wstore(0);
+    if (!WRES) wstore(rwA, 0);
     ys_barrier_lds();
+    TL_STAMP();
     advance(ntx, nty, nb);
     // everything older (the patch just consumed, the previous epilogue's conditional loads / stores) has already been waited
     // for above; saying so explicitly resets the compiler's "may still be in flight" state for the accumulator registers
@@ -823,33 +862,58 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #pragma unroll
       for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
 
-    for (int grp = 0; grp < ngroups; grp++) {
-      if (!WRES && grp + 1 < ngroups) wfetch(grp + 1);
-      const int s0 = WRES ? 0 : grp * KG;
-      const int s1 = WRES ? g.nsteps : ((s0 + KG) < g.nsteps ? (s0 + KG) : g.nsteps);
-      const uint4* wbuf = sW + (WRES ? 0 : (grp & 1) * BN * g.wpitch);
-      // (reading the operand fragments of step s+1 during the MFMAs of step s -- two register sets -- was measured neutral:
-      //  12.95 -> 13.00 ms/step; the other waves of the SIMD already cover the LDS round trips)
+    // ---- K loop in register groups of G K-steps.  The one-step-at-a-time form (table read -> wait -> operand reads -> wait ->
+    // MFMAs) cost ~350 cycles per K-step whatever the number of MFMAs in it (s_memtime stamps: 90-180 cycles per MFMA against 16
+    // of issue time): two dependent LDS round trips per step with only 2-3 waves per SIMD to cover them.  Now one LDS wait serves
+    // G steps (about 16 MFMAs), and the next group's table entries are fetched while the MFMAs issue, so the chain per group is
+    // one round trip + the MFMAs -- which the SIMD's other waves overlap.  (Double-buffered fragment sets cost 50-100 registers
+    // and spilled in most variants.)  Reads past the last real step land in valid LDS; their weights are zero.
+    struct Frags { uint4 w[G][NR]; uint4 x[G][MR]; };
+    auto read_offs = [&](int (&off)[G], int s) {
+      const int* pq = sOff + q * g.nsp + s;
+      if (G == 4) { const uint4 v = *(const uint4*)pq; off[0] = (int)v.x; off[G > 1 ? 1 : 0] = (int)v.y; off[G > 2 ? 2 : 0] = (int)v.z; off[G > 3 ? 3 : 0] = (int)v.w; }
+      else if (G == 2) { const uint2 v = *(const uint2*)pq; off[0] = (int)v.x; off[G > 1 ? 1 : 0] = (int)v.y; }
+      else off[0] = pq[0];
+    };
+    // ng register groups starting at table step sbase, weight units from 0 in wbuf
+    auto kloop = [&](const uint4* wbuf, int sbase, int ng) {
+      if (P2_DBG(2)) return;
+      int off[G];
+      read_offs(off, sbase);
 #pragma unroll 1
-      for (int s = P2_DBG(2) ? s1 : s0; s < s1; s++) {
-        const int off = sOff[s * 4 + q];
-        const int u = (s - s0) * 4 + q;
-        uint4 wf[NR], xf[MR];
+      for (int gi = 0; gi < ng; gi++) {
+        Frags f;
 #pragma unroll
-        for (int nf = 0; nf < NR; nf++) wf[nf] = wbuf[(nf * 16 + li) * g.wpitch + u];
+        for (int gs = 0; gs < G; gs++) {
 #pragma unroll
-        for (int mf = 0; mf < MR; mf++) xf[mf] = *(const uint4*)(sPb + pixbase[mf] + off);
+          for (int nf = 0; nf < NR; nf++) f.w[gs][nf] = wbuf[(nf * 16 + li) * g.wpitch + (gi * G + gs) * 4 + q];
 #pragma unroll
-        for (int nf = 0; nf < NR; nf++)
+          for (int mf = 0; mf < MR; mf++) f.x[gs][mf] = *(const uint4*)(sPb + pixbase[mf] + off[gs]);
+        }
+        read_offs(off, sbase + (gi + 1) * G);
+        YS_SCHED_FENCE();                        // every read of the group is issued before its first MFMA
 #pragma unroll
-          for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(wf[nf], xf[mf], acc[mf][nf]);
+        for (int gs = 0; gs < G; gs++)
+#pragma unroll
+          for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+            for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(f.w[gs][nf], f.x[gs][mf], acc[mf][nf]);
       }
-      if (!WRES) {
-        if (grp + 1 < ngroups) wstore((grp + 1) & 1);
+    };
+    if (WRES) {
+      kloop(sW, 0, (g.nsteps + G - 1) / G);
+    } else {
+      constexpr int NGS = KG / G;               // register groups per streamed weight slot
+#pragma unroll 1
+      for (int grp = 0; grp < ngroups; grp++) {
+        wfetch(rwA, grp + 1);                   // unconditional (past the end: zeros); lands during this group's MFMAs
+        kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS);
+        wstore(rwA, (grp + 1) & 1);
         ys_barrier_lds();
       }
     }
     if (WRES) ys_barrier_lds();               // every wave finished reading the patch: it becomes the staging area
+    TL_STAMP();
 
     long orow[MR];
     bool pv[MR];
@@ -861,9 +925,14 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     }
     char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 16);
     if (!P2_DBG(4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
+    TL_STAMP();
     txi = ntx; tyi = nty; b = nb;
   }
-  if (a.stats) p2_stats_flush<NR, NWV>(a, n0, st1, st2, sStat, (long)blockIdx.x);
+  if (a.stats) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+  TL_STAMP();
+#ifdef YS_P2_TIMELINE
+  if (tl_p) tl_p[0] = (unsigned long long)tl_n;
+#endif
 }
 
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
@@ -886,29 +955,31 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   g.nsteps = (taps * a.Cin + 31) / 32;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
   // workgroup per CU); YS_P2_WRESMAX overrides for experiments
-  static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 40 * 1024;
+  static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 44 * 1024;   // rows padded to 4 K-steps
   // Streamed weights cost one L2 round trip per K-group on the critical path of every tile.  When half the output channels
   // would make the weight set resident, split the channels over two workgroup columns instead (the patch is then read
   // twice, from L2).
   static const double tileconst = getenv("YS_P2_TILECONST") ? atof(getenv("YS_P2_TILECONST")) : 3000.0;
   static const int nrsplit = getenv("YS_P2_NRSPLIT") ? atoi(getenv("YS_P2_NRSPLIT")) : 1;   // measured 13.00 -> 12.86 ms/step
-  if (nrsplit && (size_t)nr * 16 * ((g.nsteps * 4) | 1) * 16 > wresmax && nr % 2 == 0 &&
-      (size_t)(nr / 2) * 16 * ((g.nsteps * 4) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
+  const int nsteps4 = (g.nsteps + 3) & ~3;           // resident weight rows are zero-padded to whole register groups (<= 4 K-steps)
+  g.nsp = nsteps4 + 12;                              // + slack: the pipelined loop reads table entries up to two groups ahead
+  if (nrsplit && (size_t)nr * 16 * ((nsteps4 * 4) | 1) * 16 > wresmax && nr % 2 == 0 &&
+      (size_t)(nr / 2) * 16 * ((nsteps4 * 4) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
     nr /= 2;
   const int bn = nr * 16;
-  const size_t wres_bytes = (size_t)bn * ((g.nsteps * 4) | 1) * 16;
+  const size_t wres_bytes = (size_t)bn * ((nsteps4 * 4) | 1) * 16;
   const int wres = wres_bytes <= wresmax ? 1 : 0;
   g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
-  g.wpitch = wres ? ((g.nsteps * 4) | 1) : ((g.kg * 4) | 1);
+  g.wpitch = wres ? ((nsteps4 * 4) | 1) : ((g.kg * 4) | 1);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
-  const size_t tab = ((size_t)g.nsteps * 16 + 15) / 16 * 16;
+  const size_t tab = ((size_t)g.nsp * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
   // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed
   // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
   static const int maxcin3 = getenv("YS_P2_MAXCIN3") ? atoi(getenv("YS_P2_MAXCIN3")) : 255;
   if (k3 && a.SA == 1 && a.Cin > maxcin3) return p;
-  for (size_t budget = (wres && wres_bytes > 40 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
+  for (size_t budget = (wres && wres_bytes > 44 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
   // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
   // enough.  (512-thread workgroups -- 8 waves x 2 fragments, same LDS footprint -- were measured 13 % slower: the 128-register
@@ -925,6 +996,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         int th = npx / tw; if (th > a.Hout) th = a.Hout;
         const int ph = (th - 1) * a.SA + a.KH, pw = (tw - 1) * a.SA + a.KW;
         size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
+        if (pbytes < (size_t)16 * nt * 4) pbytes = (size_t)16 * nt * 4;   // statistics scratch of p2_stats_flush
         const size_t lds = tab + wbytes + pbytes + stat;
         if (lds > budget || ph * pw * cu > npu_max * nt) continue;
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
@@ -963,21 +1035,22 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   int dev = 0;
   hipGetDevice(&dev);
   const P2Args& g = p.g;
-  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.nsteps, p.mr, p.npu, p.nt};
+  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.nsteps, g.nsp, p.mr, p.npu, p.nt};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   const int NT = p.nt;
   const int cu = a.Cin / 8, Ktot = a.KH * a.KW * a.Cin, npatch = g.PH * g.PW * cu;
-  std::vector<int> h((size_t)g.nsteps * 4 + (size_t)p.mr * 3 * NT + (size_t)p.npu * 2 * NT, 0);
-  for (int e = 0; e < g.nsteps * 4; e++) {
-    const int k0 = (e >> 2) * 32 + (e & 3) * 8;
-    if (k0 < Ktot) {
-      const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
-      const int kh = tap / a.KW, kw = tap - kh * a.KW;
-      h[e] = (kh * g.PW + kw) * g.ppb + ch * 2;
+  std::vector<int> h((size_t)g.nsp * 4 + (size_t)p.mr * 3 * NT + (size_t)p.npu * 2 * NT, 0);
+  for (int qq = 0; qq < 4; qq++)            // q-major: [quarter][K-step]; steps past the last real one keep offset 0 (their weights are zero)
+    for (int st = 0; st < g.nsteps; st++) {
+      const int k0 = st * 32 + qq * 8;
+      if (k0 < Ktot) {
+        const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        h[(size_t)qq * g.nsp + st] = (kh * g.PW + kw) * g.ppb + ch * 2;
+      }
     }
-  }
-  int* tpx = h.data() + g.nsteps * 4;
+  int* tpx = h.data() + g.nsp * 4;
   for (int tid = 0; tid < NT; tid++) {
     const int wave = tid >> 6, li = tid & 15;
     for (int mf = 0; mf < p.mr; mf++) {
@@ -1026,7 +1099,35 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   YsKprofScope prof(st, "conv_igemm", lab);
   const int* tab = p2_tables(a, p);
   if (!tab) { ys_set_error("conv p2: cannot allocate the index tables"); return YS_ERR_OOM; }
+#ifdef YS_P2_TIMELINE
+  static unsigned long long* tl_buf = nullptr;
+  const char* tl_path = getenv("YS_P2_TL");
+  if (tl_path) {
+    if (!tl_buf) hipMalloc(&tl_buf, 64 * 64 * 8);
+    hipMemsetAsync(tl_buf, 0, 64 * 64 * 8, st);
+    a.tl = tl_buf;
+  }
+#endif
   YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU, NT>), dim3(p.gx, p.gy), NT, p.lds, st, a, p.g, tab);
+#ifdef YS_P2_TIMELINE
+  if (tl_path) {
+    static unsigned long long h[64 * 64];
+    hipStreamSynchronize(st);
+    hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
+    FILE* f = fopen(tl_path, "a");
+    if (f) {
+      fprintf(f, "# k%d%d s%d cin%d cout%d M%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d ntiles%d nsteps%d\n", a.KH, a.KW, a.SA, a.Cin, a.Cout, a.M, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds, p.g.ntiles, p.g.nsteps);
+      for (int w = 0; w < 64 && w * 37 < p.gx; w++) {
+        const int n = (int)h[w * 64];
+        if (n <= 0) continue;
+        fprintf(f, "wg%d:", w * 37);
+        for (int i = 1; i < n; i++) fprintf(f, " %llu", h[w * 64 + 1 + i] - h[w * 64 + 1]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   return YS_OK;
 }
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {

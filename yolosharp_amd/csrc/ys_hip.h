@@ -30,6 +30,14 @@
 #define YS_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
 
+// Scheduling fence: hipcc's machine scheduler otherwise sinks LDS reads next to their first use (fewer live registers), which
+// serialises every read's latency with the MFMAs; a fence keeps "issue all reads, then all MFMAs" as written.
+#ifdef YS_EMU_BUILD
+#define YS_SCHED_FENCE() ((void)0)
+#else
+#define YS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // launch with dynamic LDS; YS_DYN_LDS(name) declares the dynamic region inside a kernel as `uint4* name`
 #ifdef YS_EMU_BUILD
 #define YS_LAUNCH_LDS(KERNEL, GRID, BLOCK, LDS_BYTES, STREAM, ...) \

@@ -27,6 +27,7 @@ struct ConvArgs {
   int pad_w_delta;               // width gather uses PAD + pad_w_delta (phase (dh,dw): PAD=-dh, delta=dh-dw)
   int out_rh, out_rw;            // out_rh != 0: output row = b*out_bstride + oh*out_rh + ow*out_rw + out_r0
   long out_r0;                   //   (writes phase (dh,dw) of a 2x upsampled grid: rh = 4W, rw = 2, r0 = dh*2W + dw)
+  unsigned long long* tl;        // triage builds (-DYS_P2_TIMELINE): per-workgroup s_memtime stamps of the tile phases; null otherwise
 };
 
 struct WgradArgs {
