@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--imgsz", type=int, default=640, help="square input size (BASELINE configs: 640; config 5 shape: 1280)")
     ap.add_argument("--family", type=int, default=8, choices=[8, 11], help="graph family (8 = YOLOv8, 11 = YOLOv11); default = BASELINE config 2")
     ap.add_argument("--task", default="detect", choices=["detect", "segment"])
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"], help="fp8 = bf16 storage + fp8 MFMA forward / dgrad convolutions (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--no-infer", action="store_true", help="skip the eval-forward secondary metric (profiling runs)")
@@ -177,7 +177,7 @@ def main():
 
     out = None
     if rank == 0:
-        es = 2 if args.dtype == "bf16" else 4
+        es = 2 if args.dtype in ("bf16", "fp8") else 4      # fp8 mode stores activations in bf16 (f8.hip)
         if headline:
             wk = step_work(args.size, nc, H, W, es)
         else:   # SURVEY.md 8d totals for the other configurations (per image, bf16 bytes scaled by the element size)

@@ -35,7 +35,10 @@ enum ys_status {
   YS_ERR_UNSUPPORTED = 4,
   YS_ERR_STATE = 5
 };
-enum ys_dtype { YS_F32 = 0, YS_BF16 = 1 };          /* compute/storage type of activations+weights */
+/* compute/storage type of activations+weights.  YS_FP8 (BASELINE config 5): bf16 storage, statistics and optimizer with the
+ * forward / input-gradient convolutions on the fp8 MFMA path -- e4m3 weights (current per-tensor scale) and activations, e5m2
+ * gradients (delayed per-tensor scales), fp32 accumulation; layers whose channel count is not a multiple of 32 stay in bf16. */
+enum ys_dtype { YS_F32 = 0, YS_BF16 = 1, YS_FP8 = 2 };
 enum ys_family { YS_YOLOV8 = 8, YS_YOLOV11 = 11 };   /* Models/Yolo.cs:10-135, :200-258 */
 enum ys_size { YS_N = 0, YS_S = 1, YS_M = 2, YS_L = 3, YS_X = 4 }; /* Types/YoloTypes.cs YoloSize; Yolo.cs:43-51 */
 enum ys_task { YS_DETECT = 0, YS_SEGMENT = 1 };
@@ -66,7 +69,7 @@ typedef struct ys_model_desc {
   int32_t height;     /* input H (multiple of 32) */
   int32_t width;      /* input W (multiple of 32) */
   int32_t max_batch;  /* capacity; forward may use any B <= max_batch */
-  int32_t dtype;      /* ys_dtype: YS_F32 = parity path, YS_BF16 = performance path */
+  int32_t dtype;      /* ys_dtype: YS_F32 = parity path, YS_BF16 = performance path, YS_FP8 = bf16 + fp8 MFMA convolutions */
   int32_t max_labels; /* initial capacity of ground-truth rows PER IMAGE for the loss (0 = 64).  Not a limit: host-label loss calls
                          grow the workspace to the batch's largest per-image count (the reference pads to counts.max(),
                          Utils/Loss.cs:363-390); device-label callers reserve with ys_model_reserve_labels */

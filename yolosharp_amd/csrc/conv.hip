@@ -635,6 +635,8 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
 #define P2_KG 2            // K-steps (32 K each) per streamed weight group
 #endif
 #define P2_NPU 12          // max patch units (16 B) a thread keeps in flight: 12 x 256 x 16 B = 48 KB per workgroup (small layers: 6)
+struct P2Tag0 { static constexpr int value = 0; };
+struct P2Tag1 { static constexpr int value = 1; };
 // K-steps per register group of the pipelined K loop: enough MFMAs per group (>= 8) to cover an LDS round trip
 // G K-steps share one LDS wait: about 16 MFMAs per group, so that a group's MFMA time matches the LDS round trip the SIMD's other
 // waves have to cover -- bounded by the fragment registers a group keeps live, 4 * G * (MR + NR): <= 64 in the 256-register
@@ -655,10 +657,17 @@ struct P2Args {
   int off_w, off_p, off_stat;   // LDS byte offsets (offset table sits at 0)
 };
 
-template <int MR, int NR, int WRES, int NPU, int NT>
-__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD   // waves per SIMD the LDS budget allows (512 threads: 2 workgroups x 2)
+// F8 = 1: fp8 mode.  Global activations stay bf16 (same HBM bytes); the patch is quantised to fp8 (e4m3, or e5m2 for a
+// gradient input) with a per-tensor scale as it is written to LDS, the weights arrive pre-quantised (e4m3), and the K loop
+// runs v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: 128 K per instruction at twice the bf16 MFMA rate, and half
+// the LDS bytes per K (the K loop of this kernel is LDS-bandwidth-bound for small register tiles).  A K-step is then 128 K =
+// four 32-channel pieces (one per lane quarter); Cin % 32 == 0.  The fp32 accumulators are scaled back in the epilogue.
+template <int MR, int NR, int WRES, int NPU, int NT, int F8>
+__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD
 conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
+  constexpr int WES = F8 ? 1 : 2;             // bytes per weight element
+  constexpr int UPS = F8 ? 8 : 4;             // 16-byte LDS units per weight row and K-step
   if (P2_DBG(64)) return;                     // ablation: launch + dispatch cost only
   constexpr int BN = NR * 16;
   constexpr int NWV = NT / 64;
@@ -672,7 +681,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #define TL_STAMP() ((void)0)
 #endif
   TL_STAMP();
-  constexpr int NWU = WRES ? 1 : (BN * P2_KG * 4 + NT - 1) / NT;   // streamed weight units per thread
+  constexpr int NWU = WRES ? 1 : (BN * P2_KG * UPS + NT - 1) / NT;   // streamed weight units per thread
   YS_DYN_LDS(lds);
   char* lb = (char*)lds;
   int* sOff = (int*)lb;                       // [nsteps][4]
@@ -683,10 +692,12 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.y * BN;
   const char* xb = (const char*)a.x;
-  const char* wb = (const char*)a.w;
+  const char* wb = (const char*)(F8 ? a.w8 : a.w);
   const int taps = a.KH * a.KW;
   const int Ktot = taps * a.Cin;
-  const int cu = a.Cin >> 3;                  // 16-byte units per patch pixel
+  const int cu = a.Cin >> 3;                  // 16-byte units per patch pixel in GLOBAL memory (bf16)
+  const float qs = F8 ? a.qscale[0] : 1.0f;   // quantisation multiplier of the input tensor
+  float amx = 0.f;                            // fp8: running amax(|input|) of what this thread stages (next step's scale)
   const int npatch = g.PH * g.PW * cu;
 
   // ---- tile-independent tables, computed once per layer geometry on the host (p2_tables): per-(quarter, K-step) patch
@@ -702,9 +713,9 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     ptx[mf] = tpx[(mf * 3 + 2) * NT + tid];
   }
   constexpr int KG = P2_KG;                    // K-steps per streamed weight group
-  constexpr int GU = KG * 4;                   // 16-byte units per weight row and group
+  constexpr int GU = KG * UPS;                 // 16-byte units per weight row and group
   constexpr bool TIGHT = NT == 256 && NPU <= 6 && MR * NR <= 8;                           // 168-register variants
-  constexpr int G0 = p2_reg_group(MR, NR, TIGHT);
+  constexpr int G0 = F8 ? 1 : p2_reg_group(MR, NR, TIGHT);   // fp8: one K-step is already 128 K (32-byte fragments)
   constexpr int G = (WRES || G0 < KG) ? G0 : KG;   // K-steps per register group of the K loop
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
   uint4 rwA[NWU];
@@ -716,13 +727,13 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     const int idx = tid + NT * k;
     const int n = idx / GU;
     wun[k] = (idx < BN * GU && n0 + n < a.Cout) ? idx - n * GU : -1;
-    wrow[k] = wb + ((long)(n0 + (wun[k] >= 0 ? n : 0)) * Ktot) * 2L;
+    wrow[k] = wb + ((long)(n0 + (wun[k] >= 0 ? n : 0)) * Ktot) * (long)WES;
   }
   auto wfetch = [&](uint4 (&rw)[NWU], int grp) {   // global -> registers: weights of K-steps [grp*KG, grp*KG + KG); unconditional loads
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
       const int u = grp * GU + wun[k];
-      const bool ok = (bool)((int)(wun[k] >= 0) & (int)(u * 8 < Ktot) & (int)!P2_DBG(16));
+      const bool ok = (bool)((int)(wun[k] >= 0) & (int)(u * (16 / WES) < Ktot) & (int)!P2_DBG(16));
       rw[k] = ys_ld16(wrow[k] + (ok ? u * 16 : 0));
       if (!ok) rw[k] = ys_zero16();
     }
@@ -808,7 +819,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     // resident weights: rows padded with zeros to a multiple of 4 K-steps (the pipelined K loop runs whole register groups).
     // Loads are issued eight at a time before the first LDS store: the one-load-one-store form was a chain of dependent L2
     // round trips (measured 6-9 thousand cycles of prologue per workgroup for a 36 KB weight set).
-    const int per_row = ((g.nsteps + 3) & ~3) * 4;
+    const int per_row = ((g.nsteps + 3) & ~3) * UPS;
     const int total = BN * per_row;
     constexpr int UB = 8;
     for (int base = tid; base < total; base += NT * UB) {
@@ -818,8 +829,8 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       for (int k = 0; k < UB; k++) {
         const int idx = base + k * NT;
         const int n = idx / per_row, u = idx - n * per_row;
-        const bool ok = (bool)((int)(idx < total) & (int)(n0 + n < a.Cout) & (int)(u * 8 < Ktot));
-        const long off = ok ? ((long)(n0 + n) * Ktot + u * 8) * 2L : 0L;
+        const bool ok = (bool)((int)(idx < total) & (int)(n0 + n < a.Cout) & (int)(u * (16 / WES) < Ktot));
+        const long off = ok ? (long)(n0 + n) * Ktot * WES + u * 16L : 0L;
         v[k] = ys_ld16(wb + off);
         if (!ok) v[k] = ys_zero16();
         dst[k] = idx < total ? n * g.wpitch + u : -1;
@@ -845,7 +856,21 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #ifndef YS_EMU_BUILD
       asm volatile("" : "+v"(d));
 #endif
-      if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = ((okm_next >> k) & 1u) ? rp[k] : ys_zero16();
+      if (F8) {
+        if (d != 0xffffffffu && !P2_DBG(8)) {
+          uint2 v8; v8.x = 0u; v8.y = 0u;
+          if ((okm_next >> k) & 1u) {
+            float f[8];
+            ys_unpack<T>(rp[k], f);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { amx = fmaxf(amx, fabsf(f[e])); f[e] *= qs; }
+            v8 = a.f8 == 2 ? ys_pack_f8x8<1>(f) : ys_pack_f8x8<0>(f);
+          }
+          *(uint2*)(sPb + ((d & 8191u) << 3)) = v8;
+        }
+      } else {
+        if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = ((okm_next >> k) & 1u) ? rp[k] : ys_zero16();
+      }
     }
     if (!WRES) wstore(rwA, 0);
     ys_barrier_lds();
@@ -868,7 +893,8 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     // G steps (about 16 MFMAs), and the next group's table entries are fetched while the MFMAs issue, so the chain per group is
     // one round trip + the MFMAs -- which the SIMD's other waves overlap.  (Double-buffered fragment sets cost 50-100 registers
     // and spilled in most variants.)  Reads past the last real step land in valid LDS; their weights are zero.
-    struct Frags { uint4 w[G][NR]; uint4 x[G][MR]; };
+    constexpr int FU = F8 ? 2 : 1;             // 16-byte reads per fragment
+    struct Frags { uint4 w[G][NR][FU]; uint4 x[G][MR][FU]; };
     auto read_offs = [&](int (&off)[G], int s) {
       const int* pq = sOff + q * g.nsp + s;
       if (G == 4) { const uint4 v = *(const uint4*)pq; off[0] = (int)v.x; off[G > 1 ? 1 : 0] = (int)v.y; off[G > 2 ? 2 : 0] = (int)v.z; off[G > 3 ? 3 : 0] = (int)v.w; }
@@ -876,7 +902,8 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       else off[0] = pq[0];
     };
     // ng register groups starting at table step sbase, weight units from 0 in wbuf
-    auto kloop = [&](const uint4* wbuf, int sbase, int ng) {
+    auto kloop = [&](const uint4* wbuf, int sbase, int ng, auto bf8_tag) {
+      constexpr int B_BF8 = decltype(bf8_tag)::value;
       if (P2_DBG(2)) return;
       int off[G];
       read_offs(off, sbase);
@@ -886,9 +913,13 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #pragma unroll
         for (int gs = 0; gs < G; gs++) {
 #pragma unroll
-          for (int nf = 0; nf < NR; nf++) f.w[gs][nf] = wbuf[(nf * 16 + li) * g.wpitch + (gi * G + gs) * 4 + q];
+          for (int nf = 0; nf < NR; nf++)
 #pragma unroll
-          for (int mf = 0; mf < MR; mf++) f.x[gs][mf] = *(const uint4*)(sPb + pixbase[mf] + off[gs]);
+            for (int h = 0; h < FU; h++) f.w[gs][nf][h] = wbuf[(nf * 16 + li) * g.wpitch + ((gi * G + gs) * 4 + q) * FU + h];
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+            for (int h = 0; h < FU; h++) f.x[gs][mf][h] = *(const uint4*)(sPb + pixbase[mf] + off[gs] + h * 16);
         }
         read_offs(off, sbase + (gi + 1) * G);
         YS_SCHED_FENCE();                        // every read of the group is issued before its first MFMA
@@ -897,17 +928,21 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #pragma unroll
           for (int nf = 0; nf < NR; nf++)
 #pragma unroll
-            for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(f.w[gs][nf], f.x[gs][mf], acc[mf][nf]);
+            for (int mf = 0; mf < MR; mf++) {
+              if (F8) acc[mf][nf] = mfma_scale_16x16x128_f8<B_BF8>(f.w[gs][nf][0], f.w[gs][nf][FU - 1], f.x[gs][mf][0], f.x[gs][mf][FU - 1], acc[mf][nf]);
+              else acc[mf][nf] = ys_mma<T>(f.w[gs][nf][0], f.x[gs][mf][0], acc[mf][nf]);
+            }
       }
     };
+    const bool in_bf8 = F8 && a.f8 == 2;      // uniform: the input operand is a gradient quantised to e5m2
     if (WRES) {
-      kloop(sW, 0, (g.nsteps + G - 1) / G);
+      if (in_bf8) kloop(sW, 0, (g.nsteps + G - 1) / G, P2Tag1{}); else kloop(sW, 0, (g.nsteps + G - 1) / G, P2Tag0{});
     } else {
       constexpr int NGS = KG / G;               // register groups per streamed weight slot
 #pragma unroll 1
       for (int grp = 0; grp < ngroups; grp++) {
         wfetch(rwA, grp + 1);                   // unconditional (past the end: zeros); lands during this group's MFMAs
-        kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS);
+        if (in_bf8) kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS, P2Tag1{}); else kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS, P2Tag0{});
         wstore(rwA, (grp + 1) & 1);
         ys_barrier_lds();
       }
@@ -924,11 +959,21 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       orow[mf] = (long)b * a.out_bstride + (pv[mf] ? (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox)) : 0);
     }
     char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 16);
+    if (F8) {                                 // back to real units: 1 / (input scale * weight scale)
+      const float dq = a.deq[0];
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
+    }
     if (!P2_DBG(4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
     TL_STAMP();
     txi = ntx; tyi = nty; b = nb;
   }
   if (a.stats) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+  if (F8 && a.amax && blockIdx.y == 0) ys_amax_update(a.amax, amx);
   TL_STAMP();
 #ifdef YS_P2_TIMELINE
   if (tl_p) tl_p[0] = (unsigned long long)tl_n;
@@ -936,6 +981,13 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 }
 
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
+// fp8 variants whose 32-byte fragments fit the 256-register budget without spilling (hipcc -Rpass-analysis=kernel-resource-usage)
+static bool p2_f8_tile_ok(int mr, int nr, int wres) {
+  static const bool any = getenv("YS_P2_F8_ANYTILE") != nullptr;      // triage: accept the spilling variants too
+  if (any) return true;
+  if (wres) return mr * nr <= 8 && !(mr == 2 && nr == 5) && nr <= 5;
+  return mr * nr <= 4 && mr + nr <= 5;
+}
 static P2Plan conv_p2_plan(const ConvArgs& a) {
   P2Plan p{};
   // 3x3 forward / stride-1 dgrad, 1x1 forward / dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided
@@ -946,13 +998,16 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
   if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
   if (a.Cin % 8) return p;
+  const bool f8 = a.f8 != 0;
+  if (f8 && (a.Cin % 32 || !a.w8 || !a.qscale || !a.deq)) return p;
+  const int ups = f8 ? 8 : 4;                        // 16-byte LDS units per weight row and K-step
   const int nfr = (a.Cout + 15) / 16;
   int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
   const int cu = a.Cin / 8;
   P2Args g{};
-  g.ppb = a.Cin * 2 + ((cu & 1) ? 32 : 16);
+  g.ppb = f8 ? a.Cin + (((a.Cin / 16) & 1) ? 32 : 16) : a.Cin * 2 + ((cu & 1) ? 32 : 16);   // odd number of 16-byte slots per pixel
   const int taps = a.KH * a.KW;
-  g.nsteps = (taps * a.Cin + 31) / 32;
+  g.nsteps = f8 ? (taps * a.Cin + 127) / 128 : (taps * a.Cin + 31) / 32;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
   // workgroup per CU); YS_P2_WRESMAX overrides for experiments
   static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 44 * 1024;   // rows padded to 4 K-steps
@@ -963,22 +1018,23 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   static const int nrsplit = getenv("YS_P2_NRSPLIT") ? atoi(getenv("YS_P2_NRSPLIT")) : 1;   // measured 13.00 -> 12.86 ms/step
   const int nsteps4 = (g.nsteps + 3) & ~3;           // resident weight rows are zero-padded to whole register groups (<= 4 K-steps)
   g.nsp = nsteps4 + 12;                              // + slack: the pipelined loop reads table entries up to two groups ahead
-  if (nrsplit && (size_t)nr * 16 * ((nsteps4 * 4) | 1) * 16 > wresmax && nr % 2 == 0 &&
-      (size_t)(nr / 2) * 16 * ((nsteps4 * 4) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
+  if (nrsplit && (size_t)nr * 16 * ((nsteps4 * ups) | 1) * 16 > wresmax && nr % 2 == 0 &&
+      (size_t)(nr / 2) * 16 * ((nsteps4 * ups) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
     nr /= 2;
+  if (f8 && (size_t)nr * 16 * ((nsteps4 * ups) | 1) * 16 > wresmax && nr > 2 && !getenv("YS_P2_F8_ANYTILE")) nr = 2;   // streamed fp8 weights: small register tiles only
   const int bn = nr * 16;
-  const size_t wres_bytes = (size_t)bn * ((nsteps4 * 4) | 1) * 16;
+  const size_t wres_bytes = (size_t)bn * ((nsteps4 * ups) | 1) * 16;
   const int wres = wres_bytes <= wresmax ? 1 : 0;
   g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
-  g.wpitch = wres ? ((nsteps4 * 4) | 1) : ((g.kg * 4) | 1);
+  g.wpitch = wres ? ((nsteps4 * ups) | 1) : ((g.kg * ups) | 1);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
   const size_t tab = ((size_t)g.nsp * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
   // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed
   // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
   static const int maxcin3 = getenv("YS_P2_MAXCIN3") ? atoi(getenv("YS_P2_MAXCIN3")) : 255;
-  if (k3 && a.SA == 1 && a.Cin > maxcin3) return p;
+  if (k3 && a.SA == 1 && a.Cin > (f8 ? 640 : maxcin3)) return p;   // an fp8 patch pixel is half the bytes
   for (size_t budget = (wres && wres_bytes > 44 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
   // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
@@ -990,6 +1046,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     const size_t stat = (size_t)nwv * bn * 2 * 4;
     const int npu_max = nt == 512 ? 6 : P2_NPU;
     for (int mr = (nt == 512 ? 2 : (nr <= 4 ? 4 : 2)); mr >= 1; mr >>= 1) {
+      if (f8 && !p2_f8_tile_ok(mr, nr, wres)) continue;
       const int npx = 16 * nwv * mr;
       const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 16);
       for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
@@ -998,7 +1055,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
         if (pbytes < (size_t)16 * nt * 4) pbytes = (size_t)16 * nt * 4;   // statistics scratch of p2_stats_flush
         const size_t lds = tab + wbytes + pbytes + stat;
-        if (lds > budget || ph * pw * cu > npu_max * nt) continue;
+        if (lds > budget || ph * pw * cu > npu_max * nt || (size_t)ph * pw * g.ppb > (size_t)8192 * (f8 ? 8 : 16)) continue;   // 13-bit LDS slot field
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
         const long ntiles = (long)tx * ty * a.B;
         const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + tileconst;
@@ -1010,7 +1067,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
           cur.TH = th; cur.TW = tw; cur.tiles_x = tx; cur.tiles_y = ty; cur.PH = ph; cur.PW = pw; cur.ntiles = (int)ntiles;
           cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
           p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy; p.nt = nt;
-          p.npu = nt == 512 ? 6 : (ph * pw * cu <= 6 * 256 ? 6 : 12);
+          p.npu = nt == 512 ? 6 : (ph * pw * cu <= 6 * 256 && !f8 ? 6 : 12);   // fp8 is instantiated for NPU = 12 only
         }
       }
     }
@@ -1035,7 +1092,8 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   int dev = 0;
   hipGetDevice(&dev);
   const P2Args& g = p.g;
-  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.nsteps, g.nsp, p.mr, p.npu, p.nt};
+  const bool f8 = a.f8 != 0;
+  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.nsteps, g.nsp, p.mr, p.npu, p.nt, (int)f8};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   const int NT = p.nt;
@@ -1043,11 +1101,12 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   std::vector<int> h((size_t)g.nsp * 4 + (size_t)p.mr * 3 * NT + (size_t)p.npu * 2 * NT, 0);
   for (int qq = 0; qq < 4; qq++)            // q-major: [quarter][K-step]; steps past the last real one keep offset 0 (their weights are zero)
     for (int st = 0; st < g.nsteps; st++) {
-      const int k0 = st * 32 + qq * 8;
+      const int kp = f8 ? 32 : 8;             // channels per (K-step, quarter) piece
+      const int k0 = st * 4 * kp + qq * kp;
       if (k0 < Ktot) {
         const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        h[(size_t)qq * g.nsp + st] = (kh * g.PW + kw) * g.ppb + ch * 2;
+        h[(size_t)qq * g.nsp + st] = (kh * g.PW + kw) * g.ppb + ch * (f8 ? 1 : 2);
       }
     }
   int* tpx = h.data() + g.nsp * 4;
@@ -1070,7 +1129,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
       if (idx < npatch) {
         const int pix = idx / cu, u = idx - pix * cu;
         const int r = pix / g.PW, cc = pix - r * g.PW;
-        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (unsigned)(((r * g.PW + cc) * g.ppb + u * 16) >> 4);
+        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (f8 ? (unsigned)(((r * g.PW + cc) * g.ppb + u * 8) >> 3) : (unsigned)(((r * g.PW + cc) * g.ppb + u * 16) >> 4));
         go = (r * a.Win + cc) * a.in_ldc + u * 8;
       }
       tpd[(2 * k + 0) * NT + tid] = (int)d;
@@ -1083,7 +1142,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   return dptr;
 }
 
-template <int MR, int NR, int WRES, int NPU, int NT>
+template <int MR, int NR, int WRES, int NPU, int NT, int F8>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
   a.dbg = dbg;
@@ -1091,11 +1150,11 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
-    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU, NT, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "p2 k%d s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, NT, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), F8 ? "p2f8 k%d s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d" : "p2 k%d s%d div1 cin%d cout%d M%d acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, NT, MR, NR, WRES, NPU, p.g.TH, p.g.TW, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
   const int* tab = p2_tables(a, p);
   if (!tab) { ys_set_error("conv p2: cannot allocate the index tables"); return YS_ERR_OOM; }
@@ -1108,7 +1167,7 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
     a.tl = tl_buf;
   }
 #endif
-  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU, NT>), dim3(p.gx, p.gy), NT, p.lds, st, a, p.g, tab);
+  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU, NT, F8>), dim3(p.gx, p.gy), NT, p.lds, st, a, p.g, tab);
 #ifdef YS_P2_TIMELINE
   if (tl_path) {
     static unsigned long long h[64 * 64];
@@ -1132,11 +1191,17 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
 }
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
   {
-#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { \
-    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256>(st, a, p); \
-    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256>(st, a, p); }
+#define P2F(M_, N_, F_) { \
+    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_>(st, a, p); \
+    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256, F_>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256, F_>(st, a, p); }
+#define P2F8(M_, N_) { \
+    if (p.wres) return conv_p2_launch_t<M_, N_, 1, 12, 256, 1>(st, a, p); \
+    return conv_p2_launch_t<M_, N_, 0, 12, 256, 1>(st, a, p); }
+#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F8(M_, N_) else P2F(M_, N_, 0) }
     P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
 #undef P2
+#undef P2F
+#undef P2F8
   }
   ys_set_error("conv p2: no kernel for NT=%d MR=%d NR=%d", p.nt, p.mr, p.nr);
   return YS_ERR_UNSUPPORTED;
@@ -1230,6 +1295,12 @@ static int conv_pick_mr(int M, int cout) {
 }
 
 int ys_conv_grid_m(const ConvArgs& a, int dtype) {
+  if (a.f8) {                       // mirrors ys_conv_launch: the fp8 plan, else the bf16 kernels
+    const P2Plan pf = dtype == YS_BF16 ? conv_p2_plan(a) : P2Plan{};
+    if (pf.ok) return pf.gx;
+    ConvArgs b = a; b.f8 = 0;
+    return ys_conv_grid_m(b, dtype);
+  }
   if (dtype == YS_BF16) {
     const P2Plan p2 = conv_p2_plan(a);
     if (p2.ok) return p2.gx;   // one statistics row per (persistent) workgroup
@@ -1311,8 +1382,10 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a) {
     if (q.Hout <= 0 || q.Wout <= 0) continue;
     q.M = a.B * q.Hout * q.Wout;
     q.w = (const char*)a.w + (size_t)toff[ph] * a.Cout * a.Cin * 2;   // [phase][Cout = layer Cin_real][taps_p][Cin = layer Cout_pad]
+    if (a.w8) q.w8 = (const char*)a.w8 + (size_t)toff[ph] * a.Cout * a.Cin;
     q.out_rh = 2 * Wx; q.out_rw = 2; q.out_r0 = (long)pa * Wx + pb;
-    const P2Plan p2 = conv_p2_plan(q);
+    P2Plan p2 = conv_p2_plan(q);
+    if (!p2.ok && q.f8) { q.f8 = 0; p2 = conv_p2_plan(q); }          // no fp8 plan for this shape: bf16 kernel, same result type
     if (p2.ok) { const int rc = conv_p2_dispatch(st, q, p2); if (rc != YS_OK) return rc; }
     else { const int rc = conv_launch_dtype<bf16_t>(st, q); if (rc != YS_OK) return rc; }
   }
@@ -1328,6 +1401,12 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
   if (dtype == YS_BF16) {
     static const bool p2_off = getenv("YS_NO_P2") != nullptr;
     if (ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH) return conv_dgrad_s2_phases(st, a);
+    if (a.f8) {                                                       // fp8 request: only the P2 kernel has the mode
+      const P2Plan pf = conv_p2_plan(a);
+      if (pf.ok && !p2_off) return conv_p2_dispatch(st, a, pf);
+      ConvArgs b = a; b.f8 = 0;
+      return ys_conv_launch(st, dtype, b);
+    }
     const P2Plan p2 = conv_p2_plan(a);
     if (p2.ok && !p2_off) return conv_p2_dispatch(st, a, p2);
     return conv_launch_dtype<bf16_t>(st, a);

@@ -213,35 +213,41 @@ template <class T, bool ACT>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_act_apply_kernel(const T* __restrict__ y, long rows, int C, const float* __restrict__ scale,
                     const float* __restrict__ shift, const T* __restrict__ res, int res_ldc, int res_coff,
-                    T* __restrict__ z, int z_ldc, int z_coff, int small) {
+                    T* __restrict__ z, int z_ldc, int z_coff, int small, unsigned* __restrict__ amax) {
   constexpr int EPL = Elem<T>::EPL;
   const int CG = C / EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * CG) return;
-  long row; int c;
-  if (small) { const unsigned iu = (unsigned)i, r = iu / (unsigned)CG; row = r; c = (int)(iu - r * (unsigned)CG) * EPL; }
-  else { row = i / CG; c = (int)(i - row * CG) * EPL; }
-  float f[EPL], r[EPL], sc[EPL], sh[EPL];
-  ys_unpack<T>(ys_ld16(y + row * C + c), f);
-  if (res) ys_unpack<T>(ys_ld16(res + row * res_ldc + res_coff + c), r);
-  ys_ldcoef<EPL>(scale + c, sc);
-  ys_ldcoef<EPL>(shift + c, sh);
+  float mx = 0.f;
+  if (i < rows * CG) {
+    long row; int c;
+    if (small) { const unsigned iu = (unsigned)i, r = iu / (unsigned)CG; row = r; c = (int)(iu - r * (unsigned)CG) * EPL; }
+    else { row = i / CG; c = (int)(i - row * CG) * EPL; }
+    float f[EPL], r[EPL], sc[EPL], sh[EPL];
+    ys_unpack<T>(ys_ld16(y + row * C + c), f);
+    if (res) ys_unpack<T>(ys_ld16(res + row * res_ldc + res_coff + c), r);
+    ys_ldcoef<EPL>(scale + c, sc);
+    ys_ldcoef<EPL>(shift + c, sh);
 #pragma unroll
-  for (int e = 0; e < EPL; e++) {
-    float u = f[e] * sc[e] + sh[e];
-    if (ACT) u = ys_silu(u);
-    if (res) u += r[e];
-    f[e] = u;
+    for (int e = 0; e < EPL; e++) {
+      float u = f[e] * sc[e] + sh[e];
+      if (ACT) u = ys_silu(u);
+      if (res) u += r[e];
+      f[e] = u;
+      mx = fmaxf(mx, fabsf(u));
+    }
+    ys_st16(z + row * z_ldc + z_coff + c, ys_pack<T>(f));
   }
-  ys_st16(z + row * z_ldc + z_coff + c, ys_pack<T>(f));
+  // fp8 mode: amax(|z|) of the tensor this pass writes feeds the NEXT step's activation scale (delayed scaling, f8.hip); the
+  // maximum of non-negative floats is order-independent, so the atomic keeps the step deterministic
+  if (amax) ys_amax_update(amax, mx);
 }
 int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const float* scale,
                            const float* shift, int act, const void* res, int res_ldc, int res_coff, void* z,
-                           int z_ldc, int z_coff) {
+                           int z_ldc, int z_coff, unsigned* amax) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
   const int small = n < (1L << 31) ? 1 : 0;
-#define BA_LAUNCH(TT, AF) YS_LAUNCH((bn_act_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)y, rows, C, scale, shift, (const TT*)res, res_ldc, res_coff, (TT*)z, z_ldc, z_coff, small)
+#define BA_LAUNCH(TT, AF) YS_LAUNCH((bn_act_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)y, rows, C, scale, shift, (const TT*)res, res_ldc, res_coff, (TT*)z, z_ldc, z_coff, small, amax)
   if (dtype == YS_BF16) { if (act) BA_LAUNCH(bf16_t, true); else BA_LAUNCH(bf16_t, false); }
   else { if (act) BA_LAUNCH(float, true); else BA_LAUNCH(float, false); }
 #undef BA_LAUNCH
@@ -488,32 +494,37 @@ template <class T, bool ACT>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k2,
-                    const float* __restrict__ k3, T* __restrict__ dy, int small) {
+                    const float* __restrict__ k3, T* __restrict__ dy, int small, unsigned* __restrict__ amax) {
   constexpr int EPL = Elem<T>::EPL;
   const int CG = C / EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * CG) return;
-  long row; int c;
-  if (small) { const unsigned iu = (unsigned)i, r = iu / (unsigned)CG; row = r; c = (int)(iu - r * (unsigned)CG) * EPL; }
-  else { row = i / CG; c = (int)(i - row * CG) * EPL; }
-  float g[EPL], f[EPL], sc[EPL], sh[EPL], a2[EPL], a3[EPL];
-  ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
-  ys_unpack<T>(ys_ld16(y + row * C + c), f);
-  ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(k2 + c, a2); ys_ldcoef<EPL>(k3 + c, a3);
+  float mx = 0.f;
+  if (i < rows * CG) {
+    long row; int c;
+    if (small) { const unsigned iu = (unsigned)i, r = iu / (unsigned)CG; row = r; c = (int)(iu - r * (unsigned)CG) * EPL; }
+    else { row = i / CG; c = (int)(i - row * CG) * EPL; }
+    float g[EPL], f[EPL], sc[EPL], sh[EPL], a2[EPL], a3[EPL];
+    ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
+    ys_unpack<T>(ys_ld16(y + row * C + c), f);
+    ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(k2 + c, a2); ys_ldcoef<EPL>(k3 + c, a3);
 #pragma unroll
-  for (int e = 0; e < EPL; e++) {
-    const float u = f[e] * sc[e] + sh[e];
-    const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];
-    f[e] = sc[e] * du - a2[e] - f[e] * a3[e];
+    for (int e = 0; e < EPL; e++) {
+      const float u = f[e] * sc[e] + sh[e];
+      const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];
+      f[e] = sc[e] * du - a2[e] - f[e] * a3[e];
+      mx = fmaxf(mx, fabsf(f[e]));
+    }
+    ys_st16(dy + row * C + c, ys_pack<T>(f));
   }
-  ys_st16(dy + row * C + c, ys_pack<T>(f));
+  if (amax) ys_amax_update(amax, mx);          // fp8 mode: amax(|dy|) for the next step's gradient scale (f8.hip)
 }
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
-                           int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy) {
+                           int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
+                           unsigned* amax) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
   const int small = n < (1L << 31) ? 1 : 0;
-#define BB_LAUNCH(TT, AF) YS_LAUNCH((bn_bwd_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, scale, shift, k2, k3, (TT*)dy, small)
+#define BB_LAUNCH(TT, AF) YS_LAUNCH((bn_bwd_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, scale, shift, k2, k3, (TT*)dy, small, amax)
   if (dtype == YS_BF16) { if (act) BB_LAUNCH(bf16_t, true); else BB_LAUNCH(bf16_t, false); }
   else { if (act) BB_LAUNCH(float, true); else BB_LAUNCH(float, false); }
 #undef BB_LAUNCH

@@ -46,6 +46,8 @@ struct ConvL {
   int seg = 0;
   bool first = false;
   bool dw = false;       // depthwise 3x3 (groups = channels): weights [9][C] fp32, no MFMA path
+  bool f8_fwd = false, f8_bwd = false;   // fp8 mode: forward / dgrad of this layer may run the fp8 kernel (f8.hip recipe)
+  int idx = -1, prep_idx = -1;           // own index in ys_model::convs; first PrepDesc (weight-amax slot)
   bool ct = false;       // ConvTranspose2d(k=2,s=2,bias) = four 1x1 phase GEMMs (Proto.upsample, Block.cs:69); weights [4][Cout][Cin]
 };
 
@@ -96,6 +98,11 @@ struct ys_model {
   struct Range { long off, count; };
   Range seg_group[3][3];                         // [segment][adamw group]
   long step = 0;
+  // fp8 mode (ys_dtype YS_FP8: bf16 storage + fp8 MFMA convolutions, f8.hip)
+  bool f8 = false, f8_sx_valid = false, f8_sg_valid = false, f8_bwd_done = false;
+  unsigned char *wf8_all = nullptr, *wd8_all = nullptr;
+  float *amax_w = nullptr, *f8_scales = nullptr; unsigned *amax_act = nullptr, *amax_dy = nullptr;
+  F8Layer* f8_layers = nullptr; F8Conv* f8_convs = nullptr; int n_f8_convs = 0; long n_wf_pending = 0, n_wd_pending = 0;
   int group_mode = 0;                            // 0 = disjoint groups, 1 = the reference's overlapping groups as written
   unsigned char* bn_mask = nullptr;              // [n_params] 1 = BatchNorm weight / bias (listed twice in the reference's groups)
   // T weights
@@ -163,6 +170,7 @@ int add_conv(ys_model* m, const std::string& name, View in, View out, int cin, i
   c.cout_ld = (cout + m->epl - 1) / m->epl * m->epl;
   c.seg = seg;
   if (res) { c.res = *res; c.has_res = true; }
+  c.idx = (int)m->convs.size();
   m->convs.push_back(c);
   Op op; op.type = OP_CONV; op.conv = (int)m->convs.size() - 1; op.in = in; op.out = out; op.H = Hin; op.W = Win; op.seg = seg;
   m->ops.push_back(op);
@@ -600,7 +608,9 @@ int layout_params(ys_model* m) {
 template <class T>
 __global__ void __launch_bounds__(256)
 weight_prep_all_kernel(const float* __restrict__ params, const PrepDesc* __restrict__ desc, int n, long total_f, long total_d,
-                       T* __restrict__ wf_all, T* __restrict__ wd_all) {
+                       T* __restrict__ wf_all, T* __restrict__ wd_all, const float* __restrict__ amax_w,
+                       unsigned char* __restrict__ wf8_all, unsigned char* __restrict__ wd8_all) {
+  // fp8 mode: e4m3 copies of both shadows (same element order) with the layer's current scale 448 / amax(|W|)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total_f) {
     int lo = 0, hi = n - 1;
@@ -609,7 +619,9 @@ weight_prep_all_kernel(const float* __restrict__ params, const PrepDesc* __restr
     const long e = i - d.nf_start;
     const int ci = (int)(e % d.cin_pad);
     const long r = e / d.cin_pad;
-    wf_all[d.wf_off + e] = Elem<T>::from_f(ci < d.cin_real ? params[d.w_off + r * d.cin_real + ci] : 0.f);
+    const T tv = Elem<T>::from_f(ci < d.cin_real ? params[d.w_off + r * d.cin_real + ci] : 0.f);
+    wf_all[d.wf_off + e] = tv;
+    if (wf8_all) { const float aw = amax_w[lo]; wf8_all[d.wf_off + e] = ys_f32_to_e4m3_dev(Elem<T>::to_f(tv) * (aw > 0.f ? YS_E4M3_MAX / aw : 1.0f)); }
   }
   if (i < total_d) {
     int lo = 0, hi = n - 1;
@@ -627,7 +639,9 @@ weight_prep_all_kernel(const float* __restrict__ params, const PrepDesc* __restr
         ci = (int)(r / d.taps);
         tap = d.taps - 1 - tapf;
       }
-      wd_all[d.wd_off + e] = Elem<T>::from_f(co < d.cout ? params[d.w_off + ((long)co * d.taps + tap) * d.cin_real + ci] : 0.f);
+      const T tv = Elem<T>::from_f(co < d.cout ? params[d.w_off + ((long)co * d.taps + tap) * d.cin_real + ci] : 0.f);
+      wd_all[d.wd_off + e] = tv;
+      if (wd8_all) { const float aw = amax_w[lo]; wd8_all[d.wd_off + e] = ys_f32_to_e4m3_dev(Elem<T>::to_f(tv) * (aw > 0.f ? YS_E4M3_MAX / aw : 1.0f)); }
     }
   }
 }
@@ -635,10 +649,11 @@ weight_prep_all_kernel(const float* __restrict__ params, const PrepDesc* __restr
 int prep_weights(ys_model* m) {
   if (!m->weights_dirty) return YS_OK;
   const long total = std::max(m->prep_nf, m->prep_nd);
+  if (m->f8) YS_TRY(ys_f8_weight_amax_launch(m->ctx->stream, m->params, m->f8_layers, m->n_prep, m->amax_w));
   if (m->dtype == YS_BF16)
-    YS_LAUNCH((weight_prep_all_kernel<bf16_t>), ys_cdiv(total, 256), 256, m->ctx->stream, (const float*)m->params, (const PrepDesc*)m->prep_dev, m->n_prep, m->prep_nf, m->prep_nd, (bf16_t*)m->wf_all, (bf16_t*)m->wd_all);
+    YS_LAUNCH((weight_prep_all_kernel<bf16_t>), ys_cdiv(total, 256), 256, m->ctx->stream, (const float*)m->params, (const PrepDesc*)m->prep_dev, m->n_prep, m->prep_nf, m->prep_nd, (bf16_t*)m->wf_all, (bf16_t*)m->wd_all, (const float*)m->amax_w, m->wf8_all, m->wd8_all);
   else
-    YS_LAUNCH((weight_prep_all_kernel<float>), ys_cdiv(total, 256), 256, m->ctx->stream, (const float*)m->params, (const PrepDesc*)m->prep_dev, m->n_prep, m->prep_nf, m->prep_nd, (float*)m->wf_all, (float*)m->wd_all);
+    YS_LAUNCH((weight_prep_all_kernel<float>), ys_cdiv(total, 256), 256, m->ctx->stream, (const float*)m->params, (const PrepDesc*)m->prep_dev, m->n_prep, m->prep_nf, m->prep_nd, (float*)m->wf_all, (float*)m->wd_all, (const float*)nullptr, (unsigned char*)nullptr, (unsigned char*)nullptr);
   m->weights_dirty = false;
   return YS_OK;
 }
@@ -679,6 +694,35 @@ int alloc_label_ws(ys_model* m, int gcap) {
   return YS_OK;
 }
 
+// fp8 mode: which convolutions may run the fp8 kernel, the e4m3 weight shadows and the amax / scale slots (recipe: f8.hip)
+int alloc_f8(ys_model* m, const std::vector<PrepDesc>& pd) {
+  hipStream_t st = m->ctx->stream;
+  const int nb = (int)m->bufs.size(); (void)nb;
+  std::vector<F8Layer> layers(pd.size());
+  for (size_t i = 0; i < pd.size(); i++) { layers[i].w_off = pd[i].w_off; layers[i].count = (long)pd[i].cout * pd[i].taps * pd[i].cin_real; }
+  std::vector<F8Conv> fc(m->convs.size());
+  for (auto& c : m->convs) {
+    F8Conv& f = fc[c.idx];
+    f.layer = c.prep_idx >= 0 ? c.prep_idx : 0;
+    const bool dense = !c.first && !c.dw && !c.ct && c.bn;       // the plain biased head outputs feed the loss directly: kept in bf16
+    c.f8_fwd = dense && c.cin_pad % 32 == 0 && c.cin == c.cin_pad;
+    c.f8_bwd = dense && c.cout % 32 == 0 && c.cout_ld == c.cout;
+  }
+  m->n_f8_convs = (int)fc.size();
+  YS_TRY(dev_alloc(m, (void**)&m->wf8_all, (size_t)m->n_wf_pending));
+  YS_TRY(dev_alloc(m, (void**)&m->wd8_all, (size_t)m->n_wd_pending));
+  YS_TRY(dev_alloc(m, (void**)&m->amax_w, pd.size() * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->amax_act, fc.size() * YS_AMAX_WAYS * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->amax_dy, fc.size() * YS_AMAX_WAYS * 4));
+  YS_TRY(dev_alloc(m, (void**)&m->f8_scales, fc.size() * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->f8_layers, layers.size() * sizeof(F8Layer)));
+  YS_TRY(dev_alloc(m, (void**)&m->f8_convs, fc.size() * sizeof(F8Conv)));
+  YS_CHECK_HIP(hipMemcpyAsync(m->f8_layers, layers.data(), layers.size() * sizeof(F8Layer), hipMemcpyHostToDevice, st));
+  YS_CHECK_HIP(hipMemcpyAsync(m->f8_convs, fc.data(), fc.size() * sizeof(F8Conv), hipMemcpyHostToDevice, st));
+  YS_CHECK_HIP(hipStreamSynchronize(st));
+  return YS_OK;
+}
+
 int allocate(ys_model* m) {
   const int B = m->maxB;
   hipStream_t st = m->ctx->stream; (void)st;
@@ -707,6 +751,7 @@ int allocate(ys_model* m) {
     }
     c.wf_off = nf;
     c.wd_off = nd;
+    c.prep_idx = (int)pd.size();
     for (int ph = 0; ph < (c.ct ? 4 : 1); ph++) {   // ConvTranspose: one 1x1 weight matrix per output phase
       PrepDesc d{}; d.w_off = c.w_off + (long)ph * c.cout * c.cin; d.wf_off = nf; d.wd_off = nd; d.cout = c.cout; d.taps = taps;
       d.cin_real = c.cin; d.cin_pad = c.cin_pad; d.cout_pad = c.cout_ld; d.has_wd = c.first ? 0 : 1;
@@ -735,6 +780,8 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->prep_dev, pd.size() * sizeof(PrepDesc)));
   YS_CHECK_HIP(hipMemcpyAsync(m->prep_dev, pd.data(), pd.size() * sizeof(PrepDesc), hipMemcpyHostToDevice, m->ctx->stream));
   YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));   // pd is a host temporary
+  m->n_wf_pending = nf; m->n_wd_pending = nd;
+  if (m->f8) YS_TRY(alloc_f8(m, pd));
   YS_TRY(dev_alloc(m, &m->y_all, (size_t)ny * m->es));
   YS_TRY(dev_alloc(m, &m->dy_scratch, (size_t)dy_max * m->es));
   // measured on MI355X (YOLOv8n B=64): +1.4 % step throughput, but both streams' kernels fill the CUs' LDS, so they mostly
@@ -846,6 +893,15 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
   a.M = B * c.Hout * c.Wout;
   const long M = a.M;
   const bool vec = (ob.ldc % 4 == 0) && (c.out.coff % 4 == 0);
+  if (m->f8 && c.f8_fwd) {
+    unsigned* slots = m->amax_act + (size_t)c.idx * YS_AMAX_WAYS;
+    if (m->f8_sx_valid) {   // fp8 MFMA kernel where one is planned (ys_conv_launch falls back to bf16 otherwise); it records amax(|x|) itself
+      a.f8 = 1; a.w8 = m->wf8_all + c.wf_off; a.qscale = m->f8_scales + 4L * c.idx; a.deq = m->f8_scales + 4L * c.idx + 1; a.amax = slots;
+    } else {                // first pass: no scale yet -> bf16 kernels, and a bootstrap pass records the input maximum
+      YS_TRY(ys_f8_view_amax_launch(st, ib.act, (long)B * c.Hin * c.Win, c.cin_pad, ib.ldc, c.in.coff, slots));
+    }
+  }
+  unsigned* amax_slot = nullptr;
   if (c.bn && m->training) {
     void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
@@ -858,7 +914,7 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
     const void* res = nullptr; int rl = 0, rc = 0;
     if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
     YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, res, rl, rc,
-                                  ob.act, ob.ldc, c.out.coff));
+                                  ob.act, ob.ldc, c.out.coff, amax_slot));
   } else {
     a.y = view_ptr(m, ob.act, ob, c.out_rowoff);
     a.out_ldc = ob.ldc; a.out_coff = c.out.coff; a.out_bstride = ob.rows_per_b; a.vec_ok = vec ? 1 : 0;
@@ -876,6 +932,9 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
 int forward_impl(ys_model* m, int B) {
   hipStream_t st = m->ctx->stream;
   YS_TRY(prep_weights(m));
+  if (m->f8)   // delayed scaling: this pass quantises with the maxima the previous passes recorded (consumed and cleared here)
+    YS_TRY(ys_f8_scales_launch(st, m->f8_convs, m->n_f8_convs, m->amax_w, m->amax_act, m->amax_dy, m->f8_scales));
+  if (m->f8 && m->f8_bwd_done) m->f8_sg_valid = true;
   if (!m->training && m->eval_coeffs_dirty) {
     for (auto& c : m->convs)
       if (c.bn) YS_TRY(ys_bn_eval_coeffs_launch(st, c.cout, m->params + c.g_off, m->params + c.b_off, m->state + c.rm_off,
@@ -900,6 +959,7 @@ int forward_impl(ys_model* m, int B) {
       YS_TRY(ys_copy_view_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, (long)B * op.H * op.W, op.in.C, ob.act, ob.ldc, op.out.coff, 0));
     }
   }
+  if (m->f8) m->f8_sx_valid = true;        // every fp8 candidate has recorded an input maximum (bootstrap pass or its own kernel)
   if (!m->training && m->pd_buf >= 0) {
     YS_TRY(ys_detect_decode_launch(st, m->dtype, m->bufs[m->pd_buf].act, m->ld_pd, m->bufs[m->ps_buf].act, m->ld_ps, B, m->A,
                                    m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred, 4 + m->d.nc + m->nm));
@@ -1052,6 +1112,14 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
     a.vec_ok = (ib.ldc % 4 == 0 && c.in.coff % 4 == 0) ? 1 : 0;
     a.accumulate = mode;
     a.M = B * c.Hin * c.Win;
+    if (m->f8 && c.f8_bwd) {
+      unsigned* slots = m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS;
+      if (m->f8_sg_valid) {   // dgrad with the gradient quantised to e5m2 and the e4m3 dgrad weights; records amax(|dy|) itself
+        a.f8 = 2; a.w8 = m->wd8_all + c.wd_off; a.qscale = m->f8_scales + 4L * c.idx + 2; a.deq = m->f8_scales + 4L * c.idx + 3; a.amax = slots;
+      } else {
+        YS_TRY(ys_f8_view_amax_launch(st, dy, M, c.cout, dy_ldc, dy_coff, slots));
+      }
+    }
     if (c.bn && c.cout_ld != c.cout) { ys_set_error("backward: padded BN conv unsupported"); return YS_ERR_UNSUPPORTED; }
     YS_TRY(ys_conv_launch(st, m->dtype, a));
   }
@@ -1103,6 +1171,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
     YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
     m->st2_dirty = false;
   }
+  if (m->f8 && seg_hi == 2) m->f8_bwd_done = true;     // every gradient maximum of the step is recorded (last segment = stem)
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;
 }
@@ -1137,7 +1206,7 @@ extern "C" {
 
 int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
   YS_REQUIRE(ctx && desc && out, "ys_model_create: null argument");
-  YS_REQUIRE(desc->dtype == YS_F32 || desc->dtype == YS_BF16, "ys_model_create: dtype %d unsupported", desc->dtype);
+  YS_REQUIRE(desc->dtype == YS_F32 || desc->dtype == YS_BF16 || desc->dtype == YS_FP8, "ys_model_create: dtype %d unsupported", desc->dtype);
   if ((desc->family != YS_YOLOV8 && desc->family != YS_YOLOV11) || (desc->task != YS_DETECT && desc->task != YS_SEGMENT)) {
     ys_set_error("ys_model_create: YOLOv8 / YOLOv11 detect and segment are built (family %d task %d)", desc->family, desc->task);
     return YS_ERR_UNSUPPORTED;
@@ -1149,7 +1218,10 @@ int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
   YS_REQUIRE(desc->max_batch > 0, "ys_model_create: max_batch %d", desc->max_batch);
   YS_CHECK_HIP(hipSetDevice(ctx->device));
   ys_model* m = new ys_model();
-  m->ctx = ctx; m->d = *desc; m->dtype = desc->dtype; m->epl = desc->dtype == YS_BF16 ? 8 : 4; m->es = desc->dtype == YS_BF16 ? 2 : 4;
+  // YS_FP8 = the bf16 engine (storage, BN, losses, weight gradients, optimizer) with fp8 MFMA forward / dgrad convolutions
+  m->f8 = desc->dtype == YS_FP8;
+  const int store = m->f8 ? YS_BF16 : desc->dtype;
+  m->ctx = ctx; m->d = *desc; m->dtype = store; m->epl = store == YS_BF16 ? 8 : 4; m->es = store == YS_BF16 ? 2 : 4;
   m->maxB = desc->max_batch;
   for (int j = 0; j < 64; j++) m->dfl_w[j] = (float)j;
   int st = desc->family == YS_YOLOV11 ? build_v11_detect(m) : build_v8_detect(m);
@@ -1636,11 +1708,13 @@ int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, flo
 // ------------------------------------------------------------------ standalone blocks (include/yolosharp_hip.h "per-block entry points")
 int ys_block_create(ys_ctx* ctx, const ys_block_desc* bd, ys_model** out) {
   YS_REQUIRE(ctx && bd && out, "ys_block_create: null argument");
-  YS_REQUIRE(bd->dtype == YS_F32 || bd->dtype == YS_BF16, "ys_block_create: dtype %d unsupported", bd->dtype);
+  YS_REQUIRE(bd->dtype == YS_F32 || bd->dtype == YS_BF16 || bd->dtype == YS_FP8, "ys_block_create: dtype %d unsupported", bd->dtype);
   YS_REQUIRE(bd->height > 0 && bd->width > 0 && bd->max_batch > 0, "ys_block_create: geometry %dx%d batch %d", bd->height, bd->width, bd->max_batch);
   YS_CHECK_HIP(hipSetDevice(ctx->device));
   ys_model* m = new ys_model();
-  m->ctx = ctx; m->dtype = bd->dtype; m->epl = bd->dtype == YS_BF16 ? 8 : 4; m->es = bd->dtype == YS_BF16 ? 2 : 4;
+  m->f8 = bd->dtype == YS_FP8;
+  const int bstore = m->f8 ? YS_BF16 : bd->dtype;
+  m->ctx = ctx; m->dtype = bstore; m->epl = bstore == YS_BF16 ? 8 : 4; m->es = bstore == YS_BF16 ? 2 : 4;
   m->maxB = bd->max_batch; m->is_block = true; m->blk_c1 = bd->c1; m->blk_c2 = bd->c2; m->A = 0; m->nl = 0;
   m->d = ys_model_desc{}; m->d.height = bd->height; m->d.width = bd->width; m->d.max_batch = bd->max_batch; m->d.dtype = bd->dtype;
   m->d.reg_max = 1; m->d.max_labels = 1;

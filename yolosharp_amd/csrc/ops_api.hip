@@ -16,8 +16,12 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
                                   const float* bn_beta, float* bn_mean, float* bn_var, const float* bias,
                                   int act_silu, int training, float* y_nchw) {
   YS_REQUIRE(ctx && x_nchw && w_oihw && y_nchw, "ys_conv_bn_act_fwd: null argument");
-  YS_REQUIRE(dtype == YS_F32 || dtype == YS_BF16, "ys_conv_bn_act_fwd: bad dtype %d", dtype);
+  YS_REQUIRE(dtype == YS_F32 || dtype == YS_BF16 || dtype == YS_FP8, "ys_conv_bn_act_fwd: bad dtype %d", dtype);
   YS_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "ys_conv_bn_act_fwd: k=%d stride=%d unsupported", k, stride);
+  // YS_FP8: bf16 storage; the convolution runs the fp8 MFMA kernel with CURRENT per-tensor scales of this call's own tensors
+  // (s_w = 448 / amax|W|, s_x = 0.5 * 448 / amax|bf16(x)|, the recipe of f8.hip) when Cin % 32 == 0, else the bf16 kernel
+  const bool want_f8 = dtype == YS_FP8;
+  if (want_f8) dtype = YS_BF16;
   const bool has_bn = bn_gamma != nullptr;
   YS_REQUIRE(!has_bn || (bn_beta && bn_mean && bn_var), "ys_conv_bn_act_fwd: incomplete BN arguments");
   YS_CHECK_HIP(hipSetDevice(ctx->device));
@@ -68,6 +72,25 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
 
   ConvArgs a{};
   a.x = dxn.p; a.w = dwf.p;
+  DevBuf dw8, dq;
+  if (want_f8 && Cin % 32 == 0) {
+    YS_TRY(dw8.alloc((size_t)Cout * taps * cpad));
+    YS_TRY(dq.alloc(1024));                     // floats: [0] amax_w, [16..80) amax_x ways, [96..160) amax_dy ways, [200..204) scales
+    YS_CHECK_HIP(hipMemsetAsync(dq.p, 0, 1024, st));
+    float* qf = (float*)dq.p;
+    F8Layer hl{0, (long)Cout * taps * Cin};
+    F8Conv hc{0};
+    DevBuf dl, dc;
+    YS_TRY(dl.alloc(sizeof hl)); YS_TRY(dc.alloc(sizeof hc));
+    YS_CHECK_HIP(hipMemcpyAsync(dl.p, &hl, sizeof hl, hipMemcpyHostToDevice, st));
+    YS_CHECK_HIP(hipMemcpyAsync(dc.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+    YS_TRY(ys_f8_weight_amax_launch(st, (const float*)dwm.p, (const F8Layer*)dl.p, 1, qf));
+    YS_TRY(ys_f8_view_amax_launch(st, dxn.p, (long)B * H * W, cpad, cpad, 0, (unsigned*)(qf + 16)));
+    YS_TRY(ys_f8_scales_launch(st, (const F8Conv*)dc.p, 1, qf, (unsigned*)(qf + 16), (unsigned*)(qf + 96), qf + 200));
+    YS_TRY(ys_f8_quant_weights_launch(st, dwf.p, (long)Cout * taps * cpad, qf, dw8.p));
+    YS_CHECK_HIP(hipStreamSynchronize(st));     // hl / hc / dl / dc are temporaries of this scope
+    a.f8 = 1; a.w8 = dw8.p; a.qscale = qf + 200; a.deq = qf + 201;
+  }
   a.B = B; a.Hin = H; a.Win = W; a.Cin = cpad; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout; a.KH = k; a.KW = k;
   a.SA = stride; a.DIVS = 0; a.DIVM = 0; a.PAD = pad;
   a.in_ldc = cpad; a.in_coff = 0; a.in_bstride = (long)H * W;
@@ -111,7 +134,9 @@ extern "C" int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, i
                            const float* w_oihw, int Cout, int k, int stride, const float* dy_nchw,
                            float* dx_nchw, float* dw_oihw) {
   YS_REQUIRE(ctx && x_nchw && w_oihw && dy_nchw && dw_oihw, "ys_conv_bwd: null argument");
-  YS_REQUIRE(dtype == YS_F32 || dtype == YS_BF16, "ys_conv_bwd: bad dtype %d", dtype);
+  YS_REQUIRE(dtype == YS_F32 || dtype == YS_BF16 || dtype == YS_FP8, "ys_conv_bwd: bad dtype %d", dtype);
+  const bool want_f8 = dtype == YS_FP8;           // dgrad on the fp8 kernel (dy -> e5m2, weights -> e4m3, current scales); wgrad stays bf16
+  if (want_f8) dtype = YS_BF16;
   YS_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "ys_conv_bwd: k=%d stride=%d unsupported", k, stride);
   YS_CHECK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -158,6 +183,25 @@ extern "C" int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, i
   if (dx_nchw) {
     ConvArgs a{};
     a.x = ddyn.p; a.w = dwd.p; a.y = dgx.p;
+    DevBuf dw8, dq;
+    if (want_f8 && Cout % 32 == 0) {
+      YS_TRY(dw8.alloc((size_t)Cin * taps * copad));
+      YS_TRY(dq.alloc(1024));
+      YS_CHECK_HIP(hipMemsetAsync(dq.p, 0, 1024, st));
+      float* qf = (float*)dq.p;
+      F8Layer hl{0, (long)Cout * taps * Cin};
+      F8Conv hc{0};
+      DevBuf dl, dc;
+      YS_TRY(dl.alloc(sizeof hl)); YS_TRY(dc.alloc(sizeof hc));
+      YS_CHECK_HIP(hipMemcpyAsync(dl.p, &hl, sizeof hl, hipMemcpyHostToDevice, st));
+      YS_CHECK_HIP(hipMemcpyAsync(dc.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+      YS_TRY(ys_f8_weight_amax_launch(st, (const float*)dwm.p, (const F8Layer*)dl.p, 1, qf));
+      YS_TRY(ys_f8_view_amax_launch(st, ddyn.p, M, copad, copad, 0, (unsigned*)(qf + 96)));
+      YS_TRY(ys_f8_scales_launch(st, (const F8Conv*)dc.p, 1, qf, (unsigned*)(qf + 16), (unsigned*)(qf + 96), qf + 200));
+      YS_TRY(ys_f8_quant_weights_launch(st, dwd.p, (long)Cin * taps * copad, qf, dw8.p));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      a.f8 = 2; a.w8 = dw8.p; a.qscale = qf + 202; a.deq = qf + 203;
+    }
     a.B = B; a.Hin = Ho; a.Win = Wo; a.Cin = copad; a.Hout = H; a.Wout = W; a.Cout = Cin; a.KH = a.KW = k;
     a.SA = 1; a.DIVS = stride == 2 ? 1 : 0; a.DIVM = stride - 1; a.PAD = k - 1 - pad;
     a.in_ldc = copad; a.in_coff = 0; a.in_bstride = (long)Ho * Wo;

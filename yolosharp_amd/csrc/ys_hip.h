@@ -196,6 +196,118 @@ __device__ inline f32x4 mfma_16x16x4_f32(float a, float b, const f32x4& c) {
 #endif
 }
 
+// ---------------------------------------------------------------- OCP fp8 (e4m3fn) / bf8 (e5m2) for the fp8 convolution path
+// Hardware facts measured with tools/probe/probe_f8.hip on MI355X: v_cvt_pk_{fp8,bf8}_f32 round to nearest even, produce
+// subnormals, and do NOT saturate (e4m3: |x| >= 480 -> NaN 0x7F; e5m2: |x| >= 61440 -> inf) -- so values are clamped to the
+// largest finite magnitude first.  The software forms below are bit-identical for finite inputs (interpreter, tests).
+#define YS_E4M3_MAX 448.0f
+#define YS_E5M2_MAX 57344.0f
+__host__ __device__ inline float ys_e4m3_to_f32(unsigned char b) {
+  const int e = (b >> 3) & 15, m = b & 7;
+  float v = e == 0 ? ldexpf((float)m, -9) : ((e == 15 && m == 7) ? __builtin_nanf("") : ldexpf(1.0f + (float)m * 0.125f, e - 7));
+  return (b & 0x80) ? -v : v;
+}
+__host__ __device__ inline float ys_e5m2_to_f32(unsigned char b) {
+  const int e = (b >> 2) & 31, m = b & 3;
+  float v = e == 0 ? ldexpf((float)m, -16) : (e == 31 ? (m ? __builtin_nanf("") : __builtin_inff()) : ldexpf(1.0f + (float)m * 0.25f, e - 15));
+  return (b & 0x80) ? -v : v;
+}
+// round-to-nearest-even to a format with MB mantissa bits, exponent bias BIAS, after clamping |x| to MAXV
+template <int MB, int BIAS>
+__host__ __device__ inline unsigned char ys_f32_to_f8_sw(float x, float maxv) {
+  const unsigned char sign = (ys_f2u(x) >> 31) ? 0x80 : 0;
+  if (x != x) return (unsigned char)(sign | 0x7F);
+  float a = x < 0.f ? -x : x;
+  if (a > maxv) a = maxv;
+  const float min_normal = ldexpf(1.0f, 1 - BIAS);
+  if (a < min_normal) {                                   // subnormal grid: multiples of 2^(1 - BIAS - MB)
+    const int qv = (int)nearbyintf(ldexpf(a, BIAS - 1 + MB));
+    return (unsigned char)(sign | qv);                    // qv == 2^MB is exactly the smallest normal's encoding
+  }
+  int e;
+  const float fr = frexpf(a, &e);                         // a = fr * 2^e, fr in [0.5, 1)
+  e -= 1;                                                 // a = (2 fr) * 2^e, 2 fr in [1, 2)
+  int qv = (int)nearbyintf((2.0f * fr - 1.0f) * (float)(1 << MB));
+  if (qv == (1 << MB)) { qv = 0; e += 1; }
+  return (unsigned char)(sign | ((e + BIAS) << MB) | qv);
+}
+__host__ __device__ inline unsigned char ys_f32_to_e4m3(float x) { return ys_f32_to_f8_sw<3, 7>(x, YS_E4M3_MAX); }
+__host__ __device__ inline unsigned char ys_f32_to_e5m2(float x) { return ys_f32_to_f8_sw<2, 15>(x, YS_E5M2_MAX); }
+
+// one float -> e4m3 byte, saturating (device: v_cvt_pk_fp8_f32 after the clamp; interpreter: the software form)
+__device__ inline unsigned char ys_f32_to_e4m3_dev(float x) {
+#ifdef YS_EMU_BUILD
+  return ys_f32_to_e4m3(x);
+#else
+  return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x, -YS_E4M3_MAX, YS_E4M3_MAX), 0.f, 0u, false) & 255u);
+#endif
+}
+
+// 8 floats -> 8 fp8 bytes (FMT 0 = e4m3, 1 = e5m2), saturating
+template <int FMT> __device__ inline uint2 ys_pack_f8x8(const float* f) {
+#ifdef YS_EMU_BUILD
+  unsigned char b[8];
+  for (int i = 0; i < 8; i++) b[i] = FMT == 0 ? ys_f32_to_e4m3(f[i]) : ys_f32_to_e5m2(f[i]);
+  uint2 r;
+  r.x = (unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16) | ((unsigned)b[3] << 24);
+  r.y = (unsigned)b[4] | ((unsigned)b[5] << 8) | ((unsigned)b[6] << 16) | ((unsigned)b[7] << 24);
+  return r;
+#else
+  const float mx = FMT == 0 ? YS_E4M3_MAX : YS_E5M2_MAX;
+  float c[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) c[i] = __builtin_amdgcn_fmed3f(f[i], -mx, mx);
+  unsigned lo = 0u, hi = 0u;
+  if (FMT == 0) {
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  } else {
+    lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[6], c[7], hi, true);
+  }
+  uint2 r; r.x = lo; r.y = hi;
+  return r;
+#endif
+}
+
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 = 127): the only K = 128 fp8 MFMA (2x the bf16 MFMA rate).
+// Each lane supplies 32 K-contiguous bytes of the row operand a (e4m3: weights) and of the column operand b (e4m3 activations,
+// or e5m2 gradients when B_BF8); lane (li, q) owns row / column li and the q-th quarter of the 128 K values -- both operands
+// use the same (lane, byte) -> k map, so any consistent K order gives the same dot products (probe_f8: exact).  Result
+// layout as every 16x16 MFMA: D[4q + r][li].
+template <int B_BF8>
+__device__ inline f32x4 mfma_scale_16x16x128_f8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, const f32x4& c) {
+#ifdef YS_EMU_BUILD
+  struct Dep { uint4 a0, a1, b0, b1; } dep{a0, a1, b0, b1};
+  f32x4 d = c;
+  const int l = emu::lane();
+  emu::wave_collective(&dep, sizeof(dep), [&](unsigned char (*slot)[128]) {
+    const int j = l & 15;
+    for (int r = 0; r < 4; r++) {
+      const int i = 4 * (l >> 4) + r;
+      float acc = d[r];
+      for (int k = 0; k < 128; k++) {
+        Dep da, db;
+        memcpy(&da, slot[i + 16 * (k >> 5)], sizeof(Dep));
+        memcpy(&db, slot[j + 16 * (k >> 5)], sizeof(Dep));
+        const unsigned char* pa = (const unsigned char*)&da.a0;      // a0, a1 contiguous: 32 bytes
+        const unsigned char* pb = (const unsigned char*)&db.b0;
+        const float fb = B_BF8 ? ys_e5m2_to_f32(pb[k & 31]) : ys_e4m3_to_f32(pb[k & 31]);
+        acc += ys_e4m3_to_f32(pa[k & 31]) * fb;
+      }
+      d[r] = acc;
+    }
+  });
+  return d;
+#else
+  typedef int ys_v8i __attribute__((ext_vector_type(8)));
+  ys_v8i a, b;
+  a[0] = (int)a0.x; a[1] = (int)a0.y; a[2] = (int)a0.z; a[3] = (int)a0.w; a[4] = (int)a1.x; a[5] = (int)a1.y; a[6] = (int)a1.z; a[7] = (int)a1.w;
+  b[0] = (int)b0.x; b[1] = (int)b0.y; b[2] = (int)b0.z; b[3] = (int)b0.w; b[4] = (int)b1.x; b[5] = (int)b1.y; b[6] = (int)b1.z; b[7] = (int)b1.w;
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, B_BF8 ? 1 : 0, 0, 127, 0, 127);
+#endif
+}
+
 // One "k-step" of the tile product for storage type T: each lane holds 16 bytes of the
 // row operand (a) and 16 bytes of the column operand (b), both K-contiguous.
 //   bf16: one 16x16x32 MFMA (lane's 8 elements = k 8q..8q+7).
@@ -273,6 +385,22 @@ __device__ inline float ys_wave_sum(float v) {
 __device__ inline float ys_wave_max(float v) {
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
   return v;
+}
+
+// amax slot update (fp8 delayed scaling): wave maximum, then ONE atomic per wave -- and only when the wave's value would raise
+// the slot.  The plain read may be stale (lower), which costs an unnecessary atomic, never a wrong result; after the first few
+// workgroups nearly every wave skips.  (One unconditional atomic per wave serialised ~10^6 updates of a single address per
+// large tensor: +260 ms on the YOLOv8x 1280 step.)  Non-negative floats order like their bit patterns.
+// Each tensor owns YS_AMAX_WAYS slots (workgroup index modulo): the first wavefront of a grid -- thousands of waves that all
+// still read 0 -- would otherwise queue its atomics on one address (~160 us per pass); the consumer takes the max of the ways.
+#define YS_AMAX_WAYS 64
+__device__ inline void ys_amax_update(unsigned* slots, float mx) {
+  mx = ys_wave_max(mx);
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) {
+    unsigned* slot = slots + (blockIdx.x & (YS_AMAX_WAYS - 1));
+    const unsigned cur = *(volatile unsigned*)slot;
+    if (ys_f2u(mx) > cur) atomicMax(slot, ys_f2u(mx));
+  }
 }
 
 // wave-level ordering point for LDS traffic that is private to one wave: LDS operations of a wave execute in order on

@@ -27,6 +27,12 @@ struct ConvArgs {
   int pad_w_delta;               // width gather uses PAD + pad_w_delta (phase (dh,dw): PAD=-dh, delta=dh-dw)
   int out_rh, out_rw;            // out_rh != 0: output row = b*out_bstride + oh*out_rh + ow*out_rw + out_r0
   long out_r0;                   //   (writes phase (dh,dw) of a 2x upsampled grid: rh = 4W, rw = 2, r0 = dh*2W + dw)
+  // fp8 convolution path (conv_p2_kernel<F8 = 1>): the bf16 input is quantised while its patch is staged in LDS
+  int f8;                        // 0 = off; 1 = e4m3 input (forward); 2 = e5m2 input (dgrad: the input is dy)
+  const void* w8;                // fp8 (e4m3) weights, same element order as w
+  const float* qscale;           // device scalar: quantisation multiplier of the input tensor
+  const float* deq;              // device scalar: 1 / (input scale * weight scale), applied to the fp32 accumulators
+  unsigned* amax;                // optional: YS_AMAX_WAYS slots receiving amax(|input|) of this launch (next step's scale)
   unsigned long long* tl;        // triage builds (-DYS_P2_TIMELINE): per-workgroup s_memtime stamps of the tile phases; null otherwise
 };
 
@@ -91,7 +97,7 @@ int ys_bn_eval_coeffs_launch(hipStream_t st, int C, const float* gamma, const fl
 // z[out view] = act(y*scale+shift) (+ residual view)
 int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const float* scale,
                            const float* shift, int act, const void* res, int res_ldc, int res_coff, void* z,
-                           int z_ldc, int z_coff);
+                           int z_ldc, int z_coff, unsigned* amax = nullptr);
 // backward of z = act(BN(y)): pass 1 partial sums of du and du*xhat; optionally res_grad += dz
 int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
                             int C, const float* scale, const float* shift, const float* mean, const float* rstd,
@@ -101,7 +107,8 @@ int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, in
                               float* dbeta, float* k2, float* k3, const float* scale, const float* mean, const float* rstd);
 // pass 2: dy = gamma*rstd*(du - mean(du) - xhat*mean(du*xhat)) = scale*du - k2 - y*k3
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
-                           int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy);
+                           int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
+                           unsigned* amax = nullptr);
 // column sums of a [rows][ldc] view into grad[C] (+=)   (bias gradients)
 int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
                      long bstride, int C, float* partial, float* grad);
@@ -131,6 +138,16 @@ int ys_adamw_launch(hipStream_t st, float* p, const float* g, float* m, float* v
 int ys_fill_launch(hipStream_t st, float* p, long n, float v);
 
 int ys_chan_stats_launch(hipStream_t st, int dtype, const void* y, long rows, int C, float* partial, int* nblk_out);
+
+// ---- f8.hip (scaling machinery of the fp8 convolution path)
+struct F8Layer { long w_off, count; };                       // fp32 master weights of one conv layer in the flat parameter buffer
+struct F8Conv { int layer; };                                // index of the layer's weight-amax slot
+int ys_f8_weight_amax_launch(hipStream_t st, const float* params, const F8Layer* layers, int n, float* amax_w);
+int ys_f8_scales_launch(hipStream_t st, const F8Conv* convs, int n, const float* amax_w, unsigned* amax_x, unsigned* amax_dy,
+                        float* out /*[n][4]: s_x, deq_fwd, s_g, deq_dgrad*/);
+// amax(|x|) of a [rows][C] bf16 view (channel stride ldc, offset coff) into YS_AMAX_WAYS slots (bootstrap of the delayed scales)
+int ys_f8_view_amax_launch(hipStream_t st, const void* x_bf16, long rows, int C, int ldc, int coff, unsigned* slots);
+int ys_f8_quant_weights_launch(hipStream_t st, const void* w_bf16, long n, const float* amax_w, void* w8);
 
 // ---- attn_dw.hip (YOLOv11 operators)
 int ys_dwconv_launch(hipStream_t st, int dtype, int flip, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,

@@ -197,7 +197,7 @@ class Engine:
         p = k // 2
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = np.empty((B, Cout, Ho, Wo), np.float32)
-        dt = 1 if dtype in ("bf16", 1) else 0
+        dt = {"f32": 0, 0: 0, "bf16": 1, 1: 1, "fp8": 2, 2: 2}[dtype]
         g = b = rm = rv = None
         if bn is not None:
             g = np.ascontiguousarray(bn["weight"], np.float32)

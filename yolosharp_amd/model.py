@@ -16,7 +16,7 @@ from . import _lib
 from .engine import Engine, _ptr
 
 SIZES = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
-DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "float8": 2}
 
 
 class Yolov8:
