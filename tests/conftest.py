@@ -12,6 +12,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The fp8 mode keeps layers below 128 input channels on the bf16 kernel by default (they are HBM-bound: csrc/conv.hip); the tests
+# lower the threshold so that the small shapes an oracle can check in seconds go through the fp8 kernel too.  Read once, at the
+# first convolution plan of the process.
+os.environ.setdefault("YS_F8_MIN_CIN", "32")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -663,7 +663,7 @@ struct P2Args {
 // the LDS bytes per K (the K loop of this kernel is LDS-bandwidth-bound for small register tiles).  A K-step is then 128 K =
 // four 32-channel pieces (one per lane quarter); Cin % 32 == 0.  The fp32 accumulators are scaled back in the epilogue.
 template <int MR, int NR, int WRES, int NPU, int NT, int F8>
-__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD
+__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 && !F8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD
 conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
   constexpr int WES = F8 ? 1 : 2;             // bytes per weight element
@@ -714,7 +714,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   }
   constexpr int KG = P2_KG;                    // K-steps per streamed weight group
   constexpr int GU = KG * UPS;                 // 16-byte units per weight row and group
-  constexpr bool TIGHT = NT == 256 && NPU <= 6 && MR * NR <= 8;                           // 168-register variants
+  constexpr bool TIGHT = NT == 256 && NPU <= 6 && MR * NR <= 8 && !F8;                    // 168-register variants
   constexpr int G0 = F8 ? 1 : p2_reg_group(MR, NR, TIGHT);   // fp8: one K-step is already 128 K (32-byte fragments)
   constexpr int G = (WRES || G0 < KG) ? G0 : KG;   // K-steps per register group of the K loop
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
@@ -982,11 +982,11 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
 // fp8 variants whose 32-byte fragments fit the 256-register budget without spilling (hipcc -Rpass-analysis=kernel-resource-usage)
-static bool p2_f8_tile_ok(int mr, int nr, int wres) {
+static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
   static const bool any = getenv("YS_P2_F8_ANYTILE") != nullptr;      // triage: accept the spilling variants too
   if (any) return true;
-  if (wres) return mr * nr <= 8 && !(mr == 2 && nr == 5) && nr <= 5;
-  return mr * nr <= 4 && mr + nr <= 5;
+  if (wres) return npu == 6 ? !(mr == 4 && nr == 4) : (mr * nr <= 8 && !(mr == 2 && nr == 5));
+  return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
 }
 static P2Plan conv_p2_plan(const ConvArgs& a) {
   P2Plan p{};
@@ -999,7 +999,10 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
   if (a.Cin % 8) return p;
   const bool f8 = a.f8 != 0;
-  if (f8 && (a.Cin % 32 || !a.w8 || !a.qscale || !a.deq)) return p;
+  // fp8 pays where the K loop dominates (LDS / MFMA bound layers); the HBM-bound small-channel layers gain nothing from it and pay
+  // the on-the-fly quantisation (measured: 32-channel layers 1.6x slower in fp8) -> they keep the bf16 kernel
+  static const int f8_min_cin = getenv("YS_F8_MIN_CIN") ? atoi(getenv("YS_F8_MIN_CIN")) : 128;
+  if (f8 && (a.Cin % 32 || a.Cin < f8_min_cin || !a.w8 || !a.qscale || !a.deq)) return p;
   const int ups = f8 ? 8 : 4;                        // 16-byte LDS units per weight row and K-step
   const int nfr = (a.Cout + 15) / 16;
   int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
@@ -1010,7 +1013,9 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   g.nsteps = f8 ? (taps * a.Cin + 127) / 128 : (taps * a.Cin + 31) / 32;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
   // workgroup per CU); YS_P2_WRESMAX overrides for experiments
-  static const size_t wresmax = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 44 * 1024;   // rows padded to 4 K-steps
+  static const size_t wresmax_env = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 0;
+  // rows padded to 4 K-steps; fp8: 52 KB (the streamed fp8 variants are limited to small register tiles; YOLOv8x 1280 step 165.3 -> 161.7 ms)
+  const size_t wresmax = wresmax_env ? wresmax_env : (f8 ? 52 * 1024 : 44 * 1024);
   // Streamed weights cost one L2 round trip per K-group on the critical path of every tile.  When half the output channels
   // would make the weight set resident, split the channels over two workgroup columns instead (the patch is then read
   // twice, from L2).
@@ -1035,7 +1040,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
   static const int maxcin3 = getenv("YS_P2_MAXCIN3") ? atoi(getenv("YS_P2_MAXCIN3")) : 255;
   if (k3 && a.SA == 1 && a.Cin > (f8 ? 640 : maxcin3)) return p;   // an fp8 patch pixel is half the bytes
-  for (size_t budget = (wres && wres_bytes > 44 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
+  for (size_t budget = (wres && wres_bytes > 52 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
   // weights, output) plus a per-tile constant; among shapes that give the chip >= 512 workgroups when the layer is large
   // enough.  (512-thread workgroups -- 8 waves x 2 fragments, same LDS footprint -- were measured 13 % slower: the 128-register
@@ -1046,7 +1051,6 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     const size_t stat = (size_t)nwv * bn * 2 * 4;
     const int npu_max = nt == 512 ? 6 : P2_NPU;
     for (int mr = (nt == 512 ? 2 : (nr <= 4 ? 4 : 2)); mr >= 1; mr >>= 1) {
-      if (f8 && !p2_f8_tile_ok(mr, nr, wres)) continue;
       const int npx = 16 * nwv * mr;
       const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 16);
       for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
@@ -1055,6 +1059,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
         if (pbytes < (size_t)16 * nt * 4) pbytes = (size_t)16 * nt * 4;   // statistics scratch of p2_stats_flush
         const size_t lds = tab + wbytes + pbytes + stat;
+        if (f8 && !p2_f8_tile_ok(mr, nr, wres, ph * pw * cu <= 6 * 256 ? 6 : 12)) continue;
         if (lds > budget || ph * pw * cu > npu_max * nt || (size_t)ph * pw * g.ppb > (size_t)8192 * (f8 ? 8 : 16)) continue;   // 13-bit LDS slot field
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
         const long ntiles = (long)tx * ty * a.B;
@@ -1067,7 +1072,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
           cur.TH = th; cur.TW = tw; cur.tiles_x = tx; cur.tiles_y = ty; cur.PH = ph; cur.PW = pw; cur.ntiles = (int)ntiles;
           cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
           p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy; p.nt = nt;
-          p.npu = nt == 512 ? 6 : (ph * pw * cu <= 6 * 256 && !f8 ? 6 : 12);   // fp8 is instantiated for NPU = 12 only
+          p.npu = nt == 512 ? 6 : (ph * pw * cu <= 6 * 256 ? 6 : 12);
         }
       }
     }
@@ -1194,9 +1199,7 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
 #define P2F(M_, N_, F_) { \
     if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_>(st, a, p); \
     return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256, F_>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256, F_>(st, a, p); }
-#define P2F8(M_, N_) { \
-    if (p.wres) return conv_p2_launch_t<M_, N_, 1, 12, 256, 1>(st, a, p); \
-    return conv_p2_launch_t<M_, N_, 0, 12, 256, 1>(st, a, p); }
+#define P2F8(M_, N_) P2F(M_, N_, 1)
 #define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F8(M_, N_) else P2F(M_, N_, 0) }
     P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
 #undef P2
