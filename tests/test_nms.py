@@ -51,6 +51,8 @@ CASES = [
     dict(B=1, A=200, nc=3, extra=0, ties=False, conf=0.99, iou=0.5, kw={}),              # n == 0
     dict(B=1, A=600, nc=1, extra=0, ties=True, conf=0.05, iou=0.3, kw=dict(max_nms=100)),  # n > max_nms, one class
     dict(B=2, A=257, nc=80, extra=0, ties=False, conf=0.3, iou=0.7, kw={}),              # predictor thresholds
+    dict(B=2, A=4300, nc=2, extra=1, ties=True, conf=0.0, iou=0.6, kw=dict(nc=2, max_det=12)),   # n > 4096: serial sweep path next to the bitmask path
+    dict(B=1, A=1030, nc=3, extra=0, ties=True, conf=0.02, iou=0.45, kw={}),             # A % 4 != 0: scalar filter; several 64-row mask blocks
 ]
 
 

@@ -8,44 +8,88 @@
 //   * greedy: descending score (ties: lower anchor index first), suppress iff
 //     inter/(area_i+area_j-inter) > iou  (fp32, IEEE division), keep <= max_det
 // HBM/latency-bound integer+fp32 work: no MFMA.  Three kernels:
-//   nms_filter : one thread per (image, anchor), coalesced along the anchor axis
-//   nms_select : one 1024-thread workgroup per image: LDS bitonic sort of 64-bit
-//                (score,index) keys, then the greedy pass as a workgroup-parallel
-//                IoU sweep per kept box (O(kept*n), no n^2 mask in HBM)
-//   (outputs are written by nms_select)
+//   nms_filter : one thread per (image, 4 anchors), 16-byte loads along the anchor axis
+//   nms_sort   : one 1024-thread workgroup per image: LDS bitonic sort of 64-bit (score,index) keys, gather of the
+//                class-offset boxes in score order
+//   nms_mask   : n <= 4096 candidates: the upper-triangular suppression bit matrix, all (image, 64x64 block) pairs in parallel
+//   nms_scan   : one wave per image walks the score order with the "removed" set in registers (torchvision's own scheme)
+//   nms_greedy_big : n > 4096: serial workgroup-parallel sweep per kept box (O(kept*n), no n^2 matrix)
 // Compiled with -ffp-contract=off: every fp32 op below rounds exactly like the CPU reference.
 #include "ys_internal.h"
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 
 #define NMS_THREADS 1024
 #define NMS_LDS_KEYS 16384
+#define NMS_MASK_MAX 4096          // images with <= this many candidates take the bitmask path (mask rows of 64 x 64-bit words)
+#define NMS_MASK_WORDS (NMS_MASK_MAX / 64)
+#define NMS_MASK_WGS 16            // workgroups (256 threads) per image in the mask kernel
+#define NMS_LDS_N_FWD 1024         // = NMS_LDS_N (defined with nms_scan_kernel)
 
+// Candidate filter: one thread per (image, 4 consecutive anchors) when A % 4 == 0 (16-byte loads along the anchor axis, every
+// wave instruction one contiguous 1 KB read, eight class channels in flight per trip), else one thread per anchor.  A pure
+// stream of B*C*A*4 bytes.  (Splitting the classes over adjacent lanes: 3x slower -- scattered 16-byte accesses; over the four
+// waves of a workgroup with an LDS merge: 83 vs 70 us on [64, 84, 8400] -- dropped.)
+template <int V>
 __global__ void __launch_bounds__(256)
 nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thres,
                   int* __restrict__ count, unsigned long long* __restrict__ keys, int keys_stride,
                   float* __restrict__ confs, int* __restrict__ clss) {
   const int b = blockIdx.y;
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A) return;
+  const int a0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (a0 >= A) return;
   float* p = pred + (size_t)b * C * A;
-  // xywh -> xyxy in place (Ops.cs:76-79): x - w/2, y - h/2, x + w/2, y + h/2
-  const float cx = p[a], cy = p[(size_t)A + a], w = p[2 * (size_t)A + a], h = p[3 * (size_t)A + a];
-  const float hw = w / 2.0f, hh = h / 2.0f;
-  p[a] = cx - hw;
-  p[(size_t)A + a] = cy - hh;
-  p[2 * (size_t)A + a] = cx + hw;
-  p[3 * (size_t)A + a] = cy + hh;
-  float best = p[4 * (size_t)A + a];
-  int bi = 0;
-  for (int c = 1; c < nc; c++) {
-    const float v = p[(size_t)(4 + c) * A + a];
-    if (v > best) { best = v; bi = c; }
+  auto ld = [&](int ch, float (&o)[V]) {
+    if (V == 4) { const float4 q = *(const float4*)(p + (size_t)ch * A + a0); o[0] = q.x; o[V > 1 ? 1 : 0] = q.y; o[V > 2 ? 2 : 0] = q.z; o[V > 3 ? 3 : 0] = q.w; }
+    else o[0] = p[(size_t)ch * A + a0];
+  };
+  auto st = [&](int ch, const float (&o)[V]) {
+    if (V == 4) { float4 q; q.x = o[0]; q.y = o[V > 1 ? 1 : 0]; q.z = o[V > 2 ? 2 : 0]; q.w = o[V > 3 ? 3 : 0]; *(float4*)(p + (size_t)ch * A + a0) = q; }
+    else p[(size_t)ch * A + a0] = o[0];
+  };
+  {
+    // xywh -> xyxy in place (Ops.cs:76-79): x - w/2, y - h/2, x + w/2, y + h/2
+    float cx[V], cy[V], w[V], h[V], x1[V], y1[V], x2[V], y2[V];
+    ld(0, cx); ld(1, cy); ld(2, w); ld(3, h);
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      const float hw = w[v] / 2.0f, hh = h[v] / 2.0f;
+      x1[v] = cx[v] - hw; y1[v] = cy[v] - hh; x2[v] = cx[v] + hw; y2[v] = cy[v] + hh;
+    }
+    st(0, x1); st(1, y1); st(2, x2); st(3, y2);
   }
-  if (best > conf_thres) {
-    const int slot = atomicAdd(&count[b], 1);
-    const unsigned bits = ys_f2u(best);  // best > conf >= 0 -> positive float, bit pattern monotone
-    keys[(size_t)b * keys_stride + slot] = ((unsigned long long)(~bits) << 32) | (unsigned)a;
-    confs[(size_t)b * A + a] = best;
-    clss[(size_t)b * A + a] = bi;
+  float best[V];
+  int bi[V];
+  ld(4, best);                                // class maximum, first arg-max (strict >)
+#pragma unroll
+  for (int v = 0; v < V; v++) bi[v] = 0;
+  int c = 1;
+  for (; c + 7 < nc; c += 8) {
+    float q[8][V];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ld(4 + c + k, q[k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+      for (int v = 0; v < V; v++) if (q[k][v] > best[v]) { best[v] = q[k][v]; bi[v] = c + k; }
+  }
+  for (; c < nc; c++) {
+    float v0[V];
+    ld(4 + c, v0);
+#pragma unroll
+    for (int v = 0; v < V; v++) if (v0[v] > best[v]) { best[v] = v0[v]; bi[v] = c; }
+  }
+#pragma unroll
+  for (int v = 0; v < V; v++) {
+    if (best[v] > conf_thres) {
+      const int a = a0 + v;
+      const int slot = atomicAdd(&count[b], 1);
+      const unsigned bits = ys_f2u(best[v]);  // best > conf >= 0 -> positive float, bit pattern monotone
+      keys[(size_t)b * keys_stride + slot] = ((unsigned long long)(~bits) << 32) | (unsigned)a;
+      confs[(size_t)b * A + a] = best[v];
+      clss[(size_t)b * A + a] = bi[v];
+    }
   }
 }
 
@@ -64,23 +108,19 @@ __device__ inline void nms_bitonic_sort(unsigned long long* k, int np2) {
   }
 }
 
+// Per image: sort the (score, anchor) keys (descending score, ties -> lower anchor), cut to max_nms, gather the class-offset
+// boxes / areas / anchor indices in that order, zero the outputs.  n_sorted[b] = candidates entering the greedy pass.
 __global__ void __launch_bounds__(NMS_THREADS)
-nms_select_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det,
-                  int max_nms, float max_wh, const int* __restrict__ count,
-                  unsigned long long* __restrict__ keys_g, int keys_stride,
-                  const float* __restrict__ confs, const int* __restrict__ clss,
-                  float4* __restrict__ sbox, float* __restrict__ sarea, int* __restrict__ sidx,
-                  unsigned char* __restrict__ supp_g, int ncap,
-                  float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
+nms_sort_kernel(const float* __restrict__ pred, int C, int A, int nc, int max_det, int max_nms, float max_wh,
+                const int* __restrict__ count, unsigned long long* __restrict__ keys_g, int keys_stride,
+                const int* __restrict__ clss, float4* __restrict__ sbox, float* __restrict__ sarea, int* __restrict__ sidx,
+                unsigned char* __restrict__ supp_g, int ncap, int* __restrict__ n_sorted,
+                float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
   __shared__ unsigned long long skeys[NMS_LDS_KEYS];
-  __shared__ int s_red[NMS_THREADS / 64];
-  __shared__ int s_cur;
-  __shared__ int s_kept[1];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const float* p = pred + (size_t)b * C * A;
-  const int extra = C - 4 - nc;
-  const int row_w = 6 + extra;
+  const int row_w = 6 + (C - 4 - nc);
   int n = count[b];
   if (n > A) n = A;
   float* orow = out_rows + (size_t)b * max_det * row_w;
@@ -89,7 +129,7 @@ nms_select_kernel(const float* __restrict__ pred, int C, int A, int nc, float io
   for (int i = tid; i < max_det * row_w; i += NMS_THREADS) orow[i] = 0.0f;
   for (int i = tid; i < max_det; i += NMS_THREADS) okeep[i] = 0;
   if (n == 0) {
-    if (tid == 0) out_count[b] = 0;
+    if (tid == 0) { out_count[b] = 0; n_sorted[b] = 0; }
     return;
   }
   int np2 = 1;
@@ -121,9 +161,190 @@ nms_select_kernel(const float* __restrict__ pred, int C, int A, int nc, float io
     si[i] = a;
     supp[i] = 0;
   }
-  if (tid == 0) { s_cur = 0; s_kept[0] = 0; }
+  if (tid == 0) n_sorted[b] = n;
+}
+
+// torchvision's IoU test, operation for operation (fp32, IEEE division; compiled with -ffp-contract=off)
+__device__ inline bool nms_suppresses(const float4& bi, float ai, const float4& bj, float aj, float iou_thres) {
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (ai + aj - inter);
+  return ovr > iou_thres;
+}
+
+// Bitmask path, part 1 (n <= NMS_MASK_MAX): mask[i][w] = bits j - 64w of every later candidate j that box i would suppress.
+// A wave owns a (64-row block, word) pair of the upper triangle: lane l is row 64 rb + l, the word's 64 column boxes are staged
+// in LDS once and read as broadcasts.  NMS_MASK_WGS x 4 waves per image walk the pairs -- all images and all pairs in parallel
+// instead of one serial O(kept x n) sweep with three workgroup barriers per kept box.
+__global__ void __launch_bounds__(256)
+nms_mask_kernel(const int* __restrict__ n_sorted, const float4* __restrict__ sbox, const float* __restrict__ sarea, int ncap,
+                float iou_thres, unsigned long long* __restrict__ mask) {
+  __shared__ float4 sB[4][64];
+  __shared__ float sA[4][64];
+  const int b = blockIdx.x;
+  const int n = n_sorted[b];
+  if (n <= 0 || n > NMS_MASK_MAX) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = (n + 63) >> 6;
+  const int npairs = nb * (nb + 1) / 2;
+  const float4* bx = sbox + (size_t)b * ncap;
+  const float* ar = sarea + (size_t)b * ncap;
+  unsigned long long* mk = mask + (size_t)b * NMS_MASK_MAX * NMS_MASK_WORDS;
+  for (int pidx = blockIdx.y * 4 + wave; pidx < npairs; pidx += NMS_MASK_WGS * 4) {
+    int rb = 0, rem = pidx;                 // rows rb own the words rb .. nb-1
+    while (rem >= nb - rb) { rem -= nb - rb; rb++; }
+    const int w = rb + rem;
+    const int i = rb * 64 + lane, j0 = w * 64;
+    const int jl = j0 + lane;
+    ys_wave_sync();                         // the previous pair's LDS reads are done
+    sB[wave][lane] = jl < n ? bx[jl] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sA[wave][lane] = jl < n ? ar[jl] : 0.f;
+    ys_wave_sync();
+    if (i < n) {
+      const float4 bi = bx[i];
+      const float ai = ar[i];
+      unsigned long long bits = 0ull;
+      for (int t = 0; t < 64; t++) {
+        const int j = j0 + t;
+        if (j > i && j < n && nms_suppresses(bi, ai, sB[wave][t], sA[wave][t], iou_thres)) bits |= 1ull << t;
+      }
+      mk[(size_t)i * NMS_MASK_WORDS + w] = bits;
+    }
+  }
+}
+
+// Bitmask path, part 2: the greedy order, one 1024-thread workgroup per image.
+//   n <= NMS_LDS_N (the usual case after the confidence filter): the image's bit matrix (nms_mask_kernel) is staged in LDS by
+//   all 1024 threads (building it here, 16 waves per image on 64 CUs, measured 2.5x slower than the chip-wide mask kernel), then
+//   wave 0 walks the candidates in score order, word by word (64 candidates): lane l keeps word l of the "removed" set in
+//   registers, the word being walked lives in a scalar that is tested / updated with scalar instructions (the diagonal mask word
+//   of a kept row comes from a v_readlane) -- no cross-lane or memory round trip per candidate;
+//   NMS_LDS_N < n <= NMS_MASK_MAX: the same walk over the matrix nms_mask_kernel left in global memory, 32 rows requested at a
+//   time, the next chunk in flight while the current one is walked.
+// The kept positions go to LDS and all waves gather the output rows in parallel (Ops.cs:357-366: rows, anchor indices, count).
+#define NMS_LDS_N 1024
+#define NMS_LDS_WORDS (NMS_LDS_N / 64)
+#define NMS_SCAN_LDS ((size_t)NMS_LDS_N * NMS_LDS_WORDS * 8 + 16 * 64 * 20)
+__global__ void __launch_bounds__(NMS_THREADS)
+nms_scan_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det, const int* __restrict__ n_sorted,
+                const float4* __restrict__ sbox, const float* __restrict__ sarea, const int* __restrict__ sidx, int ncap,
+                const float* __restrict__ confs, const int* __restrict__ clss, const unsigned long long* __restrict__ mask,
+                float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
+  YS_DYN_LDS(lds);
+  unsigned long long* lmask = (unsigned long long*)lds;                       // [n][nw] (n <= NMS_LDS_N)
+  char* aux = (char*)lds + (size_t)NMS_LDS_N * NMS_LDS_WORDS * 8;
+  float4* sB = (float4*)aux;                                                   // [16 waves][64] column boxes (matrix phase)
+  float* sA = (float*)(aux + 16 * 64 * 16);                                    // [16][64] column areas
+  int* s_kept = (int*)aux;                                                     // walk / gather phases (<= NMS_MASK_MAX entries fit: 20 KB)
+  __shared__ int s_nkept;
+  const int b = blockIdx.x;
+  const int n = n_sorted[b];
+  if (n <= 0 || n > NMS_MASK_MAX) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = pred + (size_t)b * C * A;
+  const int extra = C - 4 - nc, row_w = 6 + extra;
+  float* orow = out_rows + (size_t)b * max_det * row_w;
+  long long* okeep = out_keep + (size_t)b * max_det;
+  const int* si = sidx + (size_t)b * ncap;
+  const int nw = (n + 63) >> 6;
+  const bool in_lds = n <= NMS_LDS_N;
+  if (in_lds) {
+    // stage the image's bit matrix (built by nms_mask_kernel on the whole chip) in LDS, compact row pitch nw: 1024 threads, coalesced
+    const unsigned long long* gm = mask + (size_t)b * NMS_MASK_MAX * NMS_MASK_WORDS;
+    for (int idx = tid; idx < n * nw; idx += NMS_THREADS) {
+      const int i = idx / nw, w = idx - i * nw;
+      lmask[idx] = w >= (i >> 6) ? gm[(size_t)i * NMS_MASK_WORDS + w] : 0ull;
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {
+    const unsigned long long* mk = in_lds ? lmask : mask + (size_t)b * NMS_MASK_MAX * NMS_MASK_WORDS;
+    const int pitch = in_lds ? nw : NMS_MASK_WORDS;
+    unsigned long long removed = 0ull;
+    int kept = 0;
+    constexpr int CH = 16;                                            // 1024-thread workgroup: 128 registers per lane
+    const int nch = (n + CH - 1) / CH;                                // chunks of 16 candidates; chunk c lies in word c >> 2
+    unsigned long long rA[CH], rB[CH];
+    auto fetch = [&](int c, unsigned long long (&rows)[CH]) {
+      const int w = c >> 2, i0 = c * CH;
+#pragma unroll
+      for (int r = 0; r < CH; r++) {
+        const int i = i0 + r < n ? i0 + r : n - 1;
+        rows[r] = (lane < nw && lane >= w) ? mk[(size_t)i * pitch + lane] : 0ull;   // words below the diagonal were never written
+      }
+    };
+    unsigned long long cur = 0ull;
+    auto walk = [&](int c, const unsigned long long (&rows)[CH]) {
+      const int w = c >> 2, i0 = c * CH, sh = (c & 3) * CH;
+      if ((c & 3) == 0) cur = ys_readlane64(removed, w);              // wave-uniform: "removed" bits of candidates 64w .. 64w+63
+#pragma unroll
+      for (int r = 0; r < CH; r++) {
+        const int i = i0 + r;
+        if (i < n && kept < max_det && !((cur >> (sh + r)) & 1ull)) {
+          if (lane == 0) s_kept[kept] = i;
+          kept++;
+          removed |= rows[r];
+          cur |= ys_readlane64(rows[r], w);
+        }
+      }
+    };
+    if (in_lds) {                                                      // LDS rows: no prefetch needed
+      for (int c = 0; c < nch && kept < max_det; c++) { fetch(c, rA); walk(c, rA); }
+    } else {
+      fetch(0, rA);
+      for (int c = 0; c < nch && kept < max_det; c += 2) {             // the next chunk's rows are in flight while this one is walked
+        if (c + 1 < nch) fetch(c + 1, rB);
+        walk(c, rA);
+        if (c + 1 >= nch || kept >= max_det) break;
+        if (c + 2 < nch) fetch(c + 2, rA);
+        walk(c + 1, rB);
+      }
+    }
+    if (lane == 0) s_nkept = kept;
+  }
   __syncthreads();
-  // greedy pass: workgroup-parallel IoU sweep per kept box
+  const int kept = s_nkept;
+  for (int idx = tid; idx < kept * row_w; idx += NMS_THREADS) {
+    const int k = idx / row_w, e = idx - k * row_w;
+    const int a = si[s_kept[k]];
+    float v;
+    if (e < 4) v = p[(size_t)e * A + a];
+    else if (e == 4) v = confs[(size_t)b * A + a];
+    else if (e == 5) v = (float)clss[(size_t)b * A + a];
+    else v = p[(size_t)(4 + nc + e - 6) * A + a];
+    orow[idx] = v;
+  }
+  for (int k = tid; k < kept; k += NMS_THREADS) okeep[k] = si[s_kept[k]];
+  if (tid == 0) out_count[b] = kept;
+}
+
+// Large images (n > NMS_MASK_MAX, up to max_nms = 30000 candidates: an n x n bit matrix would not pay): the serial sweep, one
+// 1024-thread workgroup per image, workgroup-parallel IoU pass per kept box (O(kept x n)).
+__global__ void __launch_bounds__(NMS_THREADS)
+nms_greedy_big_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det,
+                      const int* __restrict__ n_sorted, const float* __restrict__ confs, const int* __restrict__ clss,
+                      const float4* __restrict__ sbox, const float* __restrict__ sarea, const int* __restrict__ sidx,
+                      unsigned char* __restrict__ supp_g, int ncap,
+                      float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
+  __shared__ int s_red[NMS_THREADS / 64];
+  __shared__ int s_cur;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = n_sorted[b];
+  if (n <= NMS_MASK_MAX) return;
+  const float* p = pred + (size_t)b * C * A;
+  const int extra = C - 4 - nc;
+  const int row_w = 6 + extra;
+  float* orow = out_rows + (size_t)b * max_det * row_w;
+  long long* okeep = out_keep + (size_t)b * max_det;
+  const float4* bx = sbox + (size_t)b * ncap;
+  const float* ar = sarea + (size_t)b * ncap;
+  const int* si = sidx + (size_t)b * ncap;
+  unsigned char* supp = supp_g + (size_t)b * ncap;
+  if (tid == 0) s_cur = 0;
+  __syncthreads();
   int myp = tid;  // private monotone cursor over j == tid (mod NMS_THREADS)
   int kept = 0;
   for (;;) {
@@ -142,21 +363,13 @@ nms_select_kernel(const float* __restrict__ pred, int C, int A, int nc, float io
     if (kept >= max_det) break;  // i = i[:max_det] (Ops.cs:360): later boxes can never be emitted
     const float4 bi = bx[i];
     const float ai = ar[i];
-    // first j > i with j == tid (mod NMS_THREADS)
     int j0 = tid;
     if (j0 <= i) j0 += ((i - j0) / NMS_THREADS + 1) * NMS_THREADS;
     for (int j = j0; j < n; j += NMS_THREADS) {
       if (supp[j]) continue;
-      const float4 bj = bx[j];
-      const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-      const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-      const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-      const float inter = w * h;
-      const float ovr = inter / (ai + ar[j] - inter);
-      if (ovr > iou_thres) supp[j] = 1;
+      if (nms_suppresses(bi, ai, bx[j], ar[j], iou_thres)) supp[j] = 1;
     }
     __syncthreads();
-    // next unsuppressed index > i
     while (myp < n && (myp <= i || supp[myp])) myp += NMS_THREADS;
     int cand = (myp < n) ? myp : 0x7fffffff;
     for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(cand, m); cand = o < cand ? o : cand; }
@@ -189,6 +402,9 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   const size_t o_area = off;  off = align_up(off + sizeof(float) * (size_t)B * ncap, 256);
   const size_t o_idx = off;   off = align_up(off + sizeof(int) * (size_t)B * ncap, 256);
   const size_t o_supp = off;  off = align_up(off + (size_t)B * ncap, 256);
+  const size_t o_nsort = off; off = align_up(off + sizeof(int) * B, 256);
+  const bool big_possible = ncap > NMS_MASK_MAX;
+  const size_t o_mask = off;  off = align_up(off + sizeof(unsigned long long) * (size_t)B * NMS_MASK_MAX * NMS_MASK_WORDS, 256);
   if (off > ctx->nms_ws_bytes) {
     if (ctx->nms_ws) { YS_CHECK_HIP(hipStreamSynchronize(ctx->stream)); YS_CHECK_HIP(hipFree(ctx->nms_ws)); ctx->nms_ws = nullptr; ctx->nms_ws_bytes = 0; }
     YS_CHECK_HIP(hipMalloc(&ctx->nms_ws, off));
@@ -198,13 +414,43 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   int* count = (int*)(ws + o_count);
   YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));
   YsKprofScope prof(ctx->stream, "nms");
-  dim3 g1(ys_cdiv(A, 256), B);
-  YS_LAUNCH(nms_filter_kernel, g1, 256, ctx->stream, pred, C, A, nc, conf, count,
-            (unsigned long long*)(ws + o_keys), np2, (float*)(ws + o_conf), (int*)(ws + o_cls));
-  YS_LAUNCH(nms_select_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, iou, max_det, max_nms,
-            (float)max_wh, (const int*)count, (unsigned long long*)(ws + o_keys), np2,
-            (const float*)(ws + o_conf), (const int*)(ws + o_cls), (float4*)(ws + o_box), (float*)(ws + o_area),
-            (int*)(ws + o_idx), (unsigned char*)(ws + o_supp), ncap, out_rows, (long long*)out_keep, (int*)out_count);
+  static const bool dbg = getenv("YS_NMS_DEBUG") != nullptr;
+#define NMS_DBG(what) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(ctx->stream); hipError_t l_ = hipGetLastError(); fprintf(stderr, "nms %s: sync %d last %d\n", what, (int)e_, (int)l_); } } while (0)
+  NMS_DBG("entry");
+  unsigned long long* keys = (unsigned long long*)(ws + o_keys);
+  float* confs = (float*)(ws + o_conf); int* clss = (int*)(ws + o_cls);
+  float4* sbox = (float4*)(ws + o_box); float* sarea = (float*)(ws + o_area); int* sidx = (int*)(ws + o_idx);
+  unsigned char* supp = (unsigned char*)(ws + o_supp); int* nsort = (int*)(ws + o_nsort);
+  unsigned long long* mask = (unsigned long long*)(ws + o_mask);
+  if (A % 4 == 0) {
+    dim3 g1(ys_cdiv(A / 4, 64), B);
+    YS_LAUNCH(nms_filter_kernel<4>, g1, 64, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
+  } else {
+    dim3 g1(ys_cdiv(A, 256), B);
+    YS_LAUNCH(nms_filter_kernel<1>, g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
+  }
+  NMS_DBG("filter");
+  YS_LAUNCH(nms_sort_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, max_det, max_nms, (float)max_wh, (const int*)count,
+            keys, np2, (const int*)clss, sbox, sarea, sidx, supp, ncap, nsort, out_rows, (long long*)out_keep, (int*)out_count);
+  NMS_DBG("sort");
+  YS_LAUNCH(nms_mask_kernel, dim3(B, NMS_MASK_WGS), 256, ctx->stream, (const int*)nsort, (const float4*)sbox, (const float*)sarea, ncap, iou, mask);
+  NMS_DBG("mask");
+  static_assert(NMS_LDS_N_FWD == NMS_LDS_N, "mask / scan kernels disagree on the LDS-resident size");
+  static std::atomic<unsigned> attr_done{0};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
+    hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_SCAN_LDS);   // + 4 B static: 160 KB flat is refused
+    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
+  }
+  YS_LAUNCH_LDS(nms_scan_kernel, B, NMS_THREADS, NMS_SCAN_LDS, ctx->stream, (const float*)pred, C, A, nc, iou, max_det, (const int*)nsort,
+                (const float4*)sbox, (const float*)sarea, (const int*)sidx, ncap, (const float*)confs, (const int*)clss,
+                (const unsigned long long*)mask, out_rows, (long long*)out_keep, (int*)out_count);
+  NMS_DBG("scan");
+  if (big_possible)
+    YS_LAUNCH(nms_greedy_big_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, iou, max_det, (const int*)nsort,
+              (const float*)confs, (const int*)clss, (const float4*)sbox, (const float*)sarea, (const int*)sidx, supp, ncap,
+              out_rows, (long long*)out_keep, (int*)out_count);
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;
 }

@@ -403,6 +403,17 @@ __device__ inline void ys_amax_update(unsigned* slots, float mx) {
   }
 }
 
+// 64-bit value of lane `src` (wave-uniform index) as a scalar: v_readlane_b32 x2 instead of a ds_bpermute round trip
+__device__ inline unsigned long long ys_readlane64(unsigned long long v, int src) {
+#ifdef YS_EMU_BUILD
+  return __shfl(v, src);
+#else
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+#endif
+}
+
 // wave-level ordering point for LDS traffic that is private to one wave: LDS operations of a wave execute in order on
 // the hardware, so only the compiler must not reorder across it (the interpreter needs a real rendezvous).
 __device__ inline void ys_wave_sync() {
