@@ -224,6 +224,14 @@ YS_API int ys_match_predictions(ys_ctx* ctx, const float* pred_cls, int n, const
 YS_API int ys_process_mask(ys_ctx* ctx, const float* protos, const float* masks_in, const float* boxes, int on_device,
                            int n, int nm, int mh, int mw, int ih, int iw, int upsample, int crop_mode, uint8_t* out);
 
+/* Input side: Augment.LetterBox.LetterboxImage (Data/Augment.cs:757-778) and Augment.Rectangle.RectangleImage
+ * (:836-857): ratio = min(fit_w / w, fit_h / h), new = (int)(size * ratio), torchvision resize (TorchVision.NET default: nearest) and
+ * constant padding with `color` (114 for images, 0 for masks), centred on an out_w x out_h canvas.  LetterBox: fit = out;
+ * Rectangle: fit = the label's resized shape, out = its rectangle shape.  Planes [C,h,w] -> [C,out_h,out_w], uint8 or fp32
+ * (is_float).  *pad_l / *pad_u = the offsets the reference adds to boxes / keypoints / OBB corners. */
+YS_API int ys_letterbox(ys_ctx* ctx, const void* src, int is_float, int on_device, int C, int h, int w, int fit_w, int fit_h,
+                        int out_w, int out_h, int color, void* dst, int32_t* pad_l, int32_t* pad_u);
+
 /* ---- per-operator entry points (unit parity; a TorchSharp-free C# Conv wrapper) ---------------
  * Convs.Conv.forward (Convs.cs:36-62): y = act(BN(conv2d(x))) on fp32 NCHW / OIHW HOST arrays at the
  * edge (the call stages them through HBM).  training != 0 uses batch statistics and updates running stats (momentum 0.03, eps 1e-3). */

@@ -125,3 +125,29 @@ def test_segmenter_val(backend, engine):
     rmask = M.val_summary(M.ap_per_class(np.concatenate(tpms), conf, pc, tc))
     assert np.allclose(box, rbox, atol=1e-6) and np.allclose(mask, rmask, atol=1e-6), (box, rbox, mask, rmask)
     m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_letterbox_and_rectangle(backend, engine):
+    """Augment.LetterBox / Augment.Rectangle on the device (Data/Augment.cs:698-857) vs the oracle restatement (ATen nearest resize,
+    constant pad): every pixel and both offsets, uint8 images (colour 114) and fp32 masks (colour 0), up- and down-scaling."""
+    rng = np.random.default_rng(0)
+    cases = [((3, 480, 640), 640, 640), ((3, 1080, 810), 640, 640), ((3, 37, 53), 64, 96), ((1, 120, 160), 160, 160), ((3, 640, 640), 640, 640)]
+    for shape, rw, rh in cases:
+        img = rng.integers(0, 256, shape).astype(np.uint8)
+        out, pl, pu = engine.letterbox(img, rw, rh, 114)
+        rpl, rpu, ref = O.letterbox_image(img, rw, rh, 114)
+        assert (pl, pu) == (rpl, rpu) and out.shape == (shape[0], rh, rw)
+        assert np.array_equal(out, ref.numpy()), shape
+        m = rng.integers(0, 5, (1,) + shape[1:]).astype(np.float32)
+        outm, plm, pum = engine.letterbox(m, rw // 4, rh // 4, 0)
+        rplm, rpum, refm = O.letterbox_image(m, rw // 4, rh // 4, 0)
+        assert (plm, pum) == (rplm, rpum) and np.array_equal(outm, refm.numpy())
+    # Rectangle: fit box = the label's resized shape, canvas = its rectangle shape
+    img = rng.integers(0, 256, (3, 300, 500)).astype(np.uint8)
+    out, pl, pu = engine.letterbox(img, 640, 640, 114, rectangle_shape=(640, 416))
+    rpl, rpu, ref = O.letterbox_image(img, 640, 640, 114, canvas=(640, 416))
+    assert (pl, pu) == (rpl, rpu) and np.array_equal(out, ref.numpy())
+    from yolosharp_amd import YsError
+    with pytest.raises(YsError):
+        engine.letterbox(img, 640, 640, 114, rectangle_shape=(320, 100))      # the resized image does not fit the canvas

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "ys_model_set_preds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ys_model_reserve_labels": (C.c_int, [C.c_void_p, C.c_int]),
     "ys_optim_set_param_groups": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_letterbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_i32_p, c_i32_p]),
     "ys_block_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_block_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ys_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

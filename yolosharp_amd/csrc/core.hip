@@ -218,6 +218,39 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
   return YS_OK;
 }
 
+// Augment.LetterBox.LetterboxImage (Data/Augment.cs:757-778) and Augment.Rectangle.RectangleImage (:836-857) on the device:
+// ratio = min(fit_w / w, fit_h / h) in fp32, new = (int)(size * ratio), centred on an out_w x out_h canvas filled with `color`
+// (LetterBox: fit = out; Rectangle: fit = the label's resized shape, out = its rectangle shape).  src / dst: planes [C][h][w] ->
+// [C][out_h][out_w], uint8 (images) or fp32 (masks, is_float = 1).  pad_l / pad_u are returned for the box / keypoint offsets.
+int ys_letterbox(ys_ctx* ctx, const void* src, int is_float, int on_device, int C, int h, int w, int fit_w, int fit_h, int out_w, int out_h,
+                 int color, void* dst, int32_t* pad_l, int32_t* pad_u) {
+  YS_REQUIRE(ctx && src && dst, "ys_letterbox: null argument");
+  YS_REQUIRE(C > 0 && h > 0 && w > 0 && fit_w > 0 && fit_h > 0 && out_w > 0 && out_h > 0, "ys_letterbox: bad geometry");
+  const float ratio_w = (float)fit_w / (float)w, ratio_h = (float)fit_h / (float)h;
+  const float ratio = ratio_w < ratio_h ? ratio_w : ratio_h;
+  const int new_w = (int)((float)w * ratio), new_h = (int)((float)h * ratio);
+  YS_REQUIRE(new_w > 0 && new_h > 0 && new_w <= out_w && new_h <= out_h, "ys_letterbox: resized image %dx%d does not fit the %dx%d canvas", new_w, new_h, out_w, out_h);
+  const int pl = (out_w - new_w) / 2, pu = (out_h - new_h) / 2;
+  if (pad_l) *pad_l = pl;
+  if (pad_u) *pad_u = pu;
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t es = is_float ? 4 : 1;
+  const size_t nin = (size_t)C * h * w * es, nout = (size_t)C * out_h * out_w * es;
+  if (on_device) return ys_letterbox_launch(st, is_float, src, C, h, w, dst, out_h, out_w, new_h, new_w, pu, pl, (float)color);
+  void *d_in = nullptr, *d_out = nullptr;
+  int rc = YS_OK;
+  if (hipMalloc(&d_in, nin) != hipSuccess || hipMalloc(&d_out, nout) != hipSuccess) { ys_set_error("ys_letterbox: out of device memory"); rc = YS_ERR_OOM; }
+  if (rc == YS_OK && hipMemcpyAsync(d_in, src, nin, hipMemcpyHostToDevice, st) != hipSuccess) rc = YS_ERR_HIP;
+  if (rc == YS_OK) rc = ys_letterbox_launch(st, is_float, d_in, C, h, w, d_out, out_h, out_w, new_h, new_w, pu, pl, (float)color);
+  if (rc == YS_OK && hipMemcpyAsync(dst, d_out, nout, hipMemcpyDeviceToHost, st) != hipSuccess) rc = YS_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess && rc == YS_OK) rc = YS_ERR_HIP;
+  if (d_in) hipFree(d_in);
+  if (d_out) hipFree(d_out);
+  if (rc == YS_ERR_HIP) ys_set_error("ys_letterbox: HIP error");
+  return rc;
+}
+
 // Ops.process_mask (Utils/Ops.cs:462-489): masks_in[n][nm] @ protos[nm][mh][mw], crop to the boxes, optional bilinear upsample
 // to (ih, iw), threshold > 0.  out: uint8 [n][oh][ow] with (oh, ow) = upsample ? (ih, iw) : (mh, mw).
 int ys_process_mask(ys_ctx* ctx, const float* protos, const float* masks_in, const float* boxes, int on_device, int n, int nm,

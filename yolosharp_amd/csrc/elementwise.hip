@@ -93,6 +93,40 @@ int ys_pack_input_u8_launch(hipStream_t st, int dtype, const unsigned char* x, i
   return YS_OK;
 }
 
+// LetterBox / Rectangle (Data/Augment.cs:698-857): out[c, y, x] = in[c, src_y(y - pad_u), src_x(x - pad_l)] inside the resized
+// window [pad_u, pad_u + new_h) x [pad_l, pad_l + new_w), `color` elsewhere.  The resize is
+// torchvision.transforms.functional.resize(img, new_h, new_w) of TorchVision(.NET), whose default interpolation is NEAREST
+// (third-party, not vendored): ATen's legacy nearest rule  src = min(floor(dst * (float)in / out), in - 1),
+// evaluated here in the same fp32 arithmetic.  One thread per output pixel and plane; ET = unsigned char (images) or float (masks).
+template <class ET>
+__global__ void __launch_bounds__(EW_THREADS)
+letterbox_kernel(const ET* __restrict__ x, int C, int h, int w, ET* __restrict__ y, int H, int W, int new_h, int new_w,
+                 int pad_u, int pad_l, float color) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)C * H * W;
+  if (i >= n) return;
+  const int ox = (int)(i % W);
+  const int oy = (int)((i / W) % H);
+  const int c = (int)(i / ((long)W * H));
+  const int ry = oy - pad_u, rx = ox - pad_l;
+  ET v = (ET)color;
+  if (ry >= 0 && ry < new_h && rx >= 0 && rx < new_w) {
+    const float sy = (float)h / (float)new_h, sx = (float)w / (float)new_w;
+    int iy = (int)floorf((float)ry * sy), ix = (int)floorf((float)rx * sx);
+    iy = iy < h - 1 ? iy : h - 1; ix = ix < w - 1 ? ix : w - 1;
+    v = x[((long)c * h + iy) * w + ix];
+  }
+  y[i] = v;
+}
+int ys_letterbox_launch(hipStream_t st, int is_float, const void* x, int C, int h, int w, void* y, int H, int W, int new_h, int new_w,
+                        int pad_u, int pad_l, float color) {
+  const long n = (long)C * H * W;
+  if (n <= 0) return YS_OK;
+  if (is_float) YS_LAUNCH((letterbox_kernel<float>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const float*)x, C, h, w, (float*)y, H, W, new_h, new_w, pad_u, pad_l, color);
+  else YS_LAUNCH((letterbox_kernel<unsigned char>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const unsigned char*)x, C, h, w, (unsigned char*)y, H, W, new_h, new_w, pad_u, pad_l, color);
+  return YS_OK;
+}
+
 template <class T>
 __global__ void __launch_bounds__(EW_THREADS)
 unpack_nchw_kernel(const T* __restrict__ x, int ldc, int coff, int B, int C, long rpb, float* __restrict__ y) {

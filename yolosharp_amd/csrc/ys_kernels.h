@@ -84,6 +84,9 @@ __host__ __device__ inline void ys_phase_wd_index(long e, int cin_real, int cout
 int ys_pack_input_launch(hipStream_t st, int dtype, const float* x_nchw, int B, int C, int H, int W, int cpad, void* y);
 // uint8 NCHW [B,C,h,w] in 0..255 -> NHWC T [B,H,W,cpad]: / 255, bottom / right padding to (H, W) with 114 / 255
 int ys_pack_input_u8_launch(hipStream_t st, int dtype, const unsigned char* x, int B, int C, int h, int w, int H, int W, int cpad, void* y);
+// LetterBox / Rectangle resize + pad (Augment.cs:698-857): planes [C][h][w] -> [C][H][W]; element = uint8 or fp32
+int ys_letterbox_launch(hipStream_t st, int is_float, const void* x, int C, int h, int w, void* y, int H, int W, int new_h, int new_w,
+                        int pad_u, int pad_l, float color);
 // NHWC view T -> NCHW fp32
 int ys_unpack_nchw_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, int B, int C, long rows_per_b,
                           float* y_nchw);

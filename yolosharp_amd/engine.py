@@ -142,6 +142,22 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_match_predictions(self.ctx, _ptr(pc), pc.shape[0], _ptr(tc), tc.shape[0], _ptr(iou), 0, _ptr(cor)))
         return cor.astype(bool)
 
+    # ---- Augment.LetterBox / Augment.Rectangle (Data/Augment.cs:698-857)
+    def letterbox(self, img, resized_width=640, resized_height=640, color=114, rectangle_shape=None):
+        """img: uint8 or float32 [C,h,w].  LetterBox(resized_width, resized_height, color) -> (out [C,H,W], pad_l, pad_u); with
+        rectangle_shape=(w, h) it is Augment.Rectangle (fit box = the resized shape, canvas = the rectangle shape)."""
+        x = np.ascontiguousarray(img)
+        is_float = x.dtype != np.uint8
+        if is_float:
+            x = np.ascontiguousarray(x, np.float32)
+        Cc, h, w = x.shape
+        ow, oh = rectangle_shape if rectangle_shape is not None else (resized_width, resized_height)
+        out = np.empty((Cc, oh, ow), x.dtype)
+        pl, pu = C.c_int32(), C.c_int32()
+        _lib.check(self.lib, self.lib.ys_letterbox(self.ctx, _ptr(x), int(is_float), 0, Cc, h, w, resized_width, resized_height, ow, oh, int(color),
+                                                   _ptr(out), C.byref(pl), C.byref(pu)))
+        return out, pl.value, pu.value
+
     # ---- Ops.process_mask (Ops.cs:462-489)
     def process_mask(self, protos, masks_in, bboxes, shape, upsample=False, cpu_crop_branch=False):
         """protos [nm,mh,mw], masks_in [n,nm], bboxes [n,4] xyxy (image pixels), shape=(ih,iw) -> bool [n,oh,ow]."""
