@@ -201,7 +201,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the timed process)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
             if headline and tj["conv_igemm_class"]["config"] == f"YOLOv8{args.size} B={B} {H}x{W} {args.dtype}":
                 traffic = tj["conv_igemm_class"]["hbm_bytes_per_launch_corrected"]
         except Exception:
