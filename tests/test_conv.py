@@ -24,6 +24,13 @@ FWD_CASES = [
     (2, 16, 18, 36, 16, 3, 2, True, False, True, True),
     (1, 40, 23, 17, 80, 3, 1, True, False, True, False),
     (3, 64, 21, 21, 64, 3, 2, False, True, False, True),
+    # blocked-GEMM kernel of the wide layers (conv_gemm.hip; conftest lowers its size gates): every tile shape, ragged M and N,
+    # K not a multiple of the K-tile (taps straddle tiles), stride 2, 1x1, eval epilogue
+    (1, 128, 9, 11, 80, 3, 2, True, False, True, True),     # 256x80 tile
+    (2, 160, 7, 9, 64, 3, 1, True, False, True, True),      # 256x64 tile, K = 1440
+    (1, 256, 13, 10, 128, 1, 1, True, False, True, True),   # 128x128 tile, two M tiles
+    (1, 136, 17, 9, 320, 3, 1, True, False, True, False),   # 128x160 tile x 2 channel tiles, eval
+    (2, 128, 6, 6, 80, 1, 1, False, True, False, True),     # plain conv + bias
 ]
 
 
@@ -75,7 +82,9 @@ BWD_CASES = [(2, 16, 8, 8, 32, 3, 1), (2, 16, 8, 8, 16, 1, 1), (1, 32, 9, 7, 80,
              (2, 64, 6, 6, 80, 3, 2), (2, 80, 4, 4, 80, 1, 1), (1, 96, 6, 6, 64, 1, 1),
              # multi-tile images, ragged tile edges, several (cout, cin) channel tiles (LDS-tile wgrad kernel)
              (2, 32, 20, 40, 32, 3, 1), (1, 128, 12, 20, 144, 3, 1), (1, 256, 5, 5, 64, 1, 1), (2, 16, 18, 36, 16, 3, 2),
-             (3, 48, 13, 17, 32, 1, 1)]
+             (3, 48, 13, 17, 32, 1, 1),
+             # dgrad through the blocked-GEMM kernel (Cout of the layer = K of its dgrad): stride-1 3x3, 1x1, stride-2 phases
+             (1, 64, 11, 13, 160, 3, 1), (2, 80, 9, 9, 256, 1, 1), (1, 64, 14, 10, 128, 3, 2)]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -105,3 +114,33 @@ def test_conv_backward(backend, engine, dtype, case):
     tol = 1e-4 if dtype == "f32" else 1e-2   # bf16: dx is rounded to bf16 on store; dw stays fp32
     assert np.abs(dx - x.grad.numpy()).max() <= tol * np.abs(x.grad.numpy()).max()
     assert np.abs(dw - w.grad.numpy()).max() <= 1e-4 * np.abs(w.grad.numpy()).max()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
+    """The per-launch profile names the kernel a layer ran on: >= 128 input channels -> conv_gemm_kernel for forward, dgrad and the
+    four phase convolutions of a stride-2 dgrad; narrower layers stay on the whole-Cin patch kernel."""
+    import ctypes as C
+    from yolosharp_amd import _lib
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    g = torch.Generator().manual_seed(0)
+    engine.kernel_profile(True)
+    for (cin, cout, k, s) in [(128, 160, 3, 1), (32, 160, 3, 1), (64, 128, 3, 2)]:
+        x = torch.randn(1, cin, 12, 12, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+        dy = torch.randn(1, cout, 12 // s, 12 // s, generator=g)
+        engine.conv_bn_act(x.numpy(), w.numpy(), k, s, bn=None, bias=np.zeros(cout, np.float32), act=False, dtype="bf16")
+        dx = np.zeros(x.shape, np.float32); dw = np.zeros(w.shape, np.float32)
+        xn, wn, dyn = x.numpy().copy(), w.numpy().copy(), dy.numpy().copy()
+        _lib.check(engine.lib, engine.lib.ys_conv_bwd(engine.ctx, 1, vp(xn), 1, cin, 12, 12, vp(wn), cout, k, s, vp(dyn), vp(dx), vp(dw)))
+    path = tmp_path / "launches.csv"
+    engine.kernel_profile_dump(path)
+    engine.kernel_profile(False)
+    labels = [l.split(",")[1] for l in open(path).read().splitlines()[1:] if l.startswith("conv_igemm")]
+    assert sum(l.startswith("gemm k33 s1 div1 cin128 cout160") for l in labels) == 1          # forward, 128 -> 160
+    assert sum(l.startswith("gemm k33 s1 div1 cin160 cout128") for l in labels) == 1          # its dgrad
+    assert sum(l.startswith("gemm k33 s1 div1 cin160 cout32") for l in labels) == 0           # Cout < 64: not eligible
+    assert sum(l.startswith("p2 k33 s1 div1 cin32 cout160") for l in labels) == 1             # narrow forward: patch kernel
+    # stride-2 dgrad of 64 -> 128: the 1x2, 2x1 and 2x2 phase convolutions (K = 256, 256, 512); the 1x1 phase (K = 128) is below the K gate
+    assert sorted(l.split()[1] for l in labels if l.startswith("gemm k") and "cin128 cout64" in l) == ["k12", "k21", "k22"]
+    assert sum(l.startswith("p2 k11 s1 div1 cin128 cout64") for l in labels) == 1

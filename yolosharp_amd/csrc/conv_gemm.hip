@@ -1,0 +1,275 @@
+// conv_gemm.hip -- GEMM-grade implicit-GEMM convolution for the wide layers (Cin >= 128) of the bf16 path, gfx950 (CDNA4).
+//
+// Same arithmetic and argument contract as conv_p2_kernel (conv.hip): Conv2d of Modules/Convs.cs:36-62 / Head.cs:47-50 in NHWC with
+// weights [Cout][kh][kw][Cin], forward (stride 1, 2), stride-1 dgrad and the 1x1..2x2 phase convolutions of a stride-2 dgrad.
+// The whole-Cin LDS patch of conv_p2_kernel is the right shape for <= 128 channels (YOLOv8n/s); from 160-640 channels (YOLOv8x,
+// YOLOv11m: BASELINE configs 4 and 5) the patch no longer fits a useful tile and the layer is MFMA-bound, so it wants the
+// classical blocked GEMM instead:
+//
+//   D[pixel m][cout n] = sum_k A[m][k] * W[n][k],   k = (kh, kw, ci),  A gathered on the fly from the NHWC activation
+//
+//  * workgroup tile BM x BN = (WM*MR*16) x (WN*NR*16) pixels x channels (128x160 for the 80-multiples of YOLOv8x, 128x128 for the
+//    64-multiples of v11m, 256x80 / 256x64 for the narrow outputs), 4 waves, each wave MR x NR MFMA 16x16x32 tiles: 20 MFMAs per
+//    9 fragment reads (460 B of LDS per MFMA -- conv_p2_kernel's wide-layer tiles read 1.2 KB per MFMA);
+//  * K in tiles of 64 (one 128-byte line per tile row): both operands go global -> LDS by LDS DMA (global_load_lds_dwordx4),
+//    16 bytes per lane and no VGPRs in between; every lane computes its own source address, which is where the implicit-GEMM
+//    gather (tap offset, zero padding -> a zero line) and the bank swizzle live.  Two LDS stages: the DMA of tile k+1 is in flight
+//    while tile k is multiplied, one barrier per K-tile;
+//  * LDS rows are 128 B, so a fragment read (16 rows x 16 B per lane quarter) would hit 2 of 16 bank groups; unit u of row r is
+//    stored at slot u ^ ((r >> 1) & 7) -- applied to the SOURCE address of the DMA and to the ds_read address alike -> conflict-free;
+//  * persistent grid (gx, N-tiles): a workgroup keeps its output-channel tile and walks M-tiles of its XCD's contiguous share, so
+//    the workgroups that share an A tile (same x, different y) and the neighbouring tiles' halo rows meet in one XCD's L2; the BN
+//    batch statistics stay in registers across tiles and leave as one row per workgroup (p2 contract);
+//  * epilogue, statistics, bias / eval-BN / SiLU, residual and gradient accumulation: the shared wide-store stage (conv_epi.h).
+#include "conv_epi.h"
+#include <atomic>
+#include <cstdlib>
+
+// 128 B of zeros: the DMA source of every 16-byte unit that is padding (outside the image, past K, past Cout)
+__device__ uint4 ys_gemm_zero_line[8];
+
+struct GemmTap { int x, y; };   // per 16-byte K unit: offset (in units) from the tap-(0,0) pixel; kh << 8 | kw, or -1 = padding
+struct GemmArgs {
+  int nkt;          // K-tiles of 64
+  int kunits;       // real 16-byte K units = KH*KW*Cin / 8
+  int mtiles;       // ceil(M / BM)
+  int off_stage;    // LDS byte offset of the two operand stages (the tap table sits at 0)
+  int stage_bytes;  // (BM + BN) * 128
+  int HoWo;
+};
+
+template <int WM, int WN, int MR, int NR>
+__global__ void __launch_bounds__(256, 2)
+conv_gemm_kernel(ConvArgs a, GemmArgs g) {
+  typedef bf16_t T;
+  constexpr int NT = 256;
+  constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
+  constexpr int NA = BM / 32;                 // A pieces (8 rows x 128 B = one DMA instruction) per wave and K-tile
+  constexpr int NBP = BN / 8;                 // B pieces per K-tile in the workgroup
+  constexpr int NB = (NBP + 3) / 4;           // per wave (the last one may be absent: BN = 80)
+  static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 8 == 0, "tile");
+  YS_DYN_LDS(lds);
+  char* lb = (char*)lds;
+  GemmTap* sTab = (GemmTap*)lb;                     // [nkt * 8] per K unit: (16-byte unit offset from the tap-(0,0) pixel, kh << 8 | kw) or (0, -1)
+  char* sStage = lb + g.off_stage;
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, q = lane >> 4;
+#ifdef YS_EMU_BUILD
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int n0 = blockIdx.y * BN;
+  const char* xb = (const char*)a.x;
+  const char* wb = (const char*)a.w;
+  const char* zsrc = (const char*)ys_gemm_zero_line + (lane & 7) * 16;
+  const int cu = a.Cin >> 3;
+  const int ldu = a.in_ldc >> 3, cofu = a.in_coff >> 3;
+  const long Kbytes = (long)g.kunits * 16;    // bytes per weight row
+
+  for (int e = tid; e < g.nkt * 8; e += NT) {
+    GemmTap t;
+    if (e < g.kunits) {
+      const int tap = e / cu, c8 = e - tap * cu;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      t.x = (kh * a.Win + kw) * ldu + c8;
+      t.y = (kh << 8) | kw;
+    } else { t.x = 0; t.y = -1; }
+    sTab[e] = t;
+  }
+
+  // DMA roles.  Piece p of a stage = rows 8p .. 8p+7 (1 KB, one wave-wide instruction); wave w issues pieces w, w+4, ...  Lane l
+  // of a piece lands at row 8p + (l >> 3), slot l & 7, and therefore fetches unit (l & 7) ^ ((row >> 1) & 7) of that row -- the
+  // same for all of this thread's pieces since 8 * 4j / 2 is a multiple of 8.
+  const int rsub = lane >> 3;
+  const int kunit = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const char* bptr[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const int n = n0 + 8 * (wave + 4 * j) + rsub;
+    bptr[j] = (wave + 4 * j < NBP && n < a.Cout) ? wb + (long)n * Kbytes : nullptr;
+  }
+  long abase[NA];
+  int aiy[NA], aix[NA];
+
+  auto issue = [&](int st, int kt) {
+    char* sb = sStage + st * g.stage_bytes;
+    const int ku = kt * 8 + kunit;
+    const GemmTap te = sTab[ku];
+    const int kh = te.y >> 8, kw = te.y & 255;
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      const bool ok = (bool)((int)(te.y >= 0) & (int)((unsigned)(aiy[j] + kh) < (unsigned)a.Hin) & (int)((unsigned)(aix[j] + kw) < (unsigned)a.Win));
+      const char* src = ok ? xb + ((abase[j] + te.x) << 4) : zsrc;
+      ys_glds16(src, sb + (wave + 4 * j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      if (wave + 4 * j < NBP) {
+        const bool ok = (bool)((int)(bptr[j] != nullptr) & (int)(ku < g.kunits));
+        const char* src = ok ? bptr[j] + ((long)ku << 4) : zsrc;
+        ys_glds16(src, sb + BM * 128 + (wave + 4 * j) * 1024);
+      }
+    }
+  };
+
+  // fragment read offsets: row (16-row fragment base + li), unit (ks * 4 + q) ^ (li >> 1)
+  const int koff0 = ((0 + q) ^ (li >> 1)) << 4, koff1 = ((4 + q) ^ (li >> 1)) << 4;
+  const int arow0 = ((wm * MR) * 16 + li) * 128;
+  const int brow0 = BM * 128 + ((wn * NR) * 16 + li) * 128;
+
+  // tile order: as conv_p2_kernel -- workgroup i runs on XCD i % 8 and walks that XCD's contiguous share of the M-tiles
+  const bool xcd_order = (gridDim.x & 7) == 0;
+  const int t_per_xcd = (g.mtiles + 7) >> 3;
+  const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_end = xcd_order ? (((int)(blockIdx.x & 7) + 1) * t_per_xcd < g.mtiles ? ((int)(blockIdx.x & 7) + 1) * t_per_xcd : g.mtiles) : g.mtiles;
+
+  float st1[8], st2[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
+
+  for (int tile = t_first; tile < t_end; tile += t_step) {
+    const int m0 = tile * BM;
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      const int m = m0 + 8 * (wave + 4 * j) + rsub;
+      if (m < a.M) {
+        const int b = m / g.HoWo, rem = m - b * g.HoWo;
+        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        aiy[j] = oy * a.SA - a.PAD; aix[j] = ox * a.SA - a.PAD;
+        abase[j] = ((long)b * a.in_bstride + (long)aiy[j] * a.Win + aix[j]) * ldu + cofu;
+      } else { aiy[j] = -(1 << 20); aix[j] = 0; abase[j] = 0; }
+    }
+    ys_barrier_lds();                         // the tap table is written; the previous tile's epilogue staging is consumed
+    issue(0, 0);
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+      for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+
+#pragma unroll 1
+    for (int kt = 0; kt < g.nkt; kt++) {
+      YS_WAIT_VM0();                          // this wave's DMA pieces of tile kt have landed ...
+      ys_barrier_lds();                       // ... everybody's have, and everybody is done reading the other stage
+      if (kt + 1 < g.nkt) issue((kt + 1) & 1, kt + 1);
+      const char* sb = sStage + (kt & 1) * g.stage_bytes;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int ko = ks ? koff1 : koff0;
+        uint4 fw[NR], fx[MR];
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++) fw[nf] = *(const uint4*)(sb + brow0 + nf * 2048 + ko);
+#pragma unroll
+        for (int mf = 0; mf < MR; mf++) fx[mf] = *(const uint4*)(sb + arow0 + mf * 2048 + ko);
+        YS_SCHED_FENCE();
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(fw[nf], fx[mf], acc[mf][nf]);
+      }
+    }
+    ys_barrier_lds();                         // every wave finished reading the stages: they become the epilogue staging area
+
+    long orow[MR];
+    bool pv[MR];
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) {
+      const int m = m0 + (wm * MR + mf) * 16 + li;
+      pv[mf] = m < a.M;
+      const int mm = pv[mf] ? m : 0;
+      const int b = mm / g.HoWo, rem = mm - b * g.HoWo;
+      const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+      orow[mf] = (long)b * a.out_bstride + (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox));
+    }
+    char* stg = sStage + wave * (16 * MR * (NR * 16 + 8) * 2 + 16 * MR * 16);
+    p2_epilogue<MR, NR>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
+  }
+  if (a.stats) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
+}
+
+// ------------------------------------------------------------------ host side
+struct GemmPlan { int ok, wm, wn, mr, nr, gx, gy; size_t lds; GemmArgs g; };
+
+static GemmPlan conv_gemm_plan(const ConvArgs& a) {
+  GemmPlan p{};
+  static const bool off = getenv("YS_NO_GEMM") != nullptr;
+  static const int min_cin = getenv("YS_GEMM_MIN_CIN") ? atoi(getenv("YS_GEMM_MIN_CIN")) : 128;
+  static const int min_k = getenv("YS_GEMM_MIN_K") ? atoi(getenv("YS_GEMM_MIN_K")) : 256;
+  if (off || a.f8) return p;
+  const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
+  const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
+  const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
+  if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
+  if (a.Cin % 8 || a.in_ldc % 8 || a.in_coff % 8 || a.out_ldc % 8 || a.out_coff % 8 || a.Cout % 8) return p;
+  if (a.res && (a.res_ldc % 8 || a.res_coff % 8)) return p;
+  const int taps = a.KH * a.KW;
+  const long Ktot = (long)taps * a.Cin;
+  static const int min_m = getenv("YS_GEMM_MIN_M") ? atoi(getenv("YS_GEMM_MIN_M")) : 1024;
+  if (a.Cin < min_cin || Ktot < min_k || a.Cout < 64 || a.M < min_m) return p;
+  // output-channel tile: least padding first, then the widest (most reuse of the A tile)
+  static const int cand[4][4] = {{2, 2, 4, 5}, {2, 2, 4, 4}, {4, 1, 4, 5}, {4, 1, 4, 4}};   // WM, WN, MR, NR
+  int best = -1; long best_pad = 0;
+  for (int i = 0; i < 4; i++) {
+    const int bn = cand[i][1] * cand[i][3] * 16;
+    const long pad = (long)ys_cdiv(a.Cout, bn) * bn;
+    if (best < 0 || pad < best_pad) { best = i; best_pad = pad; }
+  }
+  p.wm = cand[best][0]; p.wn = cand[best][1]; p.mr = cand[best][2]; p.nr = cand[best][3];
+  const int bm = p.wm * p.mr * 16, bn = p.wn * p.nr * 16;
+  GemmArgs g{};
+  g.kunits = (int)(Ktot / 8);
+  g.nkt = (int)((Ktot + 63) / 64);
+  g.mtiles = ys_cdiv(a.M, bm);
+  g.HoWo = a.Hout * a.Wout;
+  const size_t tab = (size_t)g.nkt * 8 * sizeof(GemmTap);
+  g.off_stage = (int)((tab + 1023) / 1024 * 1024);
+  g.stage_bytes = (bm + bn) * 128;
+  const size_t stage2 = (size_t)2 * g.stage_bytes;
+  const size_t epi = (size_t)4 * (16 * p.mr * (p.nr * 16 + 8) * 2 + 16 * p.mr * 16);
+  if (epi > stage2 || (size_t)16 * 256 * 4 > stage2) return p;
+  p.lds = g.off_stage + stage2;
+  if (p.lds > 160 * 1024) return p;
+  p.gy = ys_cdiv(a.Cout, bn);
+  const int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
+  long gx = (256L * per_cu) / p.gy;
+  gx &= ~7L;                                  // XCD-ordered tile walk needs a multiple of 8
+  if (gx < 8) gx = 8;
+  if (gx > g.mtiles) gx = g.mtiles;
+  p.gx = (int)gx;
+  p.g = g;
+  p.ok = 1;
+  return p;
+}
+
+template <int WM, int WN, int MR, int NR>
+static int conv_gemm_launch_t(hipStream_t st, const ConvArgs& a, const GemmPlan& p) {
+  static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, MR, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
+  }
+  char lab[192] = "";
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "gemm k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, WM * MR * 16, WN * NR * 16, p.gx, p.gy, (int)p.lds);
+  YsKprofScope prof(st, "conv_igemm", lab);
+  YS_LAUNCH_LDS((conv_gemm_kernel<WM, WN, MR, NR>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+  return YS_OK;
+}
+
+int ys_conv_gemm_rows(const ConvArgs& a) {
+  const GemmPlan p = conv_gemm_plan(a);
+  return p.ok ? p.gx : 0;
+}
+
+int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a) {
+  const GemmPlan p = conv_gemm_plan(a);
+  if (!p.ok) return YS_ERR_UNSUPPORTED;
+#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return conv_gemm_launch_t<A_, B_, C_, D_>(st, a, p);
+  GM(2, 2, 4, 5) GM(2, 2, 4, 4) GM(4, 1, 4, 5) GM(4, 1, 4, 4)
+#undef GM
+  return YS_ERR_UNSUPPORTED;
+}

@@ -479,4 +479,17 @@ __device__ inline void ys_barrier_lds() {
 #endif
 }
 
+// LDS DMA (gfx950 global_load_lds_dwordx4): every lane names its own 16-byte global source; the destination is wave-uniform --
+// lane l lands at lds_wave_base + 16 * l, no VGPR in between.  Completion is counted on vmcnt like a load: wait (YS_WAIT_VM0)
+// and cross a workgroup barrier before another wave reads the bytes.  A swizzled LDS image is obtained by permuting the SOURCE
+// addresses across lanes (the destination order is fixed).
+__device__ inline void ys_glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef YS_EMU_BUILD
+  memcpy((char*)lds_wave_base + emu::lane() * 16, gsrc, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -53,6 +53,9 @@ struct WgradArgs {
 };
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
+// blocked-GEMM kernel for the wide bf16 layers (conv_gemm.hip): statistics rows of its launch, 0 when the layer is not eligible
+int ys_conv_gemm_rows(const ConvArgs& a);
+int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
 int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad);
