@@ -19,6 +19,7 @@ os.environ.setdefault("YS_F8_MIN_CIN", "32")
 # The blocked-GEMM convolution kernel (csrc/conv_gemm.hip) takes layers with >= 128 input channels and >= 1024 output pixels; the
 # tests drop the pixel gate so that oracle-sized shapes reach it.
 os.environ.setdefault("YS_GEMM_MIN_M", "1")
+os.environ.setdefault("YS_WGEMM_MIN_M", "1")      # same for its weight-gradient counterpart (csrc/conv_wgrad_gemm.hip)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

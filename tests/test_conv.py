@@ -84,7 +84,9 @@ BWD_CASES = [(2, 16, 8, 8, 32, 3, 1), (2, 16, 8, 8, 16, 1, 1), (1, 32, 9, 7, 80,
              (2, 32, 20, 40, 32, 3, 1), (1, 128, 12, 20, 144, 3, 1), (1, 256, 5, 5, 64, 1, 1), (2, 16, 18, 36, 16, 3, 2),
              (3, 48, 13, 17, 32, 1, 1),
              # dgrad through the blocked-GEMM kernel (Cout of the layer = K of its dgrad): stride-1 3x3, 1x1, stride-2 phases
-             (1, 64, 11, 13, 160, 3, 1), (2, 80, 9, 9, 256, 1, 1), (1, 64, 14, 10, 128, 3, 2)]
+             (1, 64, 11, 13, 160, 3, 1), (2, 80, 9, 9, 256, 1, 1), (1, 64, 14, 10, 128, 3, 2),
+             # wgrad through the blocked-GEMM kernel (conv_wgrad_gemm.hip): 160 / 128 tiles and both mixes, ragged channels, stride 2, 1x1
+             (1, 160, 9, 11, 320, 3, 2), (2, 256, 6, 7, 128, 1, 1), (1, 136, 10, 9, 160, 3, 1), (1, 256, 7, 9, 152, 3, 1)]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -117,6 +119,14 @@ def test_conv_backward(backend, engine, dtype, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [15, 17, 18])
+def test_wgrad_gemm_short_k_tile(backend, engine, case, monkeypatch):
+    """The 32-pixel K-tile variant of the blocked-GEMM wgrad kernel (chosen when two 64-pixel stages do not fit the LDS share)."""
+    monkeypatch.setenv("YS_WGEMM_KT", "32")
+    test_conv_backward(backend, engine, "bf16", case)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
     """The per-launch profile names the kernel a layer ran on: >= 128 input channels -> conv_gemm_kernel for forward, dgrad and the
     four phase convolutions of a stride-2 dgrad; narrower layers stay on the whole-Cin patch kernel."""
@@ -144,3 +154,6 @@ def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
     # stride-2 dgrad of 64 -> 128: the 1x2, 2x1 and 2x2 phase convolutions (K = 256, 256, 512); the 1x1 phase (K = 128) is below the K gate
     assert sorted(l.split()[1] for l in labels if l.startswith("gemm k") and "cin128 cout64" in l) == ["k12", "k21", "k22"]
     assert sum(l.startswith("p2 k11 s1 div1 cin128 cout64") for l in labels) == 1
+    wl = [l.split(",")[1] for l in open(path).read().splitlines()[1:] if l.startswith("conv_wgrad")]
+    assert sum(l.startswith("wgemm k3 s1 cin128 cout160") for l in wl) == 1                   # both sides >= 128 channels
+    assert sum(l.startswith("wgemm") for l in wl) == 1 and len(wl) == 3                        # the narrow layers keep the 9-wave kernel

@@ -508,6 +508,8 @@ static void wgrad_dispatch(hipStream_t st, const WgradArgs& a, int splits) {
 // number of pixel splits used for a layer (also sizes the partial workspace)
 int ys_wgrad_splits(const WgradArgs& a, int dtype) {
   if (dtype == YS_BF16) {
+    const int gs = ys_wgrad_gemm_splits(a);   // wide layers: blocked-GEMM kernel (conv_wgrad_gemm.hip)
+    if (gs) return gs;
     const WgPlan p = wgrad_tr_plan(a);
     if (p.ok) return p.gx;
   }
@@ -533,6 +535,10 @@ int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, i
   }
   bool done = false;
   if (dtype == YS_BF16) {
+    const int used = ys_wgrad_gemm_launch(st, a, splits);
+    if (used) { splits = used; done = true; }
+  }
+  if (dtype == YS_BF16 && !done) {
     WgPlan p = wgrad_tr_plan(a);
     if (p.ok) {
       if (splits < p.gx) p.gx = splits;     // never exceed the caller's partial workspace

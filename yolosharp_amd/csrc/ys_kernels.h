@@ -59,6 +59,10 @@ int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
 int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad);
+// blocked-GEMM weight-gradient kernel of the wide bf16 layers (conv_wgrad_gemm.hip): pixel splits it wants (0 = not eligible);
+// the launch uses at most `splits` and returns the number used (0 = not eligible, nothing launched)
+int ys_wgrad_gemm_splits(const WgradArgs& a);
+int ys_wgrad_gemm_launch(hipStream_t st, const WgradArgs& a, int splits);
 int ys_weight_prep_launch(hipStream_t st, int dtype, const float* w, int Cout, int taps, int cin_real, int cin_pad,
                           int cout_pad, void* wf, void* wd, int phase);
 // true when the dgrad of a (k, stride) layer runs as four phase convolutions and wants the phase-major dgrad weights
