@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # lower the threshold so that the small shapes an oracle can check in seconds go through the fp8 kernel too.  Read once, at the
 # first convolution plan of the process.
 os.environ.setdefault("YS_F8_MIN_CIN", "32")
+os.environ.setdefault("YS_F8_MIN_TAPS", "1")       # and 1x1 layers too (production keeps them in bf16: the quantisation pass costs more than it saves)
 # The blocked-GEMM convolution kernel (csrc/conv_gemm.hip) takes layers with >= 128 input channels and >= 1024 output pixels; the
 # tests drop the pixel gate so that oracle-sized shapes reach it.
 os.environ.setdefault("YS_GEMM_MIN_M", "1")

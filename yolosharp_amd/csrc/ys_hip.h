@@ -487,8 +487,15 @@ __device__ inline void ys_glds16(const void* gsrc, void* lds_wave_base) {
 #ifdef YS_EMU_BUILD
   memcpy((char*)lds_wave_base + emu::lane() * 16, gsrc, 16);
 #else
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc treats the builtin as a store to LDS that any later ds_read may alias
+  // and puts s_waitcnt vmcnt(0) in front of the next fragment read -- the DMA of tile k+1 was drained before tile k was
+  // multiplied (ISA of the first conv_gemm_kernel build), i.e. no overlap.  The asm form is invisible to that bookkeeping; the
+  // kernels wait for it explicitly (YS_WAIT_VM0 + barrier).  M0 = LDS byte address of the destination, written in the same
+  // statement that uses it and restored (the compiler owns M0).
+  unsigned keep;
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 #endif
 }
 

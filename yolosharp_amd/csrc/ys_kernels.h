@@ -33,6 +33,9 @@ struct ConvArgs {
   const float* qscale;           // device scalar: quantisation multiplier of the input tensor
   const float* deq;              // device scalar: 1 / (input scale * weight scale), applied to the fp32 accumulators
   unsigned* amax;                // optional: YS_AMAX_WAYS slots receiving amax(|input|) of this launch (next step's scale)
+  // fp8 blocked-GEMM path (conv_gemm_kernel<F8 = 1>): the operand tiles go to LDS by DMA, so the input must already be fp8 in memory
+  void* q8;                      // optional scratch of >= B*Hin*Win*Cin bytes: ys_conv_launch quantises the input view into it first
+  const void* x8;                // set by ys_conv_launch: the dense [B*Hin*Win][Cin] fp8 image of the input (inside q8)
   unsigned long long* tl;        // triage builds (-DYS_P2_TIMELINE): per-workgroup s_memtime stamps of the tile phases; null otherwise
 };
 
@@ -54,6 +57,8 @@ struct WgradArgs {
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
 // blocked-GEMM kernel for the wide bf16 layers (conv_gemm.hip): statistics rows of its launch, 0 when the layer is not eligible
+int ys_f8_quant_view_launch(hipStream_t st, int fmt, const void* x, long rows, int C, int ldc, int coff, const float* qscale,
+                            void* out, unsigned* slots);
 int ys_conv_gemm_rows(const ConvArgs& a);
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
