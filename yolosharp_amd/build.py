@@ -137,5 +137,7 @@ if __name__ == "__main__":
         build_oracle(True)
     if "timeline" in what:
         build_device(True, variant="tl", defines=["-DYS_P2_TIMELINE"], out=os.path.join(BUILD, "libyolosharp_hip_tl.so"))
+    if "ablate" in what:
+        build_device(True, variant="abl", defines=["-DYS_GEMM_ABLATE"], out=os.path.join(BUILD, "libyolosharp_hip_abl.so"))
     if "abi" in what or len(sys.argv) == 1:
         build_abi_smoke(True)

@@ -28,6 +28,13 @@
 // 128 B of zeros: the DMA source of every 16-byte unit that is padding (outside the image, past K, past Cout)
 __device__ uint4 ys_gemm_zero_line[8];
 
+// ablation switches for performance triage (YS_GEMM_DBG bits; compiled in only with -DYS_GEMM_ABLATE = `build.py ablate`):
+// 1 = A operand from the zero line, 2 = B operand from the zero line (no L2 traffic), 4 = no MFMAs, 8 = no epilogue
+#ifdef YS_GEMM_ABLATE
+#define GEMM_DBG(bit) ((a.dbg & (bit)) != 0)
+#else
+#define GEMM_DBG(bit) false
+#endif
 struct GemmTap { int x, y; };   // per 16-byte K unit: offset (in units) from the tap-(0,0) pixel; kh << 8 | kw, or -1 = padding
 struct GemmArgs {
   int nkt;          // K-tiles of 64
@@ -106,14 +113,14 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     const int kh = te.y >> 8, kw = te.y & 255;
 #pragma unroll
     for (int j = 0; j < NA; j++) {
-      const bool ok = (bool)((int)(te.y >= 0) & (int)((unsigned)(aiy[j] + kh) < (unsigned)a.Hin) & (int)((unsigned)(aix[j] + kw) < (unsigned)a.Win));
+      const bool ok = (bool)((int)(te.y >= 0) & (int)((unsigned)(aiy[j] + kh) < (unsigned)a.Hin) & (int)((unsigned)(aix[j] + kw) < (unsigned)a.Win) & (int)!GEMM_DBG(1));
       const char* src = ok ? xb + ((long)(abase[j] + te.x) << 4) : zsrc;
       ys_glds16(src, sb + (wave + 4 * j) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       if (wave + 4 * j < NBP) {
-        const bool ok = (bool)((int)(boff[j] >= 0) & (int)(ku < g.kunits));
+        const bool ok = (bool)((int)(boff[j] >= 0) & (int)(ku < g.kunits) & (int)!GEMM_DBG(2));
         const char* src = ok ? wb + ((long)boff[j] + ((long)ku << 4)) : zsrc;
         ys_glds16(src, sb + BM * 128 + (wave + 4 * j) * 1024);
       }
@@ -163,6 +170,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       ys_barrier_lds();                       // ... everybody's have, and everybody is done reading the other stage
       if (kt + 1 < g.nkt) issue((kt + 1) & 1, kt + 1);
       const char* sb = sStage + (kt & 1) * g.stage_bytes;
+      if (GEMM_DBG(4)) continue;
       if (F8) {
         // 32-byte fragments: the pixel fragments stay live, the weight fragments come in two groups (all at once is 72 registers
         // of fragments next to 80 accumulators: spills)
@@ -226,7 +234,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
           for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
     }
     char* stg = sStage + wave * (16 * MR * (NR * 16 + 8) * 2 + 16 * MR * 16);
-    p2_epilogue<MR, NR>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
+    if (!GEMM_DBG(8)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
   }
   if (a.stats) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
 }
@@ -288,7 +296,10 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
 }
 
 template <int WM, int WN, int MR, int NR, int F8>
-static int conv_gemm_launch_t(hipStream_t st, const ConvArgs& a, const GemmPlan& p) {
+static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
+#ifdef YS_GEMM_ABLATE
+  a.dbg = getenv("YS_GEMM_DBG") ? atoi(getenv("YS_GEMM_DBG")) : 0;
+#endif
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
