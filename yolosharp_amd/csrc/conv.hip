@@ -1287,6 +1287,16 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a) {
   return YS_OK;
 }
 
+bool ys_conv_wants_x8(const ConvArgs& a) {
+  if (!a.f8 || a.x8 || a.in_bstride != (long)a.Hin * a.Win) return false;
+  ConvArgs b = a; b.x8 = a.x;                 // any non-null pointer: the plans only test for presence
+  if (ys_conv_dgrad_uses_phases(YS_BF16, a.KH, a.DIVM + 1) && a.KW == a.KH) {
+    for (int ph = 0; ph < 4; ph++) { ConvArgs q; if (conv_dgrad_s2_phase_args(b, ph, q) && ys_conv_gemm_rows(q) != 0) return true; }
+    return false;
+  }
+  return ys_conv_gemm_rows(b) != 0;
+}
+
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   if (a.Cin % epl || a.in_ldc % epl || a.in_coff % epl) {
@@ -1297,15 +1307,12 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
     static const bool p2_off = getenv("YS_NO_P2") != nullptr;
     if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_launch(st, dtype, b); }
     const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
-    if (a.f8 && !a.x8 && a.q8 && a.in_bstride == (long)a.Hin * a.Win) {
+    if (a.f8 && !a.x8 && a.q8) {
       // fp8 on the blocked-GEMM kernel: its operand tiles reach LDS by DMA, so the input view is quantised into the caller's
       // scratch first (one pass that also records amax(|input|) for the next step's scale) -- when the layer, or a phase of its
       // stride-2 dgrad, will run that kernel
       ConvArgs b = a; b.x8 = a.q8;
-      bool want = false;
-      if (phases) { for (int ph = 0; ph < 4 && !want; ph++) { ConvArgs q; want = conv_dgrad_s2_phase_args(b, ph, q) && ys_conv_gemm_rows(q) != 0; } }
-      else want = ys_conv_gemm_rows(b) != 0;
-      if (want) {
+      if (ys_conv_wants_x8(a)) {
         const int rc = ys_f8_quant_view_launch(st, a.f8 == 2 ? 1 : 0, a.x, (long)a.B * a.Hin * a.Win, a.Cin, a.in_ldc, a.in_coff, a.qscale, a.q8, a.amax);
         if (rc != YS_OK) return rc;
         b.amax = nullptr;                                               // recorded by the quantisation pass

@@ -275,6 +275,71 @@ bn_act_apply_kernel(const T* __restrict__ y, long rows, int C, const float* __re
   // maximum of non-negative floats is order-independent, so the atomic keeps the step deterministic
   if (amax) ys_amax_update(amax, mx);
 }
+// amax bookkeeping of a grid-stride pass: workgroup maximum through LDS, then ONE slot update per workgroup
+__device__ inline void ys_amax_update_wg(unsigned* slots, float mx) {
+  __shared__ float s_wmax[EW_THREADS / 64];
+  mx = ys_wave_max(mx);
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = s_wmax[0];
+    for (int w = 1; w < EW_THREADS / 64; w++) v = fmaxf(v, s_wmax[w]);
+    if (v > 0.f) {
+      unsigned* slot = slots + (blockIdx.x & (YS_AMAX_WAYS - 1));
+      const unsigned cur = *(volatile unsigned*)slot;
+      if (ys_f2u(v) > cur) atomicMax(slot, ys_f2u(v));
+    }
+  }
+}
+
+// fp8 mode, bf16 storage: the same pass also writes the e4m3 image (dense [rows][C], the consumer's delayed activation scale) of the
+// tensor it produces and records amax(|z|) -- used when the next convolution of the schedule reads exactly this
+// view and will run the fp8 blocked-GEMM kernel (Bottleneck cv1 -> cv2), instead of a quantisation pass over z.  Grid-stride with a
+// bounded grid: one amax atomic per workgroup.
+template <bool ACT>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_apply_q8_kernel(const bf16_t* __restrict__ y, long rows, int C, const float* __restrict__ scale, const float* __restrict__ shift,
+                       const bf16_t* __restrict__ res, int res_ldc, int res_coff, bf16_t* __restrict__ z, int z_ldc, int z_coff,
+                       unsigned char* __restrict__ q8, const float* __restrict__ qscale, unsigned* __restrict__ amax) {
+  const int CG = C / 8;
+  const long n = rows * CG;
+  const float qs = qscale[0];
+  float mx = 0.f;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) {
+    const long row = i / CG; const int c = (int)(i - row * CG) * 8;
+    float f[8], r[8], sc[8], sh[8];
+    ys_unpack<bf16_t>(ys_ld16(y + row * C + c), f);
+    if (res) ys_unpack<bf16_t>(ys_ld16(res + row * res_ldc + res_coff + c), r);
+    ys_ldcoef<8>(scale + c, sc);
+    ys_ldcoef<8>(shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float u = f[e] * sc[e] + sh[e];
+      if (ACT) u = ys_silu(u);
+      if (res) u += r[e];
+      f[e] = u;
+    }
+    const uint4 pk = ys_pack<bf16_t>(f);
+    ys_st16(z + row * z_ldc + z_coff + c, pk);
+    ys_unpack<bf16_t>(pk, f);                   // quantise the stored (bf16-rounded) value: what every other reader of z sees
+#pragma unroll
+    for (int e = 0; e < 8; e++) { mx = fmaxf(mx, fabsf(f[e])); f[e] *= qs; }
+    *(uint2*)(q8 + row * C + c) = ys_pack_f8x8<0>(f);
+  }
+  if (amax) ys_amax_update_wg(amax, mx);
+}
+int ys_bn_act_apply_q8_launch(hipStream_t st, const void* y, long rows, int C, const float* scale, const float* shift, int act,
+                              const void* res, int res_ldc, int res_coff, void* z, int z_ldc, int z_coff, void* q8,
+                              const float* qscale, unsigned* amax) {
+  const long n = rows * (C / 8);
+  static const long gcap = getenv("YS_Q8_GRID") ? atol(getenv("YS_Q8_GRID")) : 2048;
+  long g = ys_cdiv(n, EW_THREADS * 4L); if (g > gcap) g = gcap; if (g < 1) g = 1;
+#define BAQ_LAUNCH(AF) YS_LAUNCH((bn_act_apply_q8_kernel<AF>), (int)g, EW_THREADS, st, (const bf16_t*)y, rows, C, scale, shift, (const bf16_t*)res, res_ldc, res_coff, (bf16_t*)z, z_ldc, z_coff, (unsigned char*)q8, qscale, amax)
+  if (act) BAQ_LAUNCH(true); else BAQ_LAUNCH(false);
+#undef BAQ_LAUNCH
+  return YS_OK;
+}
+
 int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const float* scale,
                            const float* shift, int act, const void* res, int res_ldc, int res_coff, void* z,
                            int z_ldc, int z_coff, unsigned* amax) {
@@ -552,6 +617,53 @@ bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* 
   }
   if (amax) ys_amax_update(amax, mx);          // fp8 mode: amax(|dy|) for the next step's gradient scale (f8.hip)
 }
+// fp8 mode, bf16 storage: the same pass also writes the e5m2 image of dy (dense [rows][C], scaled by the layer's delayed gradient
+// scale) that the fp8 dgrad kernel consumes, and records amax(|dy|) for the next step's scale -- instead of a separate quantisation
+// pass over dy (f8_quant_view_kernel: 2 B read + 1 B written per element and layer).  Grid-stride with a bounded grid so that the
+// amax bookkeeping is one atomic per workgroup (one-shot waves each paying a dependent global round trip were measured 5x slower).
+template <bool ACT>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_bwd_apply_q8_kernel(const bf16_t* __restrict__ dz, int dz_ldc, int dz_coff, const bf16_t* __restrict__ y, long rows, int C,
+                       const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k2,
+                       const float* __restrict__ k3, bf16_t* __restrict__ dy, unsigned char* __restrict__ q8,
+                       const float* __restrict__ qscale, unsigned* __restrict__ amax) {
+  const int CG = C / 8;
+  const long n = rows * CG;
+  const float qs = qscale[0];
+  float mx = 0.f;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) {
+    const long row = i / CG; const int c = (int)(i - row * CG) * 8;
+    float g[8], f[8], sc[8], sh[8], a2[8], a3[8];
+    ys_unpack<bf16_t>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
+    ys_unpack<bf16_t>(ys_ld16(y + row * C + c), f);
+    ys_ldcoef<8>(scale + c, sc); ys_ldcoef<8>(shift + c, sh); ys_ldcoef<8>(k2 + c, a2); ys_ldcoef<8>(k3 + c, a3);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float u = f[e] * sc[e] + sh[e];
+      const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];
+      f[e] = sc[e] * du - a2[e] - f[e] * a3[e];
+    }
+    const uint4 pk = ys_pack<bf16_t>(f);
+    ys_st16(dy + row * C + c, pk);
+    ys_unpack<bf16_t>(pk, f);                   // quantise what the bf16 consumers (wgrad) see: the rounded value
+#pragma unroll
+    for (int e = 0; e < 8; e++) { mx = fmaxf(mx, fabsf(f[e])); f[e] *= qs; }
+    *(uint2*)(q8 + row * C + c) = ys_pack_f8x8<1>(f);
+  }
+  if (amax) ys_amax_update_wg(amax, mx);
+}
+int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C,
+                              const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
+                              void* q8, const float* qscale, unsigned* amax) {
+  const long n = rows * (C / 8);
+  static const long gcap = getenv("YS_Q8_GRID") ? atol(getenv("YS_Q8_GRID")) : 2048;
+  long g = ys_cdiv(n, EW_THREADS * 4L); if (g > gcap) g = gcap; if (g < 1) g = 1;
+#define BQ_LAUNCH(AF) YS_LAUNCH((bn_bwd_apply_q8_kernel<AF>), (int)g, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, k2, k3, (bf16_t*)dy, (unsigned char*)q8, qscale, amax)
+  if (act) BQ_LAUNCH(true); else BQ_LAUNCH(false);
+#undef BQ_LAUNCH
+  return YS_OK;
+}
+
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
                            int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
                            unsigned* amax) {

@@ -101,6 +101,7 @@ struct ys_model {
   // fp8 mode (ys_dtype YS_FP8: bf16 storage + fp8 MFMA convolutions, f8.hip)
   bool f8 = false, f8_sx_valid = false, f8_sg_valid = false, f8_bwd_done = false;
   unsigned char *wf8_all = nullptr, *wd8_all = nullptr;
+  int q8_fwd_ready = -1;                  // forward: conv index whose input image already sits in q8 (written by its producer's BN pass)
   unsigned char* q8 = nullptr;            // scratch: fp8 image of one convolution input (blocked-GEMM fp8 kernel, quantised by ys_conv_launch)
   float *amax_w = nullptr, *f8_scales = nullptr; unsigned *amax_act = nullptr, *amax_dy = nullptr;
   F8Layer* f8_layers = nullptr; F8Conv* f8_convs = nullptr; int n_f8_convs = 0; long n_wf_pending = 0, n_wd_pending = 0;
@@ -884,18 +885,26 @@ int run_convT_fwd(ys_model* m, const ConvL& c, int B) {
   return YS_OK;
 }
 
-int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
-  if (c.dw) return run_dwconv_fwd(m, c, B);
-  if (c.ct) return run_convT_fwd(m, c, B);
-  hipStream_t st = m->ctx->stream;
+// geometry / operand part of the forward convolution arguments of layer c
+static ConvArgs fwd_args(ys_model* m, const ConvL& c, int B) {
   const Buf& ib = m->bufs[c.in.buf];
-  const Buf& ob = m->bufs[c.out.buf];
   ConvArgs a{};
   a.x = ib.act; a.w = (char*)m->wf_all + (size_t)c.wf_off * m->es;
   a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.cin_pad; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.cout; a.KH = a.KW = c.k;
   a.SA = c.s; a.DIVS = 0; a.DIVM = 0; a.PAD = c.k / 2;
   a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
   a.M = B * c.Hout * c.Wout;
+  return a;
+}
+
+// `next`: the convolution that runs right after this one, when it reads exactly the view this one writes (else null)
+int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr) {
+  if (c.dw) return run_dwconv_fwd(m, c, B);
+  if (c.ct) return run_convT_fwd(m, c, B);
+  hipStream_t st = m->ctx->stream;
+  const Buf& ib = m->bufs[c.in.buf];
+  const Buf& ob = m->bufs[c.out.buf];
+  ConvArgs a = fwd_args(m, c, B);
   const long M = a.M;
   const bool vec = (ob.ldc % 4 == 0) && (c.out.coff % 4 == 0);
   if (m->f8 && c.f8_fwd) {
@@ -903,6 +912,7 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
     if (m->f8_sx_valid) {   // fp8 MFMA kernel where one is planned (ys_conv_launch falls back to bf16 otherwise); it records amax(|x|) itself
       a.f8 = 1; a.w8 = m->wf8_all + c.wf_off; a.qscale = m->f8_scales + 4L * c.idx; a.deq = m->f8_scales + 4L * c.idx + 1; a.amax = slots;
       a.q8 = m->q8;
+      if (m->q8_fwd_ready == c.idx) { a.x8 = m->q8; a.amax = nullptr; }   // image and maximum written by the producer's BN / SiLU pass
     } else {                // first pass: no scale yet -> bf16 kernels, and a bootstrap pass records the input maximum
       YS_TRY(ys_f8_view_amax_launch(st, ib.act, (long)B * c.Hin * c.Win, c.cin_pad, ib.ldc, c.in.coff, slots));
     }
@@ -919,8 +929,22 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B) {
                                  chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
     const void* res = nullptr; int rl = 0, rc = 0;
     if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
-    YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, res, rl, rc,
-                                  ob.act, ob.ldc, c.out.coff, amax_slot));
+    // fp8 mode: the next convolution of the schedule reads exactly this output and will run the fp8 blocked-GEMM kernel -> this pass also writes
+    // the e4m3 image it consumes (the consumer's delayed scale) into the scratch and records its maximum
+    bool q8_out = false;
+    if (next && m->f8 && m->f8_sx_valid && next->f8_fwd && m->q8 && m->dtype == YS_BF16 && !next->dw && !next->ct) {
+      ConvArgs q = fwd_args(m, *next, B);
+      q.f8 = 1; q.w8 = m->wf8_all + next->wf_off; q.qscale = m->f8_scales + 4L * next->idx; q.deq = m->f8_scales + 4L * next->idx + 1;
+      q8_out = ys_conv_wants_x8(q);
+    }
+    if (q8_out) {
+      YS_TRY(ys_bn_act_apply_q8_launch(st, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, res, rl, rc, ob.act, ob.ldc,
+                                       c.out.coff, m->q8, m->f8_scales + 4L * next->idx, m->amax_act + (size_t)next->idx * YS_AMAX_WAYS));
+      m->q8_fwd_ready = next->idx;
+    } else {
+      YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, res, rl, rc,
+                                    ob.act, ob.ldc, c.out.coff, amax_slot));
+    }
   } else {
     a.y = view_ptr(m, ob.act, ob, c.out_rowoff);
     a.out_ldc = ob.ldc; a.out_coff = c.out.coff; a.out_bstride = ob.rows_per_b; a.vec_ok = vec ? 1 : 0;
@@ -947,11 +971,20 @@ int forward_impl(ys_model* m, int B) {
                                                 m->state + c.rv_off, 1e-3f, chan_ptr(m, c, 0), chan_ptr(m, c, 1)));
     m->eval_coeffs_dirty = false;
   }
-  for (auto& op : m->ops) {
+  m->q8_fwd_ready = -1;
+  for (size_t oi = 0; oi < m->ops.size(); oi++) {
+    const Op& op = m->ops[oi];
     const Buf& ib = m->bufs[op.in.buf];
     const Buf& ob = m->bufs[op.out.buf];
     if (op.type == OP_CONV) {
-      YS_TRY(run_conv_fwd(m, m->convs[op.conv], B));
+      const ConvL& cc = m->convs[op.conv];
+      const ConvL* next = nullptr;               // the very next op, if it is a convolution reading exactly what this one writes
+      if (oi + 1 < m->ops.size() && m->ops[oi + 1].type == OP_CONV) {
+        const ConvL& nc = m->convs[m->ops[oi + 1].conv];
+        if (nc.in.buf == cc.out.buf && nc.in.coff == cc.out.coff && nc.in.C == cc.out.C && nc.cin_pad == cc.cout && nc.cin == cc.cout &&
+            nc.Hin == cc.Hout && nc.Win == cc.Wout) next = &nc;
+      }
+      YS_TRY(run_conv_fwd(m, cc, B, next));
     } else if (op.type == OP_MAXPOOL) {
       YS_TRY(ys_maxpool5_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc,
                                     op.out.coff, m->training ? m->argmax + op.aux_off : nullptr));
@@ -1032,6 +1065,21 @@ int run_convT_bwd(ys_model* m, const ConvL& c, int B) {
   return YS_OK;
 }
 
+// input-gradient convolution of layer c (gather form with flipped / transposed weights) reading dy as a [M][dy_ldc] view
+static ConvArgs dgrad_args(ys_model* m, const ConvL& c, int B, const void* dy, int dy_ldc, int dy_coff, long dy_bstride) {
+  const Buf& ib = m->bufs[c.in.buf];
+  ConvArgs a{};
+  a.x = dy; a.w = (char*)m->wd_all + (size_t)c.wd_off * m->es;
+  a.y = ib.grad;
+  a.B = B; a.Hin = c.Hout; a.Win = c.Wout; a.Cin = c.cout_ld; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cin; a.KH = a.KW = c.k;
+  a.SA = 1; a.DIVS = c.s == 2 ? 1 : 0; a.DIVM = c.s - 1; a.PAD = c.k - 1 - c.k / 2;
+  a.in_ldc = dy_ldc; a.in_coff = dy_coff; a.in_bstride = dy_bstride;
+  a.out_ldc = ib.ldc; a.out_coff = c.in.coff; a.out_bstride = ib.rows_per_b;
+  a.vec_ok = (ib.ldc % 4 == 0 && c.in.coff % 4 == 0) ? 1 : 0;
+  a.M = B * c.Hin * c.Win;
+  return a;
+}
+
 int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
   if (c.ct) return run_convT_bwd(m, c, B);
   hipStream_t st = m->ctx->stream;
@@ -1040,6 +1088,7 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
   const long M = (long)B * c.Hout * c.Wout;
   const void* dy = nullptr; int dy_ldc = 0, dy_coff = 0; long dy_bstride = (long)c.Hout * c.Wout;
   int slot = -1;
+  bool dy_q8 = false;                       // m->q8 already holds the e5m2 image of dy (written by the BN backward pass)
   if (c.bn) {
     const void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     void* rg = nullptr; int rgl = 0, rgc = 0;
@@ -1065,8 +1114,21 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
       dyb = m->dy_ring[slot];
       if (m->slot_busy[slot]) YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_free[slot], 0));
     }
-    YS_TRY(ys_bn_bwd_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
-                                  chan_ptr(m, c, 4), chan_ptr(m, c, 5), c.act ? 1 : 0, dyb));
+    // fp8 mode: when this layer's dgrad will run the fp8 blocked-GEMM kernel, the same pass writes the e5m2 image of dy it consumes
+    // (and records amax(|dy|)) -- no separate quantisation pass over dy
+    if (m->f8 && c.f8_bwd && m->f8_sg_valid && !c.first && !c.dw && m->q8 && m->dtype == YS_BF16 && c.cout_ld == c.cout) {
+      ConvArgs q = dgrad_args(m, c, B, dyb, c.cout, 0, (long)c.Hout * c.Wout);
+      q.f8 = 2; q.w8 = m->wd8_all + c.wd_off; q.qscale = m->f8_scales + 4L * c.idx + 2; q.deq = m->f8_scales + 4L * c.idx + 3;
+      dy_q8 = ys_conv_wants_x8(q);
+    }
+    if (dy_q8) {
+      YS_TRY(ys_bn_bwd_apply_q8_launch(st, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), chan_ptr(m, c, 4),
+                                       chan_ptr(m, c, 5), c.act ? 1 : 0, dyb, m->q8, m->f8_scales + 4L * c.idx + 2,
+                                       m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS));
+    } else {
+      YS_TRY(ys_bn_bwd_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
+                                    chan_ptr(m, c, 4), chan_ptr(m, c, 5), c.act ? 1 : 0, dyb));
+    }
     dy = dyb; dy_ldc = c.cout; dy_coff = 0;
   } else {
     // plain Conv2d with bias (head outputs): dy is the loss gradient itself
@@ -1108,21 +1170,14 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
   if (!c.first) {
     const int mode = grad_mode(m, c.in);
     if (mode < 0) { ys_set_error("backward: inconsistent gradient slice state at %s", c.name.c_str()); return YS_ERR_STATE; }
-    ConvArgs a{};
-    a.x = dy; a.w = (char*)m->wd_all + (size_t)c.wd_off * m->es;
-    a.y = ib.grad;
-    a.B = B; a.Hin = c.Hout; a.Win = c.Wout; a.Cin = c.cout_ld; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cin; a.KH = a.KW = c.k;
-    a.SA = 1; a.DIVS = c.s == 2 ? 1 : 0; a.DIVM = c.s - 1; a.PAD = c.k - 1 - c.k / 2;
-    a.in_ldc = dy_ldc; a.in_coff = dy_coff; a.in_bstride = dy_bstride;
-    a.out_ldc = ib.ldc; a.out_coff = c.in.coff; a.out_bstride = ib.rows_per_b;
-    a.vec_ok = (ib.ldc % 4 == 0 && c.in.coff % 4 == 0) ? 1 : 0;
+    ConvArgs a = dgrad_args(m, c, B, dy, dy_ldc, dy_coff, dy_bstride);
     a.accumulate = mode;
-    a.M = B * c.Hin * c.Win;
     if (m->f8 && c.f8_bwd) {
       unsigned* slots = m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS;
       if (m->f8_sg_valid) {   // dgrad with the gradient quantised to e5m2 and the e4m3 dgrad weights; records amax(|dy|) itself
         a.f8 = 2; a.w8 = m->wd8_all + c.wd_off; a.qscale = m->f8_scales + 4L * c.idx + 2; a.deq = m->f8_scales + 4L * c.idx + 3; a.amax = slots;
         a.q8 = m->q8;
+        if (dy_q8) { a.x8 = m->q8; a.amax = nullptr; }     // image and maximum already produced by the BN backward pass
       } else {
         YS_TRY(ys_f8_view_amax_launch(st, dy, M, c.cout, dy_ldc, dy_coff, slots));
       }

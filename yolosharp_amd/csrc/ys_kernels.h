@@ -60,6 +60,16 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
 int ys_f8_quant_view_launch(hipStream_t st, int fmt, const void* x, long rows, int C, int ldc, int coff, const float* qscale,
                             void* out, unsigned* slots);
 int ys_conv_gemm_rows(const ConvArgs& a);
+// true when an fp8 request (a.f8 set, a.x8 not yet) would run conv_gemm_kernel<F8> -- on the layer itself or on a phase of its
+// stride-2 dgrad -- if the dense fp8 image of the input were supplied in a.x8: the caller may then produce that image in the pass
+// that writes the bf16 tensor (ys_bn_bwd_apply_q8_launch) instead of leaving it to ys_conv_launch's quantisation pass
+bool ys_conv_wants_x8(const ConvArgs& a);
+int ys_bn_act_apply_q8_launch(hipStream_t st, const void* y, long rows, int C, const float* scale, const float* shift, int act,
+                              const void* res, int res_ldc, int res_coff, void* z, int z_ldc, int z_coff, void* q8,
+                              const float* qscale, unsigned* amax);
+int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C,
+                              const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
+                              void* q8, const float* qscale, unsigned* amax);
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
