@@ -40,6 +40,17 @@ void ys_kprof_end(hipStream_t st, const char* name) {
   e.open = nullptr;
 }
 
+// device scratch of the host-pointer convenience paths: freed on every exit path (an early return on a later allocation or copy
+// used to leak the earlier ones)
+namespace {
+struct ScratchBuf {
+  void* p = nullptr;
+  ~ScratchBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+  template <class U> U* as() const { return (U*)p; }
+};
+}  // namespace
+
 extern "C" {
 
 int ys_ctx_kernel_profile(ys_ctx* ctx, int enable) {
@@ -198,11 +209,12 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
   const size_t n_pred = (size_t)B * C * A, n_rows = (size_t)B * max_det * (6 + extra), n_keep = (size_t)B * max_det;
   YsTimer timer(ctx, "nms");
   if (on_device) return ys_nms_launch(ctx, pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, out_rows, out_keep, out_count);
-  float* d_pred = nullptr; float* d_rows = nullptr; int64_t* d_keep = nullptr; int32_t* d_cnt = nullptr;
-  YS_CHECK_HIP(hipMalloc(&d_pred, n_pred * 4));
-  YS_CHECK_HIP(hipMalloc(&d_rows, n_rows * 4));
-  YS_CHECK_HIP(hipMalloc(&d_keep, n_keep * 8));
-  YS_CHECK_HIP(hipMalloc(&d_cnt, (size_t)B * 4));
+  ScratchBuf b_pred, b_rows, b_keep, b_cnt;
+  YS_CHECK_HIP(b_pred.alloc(n_pred * 4));
+  YS_CHECK_HIP(b_rows.alloc(n_rows * 4));
+  YS_CHECK_HIP(b_keep.alloc(n_keep * 8));
+  YS_CHECK_HIP(b_cnt.alloc((size_t)B * 4));
+  float* d_pred = b_pred.as<float>(); float* d_rows = b_rows.as<float>(); int64_t* d_keep = b_keep.as<int64_t>(); int32_t* d_cnt = b_cnt.as<int32_t>();
   YS_CHECK_HIP(hipMemcpyAsync(d_pred, pred, n_pred * 4, hipMemcpyHostToDevice, ctx->stream));
   int st = ys_nms_launch(ctx, d_pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, d_rows, d_keep, d_cnt);
   if (st == YS_OK) {
@@ -212,7 +224,6 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
     hipMemcpyAsync(out_count, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream);
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_pred); hipFree(d_rows); hipFree(d_keep); hipFree(d_cnt);
   if (st != YS_OK) return st;
   if (e != hipSuccess) { ys_set_error("ys_nms_batched: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
   return YS_OK;
@@ -263,18 +274,18 @@ int ys_process_mask(ys_ctx* ctx, const float* protos, const float* masks_in, con
   YsTimer timer(ctx, "process_mask");
   if (on_device) return ys_process_mask_launch(ctx->stream, protos, masks_in, boxes, n, nm, mh, mw, ih, iw, upsample, crop_mode, out);
   const size_t np = (size_t)nm * mh * mw, no = (size_t)n * (upsample ? (size_t)ih * iw : (size_t)mh * mw);
-  float *d_p = nullptr, *d_m = nullptr, *d_b = nullptr; unsigned char* d_o = nullptr;
-  YS_CHECK_HIP(hipMalloc(&d_p, np * 4));
-  YS_CHECK_HIP(hipMalloc(&d_m, (size_t)n * nm * 4));
-  YS_CHECK_HIP(hipMalloc(&d_b, (size_t)n * 16));
-  YS_CHECK_HIP(hipMalloc(&d_o, no));
+  ScratchBuf b_p, b_m, b_b, b_o;
+  YS_CHECK_HIP(b_p.alloc(np * 4));
+  YS_CHECK_HIP(b_m.alloc((size_t)n * nm * 4));
+  YS_CHECK_HIP(b_b.alloc((size_t)n * 16));
+  YS_CHECK_HIP(b_o.alloc(no));
+  float *d_p = b_p.as<float>(), *d_m = b_m.as<float>(), *d_b = b_b.as<float>(); unsigned char* d_o = b_o.as<unsigned char>();
   hipMemcpyAsync(d_p, protos, np * 4, hipMemcpyHostToDevice, ctx->stream);
   hipMemcpyAsync(d_m, masks_in, (size_t)n * nm * 4, hipMemcpyHostToDevice, ctx->stream);
   hipMemcpyAsync(d_b, boxes, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
   int st = ys_process_mask_launch(ctx->stream, d_p, d_m, d_b, n, nm, mh, mw, ih, iw, upsample, crop_mode, d_o);
   if (st == YS_OK) hipMemcpyAsync(out, d_o, no, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_p); hipFree(d_m); hipFree(d_b); hipFree(d_o);
   if (st != YS_OK) return st;
   if (e != hipSuccess) { ys_set_error("ys_process_mask: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
   return YS_OK;

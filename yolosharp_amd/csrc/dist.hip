@@ -81,12 +81,23 @@ int ys_dist_init(ys_ctx* ctx, int rank, int world, const void* id128) {
   YS_CHECK_HIP(hipSetDevice(ctx->device));
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
+  // the context is touched only when every resource exists: a failure half way destroys what was created and leaves it unchanged
   ncclComm_t comm = nullptr;
   YS_CHECK_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  hipStream_t cs = nullptr; hipEvent_t e_ready = nullptr, e_done = nullptr;
+  hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&e_ready, hipEventDisableTiming);
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&e_done, hipEventDisableTiming);
+  if (he != hipSuccess) {
+    if (e_done) hipEventDestroy(e_done);
+    if (e_ready) hipEventDestroy(e_ready);
+    if (cs) hipStreamDestroy(cs);
+    g_rccl.CommDestroy(comm);
+    ys_set_error("ys_dist_init: %s", hipGetErrorString(he));
+    return YS_ERR_HIP;
+  }
   ctx->dist_comm = comm; ctx->dist_rank = rank; ctx->dist_world = world;
-  YS_CHECK_HIP(hipStreamCreateWithFlags(&ctx->dist_stream, hipStreamNonBlocking));
-  YS_CHECK_HIP(hipEventCreateWithFlags(&ctx->dist_ready, hipEventDisableTiming));
-  YS_CHECK_HIP(hipEventCreateWithFlags(&ctx->dist_done, hipEventDisableTiming));
+  ctx->dist_stream = cs; ctx->dist_ready = e_ready; ctx->dist_done = e_done;
   return YS_OK;
 #endif
 }
