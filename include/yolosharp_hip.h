@@ -196,6 +196,20 @@ YS_API int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int batch, in
                           float conf_thres, float iou_thres, int max_det, int nc, int max_nms, int max_wh,
                           float* out_rows, int64_t* out_keep, int32_t* out_count);
 
+/* Ops.non_max_suppression(rotated: true) (Utils/Ops.cs:286,349-353): oriented boxes.  pred [B, 4+nc+extra, A] with the angle
+ * (radians) as the LAST channel; boxes stay xywh (no in-place conversion); candidates are ordered by score and candidate j is
+ * dropped iff any earlier candidate i has Metrics.batch_probiou(i, j) >= iou_thres (Ops.nms_rotated, :373-401 -- not the greedy
+ * rule of ys_nms_batched).  Outputs as ys_nms_batched with rows (x, y, w, h, conf, cls, extra..., angle). */
+YS_API int ys_nms_rotated_batched(ys_ctx* ctx, float* pred, int on_device, int batch, int channels, int anchors,
+                                  float conf_thres, float iou_thres, int max_det, int nc, int max_nms, int max_wh,
+                                  float* out_rows, int64_t* out_keep, int32_t* out_count);
+
+/* Metrics.probiou (Utils/Metrics.cs:137-177): probabilistic IoU of n pairs of oriented boxes xywhr [n,5] -> out [n]; ciou != 0 adds
+ * the aspect-ratio term of the reference's CIoU option.  Metrics.batch_probiou (:223-258): all pairs, out [n, m].  eps: the
+ * reference's 1e-7.  `on_device` applies to all pointers. */
+YS_API int ys_probiou(ys_ctx* ctx, const float* obb1, const float* obb2, int on_device, int n, int ciou, float eps, float* out);
+YS_API int ys_batch_probiou(ys_ctx* ctx, const float* obb1, int n, const float* obb2, int m, int on_device, float eps, float* out);
+
 /* Validation, per-image part of Detector.Val (Models/Detector.cs:103-120), batched on the device:
  * GT boxes = bboxes[batch_idx == b] * (W,H,W,H) -> xyxy (Utils/Ops.cs:68-81); iou = Metrics.box_iou(gt, pred[:,0:4])
  * (Utils/Metrics.cs:16-34); correct = match_predictions(pred[:,5], cls, iou) (Models/YoloBaseTaskModel.cs:377-446) for the

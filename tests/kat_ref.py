@@ -219,3 +219,20 @@ def bn_train_stats(y, gamma, beta, run_mean, run_var, eps=1e-3, momentum=0.03):
         nm.append((1 - momentum) * run_mean[c] + momentum * mu)
         nv.append((1 - momentum) * run_var[c] + momentum * var * N / (N - 1))
     return z, nm, nv
+
+
+def probiou(o1, o2, eps=1e-7):
+    """Metrics.cs:223-258 (one pair of xywhr boxes), scalar fp64: Bhattacharyya distance of the two Gaussians N(xy, cov(w, h, r)),
+    cov = R diag(w^2 / 12, h^2 / 12) R^T  ->  a = sxx, b = syy, c = sxy."""
+    def cov(o):
+        a, b = o[2] * o[2] / 12.0, o[3] * o[3] / 12.0
+        cs, sn = math.cos(o[4]), math.sin(o[4])
+        return a * cs * cs + b * sn * sn, a * sn * sn + b * cs * cs, (a - b) * cs * sn
+    a1, b1, c1 = cov(o1)
+    a2, b2, c2 = cov(o2)
+    det = (a1 + a2) * (b1 + b2) - (c1 + c2) ** 2
+    t1 = ((a1 + a2) * (o1[1] - o2[1]) ** 2 + (b1 + b2) * (o1[0] - o2[0]) ** 2) / (det + eps) * 0.25
+    t2 = ((c1 + c2) * (o2[0] - o1[0]) * (o1[1] - o2[1])) / (det + eps) * 0.5
+    t3 = math.log(det / (4.0 * math.sqrt(max(a1 * b1 - c1 * c1, 0.0) * max(a2 * b2 - c2 * c2, 0.0)) + eps) + eps) * 0.5
+    bd = min(max(t1 + t2 + t3, eps), 100.0)
+    return 1.0 - math.sqrt(1.0 - math.exp(-bd) + eps)

@@ -194,9 +194,9 @@ int ys_memcpy_d2h(ys_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return YS_OK;
 }
 
-int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A, float conf_thres,
-                   float iou_thres, int max_det, int nc, int max_nms, int max_wh, float* out_rows,
-                   int64_t* out_keep, int32_t* out_count) {
+static int nms_batched_impl(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A, float conf_thres,
+                            float iou_thres, int max_det, int nc, int max_nms, int max_wh, float* out_rows,
+                            int64_t* out_keep, int32_t* out_count, int rotated) {
   YS_REQUIRE(ctx && pred && out_rows && out_keep && out_count, "ys_nms_batched: null argument");
   // Ops.cs:248-255: ArgumentException for thresholds outside [0,1]
   YS_REQUIRE(conf_thres >= 0.f && conf_thres <= 1.f, "Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", conf_thres);
@@ -204,11 +204,12 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
   YS_REQUIRE(B > 0 && A > 0 && C > 4 && max_det > 0 && max_nms > 0, "ys_nms_batched: bad shape B=%d C=%d A=%d", B, C, A);
   if (nc == 0) nc = C - 4;  // Ops.cs:269
   YS_REQUIRE(nc > 0 && nc <= C - 4, "ys_nms_batched: nc=%d incompatible with C=%d", nc, C);
+  YS_REQUIRE(!rotated || C - 4 - nc >= 1, "ys_nms_rotated_batched: oriented boxes carry their angle as the last channel (C=%d, nc=%d)", C, nc);
   YS_CHECK_HIP(hipSetDevice(ctx->device));
   const int extra = C - 4 - nc;
   const size_t n_pred = (size_t)B * C * A, n_rows = (size_t)B * max_det * (6 + extra), n_keep = (size_t)B * max_det;
   YsTimer timer(ctx, "nms");
-  if (on_device) return ys_nms_launch(ctx, pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, out_rows, out_keep, out_count);
+  if (on_device) return ys_nms_launch(ctx, pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, out_rows, out_keep, out_count, rotated);
   ScratchBuf b_pred, b_rows, b_keep, b_cnt;
   YS_CHECK_HIP(b_pred.alloc(n_pred * 4));
   YS_CHECK_HIP(b_rows.alloc(n_rows * 4));
@@ -216,7 +217,7 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
   YS_CHECK_HIP(b_cnt.alloc((size_t)B * 4));
   float* d_pred = b_pred.as<float>(); float* d_rows = b_rows.as<float>(); int64_t* d_keep = b_keep.as<int64_t>(); int32_t* d_cnt = b_cnt.as<int32_t>();
   YS_CHECK_HIP(hipMemcpyAsync(d_pred, pred, n_pred * 4, hipMemcpyHostToDevice, ctx->stream));
-  int st = ys_nms_launch(ctx, d_pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, d_rows, d_keep, d_cnt);
+  int st = ys_nms_launch(ctx, d_pred, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, d_rows, d_keep, d_cnt, rotated);
   if (st == YS_OK) {
     hipMemcpyAsync(pred, d_pred, n_pred * 4, hipMemcpyDeviceToHost, ctx->stream);  // in-place xyxy visible to the caller
     hipMemcpyAsync(out_rows, d_rows, n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -227,6 +228,43 @@ int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A,
   if (st != YS_OK) return st;
   if (e != hipSuccess) { ys_set_error("ys_nms_batched: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
   return YS_OK;
+}
+
+int ys_nms_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A, float conf_thres,
+                   float iou_thres, int max_det, int nc, int max_nms, int max_wh, float* out_rows,
+                   int64_t* out_keep, int32_t* out_count) {
+  return nms_batched_impl(ctx, pred, on_device, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, out_rows, out_keep, out_count, 0);
+}
+
+// Ops.non_max_suppression(rotated: true) (Ops.cs:286,349-353) = Ops.nms_rotated (:373-401) on Metrics.batch_probiou
+int ys_nms_rotated_batched(ys_ctx* ctx, float* pred, int on_device, int B, int C, int A, float conf_thres,
+                           float iou_thres, int max_det, int nc, int max_nms, int max_wh, float* out_rows,
+                           int64_t* out_keep, int32_t* out_count) {
+  return nms_batched_impl(ctx, pred, on_device, B, C, A, conf_thres, iou_thres, max_det, nc, max_nms, max_wh, out_rows, out_keep, out_count, 1);
+}
+
+// Metrics.probiou (pairwise [n] with optional CIoU term, Metrics.cs:137-177) / Metrics.batch_probiou ([n, m], :223-258) on xywhr boxes
+static int probiou_impl(ys_ctx* ctx, const float* obb1, const float* obb2, int on_device, long n, long m, int pairwise, int ciou, float eps, float* out) {
+  YS_REQUIRE(ctx && obb1 && obb2 && out, "ys_probiou: null argument");
+  YS_REQUIRE(n >= 0 && m >= 0, "ys_probiou: bad shape");
+  const long total = pairwise ? n : n * m;
+  if (total == 0) return YS_OK;
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  if (on_device) return ys_probiou_launch(ctx->stream, obb1, obb2, n, m, pairwise, ciou, eps, out);
+  ScratchBuf b1, b2, bo;
+  YS_CHECK_HIP(b1.alloc((size_t)n * 20)); YS_CHECK_HIP(b2.alloc((size_t)m * 20)); YS_CHECK_HIP(bo.alloc((size_t)total * 4));
+  YS_CHECK_HIP(hipMemcpyAsync(b1.p, obb1, (size_t)n * 20, hipMemcpyHostToDevice, ctx->stream));
+  YS_CHECK_HIP(hipMemcpyAsync(b2.p, obb2, (size_t)m * 20, hipMemcpyHostToDevice, ctx->stream));
+  YS_TRY(ys_probiou_launch(ctx->stream, b1.as<float>(), b2.as<float>(), n, m, pairwise, ciou, eps, bo.as<float>()));
+  YS_CHECK_HIP(hipMemcpyAsync(out, bo.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  YS_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return YS_OK;
+}
+int ys_probiou(ys_ctx* ctx, const float* obb1, const float* obb2, int on_device, int n, int ciou, float eps, float* out) {
+  return probiou_impl(ctx, obb1, obb2, on_device, n, n, 1, ciou, eps, out);
+}
+int ys_batch_probiou(ys_ctx* ctx, const float* obb1, int n, const float* obb2, int m, int on_device, float eps, float* out) {
+  return probiou_impl(ctx, obb1, obb2, on_device, n, m, 0, 0, eps, out);
 }
 
 // Augment.LetterBox.LetterboxImage (Data/Augment.cs:757-778) and Augment.Rectangle.RectangleImage (:836-857) on the device:

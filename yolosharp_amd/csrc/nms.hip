@@ -31,7 +31,8 @@
 // wave instruction one contiguous 1 KB read, eight class channels in flight per trip), else one thread per anchor.  A pure
 // stream of B*C*A*4 bytes.  (Splitting the classes over adjacent lanes: 3x slower -- scattered 16-byte accesses; over the four
 // waves of a workgroup with an LDS merge: 83 vs 70 us on [64, 84, 8400] -- dropped.)
-template <int V>
+// ROT: oriented boxes (Ops.cs:286: `if (!rotated)` around the xywh -> xyxy conversion) -- the boxes stay xywh, the angle is the last channel
+template <int V, bool ROT>
 __global__ void __launch_bounds__(256)
 nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thres,
                   int* __restrict__ count, unsigned long long* __restrict__ keys, int keys_stride,
@@ -48,7 +49,7 @@ nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thr
     if (V == 4) { float4 q; q.x = o[0]; q.y = o[V > 1 ? 1 : 0]; q.z = o[V > 2 ? 2 : 0]; q.w = o[V > 3 ? 3 : 0]; *(float4*)(p + (size_t)ch * A + a0) = q; }
     else p[(size_t)ch * A + a0] = o[0];
   };
-  {
+  if (!ROT) {
     // xywh -> xyxy in place (Ops.cs:76-79): x - w/2, y - h/2, x + w/2, y + h/2
     float cx[V], cy[V], w[V], h[V], x1[V], y1[V], x2[V], y2[V];
     ld(0, cx); ld(1, cy); ld(2, w); ld(3, h);
@@ -115,7 +116,8 @@ nms_sort_kernel(const float* __restrict__ pred, int C, int A, int nc, int max_de
                 const int* __restrict__ count, unsigned long long* __restrict__ keys_g, int keys_stride,
                 const int* __restrict__ clss, float4* __restrict__ sbox, float* __restrict__ sarea, int* __restrict__ sidx,
                 unsigned char* __restrict__ supp_g, int ncap, int* __restrict__ n_sorted,
-                float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
+                float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count,
+                float4* __restrict__ scov) {
   __shared__ unsigned long long skeys[NMS_LDS_KEYS];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -152,6 +154,20 @@ nms_sort_kernel(const float* __restrict__ pred, int C, int A, int nc, int max_de
     const int a = (int)(k[i] & 0xffffffffull);
     const float off = (float)clss[(size_t)b * A + a] * max_wh;  // Ops.cs:345
     float4 q;
+    if (scov) {
+      // rotated (Ops.cs:351): boxes = (xy + c, wh, angle = last column); covariance terms of Metrics._get_covariance_matrix
+      // (Metrics.cs:264-283) once per box, as the reference computes them once per tensor
+      q.x = p[a] + off; q.y = p[(size_t)A + a] + off; q.z = p[2 * (size_t)A + a]; q.w = p[3 * (size_t)A + a];
+      const float r = p[(size_t)(C - 1) * A + a];
+      const float ga = q.z * q.z / 12.0f, gb = q.w * q.w / 12.0f;
+      const float cs = cosf(r), sn = sinf(r);
+      const float cos2 = cs * cs, sin2 = sn * sn;
+      float4 cv;
+      cv.x = ga * cos2 + gb * sin2; cv.y = ga * sin2 + gb * cos2; cv.z = (ga - gb) * cs * sn; cv.w = 0.f;
+      (scov + (size_t)b * ncap)[i] = cv;
+      bx[i] = q; ar[i] = 0.f; si[i] = a; supp[i] = 0;
+      continue;
+    }
     q.x = p[a] + off;                       // Ops.cs:356 boxes = x[:, :4] + c
     q.y = p[(size_t)A + a] + off;
     q.z = p[2 * (size_t)A + a] + off;
@@ -385,10 +401,141 @@ nms_greedy_big_kernel(const float* __restrict__ pred, int C, int A, int nc, floa
   if (tid == 0) out_count[b] = kept;
 }
 
+// ------------------------------------------------------------------ oriented boxes: probiou + nms_rotated
+// Metrics.batch_probiou (Metrics.cs:223-258), operation for operation in fp32: box 1 = (x1, y1, a1, b1, c1), box 2 likewise
+__device__ inline float nms_probiou(float x1, float y1, float a1, float b1, float c1, float x2, float y2, float a2, float b2, float c2, float eps) {
+  const float sa = a1 + a2, sb = b1 + b2, sc = c1 + c2;
+  const float dy = y1 - y2, dx = x1 - x2;
+  const float det = sa * sb - sc * sc;
+  const float t1 = ((sa * (dy * dy) + sb * (dx * dx)) / (det + eps)) * 0.25f;
+  const float t2 = ((sc * (x2 - x1) * dy) / (det + eps)) * 0.5f;
+  const float d1 = fmaxf(a1 * b1 - c1 * c1, 0.f), d2 = fmaxf(a2 * b2 - c2 * c2, 0.f);
+  const float t3 = logf(det / (4.0f * sqrtf(d1 * d2) + eps) + eps) * 0.5f;
+  float bd = t1 + t2 + t3;
+  bd = fminf(fmaxf(bd, eps), 100.0f);
+  const float hd = sqrtf(1.0f - expf(-bd) + eps);
+  return 1.0f - hd;
+}
+
+// Ops.nms_rotated (Ops.cs:373-401, use_triu): in score order, candidate j is dropped iff ANY earlier candidate i < j has
+// probiou(i, j) >= threshold -- not the greedy rule of torchvision.nms: a dropped box still drops others.  One thread per j,
+// the earlier boxes staged through LDS in tiles of 256; O(n^2 / 2) evaluations per image, any n up to max_nms.
+__global__ void __launch_bounds__(256)
+nms_rot_removed_kernel(const int* __restrict__ n_sorted, const float4* __restrict__ sbox, const float4* __restrict__ scov, int ncap,
+                       float iou_thres, unsigned char* __restrict__ supp_g) {
+  __shared__ float4 sB[256], sC[256];
+  const int b = blockIdx.y;
+  const int n = n_sorted[b];
+  if ((int)blockIdx.x * 256 >= n) return;
+  const float4* bx = sbox + (size_t)b * ncap;
+  const float4* cv = scov + (size_t)b * ncap;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  float4 bj = make_float4(0.f, 0.f, 0.f, 0.f), cj = bj;
+  if (j < n) { bj = bx[j]; cj = cv[j]; }
+  bool removed = false;
+  for (int t0 = 0; t0 <= (int)blockIdx.x * 256; t0 += 256) {
+    __syncthreads();
+    const int i0 = t0 + threadIdx.x;
+    sB[threadIdx.x] = i0 < n ? bx[i0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sC[threadIdx.x] = i0 < n ? cv[i0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (j < n && !removed) {
+      const int lim = (j - t0) < 256 ? (j - t0) : 256;                 // rows i = t0 .. t0 + lim - 1 < j
+      for (int t = 0; t < lim; t++) {
+        const float4 bi = sB[t], ci = sC[t];
+        if (nms_probiou(bi.x, bi.y, ci.x, ci.y, ci.z, bj.x, bj.y, cj.x, cj.y, cj.z, 1e-7f) >= iou_thres) { removed = true; break; }
+      }
+    }
+  }
+  if (j < n) supp_g[(size_t)b * ncap + j] = removed ? 1 : 0;
+}
+
+// kept candidates in score order, first max_det (Ops.cs:360), output rows / anchor indices / count: one workgroup per image
+__global__ void __launch_bounds__(NMS_THREADS)
+nms_rot_pick_kernel(const float* __restrict__ pred, int C, int A, int nc, int max_det, const int* __restrict__ n_sorted,
+                    const int* __restrict__ sidx, const unsigned char* __restrict__ supp_g, int ncap, const float* __restrict__ confs,
+                    const int* __restrict__ clss, float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
+  __shared__ int s_wcnt[NMS_THREADS / 64];
+  __shared__ int s_base;
+  YS_DYN_LDS(nms_pick_dyn);
+  int* s_kept = (int*)nms_pick_dyn;               // [max_det]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = n_sorted[b];
+  const int row_w = 6 + (C - 4 - nc);
+  const float* p = pred + (size_t)b * C * A;
+  const int* si = sidx + (size_t)b * ncap;
+  const unsigned char* supp = supp_g + (size_t)b * ncap;
+  float* orow = out_rows + (size_t)b * max_det * row_w;
+  long long* okeep = out_keep + (size_t)b * max_det;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += NMS_THREADS) {
+    const int i = c0 + tid;
+    const bool keep = i < n && supp[i] == 0;
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; w++) before += s_wcnt[w];
+    const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep && pos < max_det) s_kept[pos] = i;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < NMS_THREADS / 64; w++) t += s_wcnt[w]; s_base += t; }
+    __syncthreads();
+    if (s_base >= max_det) break;
+  }
+  const int kept = s_base < max_det ? s_base : max_det;
+  for (int idx = tid; idx < kept * row_w; idx += NMS_THREADS) {
+    const int k = idx / row_w, e = idx - k * row_w;
+    const int a = si[s_kept[k]];
+    float v;
+    if (e < 4) v = p[(size_t)e * A + a];
+    else if (e == 4) v = confs[(size_t)b * A + a];
+    else if (e == 5) v = (float)clss[(size_t)b * A + a];
+    else v = p[(size_t)(4 + nc + e - 6) * A + a];
+    orow[idx] = v;
+  }
+  for (int k = tid; k < kept; k += NMS_THREADS) okeep[k] = si[s_kept[k]];
+  if (tid == 0) out_count[b] = kept;
+}
+
+// Metrics.probiou (pairwise, Metrics.cs:137-177; CIoU adds only the aspect-ratio term) and Metrics.batch_probiou (N x M)
+__global__ void __launch_bounds__(256)
+probiou_kernel(const float* __restrict__ o1, const float* __restrict__ o2, long n, long m, int pairwise, int ciou, float eps, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = pairwise ? n : n * m;
+  if (idx >= total) return;
+  const long i = pairwise ? idx : idx / m, j = pairwise ? idx : idx - i * m;
+  const float* p1 = o1 + i * 5; const float* p2 = o2 + j * 5;
+  auto cov = [](const float* q, float& a, float& b, float& c) {
+    const float ga = q[2] * q[2] / 12.0f, gb = q[3] * q[3] / 12.0f;
+    const float cs = cosf(q[4]), sn = sinf(q[4]);
+    const float cos2 = cs * cs, sin2 = sn * sn;
+    a = ga * cos2 + gb * sin2; b = ga * sin2 + gb * cos2; c = (ga - gb) * cs * sn;
+  };
+  float a1, b1, c1, a2, b2, c2;
+  cov(p1, a1, b1, c1); cov(p2, a2, b2, c2);
+  float iou = nms_probiou(p1[0], p1[1], a1, b1, c1, p2[0], p2[1], a2, b2, c2, eps);
+  if (pairwise && ciou) {
+    const float d = atanf(p2[2] / p2[3]) - atanf(p1[2] / p1[3]);
+    const float v = 0.40528473456935109f * (d * d);                    // 4 / pi^2
+    const float alpha = v / (v - iou + (1.0f + eps));
+    iou = iou - v * alpha;
+  }
+  out[idx] = iou;
+}
+
+int ys_probiou_launch(hipStream_t st, const float* o1, const float* o2, long n, long m, int pairwise, int ciou, float eps, float* out) {
+  const long total = pairwise ? n : n * m;
+  if (total <= 0) return YS_OK;
+  YS_LAUNCH(probiou_kernel, ys_cdiv(total, 256), 256, st, o1, o2, n, m, pairwise, ciou, eps, out);
+  return YS_OK;
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, float iou, int max_det,
-                  int nc, int max_nms, int max_wh, float* out_rows, int64_t* out_keep, int32_t* out_count) {
+                  int nc, int max_nms, int max_wh, float* out_rows, int64_t* out_keep, int32_t* out_count, int rotated) {
   int np2 = 1;
   while (np2 < A) np2 <<= 1;
   const int ncap = A < max_nms ? A : max_nms;
@@ -405,6 +552,7 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   const size_t o_nsort = off; off = align_up(off + sizeof(int) * B, 256);
   const bool big_possible = ncap > NMS_MASK_MAX;
   const size_t o_mask = off;  off = align_up(off + sizeof(unsigned long long) * (size_t)B * NMS_MASK_MAX * NMS_MASK_WORDS, 256);
+  const size_t o_cov = off;   if (rotated) off = align_up(off + sizeof(float4) * (size_t)B * ncap, 256);
   if (off > ctx->nms_ws_bytes) {
     if (ctx->nms_ws) { YS_CHECK_HIP(hipStreamSynchronize(ctx->stream)); YS_CHECK_HIP(hipFree(ctx->nms_ws)); ctx->nms_ws = nullptr; ctx->nms_ws_bytes = 0; }
     YS_CHECK_HIP(hipMalloc(&ctx->nms_ws, off));
@@ -422,17 +570,27 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   float4* sbox = (float4*)(ws + o_box); float* sarea = (float*)(ws + o_area); int* sidx = (int*)(ws + o_idx);
   unsigned char* supp = (unsigned char*)(ws + o_supp); int* nsort = (int*)(ws + o_nsort);
   unsigned long long* mask = (unsigned long long*)(ws + o_mask);
+  float4* scov = rotated ? (float4*)(ws + o_cov) : nullptr;
   if (A % 4 == 0) {
     dim3 g1(ys_cdiv(A / 4, 64), B);
-    YS_LAUNCH(nms_filter_kernel<4>, g1, 64, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
+    if (rotated) YS_LAUNCH((nms_filter_kernel<4, true>), g1, 64, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
+    else YS_LAUNCH((nms_filter_kernel<4, false>), g1, 64, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
   } else {
     dim3 g1(ys_cdiv(A, 256), B);
-    YS_LAUNCH(nms_filter_kernel<1>, g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
+    if (rotated) YS_LAUNCH((nms_filter_kernel<1, true>), g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
+    else YS_LAUNCH((nms_filter_kernel<1, false>), g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
   }
   NMS_DBG("filter");
   YS_LAUNCH(nms_sort_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, max_det, max_nms, (float)max_wh, (const int*)count,
-            keys, np2, (const int*)clss, sbox, sarea, sidx, supp, ncap, nsort, out_rows, (long long*)out_keep, (int*)out_count);
+            keys, np2, (const int*)clss, sbox, sarea, sidx, supp, ncap, nsort, out_rows, (long long*)out_keep, (int*)out_count, scov);
   NMS_DBG("sort");
+  if (rotated) {
+    YS_LAUNCH(nms_rot_removed_kernel, dim3(ys_cdiv(ncap, 256), B), 256, ctx->stream, (const int*)nsort, (const float4*)sbox, (const float4*)scov, ncap, iou, supp);
+    YS_LAUNCH_LDS(nms_rot_pick_kernel, B, NMS_THREADS, (size_t)max_det * sizeof(int), ctx->stream, (const float*)pred, C, A, nc, max_det, (const int*)nsort,
+                  (const int*)sidx, (const unsigned char*)supp, ncap, (const float*)confs, (const int*)clss, out_rows, (long long*)out_keep, (int*)out_count);
+    YS_CHECK_HIP(hipGetLastError());
+    return YS_OK;
+  }
   YS_LAUNCH(nms_mask_kernel, dim3(B, NMS_MASK_WGS), 256, ctx->stream, (const int*)nsort, (const float4*)sbox, (const float*)sarea, ncap, iou, mask);
   NMS_DBG("mask");
   static_assert(NMS_LDS_N_FWD == NMS_LDS_N, "mask / scan kernels disagree on the LDS-resident size");

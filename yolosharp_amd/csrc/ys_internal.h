@@ -79,4 +79,5 @@ struct YsKprofScope {
 
 // ---- kernels' host launchers (defined in the .hip files) ----
 int ys_nms_launch(ys_ctx* ctx, float* pred_dev, int B, int C, int A, float conf, float iou, int max_det,
-                  int nc, int max_nms, int max_wh, float* out_rows, int64_t* out_keep, int32_t* out_count);
+                  int nc, int max_nms, int max_wh, float* out_rows, int64_t* out_keep, int32_t* out_count, int rotated = 0);
+int ys_probiou_launch(hipStream_t st, const float* o1, const float* o2, long n, long m, int pairwise, int ciou, float eps, float* out);

@@ -178,9 +178,11 @@ class Engine:
         """prediction: float32 ndarray [B, 4+nc+extra, A] (xywh, probabilities).  Returns (output, keepi):
         lists of [n_i, 6+extra] float32 rows (x1,y1,x2,y2,conf,cls,extra) and [n_i] int64 anchor indices.
         Like the reference, `prediction[:, 0:4]` is converted to xyxy in place when in_place=True, the
-        `agnostic` flag is accepted but ignored (Ops.cs:345), and invalid thresholds raise (YsError status 1)."""
-        if rotated or end2end:
-            raise NotImplementedError("rotated / end2end NMS are outside the hot path (SURVEY.md 8a)")
+        `agnostic` flag is accepted but ignored (Ops.cs:345), and invalid thresholds raise (YsError status 1).
+        rotated=True (Ops.cs:286,349-353): oriented boxes, angle = last channel, boxes stay xywh, Ops.nms_rotated's
+        "any earlier box overlaps" rule on Metrics.batch_probiou."""
+        if end2end:
+            raise NotImplementedError("end2end NMS is outside the hot path (SURVEY.md 8a)")
         pred = prediction if in_place else prediction.copy()
         if pred.dtype != np.float32 or not pred.flags["C_CONTIGUOUS"]:
             raise TypeError("prediction must be a C-contiguous float32 array [B, C, A]")
@@ -190,11 +192,27 @@ class Engine:
         rows = np.zeros((B, max_det, 6 + extra), np.float32)
         keep = np.zeros((B, max_det), np.int64)
         cnt = np.zeros((B,), np.int32)
-        _lib.check(self.lib, self.lib.ys_nms_batched(self.ctx, _ptr(pred), 0, B, Cc, A, conf_thres, iou_thres, max_det,
-                                                     int(nc), max_nms, max_wh, _ptr(rows), _ptr(keep), _ptr(cnt)))
+        fn = self.lib.ys_nms_rotated_batched if rotated else self.lib.ys_nms_batched
+        _lib.check(self.lib, fn(self.ctx, _ptr(pred), 0, B, Cc, A, conf_thres, iou_thres, max_det,
+                                int(nc), max_nms, max_wh, _ptr(rows), _ptr(keep), _ptr(cnt)))
         output = [rows[b, :cnt[b]].copy() for b in range(B)]
         keepi = [keep[b, :cnt[b]].copy() for b in range(B)]
         return output, keepi
+
+    # ---- Metrics.probiou / batch_probiou (Metrics.cs:137-177, 223-258): oriented boxes xywhr
+    def probiou(self, obb1, obb2, CIoU=False, eps=1e-7):
+        o1 = np.ascontiguousarray(obb1, np.float32).reshape(-1, 5); o2 = np.ascontiguousarray(obb2, np.float32).reshape(-1, 5)
+        if o1.shape != o2.shape:
+            raise ValueError("probiou: obb1 and obb2 must have the same shape [N, 5]")
+        out = np.zeros((o1.shape[0],), np.float32)
+        _lib.check(self.lib, self.lib.ys_probiou(self.ctx, _ptr(o1), _ptr(o2), 0, o1.shape[0], int(bool(CIoU)), eps, _ptr(out)))
+        return out
+
+    def batch_probiou(self, obb1, obb2, eps=1e-7):
+        o1 = np.ascontiguousarray(obb1, np.float32).reshape(-1, 5); o2 = np.ascontiguousarray(obb2, np.float32).reshape(-1, 5)
+        out = np.zeros((o1.shape[0], o2.shape[0]), np.float32)
+        _lib.check(self.lib, self.lib.ys_batch_probiou(self.ctx, _ptr(o1), o1.shape[0], _ptr(o2), o2.shape[0], 0, eps, _ptr(out)))
+        return out
 
     def nms_device(self, pred_dev, B, Cc, A, conf_thres, iou_thres, max_det, nc, rows_dev, keep_dev, cnt_dev,
                    max_nms=30000, max_wh=7680):
