@@ -12,8 +12,8 @@
 //    64-multiples of v11m, 256x80 / 256x64 for the narrow outputs), 4 waves, each wave MR x NR MFMA 16x16x32 tiles: 20 MFMAs per
 //    9 fragment reads (460 B of LDS per MFMA -- conv_p2_kernel's wide-layer tiles read 1.2 KB per MFMA);
 //  * K in tiles of 64 (one 128-byte line per tile row): both operands go global -> LDS by LDS DMA (global_load_lds_dwordx4),
-//    16 bytes per lane and no VGPRs in between; every lane computes its own source address, which is where the implicit-GEMM
-//    gather (tap offset, zero padding -> a zero line) and the bank swizzle live.  Two LDS stages: the DMA of tile k+1 is in flight
+//    16 bytes per lane and no VGPRs in between; every lane computes its own source offset into a buffer descriptor, which is where the
+//    implicit-GEMM gather (tap offset; zero padding = an out-of-range offset, the hardware returns zeros) and the bank swizzle live.  Two LDS stages: the DMA of tile k+1 is in flight
 //    while tile k is multiplied, one barrier per K-tile;
 //  * LDS rows are 128 B, so a fragment read (16 rows x 16 B per lane quarter) would hit 2 of 16 bank groups; unit u of row r is
 //    stored at slot u ^ ((r >> 1) & 7) -- applied to the SOURCE address of the DMA and to the ds_read address alike -> conflict-free;
@@ -25,11 +25,8 @@
 #include <atomic>
 #include <cstdlib>
 
-// 128 B of zeros: the DMA source of every 16-byte unit that is padding (outside the image, past K, past Cout)
-__device__ uint4 ys_gemm_zero_line[8];
-
 // ablation switches for performance triage (YS_GEMM_DBG bits; compiled in only with -DYS_GEMM_ABLATE = `build.py ablate`):
-// 1 = A operand from the zero line, 2 = B operand from the zero line (no L2 traffic), 4 = no MFMAs, 8 = no epilogue
+// 1 = A operand requests out of range, 2 = B operand requests out of range (zeros, no L2 traffic), 4 = no MFMAs, 8 = no epilogue
 #ifdef YS_GEMM_ABLATE
 #define GEMM_DBG(bit) ((a.dbg & (bit)) != 0)
 #else
@@ -43,6 +40,7 @@ struct GemmArgs {
   int off_stage;    // LDS byte offset of the two operand stages (the tap table sits at 0)
   int stage_bytes;  // (BM + BN) * 128
   int HoWo;
+  unsigned abytes;  // bytes of the input view from its first channel to the end of the last image (descriptor range, < 2^31)
 };
 
 // F8 = 1 (e4m3 input) / 2 (e5m2 input: a gradient): both operands are fp8 in memory (the input as the dense image ys_conv_launch quantises into a.q8 with the tensor's
@@ -75,7 +73,6 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   const int n0 = blockIdx.y * BN;
   const char* xb = (const char*)(F8 ? a.x8 : a.x);
   const char* wb = (const char*)(F8 ? a.w8 : a.w);
-  const char* zsrc = (const char*)ys_gemm_zero_line + (lane & 7) * 16;
   const int cu = a.Cin / EPU;
   const int ldu = F8 ? cu : (a.in_ldc >> 3), cofu = F8 ? 0 : (a.in_coff >> 3);     // the fp8 image is dense: [pixel][Cin]
   const long bstride = F8 ? (long)a.Hin * a.Win : a.in_bstride;
@@ -86,7 +83,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     if (e < g.kunits) {
       const int tap = e / cu, c8 = e - tap * cu;
       const int kh = tap / a.KW, kw = tap - kh * a.KW;
-      t.x = (kh * a.Win + kw) * ldu + c8;
+      t.x = ((kh * a.Win + kw) * ldu + c8) * 16;       // byte offset from the tap-(0,0) pixel
       t.y = (kh << 8) | kw;
     } else { t.x = 0; t.y = -1; }
     sTab[e] = t;
@@ -97,13 +94,19 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   // same for all of this thread's pieces since 8 * 4j / 2 is a multiple of 8.
   const int rsub = lane >> 3;
   const int kunit = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-  int boff[NB];                               // byte offset of this thread's weight rows (weight sets < 2 GB); -1 = no such row
+  // Requests go through buffer descriptors (ys_bufld_lds16): the weight rows need no per-lane work at all -- a lane's offset
+  // (row n, unit kunit) never changes, the K-tile is the scalar offset, rows past Cout and the overrun of the last row are out of
+  // range = zeros; an activation unit is one 32-bit add of the tap offset, padding = the out-of-range offset.  (With 64-bit
+  // per-lane addresses and a zero line a request cost ~14 VALU instructions, ~100 cycles of the wave's time.)
+  const ys_rsrc_t rsB = ys_make_rsrc(wb, (unsigned)((long)a.Cout * Kbytes));
+  const ys_rsrc_t rsA = ys_make_rsrc(xb + ((long)cofu << 4), g.abytes);
+  unsigned boff[NB];
 #pragma unroll
   for (int j = 0; j < NB; j++) {
     const int n = n0 + 8 * (wave + 4 * j) + rsub;
-    boff[j] = (wave + 4 * j < NBP && n < a.Cout) ? (int)((long)n * Kbytes) : -1;
+    boff[j] = (wave + 4 * j < NBP && n < a.Cout && !GEMM_DBG(2)) ? (unsigned)((long)n * Kbytes) + (unsigned)kunit * 16u : YS_BUF_OOB;
   }
-  int abase[NA];                              // 16-byte unit offsets (tensors < 32 GB)
+  int abase[NA];                              // byte offset of the row's tap-(0,0) pixel from the descriptor base (views < 2 GB)
   int aiy[NA], aix[NA];
 
   auto issue = [&](int st, int kt) {
@@ -114,17 +117,11 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NA; j++) {
       const bool ok = (bool)((int)(te.y >= 0) & (int)((unsigned)(aiy[j] + kh) < (unsigned)a.Hin) & (int)((unsigned)(aix[j] + kw) < (unsigned)a.Win) & (int)!GEMM_DBG(1));
-      const char* src = ok ? xb + ((long)(abase[j] + te.x) << 4) : zsrc;
-      ys_glds16(src, sb + (wave + 4 * j) * 1024);
+      ys_bufld_lds16(rsA, ok ? (unsigned)(abase[j] + te.x) : YS_BUF_OOB, 0u, sb + (wave + 4 * j) * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < NB; j++) {
-      if (wave + 4 * j < NBP) {
-        const bool ok = (bool)((int)(boff[j] >= 0) & (int)(ku < g.kunits) & (int)!GEMM_DBG(2));
-        const char* src = ok ? wb + ((long)boff[j] + ((long)ku << 4)) : zsrc;
-        ys_glds16(src, sb + BM * 128 + (wave + 4 * j) * 1024);
-      }
-    }
+    for (int j = 0; j < NB; j++)
+      if (wave + 4 * j < NBP) ys_bufld_lds16(rsB, boff[j], (unsigned)kt * 128u, sb + BM * 128 + (wave + 4 * j) * 1024);
   };
 
   // fragment read offsets: row (16-row fragment base + li); bf16: unit (ks * 4 + q) ^ (li >> 1) of K-step ks; fp8: the lane's 32
@@ -153,7 +150,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
         const int b = m / g.HoWo, rem = m - b * g.HoWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         aiy[j] = oy * a.SA - a.PAD; aix[j] = ox * a.SA - a.PAD;
-        abase[j] = (int)(((long)b * bstride + (long)aiy[j] * a.Win + aix[j]) * ldu + cofu);
+        abase[j] = (int)((((long)b * bstride + (long)aiy[j] * a.Win + aix[j]) * ldu) << 4);
       } else { aiy[j] = -(1 << 20); aix[j] = 0; abase[j] = 0; }
     }
     ys_barrier_lds();                         // the tap table is written; the previous tile's epilogue staging is consumed
@@ -275,6 +272,12 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   g.nkt = (int)((Ktot + (f8 ? 127 : 63)) / (f8 ? 128 : 64));
   g.mtiles = ys_cdiv(a.M, bm);
   g.HoWo = a.Hout * a.Wout;
+  {
+    const long pix = f8 ? (long)a.B * a.Hin * a.Win : ((long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win);
+    const long ab = f8 ? pix * a.Cin : (pix * a.in_ldc - a.in_coff) * 2L;
+    if (ab <= 0 || ab >= (1L << 31) || (long)a.Cout * Ktot * (f8 ? 1 : 2) >= (1L << 31)) return p;   // 32-bit request offsets
+    g.abytes = (unsigned)ab;
+  }
   const size_t tab = (size_t)g.nkt * 8 * sizeof(GemmTap);
   g.off_stage = (int)((tab + 1023) / 1024 * 1024);
   g.stage_bytes = (bm + bn) * 128;

@@ -499,4 +499,38 @@ __device__ inline void ys_glds16(const void* gsrc, void* lds_wave_base) {
 #endif
 }
 
+// LDS DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): source = descriptor base + voffset (per lane, 32 bit) +
+// soffset (scalar), destination as ys_glds16.  Measured on MI355X (tools/probe/probe_buflds.hip): a lane whose voffset + soffset
+// is >= the descriptor's byte count gets ZEROS in its LDS slot -- so padding is an out-of-range offset (YS_BUF_OOB), not a
+// 64-bit select against a zero line, and whatever is uniform across the wave moves from per-lane VALU into the scalar offset.
+#define YS_BUF_OOB 0x80000000u               // descriptors are built with < 2^31 bytes
+#ifdef YS_EMU_BUILD
+struct ys_rsrc_t { const char* base; unsigned bytes; };
+__device__ inline ys_rsrc_t ys_make_rsrc(const void* base, unsigned bytes) { ys_rsrc_t r; r.base = (const char*)base; r.bytes = bytes; return r; }
+__device__ inline void ys_bufld_lds16(const ys_rsrc_t& r, unsigned voff, unsigned soff, void* lds_wave_base) {
+  char* d = (char*)lds_wave_base + emu::lane() * 16;
+  if ((unsigned long long)voff + soff + 16ull > (unsigned long long)r.bytes) memset(d, 0, 16);
+  else memcpy(d, r.base + voff + soff, 16);
+}
+#else
+typedef int ys_rsrc_t __attribute__((ext_vector_type(4)));
+// base / bytes must be wave-uniform (kernel arguments and blockIdx-derived scalars): the descriptor lives in SGPRs
+__device__ inline ys_rsrc_t ys_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  ys_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((p >> 32) & 0xffffull));   // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ inline void ys_bufld_lds16(const ys_rsrc_t& r, unsigned voff, unsigned soff, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_wave_base);
+  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(r), "s"(so), "s"(dst) : "memory");
+}
+#endif
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
