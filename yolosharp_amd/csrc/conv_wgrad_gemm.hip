@@ -25,8 +25,6 @@
 #include <atomic>
 #include <cstdlib>
 
-__device__ uint4 ys_wgemm_zero_line[8];      // 128 B of zeros: DMA source of padded rows / channels
-
 struct WgGemmArgs {
   int gy;           // (cout tile, cin tile, tap) blocks
   int co_tiles, ci_tiles, taps;
@@ -34,6 +32,7 @@ struct WgGemmArgs {
   int per;          // K-tiles per pixel split
   int HoWo;
   float inv_howo, inv_wo;
+  unsigned dybytes, xbytes;   // bytes of the dy / x views from their first channel to the end of the last image (descriptor ranges)
 };
 
 // floor(n / d) for 0 <= n < 2^24 with a precomputed float reciprocal (one multiply + a +-1 fix-up instead of a 32-bit division)
@@ -85,9 +84,12 @@ conv_wgrad_gemm_kernel(WgradArgs a, WgGemmArgs g) {
   const bool ld_dy = KT == 64 || wave < 2, ld_x = KT == 64 || wave >= 2;
   const int rblk = KT == 64 ? wave : (wave & 1);       // 16-row block of this wave's rows
   const int sl = (tid & 3) ^ (((ldrow >> 2) & 1) << 1);   // source 16-byte unit inside a 64-byte chunk (halves swapped on rows 4-7 of 8)
-  const char* dyb = (const char*)a.dy;
-  const char* xb = (const char*)a.x;
-  const char* zsrc = (const char*)ys_wgemm_zero_line + (lane & 7) * 16;
+  // requests through buffer descriptors (ys_bufld_lds16): per K-tile a thread computes ONE 32-bit row offset per operand; the 64-byte
+  // chunks of the row are scalar offsets, a padded row (outside the image / past M) is the out-of-range offset -> zeros.  Channels
+  // past Cout / Cin of a ragged last tile read whatever follows in the row (finite activations) or zeros past the buffer end: those
+  // output rows / columns are never stored.
+  const ys_rsrc_t rsD = ys_make_rsrc((const char*)a.dy + ((long)a.dy_coff + co0) * 2L, g.dybytes > (unsigned)co0 * 2u ? g.dybytes - (unsigned)co0 * 2u : 0u);
+  const ys_rsrc_t rsX = ys_make_rsrc((const char*)a.x + ((long)a.in_coff + ci0) * 2L, g.xbytes > (unsigned)ci0 * 2u ? g.xbytes - (unsigned)ci0 * 2u : 0u);
 
   auto issue = [&](int st, int kt) {
     char* sb = lb + st * STAGE;
@@ -97,24 +99,16 @@ conv_wgrad_gemm_kernel(WgradArgs a, WgGemmArgs g) {
     const int b = ys_div24(mm, g.HoWo, g.inv_howo), rem = mm - b * g.HoWo;
     const int oy = ys_div24(rem, a.Wout, g.inv_wo), ox = rem - oy * a.Wout;
     if (ld_dy) {
-      const char* base = dyb + (((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc + a.dy_coff + co0) * 2L;
+      const unsigned vo = mok ? (unsigned)((((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc) * 2L) + (unsigned)sl * 16u : YS_BUF_OOB;
 #pragma unroll
-      for (int i = 0; i < CD; i++) {
-        const int u = i * 4 + sl;
-        const bool ok = (bool)((int)mok & (int)(co0 + u * 8 < a.Cout));
-        ys_glds16(ok ? base + u * 16 : zsrc, sb + (i * RW + rblk) * 1024);
-      }
+      for (int i = 0; i < CD; i++) ys_bufld_lds16(rsD, vo, (unsigned)i * 64u, sb + (i * RW + rblk) * 1024);
     }
     if (ld_x) {
       const int iy = oy * a.stride + kh - a.pad, ix = ox * a.stride + kw - a.pad;
       const bool pok = (bool)((int)mok & (int)((unsigned)iy < (unsigned)a.Hin) & (int)((unsigned)ix < (unsigned)a.Win));
-      const char* base = xb + (((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc + a.in_coff + ci0) * 2L;
+      const unsigned vo = pok ? (unsigned)((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) * 2L) + (unsigned)sl * 16u : YS_BUF_OOB;
 #pragma unroll
-      for (int i = 0; i < CX; i++) {
-        const int u = i * 4 + sl;
-        const bool ok = (bool)((int)pok & (int)(ci0 + u * 8 < a.Cin));
-        ys_glds16(ok ? base + u * 16 : zsrc, sb + DY_BYTES + (i * RW + rblk) * 1024);
-      }
+      for (int i = 0; i < CX; i++) ys_bufld_lds16(rsX, vo, (unsigned)i * 64u, sb + DY_BYTES + (i * RW + rblk) * 1024);
     }
   };
 
@@ -213,6 +207,12 @@ static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
   g.nkt = ys_cdiv(a.M, p.kt);
   g.HoWo = a.Hout * a.Wout;
   g.inv_howo = 1.0f / (float)g.HoWo; g.inv_wo = 1.0f / (float)a.Wout;
+  {
+    const long dpix = (long)(a.B - 1) * a.dy_bstride + (long)a.Hout * a.Wout, xpix = (long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win;
+    const long db = (dpix * a.dy_ldc - a.dy_coff) * 2L, xbts = (xpix * a.in_ldc - a.in_coff) * 2L;
+    if (db <= 0 || xbts <= 0 || db >= (1L << 31) || xbts >= (1L << 31)) return p;      // 32-bit request offsets
+    g.dybytes = (unsigned)db; g.xbytes = (unsigned)xbts;
+  }
   const int wpc = wpc_env ? wpc_env : 2;     // 256-register waves: two workgroups per CU
   long gx = (256L * wpc) / g.gy;
   if (gx < 1) gx = 1;

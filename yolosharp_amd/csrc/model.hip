@@ -811,6 +811,12 @@ int allocate(ys_model* m) {
     if (c.dw) continue;
     WgradArgs a{}; a.Cin = c.cin_pad; a.Cout = c.cout; a.KH = a.KW = c.k; a.M = (int)((long)B * c.Hout * c.Wout);
     a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout; a.stride = c.s; a.pad = c.k / 2;
+    {                                        // the view geometry the launch will see (the blocked-GEMM plan depends on it)
+      const Buf& ib = m->bufs[c.in.buf]; const Buf& ob = m->bufs[c.out.buf];
+      a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
+      if (c.bn) { a.dy_ldc = c.cout; a.dy_coff = 0; a.dy_bstride = (long)c.Hout * c.Wout; }
+      else { a.dy_ldc = ob.ldc; a.dy_coff = c.out.coff; a.dy_bstride = ob.rows_per_b; }
+    }
     if (c.ct) { a.Hout = c.Hin; a.Wout = c.Win; a.M = (int)((long)B * c.Hin * c.Win); a.dy_rh = 1; }
     wgp = std::max(wgp, (long)ys_wgrad_splits(a, m->dtype) * c.cout * c.k * c.k * c.cin_pad);
   }
