@@ -516,6 +516,7 @@ struct P2Args {
   int nsp;       // row length of the q-major offset table [4][nsp]: nsteps rounded up to 4, plus slack for the pipelined over-read
   int kg;        // K-steps per streamed weight group
   int off_w, off_p, off_stat;   // LDS byte offsets (offset table sits at 0)
+  unsigned xbytes;              // bytes of the input view from its first channel to the end of the last image (descriptor range, < 2^31)
 };
 
 // F8 = 1: fp8 mode.  Global activations stay bf16 (same HBM bytes); the patch is quantised to fp8 (e4m3, or e5m2 for a
@@ -642,13 +643,15 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     tyi += sty; if (tyi >= g.tiles_y) { tyi -= g.tiles_y; b++; }
     b += sb;
   };
-  // Every unit issues its load unconditionally -- units that are unused or fall into the zero padding read a harmless valid
-  // address and are zeroed from the returned bit mask when the patch is written to LDS.  Loads inside exec-masked branches make
-  // the compiler lose count of what is in flight and fall back to s_waitcnt vmcnt(0) BEFORE the MFMA loop, i.e. no overlap.
-  const long safe_off = (long)a.in_coff * 2L;
+  // Every unit issues its load unconditionally (loads inside exec-masked branches make the compiler lose count of what is in
+  // flight and fall back to s_waitcnt vmcnt(0) BEFORE the MFMA loop, i.e. no overlap).  The loads go through a buffer descriptor
+  // of the input view: a unit that is unused or falls into the zero padding gets the out-of-range offset and the hardware
+  // returns zeros -- one 32-bit add and one select per unit instead of a 64-bit address, a 64-bit select against a safe address
+  // and a second select when the patch is written to LDS.
+  const ys_rsrcv_t rsP = ys_make_rsrcv(xb + (long)a.in_coff * 2L, g.xbytes);
   auto pfetch = [&](int txi, int tyi, int b) -> unsigned {
     const int iy0 = tyi * g.TH * a.SA - a.PAD, ix0 = txi * g.TW * a.SA - a.PAD;
-    const long toff = (((long)b * a.in_bstride + (long)iy0 * a.Win + ix0) * a.in_ldc + a.in_coff) * 2L;
+    const int toff = (int)((((long)b * a.in_bstride + (long)iy0 * a.Win + ix0) * a.in_ldc) * 2L);   // may be negative for a tile on the border: only valid units use it
     unsigned okm = 0;
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
@@ -660,9 +663,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
       // branch-free validity (bitwise, not short-circuit): unit in use, row and column inside the image
       const unsigned iy = (unsigned)(iy0 + (int)(d >> 23)), ix = (unsigned)(ix0 + (int)((d >> 13) & 1023u));
       const bool ok = (bool)((int)(d != 0xffffffffu) & (int)(iy < (unsigned)a.Hin) & (int)(ix < (unsigned)a.Win) & (int)!P2_DBG(1));
-      long off = toff + (long)go * 2L;
-      off = ok ? off : safe_off;
-      rp[k] = ys_ld16(xb + off);
+      rp[k] = ys_bufld16(rsP, ok ? (unsigned)(toff + go * 2) : YS_BUF_OOB);
       okm |= (unsigned)ok << k;
     }
     return okm;
@@ -730,7 +731,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
           *(uint2*)(sPb + ((d & 8191u) << 3)) = v8;
         }
       } else {
-        if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = ((okm_next >> k) & 1u) ? rp[k] : ys_zero16();
+        if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = rp[k];     // padding units arrived as zeros
       }
     }
     if (!WRES) wstore(rwA, 0);
@@ -859,6 +860,12 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
   if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
   if (a.Cin % 8) return p;
+  long xbytes_l;
+  {
+    const long pix = (long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win;
+    xbytes_l = (pix * a.in_ldc - a.in_coff) * 2L;
+    if (xbytes_l <= 0 || xbytes_l >= (1L << 31)) return p;     // 32-bit descriptor offsets (larger views: the round-1 kernels)
+  }
   const bool f8 = a.f8 != 0;
   // fp8 pays where the K loop dominates (LDS / MFMA bound layers); the HBM-bound small-channel layers gain nothing from it and pay
   // the on-the-fly quantisation (measured: 32-channel layers 1.6x slower in fp8) -> they keep the bf16 kernel
@@ -869,6 +876,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   int nr = nfr <= 4 ? nfr : (nfr % 5 == 0 ? 5 : 4);
   const int cu = a.Cin / 8;
   P2Args g{};
+  g.xbytes = (unsigned)xbytes_l;
   g.ppb = f8 ? a.Cin + (((a.Cin / 16) & 1) ? 32 : 16) : a.Cin * 2 + ((cu & 1) ? 32 : 16);   // odd number of 16-byte slots per pixel
   const int taps = a.KH * a.KW;
   g.nsteps = f8 ? (taps * a.Cin + 127) / 128 : (taps * a.Cin + 31) / 32;

@@ -533,4 +533,26 @@ __device__ inline void ys_bufld_lds16(const ys_rsrc_t& r, unsigned voff, unsigne
 }
 #endif
 
+// 16-byte load through a buffer descriptor into registers: zeros for an out-of-range offset.  A compiler-visible load (builtin):
+// hipcc counts it in its vmcnt bookkeeping like a global load.  The descriptor type is the compiler's own.
+#ifdef YS_EMU_BUILD
+typedef ys_rsrc_t ys_rsrcv_t;
+__device__ inline ys_rsrcv_t ys_make_rsrcv(const void* base, unsigned bytes) { return ys_make_rsrc(base, bytes); }
+__device__ inline uint4 ys_bufld16(const ys_rsrcv_t& r, unsigned voff) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if ((unsigned long long)voff + 16ull <= (unsigned long long)r.bytes) memcpy(&v, r.base + voff, 16);
+  return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t ys_rsrcv_t;
+__device__ inline ys_rsrcv_t ys_make_rsrcv(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
+}
+__device__ inline uint4 ys_bufld16(const ys_rsrcv_t& r, unsigned voff) {
+  typedef unsigned ys_u32x4 __attribute__((ext_vector_type(4)));
+  const ys_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return make_uint4(q[0], q[1], q[2], q[3]);
+}
+#endif
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
