@@ -230,6 +230,10 @@ conv_wgrad_tr_kernel(WgradArgs a) {
 
   for (int i = tid; i < a.pdb / 4; i += NT) ((unsigned*)(sDb + (size_t)ZR * a.pdb))[i] = 0u;
 
+  // both operands through buffer descriptors: every unit's load is unconditional, padding / unused units carry the out-of-range
+  // offset and arrive as zeros (the exec-masked `if (valid) load` form made the compiler wait vmcnt(0) at the join)
+  const ys_rsrcv_t rsD = ys_make_rsrcv(dyb + (long)a.dy_coff * 2L, a.dybytes);
+  const ys_rsrcv_t rsX = ys_make_rsrcv(xb + (long)a.in_coff * 2L, a.xbytes);
   uint4 rd[ND], rx[NX];
   auto fetch = [&](int tile) {
     int t = tile;
@@ -240,30 +244,22 @@ conv_wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
     for (int k = 0; k < ND; k++) {
       const int idx = tid + NT * k;
-      uint4 v = ys_zero16();
-      if (idx < TP * DV) {
-        const int p = idx / DV, u = idx - p * DV;
-        const int oy = oy0 + (p >> a.TWS), ox = ox0 + (p & (TW - 1));
-        const int c = co0 + u * 8;
-        if (oy < a.Hout && ox < a.Wout && c < a.Cout)
-          v = ys_ld16(dyb + ((((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc) + a.dy_coff + c) * 2L);
-      }
-      rd[k] = v;
+      const int p = idx / DV, u = idx - p * DV;
+      const int oy = oy0 + (p >> a.TWS), ox = ox0 + (p & (TW - 1));
+      const int c = co0 + u * 8;
+      const bool ok = (bool)((int)(idx < TP * DV) & (int)(oy < a.Hout) & (int)(ox < a.Wout) & (int)(c < a.Cout));
+      rd[k] = ys_bufld16(rsD, ok ? (unsigned)(((((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc) + c) * 2L) : YS_BUF_OOB);
     }
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
 #pragma unroll
     for (int k = 0; k < NX; k++) {
       const int idx = tid + NT * k;
-      uint4 v = ys_zero16();
-      if (idx < npatch) {
-        const int pix = idx / XV, u = idx - pix * XV;
-        const int r = pix / a.PW, cc = pix - r * a.PW;
-        const int iy = iy0 + r, ix = ix0 + cc;
-        const int c = ci0 + u * 8;
-        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.Cin)
-          v = ys_ld16(xb + ((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) + a.in_coff + c) * 2L);
-      }
-      rx[k] = v;
+      const int pix = idx / XV, u = idx - pix * XV;
+      const int r = pix / a.PW, cc = pix - r * a.PW;
+      const int iy = iy0 + r, ix = ix0 + cc;
+      const int c = ci0 + u * 8;
+      const bool ok = (bool)((int)(idx < npatch) & (int)((unsigned)iy < (unsigned)a.Hin) & (int)((unsigned)ix < (unsigned)a.Win) & (int)(c < a.Cin));
+      rx[k] = ys_bufld16(rsX, ok ? (unsigned)(((((long)b * a.in_bstride + (long)iy * a.Win + ix) * a.in_ldc) + c) * 2L) : YS_BUF_OOB);
     }
   };
 
@@ -390,8 +386,17 @@ static int wg_pitch_bytes(int ch) {       // smallest row pitch >= ch*2 bytes wh
   if (!(s & 1)) s++;
   return s * 32;
 }
+// descriptor ranges of the dy / x views (bytes from the first channel to the end of the last image); false if either is >= 2 GB
+static bool wgrad_view_bytes(const WgradArgs& a, unsigned& dyb, unsigned& xb) {
+  const long dpix = (long)(a.B - 1) * a.dy_bstride + (long)a.Hout * a.Wout, xpix = (long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win;
+  const long d = (dpix * a.dy_ldc - a.dy_coff) * 2L, x = (xpix * a.in_ldc - a.in_coff) * 2L;
+  if (d <= 0 || x <= 0 || d >= (1L << 31) || x >= (1L << 31)) return false;
+  dyb = (unsigned)d; xb = (unsigned)x;
+  return true;
+}
 static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   WgPlan p{};
+  { unsigned d0, x0; if (!wgrad_view_bytes(a, d0, x0)) return p; }
   const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2);
   const bool k1 = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1;
   if (a.dy_rh || !(k3 || k1)) return p;
@@ -455,6 +460,7 @@ static WgPlan wgrad_tr_plan(const WgradArgs& a) {
 template <int MRA, int NRB, int TAPS>
 static void wgrad_tr_launch_t(hipStream_t st, WgradArgs a, const WgPlan& p) {
   a.TH = p.th; a.TWS = p.tws; a.tiles_x = p.tx; a.tiles_y = p.ty; a.ntiles = p.tx * p.ty * a.B;
+  wgrad_view_bytes(a, a.dybytes, a.xbytes);
   a.PH = p.ph; a.PW = p.pw; a.pdb = p.pdb; a.pxb = p.pxb;
   const int gy = ys_cdiv(a.Cout, MRA * 16) * ys_cdiv(a.Cin, NRB * 16);
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object

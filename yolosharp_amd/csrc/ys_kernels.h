@@ -53,6 +53,7 @@ struct WgradArgs {
   long dy_r0;
   // tile geometry of the bf16 LDS-tile kernel (filled by the launcher)
   int TH, TWS, tiles_x, tiles_y, ntiles, PH, PW, pdb, pxb;
+  unsigned dybytes, xbytes;   // descriptor ranges of the dy / x views (filled by the launcher)
 };
 
 int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a);
