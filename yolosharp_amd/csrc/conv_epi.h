@@ -70,13 +70,20 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   }
   char* yb = (char*)a.y;
   const char* rb = (const char*)a.res;
+  // Stores go through a buffer descriptor of the output buffer: masked lanes (pixel outside the image, channel tile past Cout,
+  // idle lanes of the wave) carry the out-of-range offset and the hardware drops them, so the store is issued unconditionally,
+  // NITER times per tile -- a static count the compiler can keep in flight (vmcnt(N)) across the next tile's loads instead of the
+  // vmcnt(0) that exec-masked stores forced.  Valid offsets are < 2^31 (checked by the launch plans).
+  const ys_rsrcv_t rsY = ys_make_rsrcv(yb, 0x7ffffff0u);
 #pragma unroll 2
   for (int it = 0; it < NITER; it++) {
     const int px = it * PPI + pl;
-    if (active && px < NPX && c < a.Cout) {
-      const long rofs = rowtab[px];
+    const bool lane_ok = active && px < NPX && c < a.Cout;
+    const long rofs = lane_ok ? rowtab[px] : -1L;
+    uint4 val = ys_zero16();
+    {
       if (rofs >= 0) {
-        uint4 val = *(const uint4*)(stg + px * PITCH + cv * 16);
+        val = *(const uint4*)(stg + px * PITCH + cv * 16);
         float f[8];
         ys_unpack<T>(val, f);
         if (do_stats) {
@@ -110,9 +117,9 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
           }
           val = ys_pack<T>(f);
         }
-        ys_st16(yp, val);
       }
     }
+    ys_bufst16(rsY, rofs >= 0 ? (unsigned)(rofs + (long)c * 2L) : YS_BUF_OOB, val);
   }
   ys_wave_sync();
 }

@@ -276,6 +276,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
     const long pix = f8 ? (long)a.B * a.Hin * a.Win : ((long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win);
     const long ab = f8 ? pix * a.Cin : (pix * a.in_ldc - a.in_coff) * 2L;
     if (ab <= 0 || ab >= (1L << 31) || (long)a.Cout * Ktot * (f8 ? 1 : 2) >= (1L << 31)) return p;   // 32-bit request offsets
+    if ((long)a.B * a.out_bstride * a.out_ldc * 2L >= (1L << 31)) return p;                             // the epilogue's store offsets
     g.abytes = (unsigned)ab;
   }
   const size_t tab = (size_t)g.nkt * 8 * sizeof(GemmTap);

@@ -555,4 +555,16 @@ __device__ inline uint4 ys_bufld16(const ys_rsrcv_t& r, unsigned voff) {
 }
 #endif
 
+// 16-byte store through a buffer descriptor: a lane with an out-of-range offset stores nothing (hardware drops it), so masked
+// lanes need no branch and the number of store instructions per wave is static -- the compiler can count them in vmcnt.
+__device__ inline void ys_bufst16(const ys_rsrcv_t& r, unsigned voff, const uint4& v) {
+#ifdef YS_EMU_BUILD
+  if ((unsigned long long)voff + 16ull <= (unsigned long long)r.bytes) memcpy((char*)r.base + voff, &v, 16);
+#else
+  typedef unsigned ys_u32x4 __attribute__((ext_vector_type(4)));
+  ys_u32x4 q; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)voff, 0, 0);
+#endif
+}
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
