@@ -209,8 +209,9 @@ def main():
         if not headline:   # no per-class byte table for this graph: report the whole step against the HBM roofline
             achieved = wk["train_bytes"] * B / (ms * 1e-3) / 1e9
             bytes_per_launch = wk["train_bytes"] * B
-        kdesc = ("conv_igemm class = every forward + dgrad convolution launch of the step: conv_p2_kernel (3x3 forward s1/s2 and "
-                 "stride-1 dgrad, whole-Cin LDS patch), conv_igemm_kernel (1x1), conv3x3_tile_kernel (stride-2 dgrads)") if headline else \
+        kdesc = ("conv_igemm class = every forward + dgrad convolution launch of the step: conv_p2_kernel (< 128 input channels: 3x3 "
+                 "s1/s2, 1x1, dgrad phases; whole-Cin LDS patch) and conv_gemm_kernel (>= 128 input channels: blocked implicit GEMM, "
+                 "LDS-DMA operand staging)") if headline else \
                 "whole training step (all kernels), algorithmic bytes from SURVEY.md 8d"
         roofline = {"bound": "hbm", "kernel": kdesc, "achieved": round(achieved, 1),
                     "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
