@@ -69,7 +69,7 @@ int ys_dwconv_launch(hipStream_t st, int dtype, int flip, const void* x, int x_l
 template <class T>
 __global__ void __launch_bounds__(AD_THREADS)
 dwconv_wgrad_kernel(const T* __restrict__ x, int x_ldc, int x_coff, const T* __restrict__ dy, int B, int H, int W, int C,
-                    float* __restrict__ partial) {
+                    float* __restrict__ partial, unsigned xbytes) {
   constexpr int EPL = Elem<T>::EPL;
   __shared__ float sAcc[AD_THREADS][EPL];
   const int CG = C / EPL;
@@ -87,25 +87,33 @@ dwconv_wgrad_kernel(const T* __restrict__ x, int x_ldc, int x_coff, const T* __r
   for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int e = 0; e < EPL; e++) acc[t][e] = 0.f;
+  // the nine taps of a pixel are nine unconditional 16-byte loads through a buffer descriptor of the x view (a tap outside the image
+  // = the out-of-range offset = zeros), all in flight together; the exec-masked `if (inside) load` form serialised them
+  // (1.15 TB/s on the Detect cv3 depthwise layers of YOLOv11m)
+  const ys_rsrcv_t rsX = ys_make_rsrcv((const char*)(x + x_coff), xbytes);
   if (rl < RP) {
     for (long row = r0 + rl; row < r1; row += RP) {
       const int ww = (int)(row % W), hh = (int)((row / W) % H);
       const long b = row / ((long)W * H);
       float g[EPL];
       ys_unpack<T>(ys_ld16(dy + row * C + c), g);
+      uint4 xv[9];
 #pragma unroll
       for (int kh = 0; kh < 3; kh++) {
         const int ih = hh + kh - 1;
 #pragma unroll
         for (int kw = 0; kw < 3; kw++) {
           const int iw = ww + kw - 1;
-          if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
-            float f[EPL];
-            ys_unpack<T>(ys_ld16(x + ((b * H + ih) * W + iw) * x_ldc + x_coff + c), f);
-#pragma unroll
-            for (int e = 0; e < EPL; e++) acc[kh * 3 + kw][e] += g[e] * f[e];
-          }
+          const bool ok = (bool)((int)((unsigned)ih < (unsigned)H) & (int)((unsigned)iw < (unsigned)W));
+          xv[kh * 3 + kw] = ys_bufld16(rsX, ok ? (unsigned)((((b * H + ih) * W + iw) * x_ldc + c) * (long)sizeof(T)) : YS_BUF_OOB);
         }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        float f[EPL];
+        ys_unpack<T>(xv[t], f);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) acc[t][e] += g[e] * f[e];
       }
     }
   }
@@ -125,20 +133,36 @@ dwconv_wgrad_kernel(const T* __restrict__ x, int x_ldc, int x_coff, const T* __r
   }
 }
 
+// grad[i] += sum_k partial[k][i]: 32 outputs x 8 split lanes per workgroup (consecutive threads = consecutive outputs: coalesced
+// rows), every lane walks its share of the nblk partials, the eight lane sums are combined in a fixed order -> deterministic.
+// (One thread per output walking all partials serially: 155 us per layer at 1024 partials.)
 __global__ void __launch_bounds__(AD_THREADS)
 dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ grad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nblk; k++) s += partial[(long)k * n + i];
-  grad[i] += s;
+  __shared__ float sred[AD_THREADS / 32][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  constexpr int NS = AD_THREADS / 32;
+  const int i = blockIdx.x * 32 + o;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int k = sl;
+    for (; k + NS < nblk; k += 2 * NS) { s0 += partial[(long)k * n + i]; s1 += partial[(long)(k + NS) * n + i]; }
+    if (k < nblk) s0 += partial[(long)k * n + i];
+  }
+  sred[sl][o] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NS; q++) t += sred[q][o];
+    grad[i] += t;
+  }
 }
 
 int ys_dwconv_wgrad_blocks(long rows, int C, int dtype) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const int rp = AD_THREADS / (C / epl);
   long nb = (rows + (long)rp * 8 - 1) / ((long)rp * 8);
-  if (nb > 256) nb = 256;
+  if (nb > 1024) nb = 1024;     // four workgroups per CU: a streaming pass wants the bytes in flight (256: 1.15 TB/s)
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -148,9 +172,11 @@ int ys_dwconv_wgrad_launch(hipStream_t st, int dtype, const void* x, int x_ldc, 
   const int epl = dtype == YS_BF16 ? 8 : 4;
   if (C % epl || C / epl > AD_THREADS) { ys_set_error("dwconv wgrad: unsupported C=%d", C); return YS_ERR_UNSUPPORTED; }
   const int nb = ys_dwconv_wgrad_blocks((long)B * H * W, C, dtype);
-  if (dtype == YS_BF16) YS_LAUNCH((dwconv_wgrad_kernel<bf16_t>), nb, AD_THREADS, st, (const bf16_t*)x, x_ldc, x_coff, (const bf16_t*)dy, B, H, W, C, partial);
-  else YS_LAUNCH((dwconv_wgrad_kernel<float>), nb, AD_THREADS, st, (const float*)x, x_ldc, x_coff, (const float*)dy, B, H, W, C, partial);
-  YS_LAUNCH(dwconv_wgrad_finalize_kernel, ys_cdiv(9 * C, AD_THREADS), AD_THREADS, st, (const float*)partial, nb, 9 * C, grad);
+  const long xb = ((long)B * H * W * x_ldc - x_coff) * (dtype == YS_BF16 ? 2L : 4L);     // bytes of the x view from its first channel
+  if (xb <= 0 || xb >= (1L << 31)) { ys_set_error("dwconv wgrad: input view of %ld bytes exceeds the 2 GB descriptor range", xb); return YS_ERR_UNSUPPORTED; }
+  if (dtype == YS_BF16) YS_LAUNCH((dwconv_wgrad_kernel<bf16_t>), nb, AD_THREADS, st, (const bf16_t*)x, x_ldc, x_coff, (const bf16_t*)dy, B, H, W, C, partial, (unsigned)xb);
+  else YS_LAUNCH((dwconv_wgrad_kernel<float>), nb, AD_THREADS, st, (const float*)x, x_ldc, x_coff, (const float*)dy, B, H, W, C, partial, (unsigned)xb);
+  YS_LAUNCH(dwconv_wgrad_finalize_kernel, ys_cdiv(9 * C, 32), AD_THREADS, st, (const float*)partial, nb, 9 * C, grad);
   return YS_OK;
 }
 
@@ -237,31 +263,84 @@ attn_bwd_q_kernel(const T* __restrict__ qkv, int ldq, int B, int N, int heads, i
   }
 }
 
-// pass 2 (per key column m): dk = scale * dS^T q ; dv = dO P  (added to the gradient that arrived through pe(v))
-template <class T>
+// pass 2 (per key column m): dk = scale * dS^T q ; dv = dO P  (added to the gradient that arrived through pe(v)).
+// A workgroup owns 64 key columns of one (image, head) and walks the query rows in chunks of 32: the dS / P tiles [32][64] are
+// read as full rows (coalesced) into LDS together with the q and dO rows of the chunk, then thread (m, d-slice) accumulates its
+// outputs over the chunk -- rows in ascending order, the same summation order as one thread per output walking a column.
+// (The round-1 form read dS and P column-wise, one 4-byte element per 1600-byte stride: 1.59 ms on BASELINE config 4.)
+#define AKV_TM 64
+#define AKV_TN 32
+template <class T, int KD4, int HD4>         // accumulators per thread: kd / 4 and hd / 4 (4 waves split the d axis)
 __global__ void __launch_bounds__(AD_THREADS)
 attn_bwd_kv_kernel(const T* __restrict__ qkv, int ldq, int B, int N, int heads, int kd, int hd, float scale,
                    const T* __restrict__ dao, int ldo, const float* __restrict__ P, const float* __restrict__ dS,
                    T* __restrict__ dqkv) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x * (AD_THREADS / 64) + wave;
+  __shared__ float sS[AKV_TN][AKV_TM], sPt[AKV_TN][AKV_TM];
+  __shared__ float sQ[AKV_TN][KD4 * 4], sO[AKV_TN][HD4 * 4];
+  const int tid = threadIdx.x, wave = tid >> 6, ml = tid & 63;
+  const int m0 = blockIdx.x * AKV_TM, m = m0 + ml;
   const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
   const int hs = 2 * kd + hd;
-  if (m >= N) return;
   const T* base = qkv + (long)b * N * ldq + h * hs;
-  const float* Pc = P + (long)bh * N * N + m;
-  const float* Sc = dS + (long)bh * N * N + m;
-  for (int d = lane; d < kd; d += 64) {
-    float acc = 0.f;
-    for (int n = 0; n < N; n++) acc += Sc[(long)n * N] * Elem<T>::to_f(base[(long)n * ldq + d]);
-    dqkv[((long)b * N + m) * ldq + h * hs + kd + d] = Elem<T>::from_f(acc * scale);
+  const float* Pb = P + (long)bh * N * N;
+  const float* Sb = dS + (long)bh * N * N;
+  float ak[KD4], av[HD4];
+#pragma unroll
+  for (int j = 0; j < KD4; j++) ak[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < HD4; j++) av[j] = 0.f;
+  for (int n0 = 0; n0 < N; n0 += AKV_TN) {
+    __syncthreads();
+    for (int i = tid; i < AKV_TN * AKV_TM; i += AD_THREADS) {
+      const int r = i / AKV_TM, c = i - r * AKV_TM;
+      const bool ok = n0 + r < N && m0 + c < N;
+      sS[r][c] = ok ? Sb[(long)(n0 + r) * N + m0 + c] : 0.f;
+      sPt[r][c] = ok ? Pb[(long)(n0 + r) * N + m0 + c] : 0.f;
+    }
+    for (int i = tid; i < AKV_TN * kd; i += AD_THREADS) {
+      const int r = i / kd, d = i - r * kd;
+      sQ[r][d] = n0 + r < N ? Elem<T>::to_f(base[(long)(n0 + r) * ldq + d]) : 0.f;
+    }
+    for (int i = tid; i < AKV_TN * hd; i += AD_THREADS) {
+      const int r = i / hd, d = i - r * hd;
+      sO[r][d] = n0 + r < N ? Elem<T>::to_f(dao[((long)b * N + n0 + r) * ldo + h * hd + d]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < AKV_TN; r++) {
+      const float sv = sS[r][ml], pv = sPt[r][ml];
+#pragma unroll
+      for (int j = 0; j < KD4; j++) ak[j] += sv * sQ[r][wave + 4 * j];
+#pragma unroll
+      for (int j = 0; j < HD4; j++) av[j] += pv * sO[r][wave + 4 * j];
+    }
   }
-  for (int d = lane; d < hd; d += 64) {
-    float acc = 0.f;
-    for (int n = 0; n < N; n++) acc += Pc[(long)n * N] * Elem<T>::to_f(dao[((long)b * N + n) * ldo + h * hd + d]);
-    T* dst = dqkv + ((long)b * N + m) * ldq + h * hs + 2 * kd + d;
-    *dst = Elem<T>::from_f(acc + Elem<T>::to_f(*dst));
+  if (m < N) {
+#pragma unroll
+    for (int j = 0; j < KD4; j++) {
+      const int d = wave + 4 * j;
+      if (d < kd) dqkv[((long)b * N + m) * ldq + h * hs + kd + d] = Elem<T>::from_f(ak[j] * scale);
+    }
+#pragma unroll
+    for (int j = 0; j < HD4; j++) {
+      const int d = wave + 4 * j;
+      if (d < hd) {
+        T* dst = dqkv + ((long)b * N + m) * ldq + h * hs + 2 * kd + d;
+        *dst = Elem<T>::from_f(av[j] + Elem<T>::to_f(*dst));
+      }
+    }
   }
+}
+
+template <class T>
+static int attn_bwd_kv_dispatch(hipStream_t st, const T* qkv, int ldq, int B, int N, int heads, int kd, int hd, float scale, const T* dao,
+                                int ldo, const float* P, const float* dS, T* dqkv) {
+  dim3 grid(ys_cdiv(N, AKV_TM), B * heads);
+#define AKV(K_, H_) if (kd <= 4 * K_ && hd <= 4 * H_) { YS_LAUNCH((attn_bwd_kv_kernel<T, K_, H_>), grid, AD_THREADS, st, qkv, ldq, B, N, heads, kd, hd, scale, dao, ldo, P, dS, dqkv); return YS_OK; }
+  AKV(8, 16) AKV(16, 32) AKV(32, 64)
+#undef AKV
+  ys_set_error("attention backward: kd=%d hd=%d outside the supported range", kd, hd);
+  return YS_ERR_UNSUPPORTED;
 }
 
 int ys_attn_fwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int B, int N, int heads, int kd, int hd,
@@ -280,10 +359,10 @@ int ys_attn_bwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int 
   dim3 grid(ys_cdiv(N, AD_THREADS / 64), B * heads);
   if (dtype == YS_BF16) {
     YS_LAUNCH((attn_bwd_q_kernel<bf16_t>), grid, AD_THREADS, st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (const bf16_t*)dao, ldo, P, dS, (bf16_t*)dqkv);
-    YS_LAUNCH((attn_bwd_kv_kernel<bf16_t>), grid, AD_THREADS, st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (const bf16_t*)dao, ldo, P, (const float*)dS, (bf16_t*)dqkv);
+    YS_TRY(attn_bwd_kv_dispatch<bf16_t>(st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (const bf16_t*)dao, ldo, P, (const float*)dS, (bf16_t*)dqkv));
   } else {
     YS_LAUNCH((attn_bwd_q_kernel<float>), grid, AD_THREADS, st, (const float*)qkv, ldq, B, N, heads, kd, hd, scale, (const float*)dao, ldo, P, dS, (float*)dqkv);
-    YS_LAUNCH((attn_bwd_kv_kernel<float>), grid, AD_THREADS, st, (const float*)qkv, ldq, B, N, heads, kd, hd, scale, (const float*)dao, ldo, P, (const float*)dS, (float*)dqkv);
+    YS_TRY(attn_bwd_kv_dispatch<float>(st, (const float*)qkv, ldq, B, N, heads, kd, hd, scale, (const float*)dao, ldo, P, (const float*)dS, (float*)dqkv));
   }
   return YS_OK;
 }

@@ -752,7 +752,7 @@ int allocate(ys_model* m) {
       c.ch_off = nch; nch += 6L * ((c.cout + 3) / 4 * 4);
       dy_max = std::max(dy_max, M * c.cout_ld);
       stat_max = std::max(stat_max, 2048L * 2 * c.cout_ld);
-      stat_max = std::max(stat_max, 256L * 9 * c.cout);
+      stat_max = std::max(stat_max, 1024L * 9 * c.cout);   // depthwise weight-gradient partials (ys_dwconv_wgrad_blocks <= 1024)
       continue;
     }
     c.wf_off = nf;

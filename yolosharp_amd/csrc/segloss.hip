@@ -76,10 +76,24 @@ __device__ inline void seg_crop_bounds(const float* e, int mw, int mh, int trunc
   c1 = c1 > mw ? mw : c1; r1 = r1 > mh ? mh : r1;
 }
 
+// NM prototypes of one pixel -> floats.  NMC = the compile-time count (32: Proto's nm, Head.cs:238; vector loads, registers) or 0 =
+// run-time a.nm (then the per-thread arrays are indexed by a run-time loop and live in scratch: the round-1 form, kept for other nm)
+template <class T, int NMC>
+__device__ inline void seg_load_row(const T* pr, int nm, float* pv) {
+  if (NMC > 0) {
+    constexpr int EPL = Elem<T>::EPL;
+#pragma unroll
+    for (int k = 0; k < (NMC > 0 ? NMC : 1); k += EPL) ys_unpack<T>(ys_ld16(pr + k), pv + k);
+  } else {
+    for (int k = 0; k < nm; k++) pv[k] = Elem<T>::to_f(pr[k]);
+  }
+}
+
 // pass 1: one workgroup per foreground anchor: loss term + d(coeff)
-template <class T>
+template <class T, int NMC>
 __global__ void __launch_bounds__(SG_THREADS)
 seg_anchor_kernel(SegArgs a) {
+  const int nm = NMC > 0 ? NMC : a.nm;
   __shared__ float sco[SG_NM_MAX];
   __shared__ float sred[SG_THREADS / 64][SG_NM_MAX + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,7 +115,7 @@ seg_anchor_kernel(SegArgs a) {
       en[0] = nx1 * (float)a.mw; en[1] = ny1 * (float)a.mh; en[2] = nx2 * (float)a.mw; en[3] = ny2 * (float)a.mh;
       en[4] = scale; en[5] = (float)(g + 1);
     }
-    if (tid < a.nm) sco[tid] = Elem<T>::to_f(((const T*)a.mc)[row * a.ld_mc + tid]);
+    if (tid < nm) sco[tid] = Elem<T>::to_f(((const T*)a.mc)[row * a.ld_mc + tid]);
     __syncthreads();
     int c0, c1, r0, r1;
     seg_crop_bounds(en, a.mw, a.mh, a.trunc_crop, a.cnt[b], c0, c1, r0, r1);
@@ -109,67 +123,112 @@ seg_anchor_kernel(SegArgs a) {
     const int npx = bw > 0 && bh > 0 ? bw * bh : 0;
     float lsum = 0.f;
     float dco[SG_NM_MAX];
-    for (int k = 0; k < a.nm; k++) dco[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) dco[k] = 0.f;
     const float gid = (float)(g + 1);
     for (int i = tid; i < npx; i += SG_THREADS) {
       const int rr = r0 + i / bw, cc = c0 + i % bw;
       const long p = (long)b * a.mh * a.mw + (long)rr * a.mw + cc;
       const T* pr = (const T*)a.proto + p * a.ld_pr;
       float pv[SG_NM_MAX];
+      seg_load_row<T, NMC>(pr, nm, pv);
       float x = 0.f;
-      for (int k = 0; k < a.nm; k++) { pv[k] = Elem<T>::to_f(pr[k]); x += sco[k] * pv[k]; }
+#pragma unroll
+      for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) x += sco[k] * pv[k];
       const float t = a.masks[p] == gid ? 1.0f : 0.0f;
       lsum += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
       const float d = ys_sigmoid(x) - t;
-      for (int k = 0; k < a.nm; k++) dco[k] += d * pv[k];
+#pragma unroll
+      for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) dco[k] += d * pv[k];
     }
     // workgroup reduction of (loss, dcoeff[nm]) in a fixed order
     lsum = ys_wave_sum(lsum);
-    for (int k = 0; k < a.nm; k++) dco[k] = ys_wave_sum(dco[k]);
-    if (lane == 0) { sred[wave][a.nm] = lsum; for (int k = 0; k < a.nm; k++) sred[wave][k] = dco[k]; }
+#pragma unroll
+    for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) dco[k] = ys_wave_sum(dco[k]);
+    if (lane == 0) {
+      sred[wave][nm] = lsum;
+#pragma unroll
+      for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) sred[wave][k] = dco[k];
+    }
     __syncthreads();
     const float gsc = a.hyp_box * (float)a.B / (float)ntot * scale;
-    if (tid <= a.nm) {
+    if (tid <= nm) {
       float s = 0.f;
       for (int w = 0; w < SG_THREADS / 64; w++) s += sred[w][tid];
-      if (tid == a.nm) a.part[e] = s * scale;
+      if (tid == nm) a.part[e] = s * scale;
       else ((T*)a.dmc)[row * a.ld_mc + tid] = Elem<T>::from_f(s * gsc);
     }
     __syncthreads();
   }
 }
 
-// pass 2: one thread per prototype pixel: d(proto)[p][k] = sum over the image's foreground anchors whose crop holds p
-template <class T>
+// pass 2: one thread per prototype pixel: d(proto)[p][k] = sum over the image's foreground anchors whose crop holds p, in list
+// order (fixed summation order).  The image's entries (crop bounds, gradient scale, instance id, coefficient vector) are staged
+// through LDS in chunks by the whole workgroup and read back as broadcasts; an entry whose crop rows miss the workgroup's pixel
+// rows is skipped by all threads at once.  (Round-1 form: every thread re-read every entry from global memory and kept its
+// nm-vectors in scratch: 1.72 ms on BASELINE config 4.)
+#define SG_ECH 32                       // entries per LDS chunk
+template <class T, int NMC>
 __global__ void __launch_bounds__(SG_THREADS)
 seg_proto_grad_kernel(SegArgs a) {
-  const int b = blockIdx.y;
-  const int p = blockIdx.x * SG_THREADS + threadIdx.x;
+  const int nm = NMC > 0 ? NMC : a.nm;
+  __shared__ int sbnd[SG_ECH][4];       // c0, c1, r0, r1
+  __shared__ float sval[SG_ECH][2];     // gradient scale, instance id
+  __shared__ float scf[SG_ECH][SG_NM_MAX];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int npix = a.mh * a.mw;
-  if (p >= npix) return;
-  const int rr = p / a.mw, cc = p % a.mw;
-  const long gp = (long)b * npix + p;
-  const T* pr = (const T*)a.proto + gp * a.ld_pr;
+  const int p0 = blockIdx.x * SG_THREADS;
+  const int p = p0 + tid;
+  const bool live = p < npix;
+  const int pc = live ? p : npix - 1;
+  const int rr = pc / a.mw, cc = pc - rr * a.mw;
+  const int wr0 = p0 / a.mw, wr1 = ((p0 + SG_THREADS - 1 < npix ? p0 + SG_THREADS - 1 : npix - 1)) / a.mw;   // pixel rows of this workgroup
+  const long gp = (long)b * npix + pc;
   float pv[SG_NM_MAX], acc[SG_NM_MAX];
-  for (int k = 0; k < a.nm; k++) { pv[k] = Elem<T>::to_f(pr[k]); acc[k] = 0.f; }
+  seg_load_row<T, NMC>((const T*)a.proto + gp * a.ld_pr, nm, pv);
+#pragma unroll
+  for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) acc[k] = 0.f;
   const int ntot = a.off[a.B];
   const int e0 = a.off[b], e1 = a.off[b + 1];
   const float mval = a.masks[gp];
-  for (int e = e0; e < e1; e++) {
-    const float* en = a.ent + (long)e * 8;
-    int c0, c1, r0, r1;
-    seg_crop_bounds(en, a.mw, a.mh, a.trunc_crop, e1 - e0, c0, c1, r0, r1);
-    if (cc < c0 || cc >= c1 || rr < r0 || rr >= r1) continue;
-    const T* co = (const T*)a.mc + ((long)b * a.A + a.list[e]) * a.ld_mc;
-    float cf[SG_NM_MAX];
-    float x = 0.f;
-    for (int k = 0; k < a.nm; k++) { cf[k] = Elem<T>::to_f(co[k]); x += cf[k] * pv[k]; }
-    const float t = mval == en[5] ? 1.0f : 0.0f;
-    const float d = (ys_sigmoid(x) - t) * en[4] * a.hyp_box * (float)a.B / (float)ntot;
-    for (int k = 0; k < a.nm; k++) acc[k] += d * cf[k];
+  for (int eb = e0; eb < e1; eb += SG_ECH) {
+    const int ne = (e1 - eb) < SG_ECH ? (e1 - eb) : SG_ECH;
+    __syncthreads();
+    if (tid < ne) {
+      const float* en = a.ent + (long)(eb + tid) * 8;
+      int c0, c1, r0, r1;
+      seg_crop_bounds(en, a.mw, a.mh, a.trunc_crop, e1 - e0, c0, c1, r0, r1);
+      sbnd[tid][0] = c0; sbnd[tid][1] = c1; sbnd[tid][2] = r0; sbnd[tid][3] = r1;
+      sval[tid][0] = en[4]; sval[tid][1] = en[5];
+    }
+    for (int i = tid; i < ne * nm; i += SG_THREADS) {
+      const int el = i / nm, k = i - el * nm;
+      scf[el][k] = Elem<T>::to_f(((const T*)a.mc)[((long)b * a.A + a.list[eb + el]) * a.ld_mc + k]);
+    }
+    __syncthreads();
+    for (int el = 0; el < ne; el++) {
+      const int r0 = sbnd[el][2], r1 = sbnd[el][3];
+      if (r1 <= wr0 || r0 > wr1) continue;                               // uniform: the crop misses this workgroup's rows
+      if (cc < sbnd[el][0] || cc >= sbnd[el][1] || rr < r0 || rr >= r1) continue;
+      float x = 0.f;
+#pragma unroll
+      for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) x += scf[el][k] * pv[k];
+      const float t = mval == sval[el][1] ? 1.0f : 0.0f;
+      const float d = (ys_sigmoid(x) - t) * sval[el][0] * a.hyp_box * (float)a.B / (float)ntot;   // same association as the round-1 kernel
+#pragma unroll
+      for (int k = 0; k < (NMC > 0 ? NMC : SG_NM_MAX); k++) if (k < nm) acc[k] += d * scf[el][k];
+    }
   }
-  T* dp = (T*)a.dproto + gp * a.ld_pr;
-  for (int k = 0; k < a.nm; k++) dp[k] = Elem<T>::from_f(acc[k]);
+  if (live) {
+    T* dp = (T*)a.dproto + gp * a.ld_pr;
+    if (NMC > 0) {
+      constexpr int EPL = Elem<T>::EPL;
+#pragma unroll
+      for (int k = 0; k < (NMC > 0 ? NMC : 1); k += EPL) ys_st16(dp + k, ys_pack<T>(acc + k));
+    } else {
+      for (int k = 0; k < nm; k++) dp[k] = Elem<T>::from_f(acc[k]);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(SG_THREADS)
@@ -206,12 +265,13 @@ int ys_loss_segment_launch(hipStream_t st, int dtype, const void* mc, void* dmc,
   YS_LAUNCH(seg_compact_kernel, B, SG_THREADS, st, fg_gt, A, (const int*)off, list);
   const int g1 = 2048;
   dim3 g2(ys_cdiv(mh * mw, SG_THREADS), B);
+  const bool fast = nm == 32 && ld_mc % 8 == 0 && ld_pr % 8 == 0;      // Proto / Segment default (Head.cs:238): compile-time nm, 16-byte rows
   if (dtype == YS_BF16) {
-    YS_LAUNCH((seg_anchor_kernel<bf16_t>), g1, SG_THREADS, st, a);
-    YS_LAUNCH((seg_proto_grad_kernel<bf16_t>), g2, SG_THREADS, st, a);
+    if (fast) { YS_LAUNCH((seg_anchor_kernel<bf16_t, 32>), g1, SG_THREADS, st, a); YS_LAUNCH((seg_proto_grad_kernel<bf16_t, 32>), g2, SG_THREADS, st, a); }
+    else { YS_LAUNCH((seg_anchor_kernel<bf16_t, 0>), g1, SG_THREADS, st, a); YS_LAUNCH((seg_proto_grad_kernel<bf16_t, 0>), g2, SG_THREADS, st, a); }
   } else {
-    YS_LAUNCH((seg_anchor_kernel<float>), g1, SG_THREADS, st, a);
-    YS_LAUNCH((seg_proto_grad_kernel<float>), g2, SG_THREADS, st, a);
+    if (fast) { YS_LAUNCH((seg_anchor_kernel<float, 32>), g1, SG_THREADS, st, a); YS_LAUNCH((seg_proto_grad_kernel<float, 32>), g2, SG_THREADS, st, a); }
+    else { YS_LAUNCH((seg_anchor_kernel<float, 0>), g1, SG_THREADS, st, a); YS_LAUNCH((seg_proto_grad_kernel<float, 0>), g2, SG_THREADS, st, a); }
   }
   YS_LAUNCH(seg_finalize_kernel, 1, SG_THREADS, st, a);
   return YS_OK;
