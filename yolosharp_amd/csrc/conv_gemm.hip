@@ -149,7 +149,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       if (m < a.M) {
         const int b = m / g.HoWo, rem = m - b * g.HoWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-        aiy[j] = oy * a.SA - a.PAD; aix[j] = ox * a.SA - a.PAD;
+        aiy[j] = oy * a.SA - a.PAD; aix[j] = ox * a.SA - a.PAD - a.pad_w_delta;
         abase[j] = (int)((((long)b * bstride + (long)aiy[j] * a.Win + aix[j]) * ldu) << 4);
       } else { aiy[j] = -(1 << 20); aix[j] = 0; abase[j] = 0; }
     }
@@ -250,7 +250,9 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
   const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
   const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
-  if (!((k3 || phase || k1) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && a.pad_w_delta == 0)) return p;
+  // input-gradient phases of ConvTranspose2d(2, 2) (Proto.upsample, Block.cs:69): a strided 1x1 gather at (2 oh + dh, 2 ow + dw)
+  const bool ctd = a.KH == 1 && a.KW == 1 && a.SA == 2 && a.out_rh == 0;
+  if (!((k3 || phase || k1 || ctd) && a.DIVM == 0 && (a.SA == 1 || a.SA == 2) && (a.pad_w_delta == 0 || ctd))) return p;
   if (a.Cin % 8 || a.in_ldc % 8 || a.in_coff % 8 || a.out_ldc % 8 || a.out_coff % 8 || a.Cout % 8) return p;
   if (a.res && (a.res_ldc % 8 || a.res_coff % 8)) return p;
   const int taps = a.KH * a.KW;

@@ -99,7 +99,9 @@ conv_wgrad_gemm_kernel(WgradArgs a, WgGemmArgs g) {
     const int b = ys_div24(mm, g.HoWo, g.inv_howo), rem = mm - b * g.HoWo;
     const int oy = ys_div24(rem, a.Wout, g.inv_wo), ox = rem - oy * a.Wout;
     if (ld_dy) {
-      const unsigned vo = mok ? (unsigned)((((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc) * 2L) + (unsigned)sl * 16u : YS_BUF_OOB;
+      // dy_rh != 0: strided row map (the phases of ConvTranspose2d(2, 2): dy lives on the 2x upsampled grid)
+      const long drow = (long)b * a.dy_bstride + (a.dy_rh ? (long)oy * a.dy_rh + (long)ox * a.dy_rw + a.dy_r0 : (long)oy * a.Wout + ox);
+      const unsigned vo = mok ? (unsigned)((drow * a.dy_ldc) * 2L) + (unsigned)sl * 16u : YS_BUF_OOB;
 #pragma unroll
       for (int i = 0; i < CD; i++) ys_bufld_lds16(rsD, vo, (unsigned)i * 64u, sb + (i * RW + rblk) * 1024);
     }
@@ -193,7 +195,7 @@ static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
   if (off) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2);
   const bool k1 = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1;
-  if (a.dy_rh || !(k3 || k1)) return p;
+  if (!(k3 || k1) || (a.dy_rh && !k1)) return p;
   if (a.Cin % 8 || a.Cout % 8 || a.in_ldc % 8 || a.in_coff % 8 || a.dy_ldc % 8 || a.dy_coff % 8) return p;
   if (a.Cin < min_c || a.Cout < min_c || a.M < min_m || a.M >= (1 << 24)) return p;
   const int bco = wgemm_pick_tile(a.Cout), bci = wgemm_pick_tile(a.Cin);
@@ -208,7 +210,7 @@ static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
   g.HoWo = a.Hout * a.Wout;
   g.inv_howo = 1.0f / (float)g.HoWo; g.inv_wo = 1.0f / (float)a.Wout;
   {
-    const long dpix = (long)(a.B - 1) * a.dy_bstride + (long)a.Hout * a.Wout, xpix = (long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win;
+    const long dpix = a.dy_rh ? (long)a.B * a.dy_bstride : (long)(a.B - 1) * a.dy_bstride + (long)a.Hout * a.Wout, xpix = (long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win;
     const long db = (dpix * a.dy_ldc - a.dy_coff) * 2L, xbts = (xpix * a.in_ldc - a.in_coff) * 2L;
     if (db <= 0 || xbts <= 0 || db >= (1L << 31) || xbts >= (1L << 31)) return p;      // 32-bit request offsets
     g.dybytes = (unsigned)db; g.xbytes = (unsigned)xbts;
