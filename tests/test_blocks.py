@@ -104,10 +104,17 @@ def test_block_parity_f32_gpu(engine, backend, case):
 @pytest.mark.gpu
 # (SPPF is left to the f32 run: on bf16 activations the 5x5 max pools meet rounding ties, so gradients are routed to different
 #  -- equally valid -- positions than in the fp32 oracle and a pointwise dx comparison is meaningless)
-@pytest.mark.parametrize("case", ["conv3s2", "bottleneck", "c2f_n2_sc", "c2f_n1", "c3k2_c3k", "proto"])
+@pytest.mark.parametrize("case", ["conv3s2", "bottleneck", "c2f_n2_sc", "c2f_n1", "c3k2_c3k", "proto", "c2psa"])
 @pytest.mark.parametrize("backend", ["gpu"])
 def test_block_parity_bf16_gpu(engine, backend, case):
     _block_parity(engine, case, "bf16", 4, 4e-2, 8e-2, scale=2)
+
+
+@pytest.mark.parametrize("backend", ["emu"])
+def test_c2psa_bf16_emu(engine, backend):
+    """bf16 C2PSA (attention forward / backward, depthwise pe conv) against the fp32 oracle module; the fp32 runs above are the
+    tight parity statement."""
+    _block_parity(engine, "c2psa", "bf16", 2, 4e-2, 8e-2)
 
 
 @pytest.mark.parametrize("backend", ["emu"])
