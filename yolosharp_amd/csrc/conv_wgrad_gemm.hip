@@ -12,7 +12,7 @@
 //  * K-tiles of KT = 64 (or 32) pixels: dy rows [pixel][cout tile] and x rows [tap-shifted pixel][cin tile] go global -> LDS by
 //    LDS DMA, two stages, one barrier per K-tile.  Four lanes fetch one pixel row, 64 B per DMA instruction and row, so the LDS
 //    image of an operand is [64-byte chunk][16-row block][row][64 B]; the tap shift, the stride and the zero padding are
-//    per-lane source addresses (a zero line for pixels outside the image);
+//    per-lane source offsets into buffer descriptors (an out-of-range offset for pixels outside the image: hardware zeros);
 //  * fragments by ds_read_b64_tr_b16 (4 consecutive pixels of one channel per lane).  The 32 lanes the LDS serves together read 8
 //    consecutive rows x 32 B; rows are 64 B apart inside a block, so the two 32-byte halves of a chunk are swapped on rows 4-7
 //    of every 8 (source address of the DMA and read address alike) -> conflict-free;
