@@ -41,7 +41,7 @@ enum ys_status {
 enum ys_dtype { YS_F32 = 0, YS_BF16 = 1, YS_FP8 = 2 };
 enum ys_family { YS_YOLOV8 = 8, YS_YOLOV11 = 11 };   /* Models/Yolo.cs:10-135, :200-258 */
 enum ys_size { YS_N = 0, YS_S = 1, YS_M = 2, YS_L = 3, YS_X = 4 }; /* Types/YoloTypes.cs YoloSize; Yolo.cs:43-51 */
-enum ys_task { YS_DETECT = 0, YS_SEGMENT = 1 };
+enum ys_task { YS_DETECT = 0, YS_SEGMENT = 1, YS_OBB = 2, YS_POSE = 3 };   /* Config.cs TaskType; OBB / Pose: forward + predict, no criterion yet */
 
 YS_API const char* ys_last_error(void);
 YS_API int ys_version(void);
@@ -73,6 +73,8 @@ typedef struct ys_model_desc {
   int32_t max_labels; /* initial capacity of ground-truth rows PER IMAGE for the loss (0 = 64).  Not a limit: host-label loss calls
                          grow the workspace to the batch's largest per-image count (the reference pads to counts.max(),
                          Utils/Loss.cs:363-390); device-label callers reserve with ys_model_reserve_labels */
+  int32_t kpt_num;    /* YS_POSE: keypoints per object (0 = 17, Models/Yolo.cs:473) */
+  int32_t kpt_dim;    /* YS_POSE: 2 = (x, y), 3 = (x, y, visibility) (0 = 3) */
 } ys_model_desc;
 
 YS_API int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out);

@@ -20,7 +20,8 @@ c_i32_p = C.POINTER(C.c_int32)
 class ModelDesc(C.Structure):
     _fields_ = [("family", C.c_int32), ("size", C.c_int32), ("task", C.c_int32), ("nc", C.c_int32),
                 ("reg_max", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
-                ("max_batch", C.c_int32), ("dtype", C.c_int32), ("max_labels", C.c_int32)]
+                ("max_batch", C.c_int32), ("dtype", C.c_int32), ("max_labels", C.c_int32),
+                ("kpt_num", C.c_int32), ("kpt_dim", C.c_int32)]
 
 
 class BlockDesc(C.Structure):

@@ -969,7 +969,7 @@ template <class T>
 __global__ void __launch_bounds__(EW_THREADS)
 detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ ps, int ld_ps, int B, int A, int nc,
                      int reg_max, int nl, int o0, int o1, int o2, int w0, int w1, int w2, int s0, int s1, int s2,
-                     float* __restrict__ pred, int pred_C) {
+                     float* __restrict__ pred, int pred_C, const T* __restrict__ px, int ld_px, int xkind, int nx, int kdim) {
   // One workgroup decodes DEC_ANCH consecutive rows of the [B*A][ld] head outputs: the rows are staged in LDS with
   // coalesced 16-byte loads, (anchor, side) threads take the DFL expectation, and the class probabilities are written
   // channel-major so that consecutive lanes store consecutive anchors of pred[b][c][:].
@@ -980,6 +980,8 @@ detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ 
   float* sB = (float*)lds;                          // [DEC_ANCH][pb]
   float* sC = sB + DEC_ANCH * pb;                   // [DEC_ANCH][pc]
   float* sD = sC + DEC_ANCH * pc;                   // [DEC_ANCH][4]
+  const int px_p = nx | 1;
+  float* sX = sD + DEC_ANCH * 4;                    // [DEC_ANCH][px_p]: the Obb angle logit / the Pose keypoint outputs
   const int tid = threadIdx.x;
   const long r0 = (long)blockIdx.x * DEC_ANCH;
   const long rows = (long)B * A;
@@ -1000,6 +1002,18 @@ detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ 
       ys_unpack<T>(ys_ld16(ps + (r0 + r) * ld_ps + u * EPL), f);
 #pragma unroll
       for (int e = 0; e < EPL; e++) if (u * EPL + e < nc) sC[r * pc + u * EPL + e] = f[e];
+    }
+  }
+  if (xkind) {
+    const int ux = (nx + EPL - 1) / EPL;
+    for (int idx = tid; idx < DEC_ANCH * ux; idx += EW_THREADS) {
+      const int r = idx / ux, u = idx - r * ux;
+      if (r0 + r < rows) {
+        float f[EPL];
+        ys_unpack<T>(ys_ld16(px + (r0 + r) * ld_px + u * EPL), f);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) if (u * EPL + e < nx) sX[r * px_p + u * EPL + e] = f[e];
+      }
     }
   }
   __syncthreads();
@@ -1032,10 +1046,42 @@ detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ 
     const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
     float* o = pred + b * (long)pred_C * A + a;
     const float st = (float)ls;
-    o[0] = (x1 + x2) / 2.0f * st;
-    o[(long)A] = (y1 + y2) / 2.0f * st;
-    o[2 * (long)A] = (x2 - x1) * st;
-    o[3 * (long)A] = (y2 - y1) * st;
+    if (xkind == 2) {
+      // Obb (Head.cs:429,435-438): angle = (sigmoid(raw) - 0.25) * pi; boxes = dist2rbox (Tal.cs:389-408) * stride;
+      // the angle is appended after the class probabilities (Head.cs:411-418)
+      const float ang = (ys_sigmoid(sX[tid * px_p]) - 0.25f) * 3.14159265358979323846f;
+      const float cs = cosf(ang), sn = sinf(ang);
+      const float xf = (d[2] - d[0]) / 2.0f, yf = (d[3] - d[1]) / 2.0f;
+      o[0] = (xf * cs - yf * sn + ax) * st;
+      o[(long)A] = (xf * sn + yf * cs + ay) * st;
+      o[2 * (long)A] = (d[0] + d[2]) * st;
+      o[3 * (long)A] = (d[1] + d[3]) * st;
+      o[(long)(4 + nc) * A] = ang;
+    } else {
+      o[0] = (x1 + x2) / 2.0f * st;
+      o[(long)A] = (y1 + y2) / 2.0f * st;
+      o[2 * (long)A] = (x2 - x1) * st;
+      o[3 * (long)A] = (y2 - y1) * st;
+    }
+  }
+  if (xkind == 3) {   // Pose.kpts_decode (Head.cs:590-605): lane = anchor, the 4 waves stride over the keypoint channels
+    const int r = tid & (DEC_ANCH - 1);
+    if (r0 + r < rows) {
+      const long i = r0 + r;
+      const int a = (int)(i % A);
+      const long b = i / A;
+      int lo = o0, lw = w0, ls = s0;
+      if (nl > 1 && a >= o1) { lo = o1; lw = w1; ls = s1; }
+      if (nl > 2 && a >= o2) { lo = o2; lw = w2; ls = s2; }
+      const int cell = a - lo;
+      const float gx = (float)(cell % lw), gy = (float)(cell / lw), st = (float)ls;   // anchors - 0.5
+      float* o = pred + b * (long)pred_C * A + (long)(4 + nc) * A + a;
+      for (int c = tid / DEC_ANCH; c < nx; c += EW_THREADS / DEC_ANCH) {
+        const float v = sX[r * px_p + c];
+        const int k = c % kdim;
+        o[(long)c * A] = k == 0 ? (v * 2.0f + gx) * st : k == 1 ? (v * 2.0f + gy) * st : k == 2 && kdim == 3 ? ys_sigmoid(v) : v;
+      }
+    }
   }
   {   // class probabilities: lane = anchor, the 4 waves stride over the classes
     const int r = tid & (DEC_ANCH - 1);
@@ -1048,16 +1094,27 @@ detect_decode_kernel(const T* __restrict__ pd, int ld_pd, const T* __restrict__ 
     }
   }
 }
+__global__ void __launch_bounds__(EW_THREADS) obb_angle_kernel(float* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i < n) p[i] = (ys_sigmoid(p[i]) - 0.25f) * 3.14159265358979323846f;
+}
+int ys_obb_angle_launch(hipStream_t st, float* p, long n) {
+  if (n > 0) YS_LAUNCH(obb_angle_kernel, ys_cdiv(n, EW_THREADS), EW_THREADS, st, p, n);
+  return YS_OK;
+}
 int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
-                            int nc, int reg_max, int nl, const int* lo, const int* lw, const int* ls, float* pred, int pred_C) {
+                            int nc, int reg_max, int nl, const int* lo, const int* lw, const int* ls, float* pred, int pred_C,
+                            const void* px, int ld_px, int xkind, int nx, int kdim) {
   const long n = (long)B * A;
   const int o1 = nl > 1 ? lo[1] : 0, o2 = nl > 2 ? lo[2] : 0, w1 = nl > 1 ? lw[1] : 1, w2 = nl > 2 ? lw[2] : 1;
   const int s1 = nl > 1 ? ls[1] : 1, s2 = nl > 2 ? ls[2] : 1;
-  const size_t lds_bytes = (size_t)DEC_ANCH * ((4 * reg_max + 1) + (nc | 1) + 4) * 4;
+  if (!px) xkind = 0;
+  if (!xkind) nx = 0;
+  const size_t lds_bytes = (size_t)DEC_ANCH * ((4 * reg_max + 1) + (nc | 1) + 4 + (nx | 1)) * 4;
   if (lds_bytes > 60 * 1024 || DEC_ANCH * 4 > EW_THREADS) { ys_set_error("detect decode: nc=%d reg_max=%d too large", nc, reg_max); return YS_ERR_UNSUPPORTED; }
   if (dtype == YS_BF16)
-    YS_LAUNCH_LDS((detect_decode_kernel<bf16_t>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
+    YS_LAUNCH_LDS((detect_decode_kernel<bf16_t>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const bf16_t*)pd, ld_pd, (const bf16_t*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C, (const bf16_t*)px, ld_px, xkind, nx, kdim);
   else
-    YS_LAUNCH_LDS((detect_decode_kernel<float>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C);
+    YS_LAUNCH_LDS((detect_decode_kernel<float>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C, (const float*)px, ld_px, xkind, nx, kdim);
   return YS_OK;
 }

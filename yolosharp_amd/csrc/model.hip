@@ -33,6 +33,9 @@ struct ConvL {
   int cin = 0, cout = 0, k = 1, s = 1;
   int cin_pad = 0;       // channels of the input view (first layer: 3 -> EPL)
   int cout_ld = 0;       // channels incl. padding in the dgrad weight matrix / dy rows
+  int cout_real = 0;     // output channels of the reference module.  cout > cout_real only for the Pose towers (51 -> next 16-byte
+                         // multiple): the extra rows of every parameter stay zero, so the extra channels are exactly 0 in both BN modes,
+                         // receive zero gradients, and the state_dict surface lists the cout_real prefix
   bool bn = true, act = true;
   View in, out, res;
   bool has_res = false;
@@ -84,6 +87,8 @@ struct ys_model {
   float* attn_ws = nullptr; long n_attn = 0;   // softmax probabilities + dS of the C2PSA attention ops
   // segmentation (Head.cs:238-324): mask coefficients [B][A][ld_mc], prototypes [B][mh*mw][ld_pr]
   bool segment = false; int nm = 0, mc_buf = -1, pr_buf = -1, ld_mc = 0, ld_pr = 0, mh = 0, mw = 0;
+  // Obb (Head.cs:376-482) / Pose (Head.cs:484-606) reuse the cv4 output buffer: nm = ne (1) / nk (kpt_num * kpt_dim) channels
+  int xkind = 0, kdim = 3;       // 0 none, 1 mask coefficients, 2 angle logit, 3 keypoints (argument of ys_detect_decode_launch)
   float* masks_dev = nullptr; int *seg_cnt = nullptr, *seg_off = nullptr, *seg_list = nullptr; float *seg_ent = nullptr, *seg_part = nullptr;
   int n_items = 3; bool have_seg_loss = false;
   int dfl_after_conv = -1;   // the DFL weight registers right after Detect's cv2/cv3 (Head.cs:52-56), before Segment's proto/cv4
@@ -91,7 +96,7 @@ struct ys_model {
   bool is_block = false; int blk_out = -1, blk_c1 = 3, blk_c2 = 0;   // standalone block handle (ys_block_create)
   int ld_pd = 0, ld_ps = 0;
   // flat fp32 parameter state
-  long n_params = 0;
+  long n_params = 0, n_params_real = 0;          // flat length incl. the zero rows of padded towers / the reference's parameter count
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   float* state = nullptr; long n_state = 0;     // running_mean / running_var / num_batches_tracked
   float dfl_w[64];
@@ -170,6 +175,7 @@ int add_conv(ys_model* m, const std::string& name, View in, View out, int cin, i
   const int p = k / 2;
   c.Hout = (Hin + 2 * p - k) / s + 1; c.Wout = (Win + 2 * p - k) / s + 1;
   c.cout_ld = (cout + m->epl - 1) / m->epl * m->epl;
+  c.cout_real = cout;
   c.seg = seg;
   if (res) { c.res = *res; c.has_res = true; }
   c.idx = (int)m->convs.size();
@@ -372,6 +378,28 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4}, View{m->mc_buf, 0, nm}, c4, nm, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
     }
+    m->xkind = 1;
+  } else if (d.task == YS_OBB || d.task == YS_POSE) {
+    // Obb: ne = 1 angle logit per anchor (Head.cs:384-390); Pose: nk = kpt_num * kpt_dim outputs (Head.cs:492-499).  Both add
+    // only the cv4 towers (c4 = max(ch0/4, ne|nk)) after Detect's own modules
+    const bool obb = d.task == YS_OBB;
+    m->kdim = d.kpt_dim > 0 ? d.kpt_dim : 3;
+    const int nx = obb ? 1 : (d.kpt_num > 0 ? d.kpt_num : 17) * m->kdim;
+    if (!obb && m->kdim != 2 && m->kdim != 3) { ys_set_error("model: keypoint dim %d (2 or 3)", m->kdim); return YS_ERR_INVALID_ARG; }
+    m->nm = nx; m->xkind = obb ? 2 : 3;
+    const int c4 = std::max(ch[0] / 4, nx);                      // Pose n/s/m: 51, not a multiple of the 16-byte unit
+    const int c4p = (c4 + m->epl - 1) / m->epl * m->epl;         // tower buffers are padded; the pad channels stay zero
+    m->ld_mc = (nx + m->epl - 1) / m->epl * m->epl;
+    m->mc_buf = new_buf(m, 1, m->A, m->ld_mc);
+    for (int i = 0; i < 3; i++) {
+      const std::string tp = hp + ".cv4." + std::to_string(i);
+      const int t0 = new_buf(m, hh[i], ww[i], c4p), t1 = new_buf(m, hh[i], ww[i], c4p);
+      const int k0 = add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, c4p}, ch[i], c4p, 3, 1, true, true, hh[i], ww[i], seg);
+      const int k1 = add_conv_reg(m, tp + ".1", View{t0, 0, c4p}, View{t1, 0, c4p}, c4, c4p, 3, 1, true, true, hh[i], ww[i], seg);
+      m->convs[k0].cout_real = m->convs[k1].cout_real = c4;
+      const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4p}, View{m->mc_buf, 0, nx}, c4, nx, 1, 1, false, false, hh[i], ww[i], seg);
+      m->convs[cc].out_rowoff = m->lvl_off[i];
+    }
   }
   return YS_OK;
 }
@@ -571,6 +599,9 @@ int layout_params(ys_model* m) {
       m->seg_group[seg][grp] = {start, off - start};
     }
   m->n_params = off;
+  m->n_params_real = off;
+  for (auto& c : m->convs)
+    if (c.cout_real != c.cout) m->n_params_real -= (long)(c.cout - c.cout_real) * ((long)c.k * c.k * c.cin + (c.bn ? 2 : 1));
   long so = 0;
   for (auto& c : m->convs)
     if (c.bn) { c.rm_off = so; so += c.cout; c.rv_off = so; so += c.cout; c.nbt_off = so; so += 1; }
@@ -583,14 +614,14 @@ int layout_params(ys_model* m) {
   for (int i : reg2) {
     const ConvL& c = m->convs[i];
     if (c.bn) {
-      if (c.dw) add_tensor(m, c.name + ".conv.weight", 4, i, c.w_off, {c.cout, 1, 3, 3}, true);
-      else add_tensor(m, c.name + ".conv.weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
-      add_tensor(m, c.name + ".bn.weight", 1, i, c.g_off, {c.cout}, true);
-      add_tensor(m, c.name + ".bn.bias", 1, i, c.b_off, {c.cout}, true);
+      if (c.dw) add_tensor(m, c.name + ".conv.weight", 4, i, c.w_off, {c.cout_real, 1, 3, 3}, true);
+      else add_tensor(m, c.name + ".conv.weight", 0, i, c.w_off, {c.cout_real, c.cin, c.k, c.k}, true);
+      add_tensor(m, c.name + ".bn.weight", 1, i, c.g_off, {c.cout_real}, true);
+      add_tensor(m, c.name + ".bn.bias", 1, i, c.b_off, {c.cout_real}, true);
     } else {
       if (c.ct) add_tensor(m, c.name + ".weight", 5, i, c.w_off, {c.cin, c.cout, 2, 2}, true);   // ConvTranspose2d: [Cin][Cout][kh][kw]
-      else add_tensor(m, c.name + ".weight", 0, i, c.w_off, {c.cout, c.cin, c.k, c.k}, true);
-      add_tensor(m, c.name + ".bias", 1, i, c.g_off, {c.cout}, true);
+      else add_tensor(m, c.name + ".weight", 0, i, c.w_off, {c.cout_real, c.cin, c.k, c.k}, true);
+      add_tensor(m, c.name + ".bias", 1, i, c.g_off, {c.cout_real}, true);
     }
     if (i == m->dfl_after_conv)
       add_tensor(m, m->head_prefix + ".dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
@@ -598,8 +629,8 @@ int layout_params(ys_model* m) {
   for (int i : reg2) {
     const ConvL& c = m->convs[i];
     if (!c.bn) continue;
-    add_tensor(m, c.name + ".bn.running_mean", 2, i, c.rm_off, {c.cout}, false);
-    add_tensor(m, c.name + ".bn.running_var", 2, i, c.rv_off, {c.cout}, false);
+    add_tensor(m, c.name + ".bn.running_mean", 2, i, c.rm_off, {c.cout_real}, false);
+    add_tensor(m, c.name + ".bn.running_var", 2, i, c.rv_off, {c.cout_real}, false);
     add_tensor(m, c.name + ".bn.num_batches_tracked", 2, i, c.nbt_off, {1}, false);
   }
   return YS_OK;
@@ -1007,7 +1038,8 @@ int forward_impl(ys_model* m, int B) {
   if (m->f8) m->f8_sx_valid = true;        // every fp8 candidate has recorded an input maximum (bootstrap pass or its own kernel)
   if (!m->training && m->pd_buf >= 0) {
     YS_TRY(ys_detect_decode_launch(st, m->dtype, m->bufs[m->pd_buf].act, m->ld_pd, m->bufs[m->ps_buf].act, m->ld_ps, B, m->A,
-                                   m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred, 4 + m->d.nc + m->nm));
+                                   m->d.nc, m->d.reg_max, m->nl, m->lvl_off, m->lvl_w, m->lvl_stride, m->pred, 4 + m->d.nc + m->nm,
+                                   m->xkind >= 2 ? m->bufs[m->mc_buf].act : nullptr, m->ld_mc, m->xkind, m->nm, m->kdim));
     if (m->segment)   // Segment._inference: cat(preds, mask_coefficient) (Head.cs:309-313), raw coefficients
       YS_TRY(ys_unpack_nchw_strided_launch(st, m->dtype, m->bufs[m->mc_buf].act, m->ld_mc, 0, B, m->nm, m->A, m->pred,
                                            (long)(4 + m->d.nc + m->nm) * m->A, (long)(4 + m->d.nc) * m->A));
@@ -1275,8 +1307,8 @@ extern "C" {
 int ys_model_create(ys_ctx* ctx, const ys_model_desc* desc, ys_model** out) {
   YS_REQUIRE(ctx && desc && out, "ys_model_create: null argument");
   YS_REQUIRE(desc->dtype == YS_F32 || desc->dtype == YS_BF16 || desc->dtype == YS_FP8, "ys_model_create: dtype %d unsupported", desc->dtype);
-  if ((desc->family != YS_YOLOV8 && desc->family != YS_YOLOV11) || (desc->task != YS_DETECT && desc->task != YS_SEGMENT)) {
-    ys_set_error("ys_model_create: YOLOv8 / YOLOv11 detect and segment are built (family %d task %d)", desc->family, desc->task);
+  if ((desc->family != YS_YOLOV8 && desc->family != YS_YOLOV11) || desc->task < YS_DETECT || desc->task > YS_POSE) {
+    ys_set_error("ys_model_create: YOLOv8 / YOLOv11 detect, segment, obb and pose are built (family %d task %d)", desc->family, desc->task);
     return YS_ERR_UNSUPPORTED;
   }
   YS_REQUIRE(desc->size >= 0 && desc->size <= 4, "ys_model_create: size %d out of range", desc->size);
@@ -1323,7 +1355,7 @@ ys_ctx* ys_model_ctx(ys_model* m) { return m->ctx; }   // for dist.hip
 extern "C" {
 int ys_model_num_tensors(ys_model* m) { return m ? (int)m->tensors.size() : 0; }
 int ys_model_num_anchors(ys_model* m) { return m ? m->A : 0; }
-int64_t ys_model_num_params(ys_model* m) { return m ? (int64_t)m->n_params : 0; }
+int64_t ys_model_num_params(ys_model* m) { return m ? (int64_t)m->n_params_real : 0; }
 
 int ys_model_tensor_info(ys_model* m, int index, char* name, int name_cap, int32_t* ndim, int64_t shape[4], int32_t* is_param) {
   YS_REQUIRE(m && index >= 0 && index < (int)m->tensors.size(), "ys_model_tensor_info: index %d out of range", index);
@@ -1385,7 +1417,7 @@ static int tensor_io(ys_model* m, const char* name, float* host, size_t count, i
     const int taps = c.k * c.k;
     std::vector<float> tmp(count);
     if (what == 0) {
-      for (int co = 0; co < c.cout; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
+      for (int co = 0; co < c.cout_real; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
         tmp[((size_t)co * taps + tp) * c.cin + ci] = host[((size_t)co * c.cin + ci) * taps + tp];
       YS_CHECK_HIP(hipMemcpyAsync(dev, tmp.data(), count * 4, hipMemcpyHostToDevice, st));
       YS_CHECK_HIP(hipStreamSynchronize(st));
@@ -1393,7 +1425,7 @@ static int tensor_io(ys_model* m, const char* name, float* host, size_t count, i
     } else {
       YS_CHECK_HIP(hipMemcpyAsync(tmp.data(), dev, count * 4, hipMemcpyDeviceToHost, st));
       YS_CHECK_HIP(hipStreamSynchronize(st));
-      for (int co = 0; co < c.cout; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
+      for (int co = 0; co < c.cout_real; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
         host[((size_t)co * c.cin + ci) * taps + tp] = tmp[((size_t)co * taps + tp) * c.cin + ci];
     }
   } else {
@@ -1415,12 +1447,13 @@ int ys_model_init_weights(ys_model* m, uint64_t seed) {
   for (const auto& c : m->convs) {
     const long nw = c.dw ? (long)c.cout * 9 : c.ct ? 4L * c.cout * c.cin : (long)c.cout * c.k * c.k * c.cin;
     const float bound = c.ct ? 1.0f / sqrtf((float)(c.cout * 4)) : 1.0f / sqrtf((float)((c.dw ? 1 : c.cin) * c.k * c.k));   // kaiming_uniform(a=sqrt 5): 1/sqrt(fan_in)
-    for (long i = 0; i < nw; i++) p[c.w_off + i] = rng.uni(bound);
+    const long nwr = c.cout_real == c.cout ? nw : (long)c.cout_real * c.k * c.k * c.cin;   // padded rows stay zero
+    for (long i = 0; i < nwr; i++) p[c.w_off + i] = rng.uni(bound);
     if (c.bn) {
       for (int i = 0; i < c.cout; i++) { p[c.g_off + i] = 1.f; p[c.b_off + i] = 0.f; s[c.rm_off + i] = 0.f; s[c.rv_off + i] = 1.f; }
       s[c.nbt_off] = 0.f;
     } else {
-      for (int i = 0; i < c.cout; i++) p[c.g_off + i] = rng.uni(bound);   // Conv2d bias: U(-1/sqrt(fan_in), +)
+      for (int i = 0; i < c.cout_real; i++) p[c.g_off + i] = rng.uni(bound);   // Conv2d bias: U(-1/sqrt(fan_in), +)
     }
   }
   hipStream_t st = m->ctx->stream;
@@ -1519,6 +1552,13 @@ int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count)
     const Buf& b = m->bufs[m->pr_buf];
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, g ? b.grad : b.act, b.ldc, 0, B, m->nm, np, m->out_stage));
     YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
+  } else if ((m->xkind == 2 && k == "angle") || (m->xkind == 3 && k == "kpts")) {
+    // Obb.forward_head: angle = (sigmoid(cat cv4) - 0.25) * pi [B][ne][A] (Head.cs:421-433); Pose.forward_head: raw kpts [B][nk][A] (:531-543)
+    YS_REQUIRE(count == (size_t)B * m->nm * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * m->nm * m->A);
+    const Buf& b = m->bufs[m->mc_buf];
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, b.act, b.ldc, 0, B, m->nm, m->A, m->out_stage));
+    if (m->xkind == 2) YS_TRY(ys_obb_angle_launch(st, m->out_stage, (long)count));
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
   } else if (k == "pred") {
     const size_t pc = (size_t)(4 + m->d.nc + m->nm);
     YS_REQUIRE(!m->training, "ys_model_get_output(pred): model is in training mode (Detect returns preds only, Head.cs:103-106)");
@@ -1578,6 +1618,10 @@ int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const 
   // Training forward -> the criterion feeds backward (Amp.cs:338-348).  Eval forward -> validation loss on the eval-mode preds
   // (Detector.cs:94-97): the head logits are produced in both modes; only backward needs the training-mode state.
   YS_REQUIRE(!m->is_block && m->have_fwd, "ys_loss_detect: needs a forward of a full model first");
+  if (m->xkind >= 2) {   // v8OBBLoss (Loss.cs:486-684) / v8PoseLoss (Loss.cs:870-1071): the detection criterion is not their criterion
+    ys_set_error("ys_loss_detect: the %s criterion is not built (forward / predict only)", m->xkind == 2 ? "OBB" : "Pose");
+    return YS_ERR_UNSUPPORTED;
+  }
   YS_REQUIRE(n >= 0, "ys_loss_detect: n_labels = %d", n);
   YS_REQUIRE(n == 0 || (batch_idx && cls && bboxes), "ys_loss_detect: null label arrays");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));

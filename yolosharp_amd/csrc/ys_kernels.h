@@ -225,7 +225,10 @@ size_t ys_loss_partial_floats(int B, int A);
 // ---- decode (Head.cs:204-223)
 int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd, const void* ps, int ld_ps, int B, int A,
                             int nc, int reg_max, int nl, const int* lvl_off, const int* lvl_w, const int* lvl_stride,
-                            float* pred, int pred_C);
+                            float* pred, int pred_C, const void* px, int ld_px, int xkind, int nx, int kdim);
+// xkind 2: Obb decode (dist2rbox with the angle logit px[.][0], Head.cs:435-438, Tal.cs:389-408); 3: Pose.kpts_decode of the nx
+// keypoint outputs (Head.cs:590-605); 0/1: plain Detect decode.  In place (sigmoid(p) - 0.25) * pi (Head.cs:429):
+int ys_obb_angle_launch(hipStream_t st, float* p, long n);
 int ys_unpack_nchw_strided_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, int B, int C, long rpb, float* y,
                                   long y_bstride, long y_off);
 // ---- segloss.hip

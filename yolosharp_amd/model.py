@@ -21,15 +21,18 @@ DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "float8": 
 
 class Yolov8:
     FAMILY = 8          # ys_family: Models/Yolo.cs:10-135
-    TASK = 0            # ys_task: 0 detect, 1 segment
-    NM = 0              # mask coefficients per anchor (Segment heads: 32)
+    TASK = 0            # ys_task: 0 detect, 1 segment, 2 obb, 3 pose
+    NM = 0              # extra outputs per anchor after the class scores (Segment: 32 mask coefficients, Obb: 1 angle, Pose: nk)
 
     def __init__(self, engine: Engine, nc=80, reg_max=16, size="n", height=640, width=640, max_batch=1, dtype="bf16",
-                 max_labels=0):
+                 max_labels=0, kpt_num=17, kpt_dim=3):
         self.engine, self.lib = engine, engine.lib
         self.nc, self.reg_max, self.height, self.width, self.max_batch = nc, reg_max, height, width, max_batch
         self.dtype = dtype
-        desc = _lib.ModelDesc(self.FAMILY, SIZES[size], self.TASK, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels)
+        if self.TASK == 3:
+            self.kpt_num, self.kpt_dim, self.NM = kpt_num, kpt_dim, kpt_num * kpt_dim
+        desc = _lib.ModelDesc(self.FAMILY, SIZES[size], self.TASK, nc, reg_max, height, width, max_batch, DTYPES[dtype], max_labels,
+                              kpt_num if self.TASK == 3 else 0, kpt_dim if self.TASK == 3 else 0)
         self.handle = C.c_void_p()
         _lib.check(self.lib, self.lib.ys_model_create(engine.ctx, C.byref(desc), C.byref(self.handle)))
         self.training = True
@@ -143,7 +146,7 @@ class Yolov8:
     def get_output(self, key):
         B = self._batch
         C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc + self.NM, "dboxes": 4 * self.reg_max,
-              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM}.get(key)
+              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM, "angle": self.NM, "kpts": self.NM}.get(key)
         if key in ("proto", "dproto"):
             a = np.empty((B, self.NM, self.height // 4, self.width // 4), np.float32)
         else:
@@ -244,6 +247,53 @@ class Yolov8Segment(_SegmentMixin, Yolov8):
 
 class Yolov11Segment(_SegmentMixin, Yolov11):
     """Models/Yolo.cs:354-370."""
+
+
+class _ObbMixin:
+    """Head.Obb (Head.cs:376-482): preds gain "angle" [B,1,A] = (sigmoid(cv4) - 0.25) * pi; the eval inference tensor is
+    [B, 4+nc+1, A] = (xywh of dist2rbox * stride, class probabilities, angle) (Head.cs:411-418), the layout
+    Engine.non_max_suppression(rotated=True) reads.  Forward / predict only: v8OBBLoss (Loss.cs:486-684) is not built."""
+    TASK = 2
+    NM = 1
+
+    def forward(self, x, fetch=True):
+        inf, preds = Yolov8.forward(self, x, fetch)
+        if fetch:
+            preds["angle"] = self.get_output("angle")
+        return inf, preds
+
+    __call__ = forward
+
+
+class _PoseMixin:
+    """Head.Pose (Head.cs:484-606): preds gain the raw "kpts" [B,nk,A]; the eval inference tensor is [B, 4+nc+nk, A] with
+    kpts_decode applied (Head.cs:590-605).  Forward / predict only: v8PoseLoss (Loss.cs:870-1071) is not built."""
+    TASK = 3
+    NM = 51
+
+    def forward(self, x, fetch=True):
+        inf, preds = Yolov8.forward(self, x, fetch)
+        if fetch:
+            preds["kpts"] = self.get_output("kpts")
+        return inf, preds
+
+    __call__ = forward
+
+
+class Yolov8Obb(_ObbMixin, Yolov8):
+    """Models/Yolo.cs:406-420."""
+
+
+class Yolov11Obb(_ObbMixin, Yolov11):
+    """Models/Yolo.cs:422-436."""
+
+
+class Yolov8Pose(_PoseMixin, Yolov8):
+    """Models/Yolo.cs:470-484."""
+
+
+class Yolov11Pose(_PoseMixin, Yolov11):
+    """Models/Yolo.cs:486-500."""
 
 
 class v8DetectionLoss:
