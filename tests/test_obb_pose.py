@@ -1,5 +1,6 @@
 """Obb / Pose heads: the cv4 towers, dist2rbox / kpts_decode and the rotated predict path.
-Oracle = oracle/yolo_oracle.py (Head.cs:376-606, Tal.cs:389-408).  fp32 tolerance 1e-3; forward / predict only."""
+Oracle = oracle/yolo_oracle.py (Head.cs:376-606, Tal.cs:389-408, Loss.cs:870-1071).  fp32 tolerance 1e-3.  OBB is forward /
+predict only; Pose also has its criterion (v8PoseLoss) and the full backward."""
 import numpy as np
 import pytest
 import torch
@@ -94,6 +95,13 @@ def test_criterion_is_refused(backend, engine):
     with pytest.raises(YsError, match="OBB criterion is not built"):
         v8DetectionLoss(m)(None, batch)
     m.close()
+    from yolosharp_amd.model import Yolov8Pose
+    m = Yolov8Pose(engine, nc=1, size="n", height=32, width=32, max_batch=1, dtype="f32")
+    m.init_weights(1)
+    m.forward(np.zeros((1, 3, 32, 32), np.float32), fetch=False)
+    with pytest.raises(YsError, match="ys_loss_pose"):                 # a Pose model never trains on the detection criterion alone
+        v8DetectionLoss(m)(None, batch)
+    m.close()
 
 
 @pytest.mark.gpu
@@ -145,4 +153,119 @@ def test_obb_predict_rotated_nms(backend, engine):
     for g, w, gk, wk in zip(got, want, gkeep, wkeep):
         assert np.array_equal(gk, wk.numpy())
         assert g.shape == tuple(w.shape) and np.allclose(g, w.numpy(), rtol=1e-3, atol=1e-3)
+    m.close()
+
+
+# ----------------------------------------------------------------------------- v8PoseLoss (Loss.cs:870-1071) + backward
+def _pose_train_parity(engine, family, size, B, H, W, tol, tol_grad, kpt_num=17, kpt_dim=3, nc=1, kmax=6):
+    from yolosharp_amd import model as M
+    name = f"Yolov{family}Pose"
+    ref = make_ref(getattr(O, name), nc, size, kpt_num=kpt_num, kpt_dim=kpt_dim)
+    m = _load(engine, ref, getattr(M, name), nc, size, B, H, W, kpt_num=kpt_num, kpt_dim=kpt_dim)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3))
+    batch = O.synthetic_batch(B, H, W, nc, seed=1, kmax=kmax)
+    batch["keypoints"] = O.synthetic_keypoints(batch, kpt_num, kpt_dim)
+    nb = {k: v.numpy() for k, v in batch.items()}
+    m.train(); ref.train()
+    _, preds = m.forward(x.numpy())
+    _, rpreds = ref(x)
+    assert relerr(preds["kpts"], rpreds["kpts"].detach()) < tol
+    rpreds["kpts"].retain_grad()
+    loss, items = M.v8PoseLoss(m)(None, nb)
+    rloss, ritems = O.v8PoseLoss(nc, kpt_num, kpt_dim)(rpreds, batch)
+    assert items.shape == (5,) and float(ritems[1]) > 0 and (kpt_dim == 2 or float(ritems[2]) > 0)
+    assert np.allclose(items, ritems.numpy(), rtol=1e-3, atol=1e-5), (items, ritems)
+    assert np.allclose(loss, rloss.detach().numpy(), rtol=1e-3, atol=1e-4)
+    rloss.sum().backward()
+    r = rpreds["kpts"].grad.numpy()
+    g = m.get_output("dkpts")
+    assert np.abs(r).max() > 0 and np.abs(g - r).max() <= tol_grad * np.abs(r).max()
+    m.zero_grad(); m.backward()
+    grads = m.grads()
+    gscale = max(float(p.grad.abs().max()) for _, p in ref.named_parameters() if p.grad is not None)
+    for pname, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        r = p.grad.numpy()
+        assert np.abs(grads[pname] - r).max() <= tol_grad * np.abs(r).max() + 1e-6 * gscale, pname
+    return m, ref
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_yolov8n_pose_loss_backward_f32(backend, engine):
+    """COCO layout (17 x 3, OKS sigmas); the n model's cv4 towers are 51 wide -> padded inside, gradients listed for the 51 rows."""
+    m, _ = _pose_train_parity(engine, 8, "n", 2, 64, 64, 1e-3, 2e-3)
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_pose_loss_two_dim_keypoints_from_preds(backend, engine):
+    """kpt_dim = 2 (no visibility term, sigmas = 1/K, Loss.cs:905,1051,1062) on caller-supplied preds (Loss.cs:411)."""
+    from yolosharp_amd.model import Yolov8Pose, v8PoseLoss
+    nc, K, D, B, H, W = 2, 5, 2, 2, 64, 64
+    m = Yolov8Pose(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32", kpt_num=K, kpt_dim=D)
+    A = m.A
+    g = torch.Generator().manual_seed(11)
+    rp = {"boxes": torch.randn(B, 64, A, generator=g), "scores": torch.randn(B, nc, A, generator=g) - 2.0,
+          "kpts": (torch.randn(B, K * D, A, generator=g) * 0.5).requires_grad_(True),
+          "feats": [torch.zeros(B, 1, H // s, W // s) for s in (8, 16, 32)]}
+    batch = O.synthetic_batch(B, H, W, nc, seed=4, kmax=5)
+    batch["keypoints"] = O.synthetic_keypoints(batch, K, D)
+    m.set_preds({k: v.detach().numpy() for k, v in rp.items() if k != "feats"})
+    loss, items = v8PoseLoss(m)(None, {k: v.numpy() for k, v in batch.items()})
+    rloss, ritems = O.v8PoseLoss(nc, K, D)(rp, batch)
+    assert float(ritems[1]) > 0 and float(ritems[2]) == 0 and items[2] == 0
+    assert np.allclose(items, ritems.numpy(), rtol=1e-3, atol=1e-5), (items, ritems)
+    rloss.sum().backward()
+    r = rp["kpts"].grad.numpy()
+    assert np.abs(m.get_output("dkpts") - r).max() <= 1e-3 * np.abs(r).max()
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_pose_loss_without_labels(backend, engine):
+    """No foreground anchor: pose = kobj = 0, zero keypoint gradients (the `fg_mask.sum() > 0` guard, Loss.cs:945)."""
+    from yolosharp_amd.model import Yolov8Pose, v8PoseLoss
+    m = Yolov8Pose(engine, nc=1, size="n", height=32, width=32, max_batch=1, dtype="f32")
+    m.init_weights(3)
+    m.forward(np.random.default_rng(0).random((1, 3, 32, 32), np.float32), fetch=False)
+    e = np.zeros((0,), np.float32)
+    loss, items = v8PoseLoss(m)(None, {"batch_idx": e, "cls": e, "bboxes": e.reshape(0, 4), "keypoints": np.zeros((0, 17, 3), np.float32)})
+    assert items[1] == 0 and items[2] == 0 and items[3] > 0
+    assert not m.get_output("dkpts").any()
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_yolov11s_pose_loss_backward_full_resolution_f32(backend, engine):
+    m, _ = _pose_train_parity(engine, 11, "s", 2, 640, 640, 1e-3, 2e-3, kmax=12)
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_yolov8s_pose_bf16_train_steps(backend, engine):
+    """bf16 training steps of a Pose model: finite items, keypoint terms of the first step near the fp32 oracle's, loss decreasing."""
+    from yolosharp_amd.model import Yolov8Pose, v8PoseLoss, AMPWrapper
+    nc, B, H, W = 1, 4, 320, 320
+    ref = make_ref(O.Yolov8Pose, nc, "s")
+    m = _load(engine, ref, Yolov8Pose, nc, "s", B, H, W, dtype="bf16")
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3))
+    batch = O.synthetic_batch(B, H, W, nc, seed=1, kmax=6)
+    batch["keypoints"] = O.synthetic_keypoints(batch)
+    nb = {k: v.numpy() for k, v in batch.items()}
+    ref.train()
+    _, rpreds = ref(x)
+    _, ritems = O.v8PoseLoss(nc)(rpreds, batch)
+    amp = AMPWrapper(m, lr=2e-3)
+    crit = v8PoseLoss(m)
+    hist = []
+    for _ in range(6):
+        loss, items = amp.TrainStep(x.numpy(), nb, crit)
+        assert np.isfinite(items).all()
+        hist.append(float(loss.sum()))
+    first = hist[0] / B
+    assert abs(first - float(ritems.sum())) < 0.1 * float(ritems.sum())
+    assert hist[-1] < hist[0]
     m.close()

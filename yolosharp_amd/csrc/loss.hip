@@ -117,6 +117,7 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
     gb[0] = cx - w / 2; gb[1] = cy - h / 2; gb[2] = cx + w / 2; gb[3] = cy + h / 2;  // Ops.cs:76-79
     a.gt_cls[(long)b * a.gcap + slot] = (int)a.cls[i];
     gt_valid[(long)b * a.gcap + slot] = (gb[0] + gb[1] + gb[2] + gb[3]) > 0.0f ? 1 : 0;  // Loss.cs:431
+    gt_valid[(long)a.B * a.gcap + (long)b * a.gcap + slot] = i;   // gt_src: the label row of this slot (keypoints of v8PoseLoss, Loss.cs:1001-1005)
   }
   __syncthreads();
   // The reference pads to the batch's true per-image maximum (Loss.cs:363-390); a fixed-capacity workspace must never drop

@@ -88,6 +88,7 @@ struct ys_model {
   // segmentation (Head.cs:238-324): mask coefficients [B][A][ld_mc], prototypes [B][mh*mw][ld_pr]
   bool segment = false; int nm = 0, mc_buf = -1, pr_buf = -1, ld_mc = 0, ld_pr = 0, mh = 0, mw = 0;
   // Obb (Head.cs:376-482) / Pose (Head.cs:484-606) reuse the cv4 output buffer: nm = ne (1) / nk (kpt_num * kpt_dim) channels
+  float* kp_dev = nullptr;       // Pose: staged keypoint labels [max_labels][K][D] (grows with the label workspace)
   int xkind = 0, kdim = 3;       // 0 none, 1 mask coefficients, 2 angle logit, 3 keypoints (argument of ys_detect_decode_launch)
   float* masks_dev = nullptr; int *seg_cnt = nullptr, *seg_off = nullptr, *seg_list = nullptr; float *seg_ent = nullptr, *seg_part = nullptr;
   int n_items = 3; bool have_seg_loss = false;
@@ -387,6 +388,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
     const int nx = obb ? 1 : (d.kpt_num > 0 ? d.kpt_num : 17) * m->kdim;
     if (!obb && m->kdim != 2 && m->kdim != 3) { ys_set_error("model: keypoint dim %d (2 or 3)", m->kdim); return YS_ERR_INVALID_ARG; }
     m->nm = nx; m->xkind = obb ? 2 : 3;
+    if (!obb) m->n_items = 5;      // v8PoseLoss items: box, pose, kobj, cls, dfl (Loss.cs:923)
     const int c4 = std::max(ch[0] / 4, nx);                      // Pose n/s/m: 51, not a multiple of the 16-byte unit
     const int c4p = (c4 + m->epl - 1) / m->epl * m->epl;         // tower buffers are padded; the pad channels stay zero
     m->ld_mc = (nx + m->epl - 1) / m->epl * m->epl;
@@ -672,7 +674,7 @@ weight_prep_all_kernel(const float* __restrict__ params, const PrepDesc* __restr
         ci = (int)(r / d.taps);
         tap = d.taps - 1 - tapf;
       }
-      const T tv = Elem<T>::from_f(co < d.cout ? params[d.w_off + ((long)co * d.taps + tap) * d.cin_real + ci] : 0.f);
+      const T tv = Elem<T>::from_f(co < d.cout && ci < d.cin_real ? params[d.w_off + ((long)co * d.taps + tap) * d.cin_real + ci] : 0.f);
       wd_all[d.wd_off + e] = tv;
       if (wd8_all) { const float aw = amax_w[lo]; wd8_all[d.wd_off + e] = ys_f32_to_e4m3_dev(Elem<T>::to_f(tv) * (aw > 0.f ? YS_E4M3_MAX / aw : 1.0f)); }
     }
@@ -705,11 +707,11 @@ void dev_free_tracked(ys_model* m, void* p) {
 // Loss.cs:363-390, without a cap): raw label staging, padded GT arrays and the [B][gcap][A] assignment matrices.
 int alloc_label_ws(ys_model* m, int gcap) {
   const int B = m->maxB;
-  void* old[] = {m->lab_bidx, m->lab_cls, m->lab_box, m->gt_count, m->gt_box, m->gt_cls, m->ov, m->align, m->mpos, m->pos_align, m->pos_ov};
+  void* old[] = {m->lab_bidx, m->lab_cls, m->lab_box, m->gt_count, m->gt_box, m->gt_cls, m->ov, m->align, m->mpos, m->pos_align, m->pos_ov, m->kp_dev};
   if (m->lab_bidx) YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
   for (void* p : old) dev_free_tracked(m, p);
   m->lab_bidx = m->lab_cls = m->lab_box = nullptr; m->gt_count = nullptr; m->gt_box = nullptr; m->gt_cls = nullptr;
-  m->ov = m->align = nullptr; m->mpos = nullptr; m->pos_align = m->pos_ov = nullptr;
+  m->ov = m->align = nullptr; m->mpos = nullptr; m->pos_align = m->pos_ov = nullptr; m->kp_dev = nullptr;
   m->gcap = gcap;
   m->max_labels = gcap * B;
   const size_t GA = (size_t)B * gcap * m->A;
@@ -718,12 +720,13 @@ int alloc_label_ws(ys_model* m, int gcap) {
   YS_TRY(dev_alloc(m, (void**)&m->lab_box, (size_t)m->max_labels * 16));
   YS_TRY(dev_alloc(m, (void**)&m->gt_count, (size_t)B * 4));
   YS_TRY(dev_alloc(m, (void**)&m->gt_box, (size_t)B * gcap * 16));
-  YS_TRY(dev_alloc(m, (void**)&m->gt_cls, (size_t)B * gcap * 8));   // gt_cls + gt_valid
+  YS_TRY(dev_alloc(m, (void**)&m->gt_cls, (size_t)B * gcap * 12));  // gt_cls + gt_valid + gt_src
   YS_TRY(dev_alloc(m, (void**)&m->ov, GA * 4));
   YS_TRY(dev_alloc(m, (void**)&m->align, GA * 4));
   YS_TRY(dev_alloc(m, (void**)&m->mpos, GA));
   YS_TRY(dev_alloc(m, (void**)&m->pos_align, (size_t)B * gcap * 4));
   YS_TRY(dev_alloc(m, (void**)&m->pos_ov, (size_t)B * gcap * 4));
+  if (m->xkind == 3) YS_TRY(dev_alloc(m, (void**)&m->kp_dev, (size_t)m->max_labels * m->nm * 4));
   return YS_OK;
 }
 
@@ -795,7 +798,7 @@ int allocate(ys_model* m) {
       d.phase = (!c.ct && ys_conv_dgrad_uses_phases(m->dtype, c.k, c.s)) ? 1 : 0;
       d.nf_start = nf; d.nd_start = nd;
       nf += (long)c.cout * taps * c.cin_pad;
-      if (!c.first) nd += (long)c.cin * taps * c.cout_ld;
+      if (!c.first) nd += (long)c.cin_pad * taps * c.cout_ld;   // cin_pad > cin (Pose towers): zero rows -> zero input-gradient pad channels
       pd.push_back(d);
     }
     const long M = (long)B * c.Hout * c.Wout;
@@ -858,6 +861,12 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->pred, (size_t)B * (4 + d.nc + m->nm) * m->A * 4));
   m->n_out_stage = std::max((long)B * m->A * std::max(std::max(m->ld_pd, m->ld_ps), 4 + d.nc + m->nm), (long)B * m->mh * m->mw * std::max(m->ld_pr, 1));
   if (m->is_block) { const Buf& ob = m->bufs[m->blk_out]; m->n_out_stage = std::max(m->n_out_stage, (long)B * ob.rows_per_b * ob.ldc); }
+  if (m->xkind == 3) {   // v8PoseLoss: foreground list + per-workgroup partials
+    YS_TRY(dev_alloc(m, (void**)&m->seg_cnt, (size_t)B * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_off, (size_t)(B + 1) * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_list, (size_t)B * m->A * 4));
+    YS_TRY(dev_alloc(m, (void**)&m->seg_part, (size_t)2 * ys_loss_pose_grid(B, m->A) * 4));
+  }
   if (m->segment) {
     YS_TRY(dev_alloc(m, (void**)&m->masks_dev, (size_t)B * m->mh * m->mw * 4));
     YS_TRY(dev_alloc(m, (void**)&m->seg_cnt, (size_t)B * 4));
@@ -1109,7 +1118,7 @@ static ConvArgs dgrad_args(ys_model* m, const ConvL& c, int B, const void* dy, i
   ConvArgs a{};
   a.x = dy; a.w = (char*)m->wd_all + (size_t)c.wd_off * m->es;
   a.y = ib.grad;
-  a.B = B; a.Hin = c.Hout; a.Win = c.Wout; a.Cin = c.cout_ld; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cin; a.KH = a.KW = c.k;
+  a.B = B; a.Hin = c.Hout; a.Win = c.Wout; a.Cin = c.cout_ld; a.Hout = c.Hin; a.Wout = c.Win; a.Cout = c.cin_pad; a.KH = a.KW = c.k;
   a.SA = 1; a.DIVS = c.s == 2 ? 1 : 0; a.DIVM = c.s - 1; a.PAD = c.k - 1 - c.k / 2;
   a.in_ldc = dy_ldc; a.in_coff = dy_coff; a.in_bstride = dy_bstride;
   a.out_ldc = ib.ldc; a.out_coff = c.in.coff; a.out_bstride = ib.rows_per_b;
@@ -1286,6 +1295,7 @@ void reset_grad_state(ys_model* m) {
     std::fill(m->bufs[m->mc_buf].gw.begin(), m->bufs[m->mc_buf].gw.end(), 1);
     std::fill(m->bufs[m->pr_buf].gw.begin(), m->bufs[m->pr_buf].gw.end(), 1);
   }
+  if (m->xkind == 3) std::fill(m->bufs[m->mc_buf].gw.begin(), m->bufs[m->mc_buf].gw.end(), 1);   // keypoint gradients (poseloss.hip)
 }
 
 TensorRec* find_tensor(ys_model* m, const char* name) {
@@ -1552,6 +1562,12 @@ int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count)
     const Buf& b = m->bufs[m->pr_buf];
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, g ? b.grad : b.act, b.ldc, 0, B, m->nm, np, m->out_stage));
     YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
+  } else if (m->xkind == 3 && k == "dkpts") {                                           // d(sum(loss * B)) / d(raw kpts) [B][nk][A]
+    YS_REQUIRE(m->have_seg_loss, "ys_model_get_output(dkpts): no pose loss has run");
+    YS_REQUIRE(count == (size_t)B * m->nm * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * m->nm * m->A);
+    const Buf& b = m->bufs[m->mc_buf];
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, b.grad, b.ldc, 0, B, m->nm, m->A, m->out_stage));
+    YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
   } else if ((m->xkind == 2 && k == "angle") || (m->xkind == 3 && k == "kpts")) {
     // Obb.forward_head: angle = (sigmoid(cat cv4) - 0.25) * pi [B][ne][A] (Head.cs:421-433); Pose.forward_head: raw kpts [B][nk][A] (:531-543)
     YS_REQUIRE(count == (size_t)B * m->nm * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * m->nm * m->A);
@@ -1580,11 +1596,12 @@ int ys_model_set_preds(ys_model* m, int batch, const float* boxes, const float* 
   YS_REQUIRE(m && !m->is_block && boxes && scores, "ys_model_set_preds: null argument or block handle");
   YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_set_preds: batch %d outside (0, %d]", batch, m->maxB);
   YS_REQUIRE(!m->segment || (mask_coefficient && proto), "ys_model_set_preds: a Segment model needs mask_coefficient and proto");
+  YS_REQUIRE(m->xkind != 3 || mask_coefficient, "ys_model_set_preds: a Pose model takes its raw kpts [B,nk,A] in the mask_coefficient argument");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   struct Item { const float* src; int buf; int C; long rows; } items[4] = {
     {boxes, m->pd_buf, 4 * m->d.reg_max, m->A}, {scores, m->ps_buf, m->d.nc, m->A},
-    {m->segment ? mask_coefficient : nullptr, m->mc_buf, m->nm, m->A}, {m->segment ? proto : nullptr, m->pr_buf, m->nm, (long)m->mh * m->mw}};
+    {m->segment || m->xkind == 3 ? mask_coefficient : nullptr, m->mc_buf, m->nm, m->A}, {m->segment ? proto : nullptr, m->pr_buf, m->nm, (long)m->mh * m->mw}};
   for (const Item& it : items) {
     if (!it.src) continue;
     const Buf& b = m->bufs[it.buf];
@@ -1613,15 +1630,22 @@ int ys_model_reserve_labels(ys_model* m, int per_image) {
   return alloc_label_ws(m, (per_image + 15) / 16 * 16);
 }
 
+static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device, bool aux_follows);
+
 int ys_loss_detect(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device) {
+  return loss_detect_core(m, batch_idx, cls, bboxes, n, on_device, false);
+}
+
+static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device, bool aux_follows) {
   YS_REQUIRE(m, "null model");
   // Training forward -> the criterion feeds backward (Amp.cs:338-348).  Eval forward -> validation loss on the eval-mode preds
   // (Detector.cs:94-97): the head logits are produced in both modes; only backward needs the training-mode state.
   YS_REQUIRE(!m->is_block && m->have_fwd, "ys_loss_detect: needs a forward of a full model first");
-  if (m->xkind >= 2) {   // v8OBBLoss (Loss.cs:486-684) / v8PoseLoss (Loss.cs:870-1071): the detection criterion is not their criterion
-    ys_set_error("ys_loss_detect: the %s criterion is not built (forward / predict only)", m->xkind == 2 ? "OBB" : "Pose");
+  if (m->xkind == 2) {   // v8OBBLoss (Loss.cs:486-684): rotated assigner + probiou loss, not the detection criterion
+    ys_set_error("ys_loss_detect: the OBB criterion is not built (forward / predict only)");
     return YS_ERR_UNSUPPORTED;
   }
+  YS_REQUIRE(m->xkind != 3 || aux_follows, "ys_loss_detect: a Pose model's criterion is ys_loss_pose (keypoint terms, Loss.cs:870-1071)");
   YS_REQUIRE(n >= 0, "ys_loss_detect: n_labels = %d", n);
   YS_REQUIRE(n == 0 || (batch_idx && cls && bboxes), "ys_loss_detect: null label arrays");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -1680,6 +1704,39 @@ int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls, const
   return YS_OK;
 }
 
+// v8PoseLoss (Loss.cs:870-1071): detection part + assignment (loss.hip), then the keypoint terms (poseloss.hip).
+// keypoints: fp32 [n][kpt_num][kpt_dim] normalised to the image like bboxes (x, y[, visibility]); row i belongs to label i.
+int ys_loss_pose(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, const float* keypoints, int on_device) {
+  YS_REQUIRE(m && m->xkind == 3, "ys_loss_pose: model has no Pose head");
+  YS_REQUIRE(n == 0 || keypoints, "ys_loss_pose: null keypoints");
+  YS_TRY(loss_detect_core(m, batch_idx, cls, bboxes, n, on_device, true));
+  m->have_loss = false;
+  hipStream_t st = m->ctx->stream;
+  const float* kp = keypoints;
+  if (!on_device && n > 0) {
+    YS_REQUIRE(n <= m->max_labels, "ys_loss_pose: %d labels exceed the staging capacity %d", n, m->max_labels);
+    YS_CHECK_HIP(hipMemcpyAsync(m->kp_dev, keypoints, (size_t)n * m->nm * 4, hipMemcpyHostToDevice, st));
+    kp = m->kp_dev;
+  }
+  YsTimer timer(m->ctx, "loss_pose");
+  const Buf& kb = m->bufs[m->mc_buf];
+  PoseArgs a{};
+  a.kp = kb.act; a.dkp = kb.grad; a.ld = m->ld_mc; a.fg_gt = m->fg_gt; a.gt_box = m->gt_box;
+  a.gt_src = m->gt_cls + 2L * m->B * m->gcap;
+  a.keypoints = kp; a.part = m->seg_part; a.scalars = m->scalars;
+  a.B = m->B; a.A = m->A; a.K = m->nm / m->kdim; a.D = m->kdim; a.gcap = m->gcap; a.H = m->d.height; a.W = m->d.width; a.nl = m->nl;
+  for (int i = 0; i < 4; i++) { a.lvl_off[i] = m->lvl_off[i]; a.lvl_w[i] = m->lvl_w[i]; a.lvl_stride[i] = m->lvl_stride[i]; }
+  a.hyp_pose = 12.0f; a.hyp_kobj = 1.0f;                                                  // Loss.cs:896
+  static const float oks[17] = {0.026f, 0.025f, 0.025f, 0.035f, 0.035f, 0.079f, 0.079f, 0.072f, 0.072f, 0.062f, 0.062f, 0.107f, 0.107f,
+                                0.087f, 0.087f, 0.089f, 0.089f};                          // OKS_SIGMA (Loss.cs:9-16)
+  const bool coco = a.K == 17 && a.D == 3;                                                // Loss.cs:903-905
+  for (int k = 0; k < a.K && k < YS_POSE_KMAX; k++) a.sigma[k] = coco ? oks[k] : 1.0f / (float)a.K;
+  YS_TRY(ys_loss_pose_launch(st, m->dtype, a, m->seg_cnt, m->seg_off, m->seg_list));
+  YS_CHECK_HIP(hipGetLastError());
+  m->have_loss = true; m->have_seg_loss = true;
+  return YS_OK;
+}
+
 // device-resident labels cannot size the workspace without a host sync: the prep kernel records the batch's largest per-image
 // label count and the first synchronising read refuses a truncated assignment instead of returning it
 static int check_label_overflow(ys_model* m, float max_count) {
@@ -1702,6 +1759,9 @@ int ys_loss_read_items(ys_model* m, float* items, int n_items, float* loss_sum) 
   if (m->segment) {
     YS_REQUIRE(m->have_seg_loss, "ys_loss_read_items: the Segment model needs ys_loss_segment");
     items[0] = h[1]; items[1] = h[8]; items[2] = h[2]; items[3] = h[3]; items[4] = 0.f;
+  } else if (m->xkind == 3) {
+    YS_REQUIRE(m->have_seg_loss, "ys_loss_read_items: the Pose model needs ys_loss_pose");
+    items[0] = h[1]; items[1] = h[10]; items[2] = h[11]; items[3] = h[2]; items[4] = h[3];   // box, pose, kobj, cls, dfl (Loss.cs:965)
   } else {
     items[0] = h[1]; items[1] = h[2]; items[2] = h[3];
   }
@@ -1735,6 +1795,7 @@ int ys_model_backward(ys_model* m) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
   YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
   YS_REQUIRE(!m->segment || m->have_seg_loss, "ys_model_backward: the Segment model needs ys_loss_segment (mask gradients)");
+  YS_REQUIRE(m->xkind != 2, "ys_model_backward: OBB models are forward / predict only");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   YsTimer timer(m->ctx, "backward");
   reset_grad_state(m);

@@ -53,6 +53,13 @@ seg_compact_kernel(const int* __restrict__ fg_gt, int A, const int* __restrict__
   for (int a = a0; a < a1; a++) if (fg_gt[(long)b * A + a] >= 0) list[o++] = a;
 }
 
+int ys_fg_list_launch(hipStream_t st, const int* fg_gt, int B, int A, int* cnt, int* off, int* list) {
+  YS_LAUNCH(seg_count_kernel, B, SG_THREADS, st, fg_gt, A, cnt);
+  YS_LAUNCH(seg_offsets_kernel, 1, 64, st, (const int*)cnt, B, off);
+  YS_LAUNCH(seg_compact_kernel, B, SG_THREADS, st, fg_gt, A, (const int*)off, list);
+  return YS_OK;
+}
+
 struct SegArgs {
   const void* mc;     // mask coefficients [B][A][ld_mc]
   const void* proto;  // prototypes [B][mh*mw][ld_pr]
@@ -260,9 +267,7 @@ int ys_loss_segment_launch(hipStream_t st, int dtype, const void* mc, void* dmc,
   a.trunc_crop = trunc_crop; a.hyp_box = 7.5f;
   const size_t es = dtype == YS_BF16 ? 2 : 4;
   YS_CHECK_HIP(hipMemsetAsync(dmc, 0, (size_t)B * A * ld_mc * es, st));   // background anchors get no mask gradient
-  YS_LAUNCH(seg_count_kernel, B, SG_THREADS, st, fg_gt, A, cnt);
-  YS_LAUNCH(seg_offsets_kernel, 1, 64, st, (const int*)cnt, B, off);
-  YS_LAUNCH(seg_compact_kernel, B, SG_THREADS, st, fg_gt, A, (const int*)off, list);
+  YS_TRY(ys_fg_list_launch(st, fg_gt, B, A, cnt, off, list));
   const int g1 = 2048;
   dim3 g2(ys_cdiv(mh * mw, SG_THREADS), B);
   const bool fast = nm == 32 && ld_mc % 8 == 0 && ld_pr % 8 == 0;      // Proto / Segment default (Head.cs:238): compile-time nm, 16-byte rows

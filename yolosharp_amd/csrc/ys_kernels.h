@@ -205,7 +205,7 @@ struct LossArgs {
   // workspace (device)
   int* gt_count;       // [B]
   float* gt_box;       // [B][gcap][4] xyxy pixels
-  int* gt_cls;         // [B][gcap]
+  int* gt_cls;         // [B][gcap]   (followed by gt_valid [B][gcap] and gt_src [B][gcap] in the same allocation)
   float* pbox;         // [B][A][4] decoded pred box, grid units (xyxy)
   float* ov;           // [B][gcap][A]
   float* align;        // [B][gcap][A]
@@ -235,5 +235,27 @@ int ys_unpack_nchw_strided_launch(hipStream_t st, int dtype, const void* x, int 
 int ys_loss_segment_launch(hipStream_t st, int dtype, const void* mc, void* dmc, int ld_mc, const void* proto, void* dproto, int ld_pr,
                            const float* masks, const int* fg_gt, const float* gt_box, int* cnt, int* off, int* list, float* ent,
                            float* part, float* scalars, int B, int A, int nm, int mh, int mw, int gcap, int H, int W, int trunc_crop);
+// foreground anchors of the last assignment, ordered by image then anchor: cnt [B], off [B+1], list [off[B]]
+int ys_fg_list_launch(hipStream_t st, const int* fg_gt, int B, int A, int* cnt, int* off, int* list);
+// ---- poseloss.hip: keypoint terms of v8PoseLoss (Loss.cs:870-1071) after ys_loss_detect_launch
+#define YS_POSE_KMAX 64
+struct PoseArgs {
+  const void* kp;          // raw keypoint outputs [B][A][ld] (K*D used)
+  void* dkp;               // gradient, same layout
+  int ld;
+  const int* fg_gt;        // [B][A] assigned GT slot or -1
+  const float* gt_box;     // [B][gcap][4] xyxy pixels
+  const int* gt_src;       // [B][gcap] label row of the slot
+  const float* keypoints;  // [N][K][D] normalised (x, y[, visibility])
+  const int* off; const int* list;
+  float* part;             // [grid][2]
+  float* scalars;          // [10] pose, [11] kobj, [4] total
+  int B, A, K, D, gcap, H, W, nl;
+  int lvl_off[4], lvl_w[4], lvl_stride[4];
+  float hyp_pose, hyp_kobj;
+  float sigma[YS_POSE_KMAX];
+};
+int ys_loss_pose_grid(int B, int A);
+int ys_loss_pose_launch(hipStream_t st, int dtype, const PoseArgs& a, int* cnt, int* off, int* list);
 int ys_process_mask_launch(hipStream_t st, const float* protos, const float* masks_in, const float* boxes, int n, int nm, int mh,
                            int mw, int ih, int iw, int upsample, int trunc_crop, unsigned char* out);

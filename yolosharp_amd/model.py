@@ -146,7 +146,7 @@ class Yolov8:
     def get_output(self, key):
         B = self._batch
         C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc + self.NM, "dboxes": 4 * self.reg_max,
-              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM, "angle": self.NM, "kpts": self.NM}.get(key)
+              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM, "angle": self.NM, "kpts": self.NM, "dkpts": self.NM}.get(key)
         if key in ("proto", "dproto"):
             a = np.empty((B, self.NM, self.height // 4, self.width // 4), np.float32)
         else:
@@ -161,8 +161,8 @@ class Yolov8:
         sc = np.ascontiguousarray(preds["scores"], np.float32)
         B = bx.shape[0]
         assert bx.shape == (B, 4 * self.reg_max, self.A) and sc.shape == (B, self.nc, self.A), (bx.shape, sc.shape)
-        mc = np.ascontiguousarray(preds["mask_coefficient"], np.float32) if self.NM else None
-        pr = np.ascontiguousarray(preds["proto"], np.float32) if self.NM else None
+        mc = np.ascontiguousarray(preds["kpts" if self.TASK == 3 else "mask_coefficient"], np.float32) if self.TASK in (1, 3) else None
+        pr = np.ascontiguousarray(preds["proto"], np.float32) if self.TASK == 1 else None
         _lib.check(self.lib, self.lib.ys_model_set_preds(self.handle, B, _ptr(bx), _ptr(sc), _ptr(mc), _ptr(pr)))
         self._batch = B
 
@@ -267,7 +267,7 @@ class _ObbMixin:
 
 class _PoseMixin:
     """Head.Pose (Head.cs:484-606): preds gain the raw "kpts" [B,nk,A]; the eval inference tensor is [B, 4+nc+nk, A] with
-    kpts_decode applied (Head.cs:590-605).  Forward / predict only: v8PoseLoss (Loss.cs:870-1071) is not built."""
+    kpts_decode applied (Head.cs:590-605).  Criterion: v8PoseLoss below."""
     TASK = 3
     NM = 51
 
@@ -354,6 +354,29 @@ class v8SegmentationLoss(v8DetectionLoss):
         _lib.check(self.lib, self.lib.ys_loss_read_items(self.model.handle, items, 5, C.byref(total)))
         loss_detach = np.array(list(items), np.float32)
         return loss_detach * self.model._batch, loss_detach
+
+
+class v8PoseLoss(v8SegmentationLoss):
+    """Loss.cs:870-1071.  batch additionally carries "keypoints" [N, kpt_num, kpt_dim] normalised (x, y[, visibility]).
+    Returns (loss*B [5], loss_detach [5]) in the order box, pose, kobj, cls, dfl."""
+
+    def __init__(self, model):
+        v8DetectionLoss.__init__(self, model)
+
+    def forward_device(self, bidx_dev, cls_dev, box_dev, n, kpts_dev):
+        _lib.check(self.lib, self.lib.ys_loss_pose(self.model.handle, bidx_dev, cls_dev, box_dev, n, kpts_dev, 1))
+
+    def forward(self, preds, batch, read=True):
+        bi = np.ascontiguousarray(np.asarray(batch["batch_idx"], np.float32).reshape(-1))
+        cl = np.ascontiguousarray(np.asarray(batch["cls"], np.float32).reshape(-1))
+        bb = np.ascontiguousarray(np.asarray(batch["bboxes"], np.float32).reshape(-1, 4))
+        m = self.model
+        kp = np.ascontiguousarray(np.asarray(batch["keypoints"], np.float32))
+        assert kp.shape == (bi.shape[0], m.kpt_num, m.kpt_dim), kp.shape
+        _lib.check(self.lib, self.lib.ys_loss_pose(m.handle, _ptr(bi), _ptr(cl), _ptr(bb), bi.shape[0], _ptr(kp), 0))
+        return self.read() if read else None
+
+    __call__ = forward
 
 
 class AMPWrapper:
