@@ -239,7 +239,9 @@ def test_pose_loss_without_labels(backend, engine):
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", ["gpu"])
 def test_yolov11s_pose_loss_backward_full_resolution_f32(backend, engine):
-    m, _ = _pose_train_parity(engine, 11, "s", 2, 640, 640, 1e-3, 2e-3, kmax=12)
+    # nc = 4: with a single class and random weights the class-logit gradient is nearly constant over the 20x20 maps, the BatchNorm
+    # backward of model.7-9 cancels to ~1e-8 and fp32 summation order alone moves those tensors by ~5e-3 (tools/dev/pose_grad_diag.py)
+    m, _ = _pose_train_parity(engine, 11, "s", 2, 640, 640, 1e-3, 2e-3, kmax=12, nc=4)
     m.close()
 
 
