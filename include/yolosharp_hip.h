@@ -41,7 +41,7 @@ enum ys_status {
 enum ys_dtype { YS_F32 = 0, YS_BF16 = 1, YS_FP8 = 2 };
 enum ys_family { YS_YOLOV8 = 8, YS_YOLOV11 = 11 };   /* Models/Yolo.cs:10-135, :200-258 */
 enum ys_size { YS_N = 0, YS_S = 1, YS_M = 2, YS_L = 3, YS_X = 4 }; /* Types/YoloTypes.cs YoloSize; Yolo.cs:43-51 */
-enum ys_task { YS_DETECT = 0, YS_SEGMENT = 1, YS_OBB = 2, YS_POSE = 3 };   /* Config.cs TaskType; OBB: forward + predict only (v8OBBLoss is not built) */
+enum ys_task { YS_DETECT = 0, YS_SEGMENT = 1, YS_OBB = 2, YS_POSE = 3 };   /* Config.cs TaskType */
 
 YS_API const char* ys_last_error(void);
 YS_API int ys_version(void);
@@ -143,6 +143,13 @@ YS_API int ys_model_reserve_labels(ys_model* m, int per_image);
  * branch an accelerator run takes); 1 = its CPU "n < 50" integer-truncation branch (:421-435). */
 YS_API int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
                            int n_labels, const float* masks, int on_device, int crop_mode);
+/* v8OBBLoss.forward (Utils/Loss.cs:486-684) + RotatedTaskAlignedAssigner (Utils/Tal.cs:260-310) + RotatedBboxLoss
+ * (Loss.cs:190-228) for task = YS_OBB models.  bboxes: fp32 [n_labels, 5] = normalised cx, cy, w, h + angle (radians).
+ * Labels thinner than 2 pixels are dropped (Loss.cs:563).  Items (box, cls, dfl, angle) via ys_loss_read_items(n_items = 4).
+ * The angle head output is kept as the LOGIT: ys_model_get_output("angle") applies (sigmoid - 0.25) * pi (Head.cs:429),
+ * "dangle" is the gradient w.r.t. the logit, and ys_model_set_preds takes angle logits [B,1,A] in its mask_coefficient argument. */
+YS_API int ys_loss_obb(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
+                       int n_labels, int on_device);
 /* v8PoseLoss.forward (Utils/Loss.cs:870-1071, KeypointLoss :169-188) for task = YS_POSE models: the detection terms and
  * assignment of ys_loss_detect, then the keypoint location (OKS-style, hyp_pose 12) and visibility (BCE, hyp_kobj 1) terms and
  * d(sum(loss*B))/d(raw kpts).  keypoints: fp32 [n_labels, kpt_num, kpt_dim] normalised like bboxes (x, y[, visibility]), row i
@@ -151,7 +158,8 @@ YS_API int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls
 YS_API int ys_loss_pose(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
                         int n_labels, const float* keypoints, int on_device);
 /* Loss items in the criterion's own order: detect n_items = 3 (box, cls, dfl; Loss.cs:414);
- * segment n_items = 5 (box, seg, cls, dfl, semseg = 0; Loss.cs:719); pose n_items = 5 (box, pose, kobj, cls, dfl; Loss.cs:923).
+ * segment n_items = 5 (box, seg, cls, dfl, semseg = 0; Loss.cs:719); pose n_items = 5 (box, pose, kobj, cls, dfl; Loss.cs:923);
+ * obb n_items = 4 (box, cls, dfl, angle; Loss.cs:546).
  * *loss_sum = sum(items)*B. */
 YS_API int ys_loss_read_items(ys_model* m, float* loss_items, int n_items, float* loss_sum);
 

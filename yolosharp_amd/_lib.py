@@ -58,6 +58,7 @@ PROTOTYPES = {
     "ys_loss_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "ys_loss_read": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
     "ys_loss_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "ys_loss_obb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "ys_loss_pose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "ys_loss_read_items": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_float_p]),
     "ys_val_match_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -19,40 +19,81 @@
 #define LS_THREADS 256
 #define CIOU_EPS 1e-7f
 
-// ------------------------------------------------------------------ dual numbers (value + 4 partials)
-struct Dual4 {
+// ------------------------------------------------------------------ dual numbers (value + N partials)
+template <int N>
+struct DualN {
   float v;
-  float g[4];
+  float g[N];
 };
-__device__ inline Dual4 dconst(float c) { Dual4 r; r.v = c; r.g[0] = r.g[1] = r.g[2] = r.g[3] = 0.f; return r; }
-__device__ inline Dual4 dvar(float c, int i) { Dual4 r = dconst(c); r.g[i] = 1.f; return r; }
-__device__ inline Dual4 operator+(const Dual4& a, const Dual4& b) { Dual4 r; r.v = a.v + b.v; for (int i = 0; i < 4; i++) r.g[i] = a.g[i] + b.g[i]; return r; }
-__device__ inline Dual4 operator-(const Dual4& a, const Dual4& b) { Dual4 r; r.v = a.v - b.v; for (int i = 0; i < 4; i++) r.g[i] = a.g[i] - b.g[i]; return r; }
-__device__ inline Dual4 operator*(const Dual4& a, const Dual4& b) { Dual4 r; r.v = a.v * b.v; for (int i = 0; i < 4; i++) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
-__device__ inline Dual4 operator/(const Dual4& a, const Dual4& b) {
-  Dual4 r; r.v = a.v / b.v;
+typedef DualN<4> Dual4;   // CIoU: d/d(x1, y1, x2, y2)
+typedef DualN<5> Dual5;   // probiou: d/d(x, y, w, h, angle)
+template <int N> __device__ inline DualN<N> dconstN(float c) { DualN<N> r; r.v = c; for (int i = 0; i < N; i++) r.g[i] = 0.f; return r; }
+template <int N> __device__ inline DualN<N> dvarN(float c, int i) { DualN<N> r = dconstN<N>(c); r.g[i] = 1.f; return r; }
+__device__ inline Dual4 dconst(float c) { return dconstN<4>(c); }
+__device__ inline Dual4 dvar(float c, int i) { return dvarN<4>(c, i); }
+template <int N> __device__ inline DualN<N> operator+(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v + b.v; for (int i = 0; i < N; i++) r.g[i] = a.g[i] + b.g[i]; return r; }
+template <int N> __device__ inline DualN<N> operator-(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v - b.v; for (int i = 0; i < N; i++) r.g[i] = a.g[i] - b.g[i]; return r; }
+template <int N> __device__ inline DualN<N> operator*(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v * b.v; for (int i = 0; i < N; i++) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
+template <int N> __device__ inline DualN<N> operator/(const DualN<N>& a, const DualN<N>& b) {
+  DualN<N> r; r.v = a.v / b.v;
   const float inv = 1.0f / b.v;
-  for (int i = 0; i < 4; i++) r.g[i] = (a.g[i] - r.v * b.g[i]) * inv;
+  for (int i = 0; i < N; i++) r.g[i] = (a.g[i] - r.v * b.g[i]) * inv;
   return r;
 }
-__device__ inline Dual4 dmax(const Dual4& a, const Dual4& b) { return a.v >= b.v ? a : b; }
-__device__ inline Dual4 dmin(const Dual4& a, const Dual4& b) { return a.v <= b.v ? a : b; }
-__device__ inline Dual4 dclamp_min(const Dual4& a, float lo) { return a.v >= lo ? a : dconst(lo); }
-__device__ inline Dual4 datan(const Dual4& a) {
-  Dual4 r; r.v = atanf(a.v);
-  const float d = 1.0f / (1.0f + a.v * a.v);
-  for (int i = 0; i < 4; i++) r.g[i] = a.g[i] * d;
-  return r;
-}
-// plain-float overloads so ciou<R>() is written once
-__device__ inline float dconst_f(float c) { return c; }
+template <int N> __device__ inline DualN<N> dscale(const DualN<N>& a, float d) { DualN<N> r; r.v = a.v; for (int i = 0; i < N; i++) r.g[i] = a.g[i] * d; return r; }
+template <int N> __device__ inline DualN<N> dmax(const DualN<N>& a, const DualN<N>& b) { return a.v >= b.v ? a : b; }
+template <int N> __device__ inline DualN<N> dmin(const DualN<N>& a, const DualN<N>& b) { return a.v <= b.v ? a : b; }
+template <int N> __device__ inline DualN<N> dclamp_min(const DualN<N>& a, float lo) { return a.v >= lo ? a : dconstN<N>(lo); }
+template <int N> __device__ inline DualN<N> dclamp(const DualN<N>& a, float lo, float hi) { return a.v < lo ? dconstN<N>(lo) : (a.v > hi ? dconstN<N>(hi) : a); }
+template <int N> __device__ inline DualN<N> datan(const DualN<N>& a) { DualN<N> r = dscale(a, 1.0f / (1.0f + a.v * a.v)); r.v = atanf(a.v); return r; }
+template <int N> __device__ inline DualN<N> dsqrt(const DualN<N>& a) { const float q = sqrtf(a.v); DualN<N> r = dscale(a, 0.5f / q); r.v = q; return r; }
+template <int N> __device__ inline DualN<N> dlog(const DualN<N>& a) { DualN<N> r = dscale(a, 1.0f / a.v); r.v = logf(a.v); return r; }
+template <int N> __device__ inline DualN<N> dexp(const DualN<N>& a) { const float e = expf(a.v); DualN<N> r = dscale(a, e); r.v = e; return r; }
+template <int N> __device__ inline DualN<N> dcos(const DualN<N>& a) { DualN<N> r = dscale(a, -sinf(a.v)); r.v = cosf(a.v); return r; }
+template <int N> __device__ inline DualN<N> dsin(const DualN<N>& a) { DualN<N> r = dscale(a, cosf(a.v)); r.v = sinf(a.v); return r; }
+// plain-float overloads so ciou<R>() / probiou<R>() are written once
 __device__ inline float dmax(float a, float b) { return a >= b ? a : b; }
 __device__ inline float dmin(float a, float b) { return a <= b ? a : b; }
 __device__ inline float dclamp_min(float a, float lo) { return a >= lo ? a : lo; }
+__device__ inline float dclamp(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
 __device__ inline float datan(float a) { return atanf(a); }
+__device__ inline float dsqrt(float a) { return sqrtf(a); }
+__device__ inline float dlog(float a) { return logf(a); }
+__device__ inline float dexp(float a) { return expf(a); }
+__device__ inline float dcos(float a) { return cosf(a); }
+__device__ inline float dsin(float a) { return sinf(a); }
 template <class R> __device__ inline R rconst(float c);
 template <> __device__ inline float rconst<float>(float c) { return c; }
-template <> __device__ inline Dual4 rconst<Dual4>(float c) { return dconst(c); }
+template <> __device__ inline Dual4 rconst<Dual4>(float c) { return dconstN<4>(c); }
+template <> __device__ inline Dual5 rconst<Dual5>(float c) { return dconstN<5>(c); }
+
+// Metrics.probiou (Metrics.cs:137-160, _get_covariance_matrix :264-283): boxes (x, y, w, h, angle), eps 1e-7
+template <class R>
+__device__ inline void obb_cov(const R o[5], R& A, R& B, R& C) {
+  const R a = o[2] * o[2] / rconst<R>(12.0f), b = o[3] * o[3] / rconst<R>(12.0f);
+  const R cs = dcos(o[4]), sn = dsin(o[4]);
+  const R c2 = cs * cs, s2 = sn * sn;
+  A = a * c2 + b * s2;
+  B = a * s2 + b * c2;
+  C = (a - b) * cs * sn;
+}
+template <class R>
+__device__ inline R probiou_t(const R o1[5], const R o2[5]) {
+  const float eps = 1e-7f;
+  R a1, b1, c1, a2, b2, c2;
+  obb_cov<R>(o1, a1, b1, c1);
+  obb_cov<R>(o2, a2, b2, c2);
+  const R sa = a1 + a2, sb = b1 + b2, sc = c1 + c2;
+  const R den = sa * sb - sc * sc;
+  const R dy = o1[1] - o2[1], dxa = o1[0] - o2[0], dxb = o2[0] - o1[0];
+  const R t1 = (sa * (dy * dy) + sb * (dxa * dxa)) / (den + rconst<R>(eps)) * rconst<R>(0.25f);
+  const R t2 = (sc * dxb * dy) / (den + rconst<R>(eps)) * rconst<R>(0.5f);
+  const R d1 = dclamp_min(a1 * b1 - c1 * c1, 0.0f), d2 = dclamp_min(a2 * b2 - c2 * c2, 0.0f);
+  const R t3 = dlog(den / (rconst<R>(4.0f) * dsqrt(d1 * d2) + rconst<R>(eps)) + rconst<R>(eps)) * rconst<R>(0.5f);
+  const R bd = dclamp(t1 + t2 + t3, eps, 100.0f);
+  const R hd = dsqrt(rconst<R>(1.0f) - dexp(rconst<R>(0.0f) - bd) + rconst<R>(eps));
+  return rconst<R>(1.0f) - hd;
+}
 
 // Metrics.cs:36-111 with xywh=false, CIoU=true
 template <class R>
@@ -96,24 +137,43 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
   for (int i = tid; i < a.B; i += LS_THREADS) a.gt_count[i] = 0;
   for (int i = tid; i < a.B * a.gcap; i += LS_THREADS) { a.pos_align[i] = 0u; a.pos_ov[i] = 0u; }
   if (tid < 8) a.scalars[tid] = 0.f;
+  if (tid == 12 || tid == 13) a.scalars[tid] = 0.f;
+  const int bs_ = a.rot ? 5 : 4;                       // floats per label box / per padded GT row
+  // v8OBBLoss drops oriented boxes thinner than 2 pixels before padding (Loss.cs:561-563); a dropped label takes no slot
+  auto kept = [&](int i) { return !a.rot || (a.bboxes[5 * i + 2] * (float)a.W >= 2.0f && a.bboxes[5 * i + 3] * (float)a.H >= 2.0f); };
   // image index of every label staged in LDS: the rank loop below is O(n^2) and was a chain of global loads (57 us for 544 labels)
   constexpr int SB = 4096;
   __shared__ short s_b[SB];
   const bool staged = a.n_labels <= SB;
-  if (staged) for (int i = tid; i < a.n_labels; i += LS_THREADS) { const int bb = (int)a.batch_idx[i]; s_b[i] = (short)(bb < -1 || bb > 32766 ? -1 : bb); }
+  if (staged) for (int i = tid; i < a.n_labels; i += LS_THREADS) { const int bb = (int)a.batch_idx[i]; s_b[i] = (short)(bb < -1 || bb > 32766 || !kept(i) ? -1 : bb); }
   __syncthreads();
   for (int i = tid; i < a.n_labels; i += LS_THREADS) {
     const int b = (int)a.batch_idx[i];
-    if (b < 0 || b >= a.B) continue;
+    if (b < 0 || b >= a.B || !kept(i)) continue;
     int slot = 0;  // rank among labels of the same image, in order of appearance
     if (staged) { for (int j = 0; j < i; j++) slot += ((int)s_b[j] == b) ? 1 : 0; }
-    else { for (int j = 0; j < i; j++) slot += ((int)a.batch_idx[j] == b) ? 1 : 0; }
+    else { for (int j = 0; j < i; j++) slot += ((int)a.batch_idx[j] == b && kept(j)) ? 1 : 0; }
     atomicAdd(&a.gt_count[b], 1);
     if (slot >= a.gcap) continue;  // capacity exceeded (count is clamped below)
     const float sw = (float)a.W, shh = (float)a.H;
-    const float cx = a.bboxes[4 * i + 0] * sw, cy = a.bboxes[4 * i + 1] * shh;
-    const float w = a.bboxes[4 * i + 2] * sw, h = a.bboxes[4 * i + 3] * shh;
-    float* gb = a.gt_box + ((long)b * a.gcap + slot) * 4;
+    const float cx = a.bboxes[bs_ * i + 0] * sw, cy = a.bboxes[bs_ * i + 1] * shh;
+    float w = a.bboxes[bs_ * i + 2] * sw, h = a.bboxes[bs_ * i + 3] * shh;
+    float* gb = a.gt_box + ((long)b * a.gcap + slot) * bs_;
+    if (a.rot) {
+      // xywh * imgsz, angle as given (Loss.cs:524-527); mask_gt = sum(xywhr) > 0 (Loss.cs:571).  RotatedTaskAlignedAssigner then
+      // overwrites, IN the padded tensor, widths / heights below stride[0] with stride_val for valid rows (Tal.cs:283-287): every
+      // later use (overlaps, targets, losses) sees the widened box, so it is applied here once
+      const float r = a.bboxes[5 * i + 4];
+      const int vld = (cx + cy + w + h + r) > 0.0f ? 1 : 0;
+      const float s0 = (float)a.lvl_stride[0], sv = (float)a.lvl_stride[a.nl > 1 ? 1 : 0];
+      if (vld && w < s0) w = sv;
+      if (vld && h < s0) h = sv;
+      gb[0] = cx; gb[1] = cy; gb[2] = w; gb[3] = h; gb[4] = r;
+      a.gt_cls[(long)b * a.gcap + slot] = (int)a.cls[i];
+      gt_valid[(long)b * a.gcap + slot] = vld;
+      gt_valid[(long)a.B * a.gcap + (long)b * a.gcap + slot] = i;
+      continue;
+    }
     gb[0] = cx - w / 2; gb[1] = cy - h / 2; gb[2] = cx + w / 2; gb[3] = cy + h / 2;  // Ops.cs:76-79
     a.gt_cls[(long)b * a.gcap + slot] = (int)a.cls[i];
     gt_valid[(long)b * a.gcap + slot] = (gb[0] + gb[1] + gb[2] + gb[3]) > 0.0f ? 1 : 0;  // Loss.cs:431
@@ -166,7 +226,14 @@ loss_decode_kernel(LossArgs a) {
   }
   const int base = lane & ~3;
   const float d0 = __shfl(d, base + 0), d1 = __shfl(d, base + 1), d2 = __shfl(d, base + 2), d3 = __shfl(d, base + 3);
-  if (inb && s == 0) {
+  if (inb && s == 0 && a.rot) {   // bbox_decode of v8OBBLoss (Loss.cs:634-645): dist2rbox (Tal.cs:389-408) + the angle, grid units
+    const AnchorInfo an = anchor_of(a, (int)(row % a.A));
+    const float ang = (ys_sigmoid(Elem<T>::to_f(((const T*)a.pa)[row * a.ld_pa])) - 0.25f) * 3.14159265358979323846f;
+    const float cs = cosf(ang), sn = sinf(ang);
+    const float xf = (d2 - d0) / 2.0f, yf = (d3 - d1) / 2.0f;
+    float* o = a.pbox + row * 5;
+    o[0] = xf * cs - yf * sn + an.ax; o[1] = xf * sn + yf * cs + an.ay; o[2] = d0 + d2; o[3] = d1 + d3; o[4] = ang;
+  } else if (inb && s == 0) {
     const AnchorInfo an = anchor_of(a, (int)(row % a.A));
     float4 o;
     o.x = an.ax - d0; o.y = an.ay - d1; o.z = an.ax + d2; o.w = an.ay + d3;   // Tal.cs:345-346
@@ -187,8 +254,9 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   if (g >= a.gt_count[b]) return;
   const long gi = (long)b * a.gcap + g;
   const bool valid = gt_valid[gi] != 0;
-  const float* gb = a.gt_box + gi * 4;
+  const float* gb = a.gt_box + gi * (a.rot ? 5 : 4);
   const float g4[4] = {gb[0], gb[1], gb[2], gb[3]};
+  const float g5[5] = {gb[0], gb[1], gb[2], gb[3], a.rot ? gb[4] : 0.f};
   const int cls = a.gt_cls[gi];
   float* ovr = a.ov + gi * a.A;
   float* alr = a.align + gi * a.A;
@@ -201,16 +269,37 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   if (valid && w < (float)a.lvl_stride[0]) w = (float)a.lvl_stride[a.nl > 1 ? 1 : 0];
   if (valid && h < (float)a.lvl_stride[0]) h = (float)a.lvl_stride[a.nl > 1 ? 1 : 0];
   const float ix1 = cx - w / 2, iy1 = cy - h / 2, ix2 = cx + w / 2, iy2 = cy + h / 2;
+  // rotated in-box test (Tal.cs:289-306): corners a = ctr + v1 + v2, b = ctr + v1 - v2, d = ctr - v1 + v2 (Ops.cs:24-33)
+  float cax = 0.f, cay = 0.f, abx = 0.f, aby = 0.f, adx = 0.f, ady = 0.f, nab = 0.f, nad = 0.f;
+  if (a.rot) {
+    const float cs = cosf(g5[4]), sn = sinf(g5[4]);
+    const float v1x = g5[2] / 2 * cs, v1y = g5[2] / 2 * sn, v2x = -g5[3] / 2 * sn, v2y = g5[3] / 2 * cs;
+    cax = g5[0] + v1x + v2x; cay = g5[1] + v1y + v2y;
+    const float cbx = g5[0] + v1x - v2x, cby = g5[1] + v1y - v2y, cdx = g5[0] - v1x + v2x, cdy = g5[1] - v1y + v2y;
+    abx = cbx - cax; aby = cby - cay; adx = cdx - cax; ady = cdy - cay;
+    nab = abx * abx + aby * aby; nad = adx * adx + ady * ady;
+  }
   for (int ai = tid; ai < a.A; ai += LS_THREADS) {
     const AnchorInfo an = anchor_of(a, ai);
     const float px = an.ax * an.stride, py = an.ay * an.stride;   // anchor_points * stride_tensor (Loss.cs:439)
     const float dmin_ = fminf(fminf(px - ix1, py - iy1), fminf(ix2 - px, iy2 - py));
-    const bool ingt = dmin_ > 1e-9f;                               // Tal.cs:221
+    bool ingt = dmin_ > 1e-9f;                                     // Tal.cs:221
+    if (a.rot) {
+      const float apx = px - cax, apy = py - cay;
+      const float dab = apx * abx + apy * aby, dad = apx * adx + apy * ady;
+      ingt = dab >= 0.f && dab <= nab && dad >= 0.f && dad <= nad;
+    }
     float o = 0.f, al = 0.f;
     if (ingt && valid) {
-      const float* pb = a.pbox + ((long)b * a.A + ai) * 4;
-      const float p4[4] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride};  // Loss.cs:438
-      o = ciou_xyxy<float>(g4, p4);                                // Tal.cs:141 (box1 = gt, box2 = pred)
+      if (a.rot) {
+        const float* pb = a.pbox + ((long)b * a.A + ai) * 5;
+        const float p5[5] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride, pb[4]};   // Loss.cs:580-583
+        o = probiou_t<float>(g5, p5);                              // Tal.cs:267-270 (obb1 = gt, obb2 = pred)
+      } else {
+        const float* pb = a.pbox + ((long)b * a.A + ai) * 4;
+        const float p4[4] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride};  // Loss.cs:438
+        o = ciou_xyxy<float>(g4, p4);                              // Tal.cs:141 (box1 = gt, box2 = pred)
+      }
       o = o > 0.f ? o : 0.f;                                        // .clamp(0)
       const int cc = cls < 0 ? 0 : (cls >= a.nc ? a.nc - 1 : cls);
       const float sc = ys_sigmoid(Elem<T>::to_f(((const T*)a.ps)[((long)b * a.A + ai) * a.ld_ps + cc]));
@@ -350,7 +439,8 @@ loss_sum_kernel(const float* __restrict__ partial, int nblk, float* scalars, int
     double t[4] = {0.0, 0.0, 0.0, 0.0};
     for (int w = 0; w < LS_THREADS / 64; w++) for (int c = 0; c < 4; c++) t[c] += sbuf[w][c];
     if (mode == 0) scalars[0] = (float)(t[0] > 1.0 ? t[0] : 1.0);  // Loss.cs:444
-    if (mode == 1) for (int c = 1; c < 4; c++) scalars[4 + c] += (float)t[c];
+    if (mode >= 1) for (int c = 1; c < 4; c++) scalars[4 + c] += (float)t[c];
+    if (mode == 2) scalars[12] += (float)t[0];                       // angle term of v8OBBLoss (column 0 of the box partials)
   }
 }
 
@@ -446,25 +536,61 @@ loss_box_kernel(LossArgs a, float* partial) {
   // the four side distances of this anchor (all four lanes of an anchor share g, so they take the branch above together)
   const int base = lane & ~3;
   const float d0 = __shfl(dist, base + 0), d1 = __shfl(dist, base + 1), d2 = __shfl(dist, base + 2), d3 = __shfl(dist, base + 3);
-  float l_iou = 0.f, l_dfl = 0.f;
+  float l_iou = 0.f, l_dfl = 0.f, l_ang = 0.f;
   if (g >= 0) {
     const int b = (int)(row / a.A), ai = (int)(row - (long)b * a.A);
     const AnchorInfo an = anchor_of(a, ai);
     const float w = a.tnorm[row];                      // weight = target_scores.sum(-1) (Loss.cs:138)
     const float tss = a.scalars[0];
-    const float* gb = a.gt_box + ((long)b * a.gcap + g) * 4;
-    const float tb[4] = {gb[0] / an.stride, gb[1] / an.stride, gb[2] / an.stride, gb[3] / an.stride};  // Loss.cs:456
-    // CIoU(pred, target) with d/d(pred x1,y1,x2,y2)
-    Dual4 b1[4] = {dvar(an.ax - d0, 0), dvar(an.ay - d1, 1), dvar(an.ax + d2, 2), dvar(an.ay + d3, 3)};
-    Dual4 b2[4] = {dconst(tb[0]), dconst(tb[1]), dconst(tb[2]), dconst(tb[3])};
-    const Dual4 ci = ciou_xyxy<Dual4>(b1, b2);
-    if (s == 0) l_iou = (1.0f - ci.v) * w;
-    // d(total)/d(dist_s): loss_box*B = hyp_box*B/tss * sum((1-ciou)*w); x1 = ax - l, y1 = ay - t, x2 = ax + r, y2 = ay + b
     const float gbox = a.hyp_box * (float)a.B / tss * w;
-    const float cg = (s == 0) ? ci.g[0] : (s == 1) ? ci.g[1] : (s == 2) ? ci.g[2] : ci.g[3];
-    const float gd = (s < 2) ? (gbox * cg) : (-gbox * cg);   // -(dciou/dx1)*(-1) = +g ; -(dciou/dx2)*(+1) = -g
-    // DFL (Loss.cs:104-118, Tal.cs:365-379): target ltrb clamped to [0, reg_max-1-0.01]
-    float t = (s == 0) ? (an.ax - tb[0]) : (s == 1) ? (an.ay - tb[1]) : (s == 2) ? (tb[2] - an.ax) : (tb[3] - an.ay);
+    float gd, t;                                       // d(total)/d(dist_s) through the box term; DFL target of this side
+    if (a.rot) {
+      // RotatedBboxLoss (Loss.cs:197-227) + calculate_angle_loss (:657-676) on pred = (dist2rbox(dist, angle), angle), grid units
+      const float* gb = a.gt_box + ((long)b * a.gcap + g) * 5;
+      const float tb[5] = {gb[0] / an.stride, gb[1] / an.stride, gb[2] / an.stride, gb[3] / an.stride, gb[4]};   // Loss.cs:596
+      const float PI_F = 3.14159265358979323846f;
+      const float sg = ys_sigmoid(Elem<T>::to_f(((const T*)a.pa)[row * a.ld_pa]));
+      const float ang = (sg - 0.25f) * PI_F;
+      const float cs = cosf(ang), sn = sinf(ang);
+      const float xf = (d2 - d0) / 2.0f, yf = (d3 - d1) / 2.0f;
+      const Dual5 p5[5] = {dvarN<5>(xf * cs - yf * sn + an.ax, 0), dvarN<5>(xf * sn + yf * cs + an.ay, 1), dvarN<5>(d0 + d2, 2),
+                           dvarN<5>(d1 + d3, 3), dvarN<5>(ang, 4)};
+      const Dual5 t5[5] = {dconstN<5>(tb[0]), dconstN<5>(tb[1]), dconstN<5>(tb[2]), dconstN<5>(tb[3]), dconstN<5>(tb[4])};
+      const Dual5 pi = probiou_t<Dual5>(p5, t5);       // Loss.cs:203 (obb1 = pred, obb2 = target)
+      if (s == 0) l_iou = (1.0f - pi.v) * w;
+      const float Gx = -gbox * pi.g[0], Gy = -gbox * pi.g[1], Gw = -gbox * pi.g[2], Gh = -gbox * pi.g[3], Gt = -gbox * pi.g[4];
+      // x = xf cos - yf sin + ax, y = xf sin + yf cos + ay, w = l + r, h = t + b with xf = (r - l)/2, yf = (b - t)/2
+      gd = (s == 0) ? (Gx * (-cs / 2) + Gy * (-sn / 2) + Gw) : (s == 1) ? (Gx * (sn / 2) + Gy * (-cs / 2) + Gh)
+         : (s == 2) ? (Gx * (cs / 2) + Gy * (sn / 2) + Gw) : (Gx * (-sn / 2) + Gy * (cs / 2) + Gh);
+      const float lar = logf((tb[2] + 1e-9f) / (tb[3] + 1e-9f));
+      const float swt = expf(-(lar * lar) / 9.0f);     // lambda_val = 3
+      const float dlt = ang - tb[4];
+      const float wrp = dlt - rintf(dlt / PI_F) * PI_F;
+      const float s2 = sinf(2.0f * wrp);
+      if (s == 0) {
+        l_ang = swt * s2 * s2 * w;
+        const float gang = a.hyp_angle * (float)a.B / tss * w * swt * 2.0f * sinf(4.0f * wrp);
+        const float dth = Gx * (-xf * sn - yf * cs) + Gy * (xf * cs - yf * sn) + Gt + gang;
+        ((T*)a.dpa)[row * a.ld_pa] = Elem<T>::from_f(dth * PI_F * sg * (1.0f - sg));   // through (sigmoid - 0.25) * pi (Head.cs:429)
+      }
+      // rbox2dist (Tal.cs:418-453) target distances
+      const float ox = tb[0] - an.ax, oy = tb[1] - an.ay, ct = cosf(tb[4]), stn = sinf(tb[4]);
+      const float xft = ox * ct + oy * stn, yft = -ox * stn + oy * ct;
+      t = (s == 0) ? (tb[2] / 2 - xft) : (s == 1) ? (tb[3] / 2 - yft) : (s == 2) ? (tb[2] / 2 + xft) : (tb[3] / 2 + yft);
+    } else {
+      const float* gb = a.gt_box + ((long)b * a.gcap + g) * 4;
+      const float tb[4] = {gb[0] / an.stride, gb[1] / an.stride, gb[2] / an.stride, gb[3] / an.stride};  // Loss.cs:456
+      // CIoU(pred, target) with d/d(pred x1,y1,x2,y2)
+      Dual4 b1[4] = {dvar(an.ax - d0, 0), dvar(an.ay - d1, 1), dvar(an.ax + d2, 2), dvar(an.ay + d3, 3)};
+      Dual4 b2[4] = {dconst(tb[0]), dconst(tb[1]), dconst(tb[2]), dconst(tb[3])};
+      const Dual4 ci = ciou_xyxy<Dual4>(b1, b2);
+      if (s == 0) l_iou = (1.0f - ci.v) * w;
+      // d(total)/d(dist_s): loss_box*B = hyp_box*B/tss * sum((1-ciou)*w); x1 = ax - l, y1 = ay - t, x2 = ax + r, y2 = ay + b
+      const float cg = (s == 0) ? ci.g[0] : (s == 1) ? ci.g[1] : (s == 2) ? ci.g[2] : ci.g[3];
+      gd = (s < 2) ? (gbox * cg) : (-gbox * cg);   // -(dciou/dx1)*(-1) = +g ; -(dciou/dx2)*(+1) = -g
+      // DFL (Loss.cs:104-118, Tal.cs:365-379): target ltrb clamped to [0, reg_max-1-0.01]
+      t = (s == 0) ? (an.ax - tb[0]) : (s == 1) ? (an.ay - tb[1]) : (s == 2) ? (tb[2] - an.ax) : (tb[3] - an.ay);
+    }
     const float tmax = (float)(R - 1) - 0.01f;
     t = fminf(fmaxf(t, 0.f), tmax);
     const int tl = (int)t;
@@ -494,7 +620,7 @@ loss_box_kernel(LossArgs a, float* partial) {
       for (int j = 0; j < R; j++) drow[j] = Elem<T>::from_f(gl[j]);
     }
   }
-  block_partial4(0.f, 0.f, l_iou, l_dfl, partial + (long)blockIdx.x * 4);
+  block_partial4(l_ang, 0.f, l_iou, l_dfl, partial + (long)blockIdx.x * 4);
 }
 
 // ------------------------------------------------------------------ K7: items (Loss.cs:463-476)
@@ -507,6 +633,7 @@ __global__ void loss_items_kernel(LossArgs a) {
     sc[2] = l_cls * a.hyp_cls;
     sc[3] = l_dfl * a.hyp_dfl;
     sc[4] = (sc[1] + sc[2] + sc[3]) * (float)a.B;
+    if (a.rot) { sc[13] = sc[12] / tss * a.hyp_angle; sc[4] += sc[13] * (float)a.B; }   // Loss.cs:604,617
   }
 }
 
@@ -532,6 +659,10 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   float* part_t = a.partial;
   float* part_c = part_t + (size_t)nb_a * 4;
   float* part_b = part_c + (size_t)nb_c * 4;
+  if (a.rot) {
+    if (!a.pa || !a.dpa) { ys_set_error("loss: the OBB criterion needs the angle logits"); return YS_ERR_INVALID_ARG; }
+    YS_CHECK_HIP(hipMemsetAsync(a.dpa, 0, (size_t)a.B * a.A * a.ld_pa * sizeof(T), st));   // background anchors: no angle gradient
+  }
   YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
   if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b, LS_THREADS, st, a);
   else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b, LS_THREADS, st, a);
@@ -543,7 +674,7 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_c, nb_c, a.scalars, 1);
   if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16>), nb_b, LS_THREADS, st, a, part_b);
   else YS_LAUNCH((loss_box_kernel<T, 0>), nb_b, LS_THREADS, st, a, part_b);
-  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_b, nb_b, a.scalars, 1);
+  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_b, nb_b, a.scalars, a.rot ? 2 : 1);
   YS_LAUNCH(loss_items_kernel, 1, 64, st, a);
   return YS_OK;
 }

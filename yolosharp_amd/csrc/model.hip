@@ -388,7 +388,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
     const int nx = obb ? 1 : (d.kpt_num > 0 ? d.kpt_num : 17) * m->kdim;
     if (!obb && m->kdim != 2 && m->kdim != 3) { ys_set_error("model: keypoint dim %d (2 or 3)", m->kdim); return YS_ERR_INVALID_ARG; }
     m->nm = nx; m->xkind = obb ? 2 : 3;
-    if (!obb) m->n_items = 5;      // v8PoseLoss items: box, pose, kobj, cls, dfl (Loss.cs:923)
+    m->n_items = obb ? 4 : 5;      // v8OBBLoss: box, cls, dfl, angle (Loss.cs:546); v8PoseLoss: box, pose, kobj, cls, dfl (Loss.cs:923)
     const int c4 = std::max(ch[0] / 4, nx);                      // Pose n/s/m: 51, not a multiple of the 16-byte unit
     const int c4p = (c4 + m->epl - 1) / m->epl * m->epl;         // tower buffers are padded; the pad channels stay zero
     m->ld_mc = (nx + m->epl - 1) / m->epl * m->epl;
@@ -717,9 +717,9 @@ int alloc_label_ws(ys_model* m, int gcap) {
   const size_t GA = (size_t)B * gcap * m->A;
   YS_TRY(dev_alloc(m, (void**)&m->lab_bidx, (size_t)m->max_labels * 4));
   YS_TRY(dev_alloc(m, (void**)&m->lab_cls, (size_t)m->max_labels * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->lab_box, (size_t)m->max_labels * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->lab_box, (size_t)m->max_labels * 20));   // 4 floats per label, 5 for oriented boxes
   YS_TRY(dev_alloc(m, (void**)&m->gt_count, (size_t)B * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->gt_box, (size_t)B * gcap * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->gt_box, (size_t)B * gcap * 20));        // xyxy, or xywh + angle (OBB)
   YS_TRY(dev_alloc(m, (void**)&m->gt_cls, (size_t)B * gcap * 12));  // gt_cls + gt_valid + gt_src
   YS_TRY(dev_alloc(m, (void**)&m->ov, GA * 4));
   YS_TRY(dev_alloc(m, (void**)&m->align, GA * 4));
@@ -878,7 +878,7 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->out_stage, (size_t)m->n_out_stage * 4));
   // loss workspace (label-capacity dependent part: alloc_label_ws; grown on demand by ys_loss_detect / ys_model_reserve_labels)
   YS_TRY(alloc_label_ws(m, d.max_labels > 0 ? d.max_labels : 64));
-  YS_TRY(dev_alloc(m, (void**)&m->pbox, (size_t)B * m->A * 16));
+  YS_TRY(dev_alloc(m, (void**)&m->pbox, (size_t)B * m->A * 20));
   YS_TRY(dev_alloc(m, (void**)&m->fg_gt, (size_t)B * m->A * 4));
   YS_TRY(dev_alloc(m, (void**)&m->tnorm, (size_t)B * m->A * 4));
   YS_TRY(dev_alloc(m, (void**)&m->loss_partial, ys_loss_partial_floats(B, m->A) * 4));
@@ -1295,7 +1295,7 @@ void reset_grad_state(ys_model* m) {
     std::fill(m->bufs[m->mc_buf].gw.begin(), m->bufs[m->mc_buf].gw.end(), 1);
     std::fill(m->bufs[m->pr_buf].gw.begin(), m->bufs[m->pr_buf].gw.end(), 1);
   }
-  if (m->xkind == 3) std::fill(m->bufs[m->mc_buf].gw.begin(), m->bufs[m->mc_buf].gw.end(), 1);   // keypoint gradients (poseloss.hip)
+  if (m->xkind >= 2) std::fill(m->bufs[m->mc_buf].gw.begin(), m->bufs[m->mc_buf].gw.end(), 1);   // angle-logit / keypoint gradients
 }
 
 TensorRec* find_tensor(ys_model* m, const char* name) {
@@ -1562,8 +1562,8 @@ int ys_model_get_output(ys_model* m, const char* key, float* host, size_t count)
     const Buf& b = m->bufs[m->pr_buf];
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, g ? b.grad : b.act, b.ldc, 0, B, m->nm, np, m->out_stage));
     YS_CHECK_HIP(hipMemcpyAsync(host, m->out_stage, count * 4, hipMemcpyDeviceToHost, st));
-  } else if (m->xkind == 3 && k == "dkpts") {                                           // d(sum(loss * B)) / d(raw kpts) [B][nk][A]
-    YS_REQUIRE(m->have_seg_loss, "ys_model_get_output(dkpts): no pose loss has run");
+  } else if ((m->xkind == 3 && k == "dkpts") || (m->xkind == 2 && k == "dangle")) {   // d(sum(loss * B)) / d(raw kpts | angle LOGIT) [B][nk|1][A]
+    YS_REQUIRE(m->have_seg_loss, "ys_model_get_output(%s): the model's criterion has not run", key);
     YS_REQUIRE(count == (size_t)B * m->nm * m->A, "ys_model_get_output(%s): expected %zu elements", key, (size_t)B * m->nm * m->A);
     const Buf& b = m->bufs[m->mc_buf];
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, b.grad, b.ldc, 0, B, m->nm, m->A, m->out_stage));
@@ -1596,12 +1596,12 @@ int ys_model_set_preds(ys_model* m, int batch, const float* boxes, const float* 
   YS_REQUIRE(m && !m->is_block && boxes && scores, "ys_model_set_preds: null argument or block handle");
   YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_set_preds: batch %d outside (0, %d]", batch, m->maxB);
   YS_REQUIRE(!m->segment || (mask_coefficient && proto), "ys_model_set_preds: a Segment model needs mask_coefficient and proto");
-  YS_REQUIRE(m->xkind != 3 || mask_coefficient, "ys_model_set_preds: a Pose model takes its raw kpts [B,nk,A] in the mask_coefficient argument");
+  YS_REQUIRE(m->xkind < 2 || mask_coefficient, "ys_model_set_preds: a Pose / Obb model takes its raw kpts [B,nk,A] / angle LOGITS [B,1,A] in the mask_coefficient argument");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   struct Item { const float* src; int buf; int C; long rows; } items[4] = {
     {boxes, m->pd_buf, 4 * m->d.reg_max, m->A}, {scores, m->ps_buf, m->d.nc, m->A},
-    {m->segment || m->xkind == 3 ? mask_coefficient : nullptr, m->mc_buf, m->nm, m->A}, {m->segment ? proto : nullptr, m->pr_buf, m->nm, (long)m->mh * m->mw}};
+    {m->segment || m->xkind >= 2 ? mask_coefficient : nullptr, m->mc_buf, m->nm, m->A}, {m->segment ? proto : nullptr, m->pr_buf, m->nm, (long)m->mh * m->mw}};
   for (const Item& it : items) {
     if (!it.src) continue;
     const Buf& b = m->bufs[it.buf];
@@ -1641,11 +1641,10 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
   // Training forward -> the criterion feeds backward (Amp.cs:338-348).  Eval forward -> validation loss on the eval-mode preds
   // (Detector.cs:94-97): the head logits are produced in both modes; only backward needs the training-mode state.
   YS_REQUIRE(!m->is_block && m->have_fwd, "ys_loss_detect: needs a forward of a full model first");
-  if (m->xkind == 2) {   // v8OBBLoss (Loss.cs:486-684): rotated assigner + probiou loss, not the detection criterion
-    ys_set_error("ys_loss_detect: the OBB criterion is not built (forward / predict only)");
-    return YS_ERR_UNSUPPORTED;
-  }
+  YS_REQUIRE(m->xkind != 2 || aux_follows, "ys_loss_detect: an OBB model's criterion is ys_loss_obb (oriented labels, Loss.cs:486-684)");
   YS_REQUIRE(m->xkind != 3 || aux_follows, "ys_loss_detect: a Pose model's criterion is ys_loss_pose (keypoint terms, Loss.cs:870-1071)");
+  const bool rot = m->xkind == 2;
+  const size_t lbytes = rot ? 20 : 16;
   YS_REQUIRE(n >= 0, "ys_loss_detect: n_labels = %d", n);
   YS_REQUIRE(n == 0 || (batch_idx && cls && bboxes), "ys_loss_detect: null label arrays");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -1659,7 +1658,7 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
     if (mx > m->gcap) YS_TRY(alloc_label_ws(m, (mx + 15) / 16 * 16));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_bidx, batch_idx, (size_t)n * 4, hipMemcpyHostToDevice, st));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_cls, cls, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    YS_CHECK_HIP(hipMemcpyAsync(m->lab_box, bboxes, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    YS_CHECK_HIP(hipMemcpyAsync(m->lab_box, bboxes, (size_t)n * lbytes, hipMemcpyHostToDevice, st));
     bi = m->lab_bidx; cl = m->lab_cls; bb = m->lab_box;
   }
   YsTimer timer(m->ctx, "loss");
@@ -1673,6 +1672,10 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
   a.mpos = m->mpos; a.pos_align = m->pos_align; a.pos_ov = m->pos_ov; a.fg_gt = m->fg_gt; a.tnorm = m->tnorm;
   a.partial = m->loss_partial; a.scalars = m->scalars;
   a.hyp_box = 7.5f; a.hyp_cls = 0.5f; a.hyp_dfl = 1.5f; a.topk = 10;   // Loss.cs:344,357
+  if (rot) {                                                             // Loss.cs:489: hyp_angle = 1
+    const Buf& ab = m->bufs[m->mc_buf];
+    a.rot = 1; a.pa = ab.act; a.dpa = ab.grad; a.ld_pa = m->ld_mc; a.hyp_angle = 1.0f;
+  }
   YS_TRY(ys_loss_detect_launch(st, m->dtype, a));
   YS_CHECK_HIP(hipGetLastError());
   m->have_loss = true;
@@ -1701,6 +1704,15 @@ int ys_loss_segment(ys_model* m, const float* batch_idx, const float* cls, const
                                 m->d.height, m->d.width, crop_mode));
   YS_CHECK_HIP(hipGetLastError());
   m->have_loss = true; m->have_seg_loss = true;
+  return YS_OK;
+}
+
+// v8OBBLoss (Loss.cs:486-684): the loss.hip pipeline in its rotated mode (probiou assigner and box term, rbox2dist DFL targets,
+// angle term).  bboxes: fp32 [n][5] = normalised cx, cy, w, h + angle in radians.
+int ys_loss_obb(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, int on_device) {
+  YS_REQUIRE(m && m->xkind == 2, "ys_loss_obb: model has no Obb head");
+  YS_TRY(loss_detect_core(m, batch_idx, cls, bboxes, n, on_device, true));
+  m->have_seg_loss = true;
   return YS_OK;
 }
 
@@ -1759,6 +1771,8 @@ int ys_loss_read_items(ys_model* m, float* items, int n_items, float* loss_sum) 
   if (m->segment) {
     YS_REQUIRE(m->have_seg_loss, "ys_loss_read_items: the Segment model needs ys_loss_segment");
     items[0] = h[1]; items[1] = h[8]; items[2] = h[2]; items[3] = h[3]; items[4] = 0.f;
+  } else if (m->xkind == 2) {
+    items[0] = h[1]; items[1] = h[2]; items[2] = h[3]; items[3] = h[13];                     // box, cls, dfl, angle (Loss.cs:619)
   } else if (m->xkind == 3) {
     YS_REQUIRE(m->have_seg_loss, "ys_loss_read_items: the Pose model needs ys_loss_pose");
     items[0] = h[1]; items[1] = h[10]; items[2] = h[11]; items[3] = h[2]; items[4] = h[3];   // box, pose, kobj, cls, dfl (Loss.cs:965)
@@ -1795,7 +1809,6 @@ int ys_model_backward(ys_model* m) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
   YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
   YS_REQUIRE(!m->segment || m->have_seg_loss, "ys_model_backward: the Segment model needs ys_loss_segment (mask gradients)");
-  YS_REQUIRE(m->xkind != 2, "ys_model_backward: OBB models are forward / predict only");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   YsTimer timer(m->ctx, "backward");
   reset_grad_state(m);

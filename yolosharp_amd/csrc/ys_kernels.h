@@ -218,6 +218,13 @@ struct LossArgs {
   float* scalars;      // [8]: tss, loss_box, loss_cls, loss_dfl, total
   float hyp_box, hyp_cls, hyp_dfl;
   int topk;
+  // v8OBBLoss (Loss.cs:486-684): rot = 1 -> labels carry (cx, cy, w, h, angle), gt_box / pbox rows are 5 floats (xywh + angle),
+  // the assigner uses probiou and the rotated in-box test, the box term is 1 - probiou, plus the angle term (scalars[12..13])
+  int rot;
+  const void* pa;      // angle logits [B][A][ld_pa] (channel 0); angle = (sigmoid - 0.25) * pi (Head.cs:429)
+  void* dpa;           // gradient w.r.t. the logit
+  int ld_pa;
+  float hyp_angle;
 };
 int ys_loss_detect_launch(hipStream_t st, int dtype, const LossArgs& a);
 size_t ys_loss_partial_floats(int B, int A);

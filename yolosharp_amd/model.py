@@ -146,7 +146,7 @@ class Yolov8:
     def get_output(self, key):
         B = self._batch
         C_ = {"boxes": 4 * self.reg_max, "scores": self.nc, "pred": 4 + self.nc + self.NM, "dboxes": 4 * self.reg_max,
-              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM, "angle": self.NM, "kpts": self.NM, "dkpts": self.NM}.get(key)
+              "dscores": self.nc, "mask_coefficient": self.NM, "dmask_coefficient": self.NM, "angle": self.NM, "kpts": self.NM, "dkpts": self.NM, "dangle": self.NM}.get(key)
         if key in ("proto", "dproto"):
             a = np.empty((B, self.NM, self.height // 4, self.width // 4), np.float32)
         else:
@@ -161,7 +161,12 @@ class Yolov8:
         sc = np.ascontiguousarray(preds["scores"], np.float32)
         B = bx.shape[0]
         assert bx.shape == (B, 4 * self.reg_max, self.A) and sc.shape == (B, self.nc, self.A), (bx.shape, sc.shape)
-        mc = np.ascontiguousarray(preds["kpts" if self.TASK == 3 else "mask_coefficient"], np.float32) if self.TASK in (1, 3) else None
+        mc = None
+        if self.TASK == 2:      # the engine keeps the angle head as logits: invert angle = (sigmoid(z) - 0.25) * pi (Head.cs:429)
+            p = np.clip(np.asarray(preds["angle"], np.float64) / np.pi + 0.25, 1e-7, 1 - 1e-7)
+            mc = np.ascontiguousarray(np.log(p / (1 - p)), np.float32)
+        elif self.TASK in (1, 3):
+            mc = np.ascontiguousarray(preds["kpts" if self.TASK == 3 else "mask_coefficient"], np.float32)
         pr = np.ascontiguousarray(preds["proto"], np.float32) if self.TASK == 1 else None
         _lib.check(self.lib, self.lib.ys_model_set_preds(self.handle, B, _ptr(bx), _ptr(sc), _ptr(mc), _ptr(pr)))
         self._batch = B
@@ -252,7 +257,7 @@ class Yolov11Segment(_SegmentMixin, Yolov11):
 class _ObbMixin:
     """Head.Obb (Head.cs:376-482): preds gain "angle" [B,1,A] = (sigmoid(cv4) - 0.25) * pi; the eval inference tensor is
     [B, 4+nc+1, A] = (xywh of dist2rbox * stride, class probabilities, angle) (Head.cs:411-418), the layout
-    Engine.non_max_suppression(rotated=True) reads.  Forward / predict only: v8OBBLoss (Loss.cs:486-684) is not built."""
+    Engine.non_max_suppression(rotated=True) reads.  Criterion: v8OBBLoss below."""
     TASK = 2
     NM = 1
 
@@ -348,12 +353,35 @@ class v8SegmentationLoss(v8DetectionLoss):
 
     __call__ = forward
 
+    N_ITEMS = 5
+
     def read(self):
-        items = (C.c_float * 5)()
+        items = (C.c_float * self.N_ITEMS)()
         total = C.c_float()
-        _lib.check(self.lib, self.lib.ys_loss_read_items(self.model.handle, items, 5, C.byref(total)))
+        _lib.check(self.lib, self.lib.ys_loss_read_items(self.model.handle, items, self.N_ITEMS, C.byref(total)))
         loss_detach = np.array(list(items), np.float32)
         return loss_detach * self.model._batch, loss_detach
+
+
+class v8OBBLoss(v8SegmentationLoss):
+    """Loss.cs:486-684.  batch["bboxes"] is [N, 5] = normalised cx, cy, w, h + angle (radians).  Returns (loss*B [4],
+    loss_detach [4]) in the order box, cls, dfl, angle."""
+    N_ITEMS = 4
+
+    def __init__(self, model):
+        v8DetectionLoss.__init__(self, model)
+
+    def forward_device(self, bidx_dev, cls_dev, box_dev, n):
+        _lib.check(self.lib, self.lib.ys_loss_obb(self.model.handle, bidx_dev, cls_dev, box_dev, n, 1))
+
+    def forward(self, preds, batch, read=True):
+        bi = np.ascontiguousarray(np.asarray(batch["batch_idx"], np.float32).reshape(-1))
+        cl = np.ascontiguousarray(np.asarray(batch["cls"], np.float32).reshape(-1))
+        bb = np.ascontiguousarray(np.asarray(batch["bboxes"], np.float32).reshape(-1, 5))
+        _lib.check(self.lib, self.lib.ys_loss_obb(self.model.handle, _ptr(bi), _ptr(cl), _ptr(bb), bi.shape[0], 0))
+        return self.read() if read else None
+
+    __call__ = forward
 
 
 class v8PoseLoss(v8SegmentationLoss):
