@@ -242,7 +242,7 @@ loss_decode_kernel(LossArgs a) {
 }
 
 // ------------------------------------------------------------------ K2: metrics + top-k per (image, gt)
-template <class T>
+template <class T, bool ROT>     // ROT: RotatedTaskAlignedAssigner (Tal.cs:260-310) -- compile-time so the plain path keeps its registers
 __global__ void __launch_bounds__(LS_THREADS)
 tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   __shared__ unsigned s_ingt[1056];   // A <= 33792 anchors
@@ -254,9 +254,9 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   if (g >= a.gt_count[b]) return;
   const long gi = (long)b * a.gcap + g;
   const bool valid = gt_valid[gi] != 0;
-  const float* gb = a.gt_box + gi * (a.rot ? 5 : 4);
+  const float* gb = a.gt_box + gi * (ROT ? 5 : 4);
   const float g4[4] = {gb[0], gb[1], gb[2], gb[3]};
-  const float g5[5] = {gb[0], gb[1], gb[2], gb[3], a.rot ? gb[4] : 0.f};
+  const float g5[5] = {gb[0], gb[1], gb[2], gb[3], ROT ? gb[4] : 0.f};
   const int cls = a.gt_cls[gi];
   float* ovr = a.ov + gi * a.A;
   float* alr = a.align + gi * a.A;
@@ -271,7 +271,7 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   const float ix1 = cx - w / 2, iy1 = cy - h / 2, ix2 = cx + w / 2, iy2 = cy + h / 2;
   // rotated in-box test (Tal.cs:289-306): corners a = ctr + v1 + v2, b = ctr + v1 - v2, d = ctr - v1 + v2 (Ops.cs:24-33)
   float cax = 0.f, cay = 0.f, abx = 0.f, aby = 0.f, adx = 0.f, ady = 0.f, nab = 0.f, nad = 0.f;
-  if (a.rot) {
+  if (ROT) {
     const float cs = cosf(g5[4]), sn = sinf(g5[4]);
     const float v1x = g5[2] / 2 * cs, v1y = g5[2] / 2 * sn, v2x = -g5[3] / 2 * sn, v2y = g5[3] / 2 * cs;
     cax = g5[0] + v1x + v2x; cay = g5[1] + v1y + v2y;
@@ -284,14 +284,14 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
     const float px = an.ax * an.stride, py = an.ay * an.stride;   // anchor_points * stride_tensor (Loss.cs:439)
     const float dmin_ = fminf(fminf(px - ix1, py - iy1), fminf(ix2 - px, iy2 - py));
     bool ingt = dmin_ > 1e-9f;                                     // Tal.cs:221
-    if (a.rot) {
+    if (ROT) {
       const float apx = px - cax, apy = py - cay;
       const float dab = apx * abx + apy * aby, dad = apx * adx + apy * ady;
       ingt = dab >= 0.f && dab <= nab && dad >= 0.f && dad <= nad;
     }
     float o = 0.f, al = 0.f;
     if (ingt && valid) {
-      if (a.rot) {
+      if (ROT) {
         const float* pb = a.pbox + ((long)b * a.A + ai) * 5;
         const float p5[5] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride, pb[4]};   // Loss.cs:580-583
         o = probiou_t<float>(g5, p5);                              // Tal.cs:267-270 (obb1 = gt, obb2 = pred)
@@ -497,7 +497,7 @@ loss_cls_kernel(LossArgs a, float* partial) {
 // four consecutive lanes own one anchor (one side l,t,r,b each)
 // RR = reg_max when it is the usual 16 (compile-time: the 16 bins stay in registers, rows move as 16-byte vectors), 0 = run-time.
 // Only foreground anchors (a few per cent) need the softmax at all; every other row just receives a zero gradient.
-template <class T, int RR>
+template <class T, int RR, bool ROT>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_box_kernel(LossArgs a, float* partial) {
   constexpr int EPL = Elem<T>::EPL;
@@ -544,7 +544,7 @@ loss_box_kernel(LossArgs a, float* partial) {
     const float tss = a.scalars[0];
     const float gbox = a.hyp_box * (float)a.B / tss * w;
     float gd, t;                                       // d(total)/d(dist_s) through the box term; DFL target of this side
-    if (a.rot) {
+    if (ROT) {
       // RotatedBboxLoss (Loss.cs:197-227) + calculate_angle_loss (:657-676) on pred = (dist2rbox(dist, angle), angle), grid units
       const float* gb = a.gt_box + ((long)b * a.gcap + g) * 5;
       const float tb[5] = {gb[0] / an.stride, gb[1] / an.stride, gb[2] / an.stride, gb[3] / an.stride, gb[4]};   // Loss.cs:596
@@ -666,14 +666,20 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
   if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b, LS_THREADS, st, a);
   else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b, LS_THREADS, st, a);
-  YS_LAUNCH((tal_metrics_kernel<T>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
+  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
+  else YS_LAUNCH((tal_metrics_kernel<T, false>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
   YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);
   YS_LAUNCH((loss_cls_kernel<T>), nb_c, LS_THREADS, st, a, part_c);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_c, nb_c, a.scalars, 1);
-  if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16>), nb_b, LS_THREADS, st, a, part_b);
-  else YS_LAUNCH((loss_box_kernel<T, 0>), nb_b, LS_THREADS, st, a, part_b);
+  if (a.rot) {
+    if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16, true>), nb_b, LS_THREADS, st, a, part_b);
+    else YS_LAUNCH((loss_box_kernel<T, 0, true>), nb_b, LS_THREADS, st, a, part_b);
+  } else {
+    if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16, false>), nb_b, LS_THREADS, st, a, part_b);
+    else YS_LAUNCH((loss_box_kernel<T, 0, false>), nb_b, LS_THREADS, st, a, part_b);
+  }
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_b, nb_b, a.scalars, a.rot ? 2 : 1);
   YS_LAUNCH(loss_items_kernel, 1, 64, st, a);
   return YS_OK;
