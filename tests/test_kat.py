@@ -4,7 +4,9 @@ tests/kat_ref.py is a SECOND restatement of the cited C# -- scalar fp64 Python, 
 that shares nothing with oracle/yolo_oracle.py (no torch, no autograd).  tests/golden/kat_loss.json holds its answers for a
 hand-built case (tests/golden/make_kat.py).  Here both the ATen oracle AND the HIP kernels are checked against those answers:
 CIoU, DFL incl. both clamps, TAL (double-claimed anchor, zero-metric ties, tiny-box inflation, padded GT row), the three loss
-items, d(loss)/d(boxes, scores), and BatchNorm's batch / running statistics (momentum 0.03, unbiased running_var)."""
+items, d(loss)/d(boxes, scores), and BatchNorm's batch / running statistics (momentum 0.03, unbiased running_var).
+tests/golden/kat_tasks.json (make_kat_tasks.py) does the same for v8PoseLoss and v8OBBLoss: items and finite-difference gradients
+w.r.t. the keypoint outputs, the box / class logits and the angle logit."""
 import json
 import os
 
@@ -127,3 +129,97 @@ def test_conv_bn_silu_matches_kat(backend, engine):
     assert np.allclose(after["bn.running_var"], bn["new_running_var"], rtol=1e-4)
     assert after["bn.num_batches_tracked"][0] == 1
     blk.close()
+
+
+# ----------------------------------------------------------------------------- v8PoseLoss / v8OBBLoss known answers
+TASKS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_tasks.json")))
+
+
+def test_task_kat_file_reproduces():
+    """kat_tasks.json is what kat_ref computes today (tests/golden/make_kat_tasks.py), plus closed-form spot checks of probiou."""
+    t, k = TASKS, KAT
+    p = t["pose"]
+    items, total, _ = K.pose_loss(k["boxes"], k["scores"], p["kpts"], k["batch_idx"], k["cls"], k["bboxes"], p["keypoints"], t["H"], t["W"],
+                                  p["nc"], p["K"], p["D"])
+    assert np.allclose(items, p["items"], rtol=1e-12) and abs(total - p["total"]) < 1e-9
+    o = t["obb"]
+    items, total, tg = K.obb_loss(o["boxes"], o["scores"], o["angle_logit"], o["batch_idx"], o["cls"], o["bboxes"], t["H"], t["W"], o["nc"])
+    assert np.allclose(items, o["items"], rtol=1e-12) and abs(total - o["total"]) < 1e-9
+    assert [[bool(v) for v in x[0]] for x in tg] == o["fg"] and [x[1] for x in tg] == o["gt_idx"]
+    same = K.probiou((3.0, 4.0, 6.0, 2.0, 0.3), (3.0, 4.0, 6.0, 2.0, 0.3))        # identical boxes: bd = 0.5 log(1 + eps') -> clamp(eps)
+    assert abs(same - (1.0 - np.sqrt(1.0 - np.exp(-1e-7) + 1e-7))) < 1e-6
+    assert abs(K.probiou((0, 0, 4, 2, 0.0), (1, 0, 4, 2, 0.0)) - K.probiou((0, 0, 2, 4, np.pi / 2), (1, 0, 2, 4, np.pi / 2))) < 1e-12
+
+
+def _pose_case():
+    k, p = KAT, TASKS["pose"]
+    bx, sc, batch = _case()
+    batch["keypoints"] = np.array(p["keypoints"], np.float32)
+    return bx, sc, np.array(p["kpts"], np.float64), batch
+
+
+def _obb_case():
+    o = TASKS["obb"]
+    batch = {"batch_idx": np.array(o["batch_idx"], np.float32), "cls": np.array(o["cls"], np.float32), "bboxes": np.array(o["bboxes"], np.float32)}
+    return np.array(o["boxes"], np.float64), np.array(o["scores"], np.float64), np.array(o["angle_logit"], np.float64), batch
+
+
+def test_oracle_matches_task_kat():
+    """ATen-CPU v8PoseLoss / v8OBBLoss (+ RotatedTaskAlignedAssigner) vs the independent fp64 answers: items, autograd vs finite differences."""
+    t = TASKS
+    B, H, W = t["B"], t["H"], t["W"]
+    for dt, tol in ((torch.float64, 1e-7), (torch.float32, 2e-4)):
+        feats = [torch.zeros(B, 1, H // s, W // s, dtype=dt) for s in (8, 16, 32)]
+        # pose
+        p = t["pose"]
+        bx, sc, kp, batch = _pose_case()
+        kpts = torch.tensor(kp, dtype=dt, requires_grad=True)
+        preds = {"boxes": torch.tensor(bx, dtype=dt), "scores": torch.tensor(sc, dtype=dt), "kpts": kpts, "feats": feats}
+        loss, items = O.v8PoseLoss(p["nc"], p["K"], p["D"])(preds, {kk: torch.from_numpy(v) for kk, v in batch.items()})
+        assert np.allclose(items.detach().numpy(), p["items"], rtol=tol, atol=tol), (dt, items, p["items"])
+        loss.sum().backward()
+        want = np.array(p["dkpts"])
+        assert np.abs(kpts.grad.numpy() - want).max() <= max(tol * 50, 2e-5) * np.abs(want).max(), dt
+        # obb
+        o = t["obb"]
+        bx, sc, al, batch = _obb_case()
+        boxes = torch.tensor(bx, dtype=dt, requires_grad=True)
+        scores = torch.tensor(sc, dtype=dt, requires_grad=True)
+        logit = torch.tensor(al, dtype=dt, requires_grad=True)
+        preds = {"boxes": boxes, "scores": scores, "angle": (logit.sigmoid() - 0.25) * np.pi, "feats": feats}
+        loss, items = O.v8OBBLoss(o["nc"])(preds, {kk: torch.from_numpy(v) for kk, v in batch.items()})
+        assert np.allclose(items.detach().numpy(), o["items"], rtol=tol, atol=tol), (dt, items, o["items"])
+        loss.sum().backward()
+        for got, key in ((boxes.grad, "dboxes"), (scores.grad, "dscores"), (logit.grad, "dangle")):
+            want = np.array(o[key])
+            assert np.abs(got.numpy() - want).max() <= max(tol * 50, 2e-5) * np.abs(want).max(), (dt, key)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_engine_task_losses_match_kat(backend, engine):
+    """HIP v8PoseLoss / v8OBBLoss on caller-supplied preds vs the independent answers: items within 1e-3, gradients within 1e-3 of
+    their maximum (the OBB case holds a filtered label, a widened label, nested boxes and a padded GT row)."""
+    from yolosharp_amd.model import Yolov8Obb, Yolov8Pose, v8OBBLoss, v8PoseLoss
+    t = TASKS
+    p = t["pose"]
+    bx, sc, kp, batch = _pose_case()
+    m = Yolov8Pose(engine, nc=p["nc"], size="n", height=t["H"], width=t["W"], max_batch=t["B"], dtype="f32", kpt_num=p["K"], kpt_dim=p["D"])
+    m.set_preds({"boxes": bx, "scores": sc, "kpts": kp})
+    loss, items = v8PoseLoss(m)(None, batch)
+    assert np.allclose(items, p["items"], rtol=1e-3, atol=1e-5), (items, p["items"])
+    assert np.allclose(loss.sum(), p["total"], rtol=1e-3)
+    want = np.array(p["dkpts"])
+    assert np.abs(m.get_output("dkpts") - want).max() <= 1e-3 * np.abs(want).max()
+    m.close()
+    o = t["obb"]
+    bx, sc, al, batch = _obb_case()
+    m = Yolov8Obb(engine, nc=o["nc"], size="n", height=t["H"], width=t["W"], max_batch=t["B"], dtype="f32")
+    m.set_preds({"boxes": bx, "scores": sc, "angle": (1.0 / (1.0 + np.exp(-al)) - 0.25) * np.pi})
+    loss, items = v8OBBLoss(m)(None, batch)
+    assert np.allclose(items, o["items"], rtol=1e-3, atol=1e-5), (items, o["items"])
+    assert np.allclose(loss.sum(), o["total"], rtol=1e-3)
+    for key in ("dboxes", "dscores", "dangle"):
+        want = np.array(o[key])
+        got = m.get_output(key)
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (key, np.abs(got - want).max(), np.abs(want).max())
+    m.close()
