@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--size", default="n")
     ap.add_argument("--imgsz", type=int, default=640, help="square input size (BASELINE configs: 640; config 5 shape: 1280)")
     ap.add_argument("--family", type=int, default=8, choices=[8, 11], help="graph family (8 = YOLOv8, 11 = YOLOv11); default = BASELINE config 2")
-    ap.add_argument("--task", default="detect", choices=["detect", "segment"])
+    ap.add_argument("--task", default="detect", choices=["detect", "segment", "obb", "pose"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"], help="fp8 = bf16 storage + fp8 MFMA forward / dgrad convolutions (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
@@ -110,26 +110,35 @@ def main():
 
     from yolosharp_amd import Engine
     from yolosharp_amd.model import Yolov8, Yolov11, Yolov8Segment, Yolov11Segment, v8DetectionLoss, v8SegmentationLoss
+    from yolosharp_amd import model as ysm
     from yolosharp_amd import dist as ysd
     from yolosharp_amd.workload import step_work
 
-    nc, H, W, B = 80, args.imgsz, args.imgsz, args.batch
+    nc, H, W, B = {"obb": 15, "pose": 1}.get(args.task, 80), args.imgsz, args.imgsz, args.batch   # DOTA-15 / COCO-person class counts
     stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
     eng = Engine(local_rank, stream=stream)          # N>1: run on torch's stream so RCCL orders against our kernels
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
         raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
     seg = args.task == "segment"
     Model = {(8, False): Yolov8, (11, False): Yolov11, (8, True): Yolov8Segment, (11, True): Yolov11Segment}[(args.family, seg)]
+    if args.task in ("obb", "pose"):
+        Model = getattr(ysm, f"Yolov{args.family}{args.task.capitalize()}")
     model = Model(eng, nc=nc, size=args.size, height=H, width=W, max_batch=B, dtype=args.dtype)
     model.init_weights(2)
     model.train()
-    crit = v8SegmentationLoss(model) if seg else v8DetectionLoss(model)
+    crit = v8SegmentationLoss(model) if seg else {"obb": ysm.v8OBBLoss, "pose": ysm.v8PoseLoss}.get(args.task, v8DetectionLoss)(model)
     headline = args.family == 8 and not seg          # BASELINE.json metric/config (YOLOv8 detect)
     rng = np.random.default_rng(0 + rank)
     images = rng.random((B, 3, H, W), dtype=np.float32)
     bi, cl, bb = synth_labels(B, nc, seed=1 + rank)
     d_img = eng.to_device(images)
+    if args.task == "obb":       # oriented labels: the same boxes with an angle in [-pi/4, 3pi/4) (Head.cs:429 range)
+        bb = np.concatenate([bb, (rng.random((len(bi), 1), dtype=np.float32) - 0.25) * np.float32(np.pi)], 1).astype(np.float32)
     d_lab = (eng.to_device(bi), eng.to_device(cl), eng.to_device(bb), len(bi))
+    if args.task == "pose":      # 17 x 3 COCO keypoints scattered in each box, visibility 0 / 1 / 2
+        kxy = bb[:, None, :2] + (rng.random((len(bi), 17, 2), dtype=np.float32) - 0.5) * bb[:, None, 2:4]
+        kv = rng.integers(0, 3, (len(bi), 17, 1)).astype(np.float32)
+        d_lab = d_lab + (eng.to_device(np.ascontiguousarray(np.concatenate([np.clip(kxy, 0, 1), kv], 2), np.float32)),)
     if seg:
         d_lab = d_lab + (eng.to_device(synth_masks(bi, bb, B, H // 4, W // 4)),)
     lr0 = round(0.002 * 5 / (4 + nc), 6)
@@ -220,11 +229,11 @@ def main():
                     "class_ms_per_step": {"conv_igemm": round(ms_ig / steps_prof, 3), "conv_wgrad": round(ms_wg / steps_prof, 3)},
                     "step_algorithmic_GBps": round(wk["train_bytes"] * B / (ms * 1e-3) / 1e9, 1),
                     "step_TFLOPs": round(wk["train_flop"] * B / (ms * 1e-3) / 1e12, 2)}
-        gname = f"YOLOv{args.family}{args.size}" + ("-seg" if seg else "")
+        gname = f"YOLOv{args.family}{args.size}" + {"segment": "-seg", "obb": "-obb", "pose": "-pose"}.get(args.task, "")
         out = {"metric": f"train images/sec {gname} {W}x{H} bs={B}/GPU", "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, COCO-80 synthetic labels" + (" + instance masks" if seg else ""),
+               "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, {'COCO-80' if nc == 80 else str(nc) + '-class'} synthetic labels" + {"segment": " + instance masks", "obb": " (oriented)", "pose": " + 17x3 keypoints"}.get(args.task, ""),
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
         # ---- secondary metric: inference images/s = eval forward (BN folded into the conv epilogues) + Detect decode
@@ -242,7 +251,7 @@ def main():
                         "what": "eval forward + decode to pred [B,4+nc(+nm),A], inputs resident in HBM"}
         model.train()
         # ---- secondary metric: NMS boxes/s on [64, 84, 8400]
-        if not args.no_nms:
+        if not args.no_nms and nc == 80:      # the NMS line is quoted on the COCO-80 shape
             prng = np.random.default_rng(3)
             A = 8400
             wh = prng.uniform(0.03, 0.6, (64, 2, A)) * 640; c = prng.uniform(0, 640, (64, 2, A))
