@@ -244,6 +244,12 @@ YS_API int ys_box_iou(ys_ctx* ctx, const float* box1, int n, const float* box2, 
  * [n, npix] (ys_process_mask output) -> iou fp32 [nl, n].  Bit-exact: the reference's float matmul of 0/1 masks is an integer count. */
 YS_API int ys_mask_iou(ys_ctx* ctx, const float* gt_ids, int nl, const uint8_t* pred_masks, int n, int npix, float eps,
                        int on_device, float* iou);
+/* Metrics.kpt_iou (Utils/Metrics.cs:186-212) as PoseDetector.Val uses it (Models/PoseDetector.cs:150-158): object keypoint similarity
+ * [n, m] of ground-truth keypoints kpt1 [n, K, 3] (pixels, visibility; 2-D labels get a visibility column of ones on the host,
+ * PoseDetector.cs:144-148) against predicted keypoints kpt2 [m, K, kpt_dim]; area [n] = w * h * 0.53 of the labels' boxes;
+ * sigmas = the COCO OKS sigmas when K == 17, else 1/K. */
+YS_API int ys_kpt_iou(ys_ctx* ctx, const float* kpt1, int n, const float* kpt2, int m, const float* area, int kpt_num, int kpt_dim,
+                      float eps, int on_device, float* iou);
 /* match_predictions (Models/YoloBaseTaskModel.cs:377-446) on a caller-supplied IoU matrix [nl, n] (box, mask, OBB or keypoint
  * IoU alike): correct uint8 [n, 10] for the thresholds linspace(0.5, 0.95, 10). */
 YS_API int ys_match_predictions(ys_ctx* ctx, const float* pred_cls, int n, const float* true_cls, int nl, const float* iou,

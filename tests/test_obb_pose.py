@@ -381,3 +381,22 @@ def test_yolov8s_obb_bf16_train_steps(backend, engine):
     assert abs(hist[0] / B - float(ritems.sum())) < 0.1 * float(ritems.sum())
     assert hist[-1] < hist[0]
     m.close()
+
+
+# ----------------------------------------------------------------------------- PoseDetector.Val: Metrics.kpt_iou (Metrics.cs:186-212)
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("K,D", [(17, 3), (5, 2)])
+def test_kpt_iou(backend, engine, K, D):
+    g = torch.Generator().manual_seed(K)
+    n, m = 7, 23
+    k1 = torch.cat((torch.rand(n, K, 2, generator=g) * 640, torch.randint(0, 3, (n, K, 1), generator=g).float()), -1)
+    k1[2, :, 2] = 0                                                # an object with no labelled keypoint: 0 / eps
+    k2 = torch.cat((k1[torch.randint(0, n, (m,), generator=g), :, :2] + torch.randn(m, K, 2, generator=g) * 12, torch.rand(m, K, 1, generator=g)), -1)[..., :D]
+    area = torch.rand(n, generator=g) * 4e4 * 0.53 + 50
+    want = O.kpt_iou(k1, k2, area).numpy()
+    got = engine.kpt_iou(k1.numpy(), k2.numpy(), area.numpy())
+    assert got.shape == (n, m) and np.allclose(got, want, rtol=1e-4, atol=1e-6)
+    assert want.max() > 0.5 and not got[2].any()
+    tp = engine.match_predictions(np.zeros(m, np.float32), np.zeros(n, np.float32), got)      # the second match of PoseDetector.cs:158
+    assert np.array_equal(tp, O.match_predictions(torch.zeros(m), torch.zeros(n), torch.from_numpy(want)).numpy())
+    assert engine.kpt_iou(np.zeros((0, K, 3), np.float32), k2.numpy(), np.zeros(0, np.float32)).shape == (0, m)

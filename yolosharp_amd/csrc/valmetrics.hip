@@ -39,6 +39,30 @@ box_iou_kernel(const float* __restrict__ b1, int n, const float* __restrict__ b2
   out[i] = vm_iou(b1[4 * r], b1[4 * r + 1], b1[4 * r + 2], b1[4 * r + 3], b2[4 * c], b2[4 * c + 1], b2[4 * c + 2], b2[4 * c + 3], eps);
 }
 
+// Metrics.kpt_iou (Metrics.cs:186-212): OKS of ground-truth keypoints kpt1 [n][K][3] (x, y, visibility) against predictions
+// kpt2 [m][K][D]; area [n]; sigma = OKS sigmas when K == 17, else 1/K.  One thread per (gt, prediction) pair.
+struct KptSigma { float s[64]; };
+__global__ void __launch_bounds__(VM_THREADS)
+kpt_iou_kernel(const float* __restrict__ k1, int n, const float* __restrict__ k2, int m, const float* __restrict__ area, int K, int D,
+               KptSigma sg, float eps, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * m) return;
+  const int r = (int)(i / m), c = (int)(i - (long)r * m);
+  const float* g = k1 + (long)r * K * 3;
+  const float* p = k2 + (long)c * K * D;
+  const float ar = area[r] + eps;
+  float acc = 0.f, cnt = 0.f;
+  for (int k = 0; k < K; k++) {
+    const float dx = g[3 * k] - p[D * k], dy = g[3 * k + 1] - p[D * k + 1];
+    const float s2 = 2.0f * sg.s[k];
+    const float e = (dx * dx + dy * dy) / (s2 * s2 * ar * 2.0f);
+    const float mk = g[3 * k + 2] != 0.f ? 1.f : 0.f;
+    acc += expf(-e) * mk;
+    cnt += mk;
+  }
+  out[i] = acc / (cnt + eps);
+}
+
 // one workgroup per image
 __global__ void __launch_bounds__(VM_THREADS)
 val_match_kernel(const float* __restrict__ rows, const int* __restrict__ count, int max_det, int row_stride,
@@ -220,6 +244,33 @@ int ys_mask_iou(ys_ctx* ctx, const float* gt_ids, int nl, const uint8_t* pred_ma
   YS_CHECK_HIP(hipGetLastError());
   if (!on_device) {
     hipMemcpyAsync(iou, d_iou, (size_t)nl * n * 4, hipMemcpyDeviceToHost, st);
+    YS_CHECK_HIP(hipStreamSynchronize(st));
+  }
+  return YS_OK;
+}
+
+int ys_kpt_iou(ys_ctx* ctx, const float* kpt1, int n, const float* kpt2, int m, const float* area, int kpt_num, int kpt_dim, float eps,
+               int on_device, float* iou) {
+  YS_REQUIRE(ctx && iou && n >= 0 && m >= 0, "ys_kpt_iou: bad argument");
+  YS_REQUIRE(kpt_num > 0 && kpt_num <= 64 && (kpt_dim == 2 || kpt_dim == 3), "ys_kpt_iou: %d keypoints of dim %d", kpt_num, kpt_dim);
+  if ((long)n * m == 0) return YS_OK;
+  YS_REQUIRE(kpt1 && kpt2 && area, "ys_kpt_iou: null argument");
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  VmStage sg(st, on_device);
+  const float* d1 = (const float*)sg.in(kpt1, (size_t)n * kpt_num * 3 * 4);
+  const float* d2 = (const float*)sg.in(kpt2, (size_t)m * kpt_num * kpt_dim * 4);
+  const float* da = (const float*)sg.in(area, (size_t)n * 4);
+  float* d_iou = (float*)sg.out(iou, (size_t)n * m * 4);
+  if (!sg.ok) { ys_set_error("ys_kpt_iou: out of device memory"); return YS_ERR_OOM; }
+  static const float oks[17] = {0.026f, 0.025f, 0.025f, 0.035f, 0.035f, 0.079f, 0.079f, 0.072f, 0.072f, 0.062f, 0.062f, 0.107f, 0.107f,
+                                0.087f, 0.087f, 0.089f, 0.089f};                       // PoseDetector.cs:12-19
+  KptSigma ks{};
+  for (int k = 0; k < kpt_num; k++) ks.s[k] = kpt_num == 17 ? oks[k] : 1.0f / (float)kpt_num;   // Metrics.cs:205
+  YS_LAUNCH(kpt_iou_kernel, ys_cdiv((long)n * m, VM_THREADS), VM_THREADS, st, d1, n, d2, m, da, kpt_num, kpt_dim, ks, eps, d_iou);
+  YS_CHECK_HIP(hipGetLastError());
+  if (!on_device) {
+    hipMemcpyAsync(iou, d_iou, (size_t)n * m * 4, hipMemcpyDeviceToHost, st);
     YS_CHECK_HIP(hipStreamSynchronize(st));
   }
   return YS_OK;

@@ -111,6 +111,17 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_box_iou(self.ctx, _ptr(b1), b1.shape[0], _ptr(b2), b2.shape[0], eps, 0, _ptr(out)))
         return out
 
+    def kpt_iou(self, kpt1, kpt2, area, eps=1e-7):
+        """Metrics.kpt_iou (Metrics.cs:186-212): gt keypoints [n,K,3] x predicted keypoints [m,K,D], area [n] -> OKS [n,m] fp32."""
+        k1 = np.ascontiguousarray(kpt1, np.float32)
+        k2 = np.ascontiguousarray(kpt2, np.float32)
+        ar = np.ascontiguousarray(area, np.float32).reshape(-1)
+        n, K = k1.shape[0], k1.shape[1]
+        assert k1.shape == (n, K, 3) and k2.ndim == 3 and k2.shape[1] == K and ar.shape[0] == n, (k1.shape, k2.shape, ar.shape)
+        out = np.zeros((n, k2.shape[0]), np.float32)
+        _lib.check(self.lib, self.lib.ys_kpt_iou(self.ctx, _ptr(k1), n, _ptr(k2), k2.shape[0], _ptr(ar), K, k2.shape[2], eps, 0, _ptr(out)))
+        return out
+
     def val_match(self, rows, count, batch, img_w, img_h):
         """rows [B,max_det,6+extra] / count [B]: the padded NMS outputs (x1,y1,x2,y2,conf,cls,...); batch = collate dict
         (batch_idx, cls, bboxes normalised cxcywh).  Returns a list of bool [count[b], 10] (match_predictions per image)."""
