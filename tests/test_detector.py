@@ -151,3 +151,103 @@ def test_letterbox_and_rectangle(backend, engine):
     from yolosharp_amd import YsError
     with pytest.raises(YsError):
         engine.letterbox(img, 640, 640, 114, rectangle_shape=(320, 100))      # the resized image does not fit the canvas
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_obber_predict_and_val(backend, engine):
+    """Obber.ImagePredict / Val (Obber.cs:28-163) through the device pieces vs the same loop on the oracle's pieces (rotated NMS rows
+    -> batch_probiou -> match_predictions -> ap_per_class); the validation loss is v8OBBLoss on the eval-mode preds."""
+    from yolosharp_amd.detector import Obber
+    from yolosharp_amd.model import Yolov8Obb
+    from yolosharp_amd import metrics as M
+    from test_obb_pose import make_ref
+    nc, H, W, B = 4, 64, 64, 2
+    ref = make_ref(O.Yolov8Obb, nc, "n", seed=3)
+    with torch.no_grad():
+        for seq in ref.model[-1].cv3:
+            seq[2].bias.add_(1.0); seq[2].weight.mul_(8.0)
+    m = Yolov8Obb(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    tb = O.synthetic_obb_batch(B, H, W, nc, seed=5, kmax=4)
+    d = {k: v.numpy() for k, v in tb.items()}
+    d["images"] = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(4)).numpy()
+    ob = Obber(m)
+    loss_items, box = ob.Val([d], conf_thres=0.3)
+    ref.eval()
+    with torch.no_grad():
+        rinf, rpreds = ref(torch.from_numpy(d["images"]))
+        _, ritems = O.v8OBBLoss(nc)(rpreds, tb)
+    assert loss_items.shape == (4,) and np.allclose(loss_items, ritems.numpy(), rtol=2e-3, atol=1e-4)
+    output, _ = O.non_max_suppression_rotated(rinf["boxes"], 0.3, 0.7, nc=nc)
+    tps, confs, pcls, tcls = [], [], [], []
+    scale = torch.tensor([W, H, W, H], dtype=torch.float32)
+    for b, rows in enumerate(output):
+        sel = tb["batch_idx"].view(-1) == b
+        gt = torch.cat((tb["bboxes"][sel][:, :4] * scale, tb["bboxes"][sel][:, 4:5]), 1)
+        pred = torch.cat((rows[:, :4], rows[:, 6:7]), 1)
+        tps.append(O.match_predictions(rows[:, 5], tb["cls"].view(-1)[sel], O.batch_probiou(gt, pred)).numpy())
+        confs.append(rows[:, 4].numpy()); pcls.append(rows[:, 5].numpy()); tcls.append(tb["cls"].view(-1)[sel].numpy())
+    assert sum(len(c) for c in confs) > 4
+    rbox = M.val_summary(M.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls)))
+    assert np.allclose(box, rbox, atol=1e-6), (box, rbox)
+    img = (d["images"][0] * 255).astype(np.uint8)
+    res = ob.ImagePredict(img, 0.5, 0.3)
+    want, _ = O.non_max_suppression_rotated(rinf["boxes"][:1], 0.5, 0.3, nc=nc)
+    assert len(res) == len(want[0]) > 0
+    for r, w in zip(res, want[0].numpy()):
+        assert (r.ClassID, r.Width, r.Height) == (int(w[5]), int(w[2]), int(w[3])) and abs(r.Radian - w[6]) < 1e-3 and abs(r.Score - w[4]) < 1e-3
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_pose_detector_predict_and_val(backend, engine):
+    """PoseDetector.ImagePredict / Val (PoseDetector.cs:39-200): NMS rows carry the decoded keypoints; box_iou matching and OKS
+    matching (kpt_iou, area * 0.53) vs the same loop on the oracle's pieces."""
+    from yolosharp_amd.detector import PoseDetector
+    from yolosharp_amd.model import Yolov8Pose
+    from yolosharp_amd import metrics as M
+    from test_obb_pose import make_ref
+    nc, H, W, B, K, D = 1, 64, 64, 2, 17, 3
+    ref = make_ref(O.Yolov8Pose, nc, "n", seed=3)
+    with torch.no_grad():
+        for seq in ref.model[-1].cv3:
+            seq[2].bias.add_(1.5); seq[2].weight.mul_(8.0)
+    m = Yolov8Pose(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    tb = O.synthetic_batch(B, H, W, nc, seed=21, kmax=4)
+    tb["keypoints"] = O.synthetic_keypoints(tb, K, D)
+    d = {k: v.numpy() for k, v in tb.items()}
+    d["images"] = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(4)).numpy()
+    pdt = PoseDetector(m)
+    loss_items, box, pose = pdt.Val([d], conf_thres=0.3)
+    ref.eval()
+    with torch.no_grad():
+        rinf, rpreds = ref(torch.from_numpy(d["images"]))
+        _, ritems = O.v8PoseLoss(nc, K, D)(rpreds, tb)
+    assert loss_items.shape == (5,) and np.allclose(loss_items, ritems.numpy(), rtol=2e-3, atol=1e-4)
+    m.eval()
+    inference, _ = m.forward(d["images"])
+    output, _ = engine.non_max_suppression(inference["boxes"], 0.3, 0.7, nc=nc)
+    tps, tpps, confs, pcls, tcls = [], [], [], [], []
+    for b, rows in enumerate(output):
+        rows = torch.from_numpy(rows)
+        sel = tb["batch_idx"].view(-1) == b
+        tcl = tb["cls"].view(-1)[sel]
+        gt = O.xywh2xyxy(tb["bboxes"][sel] * torch.tensor([W, H, W, H], dtype=torch.float32))
+        tps.append(O.match_predictions(rows[:, 5], tcl, O.box_iou(gt, rows[:, :4])).numpy())
+        area = O.xyxy2xywh(gt)[:, 2:].prod(1) * 0.53
+        oks = O.kpt_iou(tb["keypoints"][sel] * torch.tensor([W, H, 1.0]), rows[:, 6:].view(-1, K, D), area)
+        tpps.append(O.match_predictions(rows[:, 5], tcl, oks).numpy())
+        confs.append(rows[:, 4].numpy()); pcls.append(rows[:, 5].numpy()); tcls.append(tcl.numpy())
+    conf, pc, tc = np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls)
+    assert len(conf) > 2
+    assert np.allclose(box, M.val_summary(M.ap_per_class(np.concatenate(tps), conf, pc, tc)), atol=1e-6)
+    assert np.allclose(pose, M.val_summary(M.ap_per_class(np.concatenate(tpps), conf, pc, tc)), atol=1e-6)
+    res = pdt.ImagePredict((d["images"][0] * 255).astype(np.uint8), 0.5, 0.5)
+    want, _ = O.non_max_suppression(rinf["boxes"][:1].clone(), 0.5, 0.5, nc=nc) if hasattr(O, "non_max_suppression") else (None, None)
+    assert len(res) > 0 and all(len(r.KeyPoints) == K for r in res)
+    if want is not None:
+        assert len(res) == len(want[0])
+        for r, w in zip(res, want[0].numpy()):
+            assert abs(r.KeyPoints[3].X - w[6 + 9]) < 1e-2 and abs(r.KeyPoints[3].VisibilityScore - w[6 + 11]) < 1e-3
+    m.close()

@@ -12,13 +12,14 @@ from .model import AMPWrapper, v8DetectionLoss
 
 class YoloResult:
     """Types/YoloResult: integer box (truncated like Detector.cs:52-68)."""
-    __slots__ = ("ClassID", "Score", "CenterX", "CenterY", "Width", "Height")
+    __slots__ = ("ClassID", "Score", "CenterX", "CenterY", "Width", "Height", "Radian", "KeyPoints")
 
     def __init__(self, row):
         x, y = int(row[0]), int(row[1])
         rw, rh = int(row[2]) - x, int(row[3]) - y
         self.ClassID, self.Score = int(row[5]), float(row[4])
         self.CenterX, self.CenterY, self.Width, self.Height = x + rw // 2, y + rh // 2, rw, rh
+        self.Radian, self.KeyPoints = 0.0, None
 
     def __repr__(self):
         return f"YoloResult(cls={self.ClassID}, score={self.Score:.3f}, cx={self.CenterX}, cy={self.CenterY}, w={self.Width}, h={self.Height})"
@@ -154,3 +155,117 @@ class Segmenter(Detector):
         box = M.val_summary(M.ap_per_class(np.concatenate(tps), conf, pc, tc))
         mask = M.val_summary(M.ap_per_class(np.concatenate(tpms), conf, pc, tc))
         return loss_sum, box, mask
+
+
+class Obber(Detector):
+    """Models/Obber.cs: ImagePredict (:28-68) = eval forward (pred = dist2rbox boxes, probabilities, angle) + rotated NMS, result =
+    truncated centre / size + Radian; Val (:70-163) = eval forward + v8OBBLoss on the eval preds, rotated NMS (conf 0.01, IoU 0.7),
+    Metrics.batch_probiou(labels xywh * scale + angle, predictions xywh + angle) -> match_predictions -> ap_per_class."""
+
+    def ImagePredict(self, image_chw_u8, predict_threshold=0.25, iou_threshold=0.5):
+        x = pad_to_32(np.asarray(image_chw_u8, np.float32))[None]
+        assert x.shape[2:] == (self.model.height, self.model.width), "create the model with the padded image size"
+        inference, _ = self.amp.Evaluate(x)
+        output, _ = self.engine.non_max_suppression(inference["boxes"], predict_threshold, iou_threshold, nc=self.model.nc, rotated=True)
+        results = []
+        for r in output[0]:                                        # Obber.cs:55-63: the rotated rows stay xywh
+            res = YoloResult.__new__(YoloResult)
+            res.CenterX, res.CenterY, res.Width, res.Height = int(r[0]), int(r[1]), int(r[2]), int(r[3])
+            res.Score, res.ClassID, res.Radian, res.KeyPoints = float(r[4]), int(r[5]), float(r[6]), None
+            results.append(res)
+        return results
+
+    def Val(self, batches, conf_thres=0.01, iou_thres=0.7, max_det=300):
+        from .model import v8OBBLoss
+        crit = v8OBBLoss(self.model)
+        tps, confs, pcls, tcls = [], [], [], []
+        loss_sum = None
+        nc = self.model.nc
+        for data in batches:
+            if np.asarray(data["batch_idx"]).size < 1:
+                continue
+            images = np.ascontiguousarray(data["images"], np.float32)
+            B, _, H, W = images.shape
+            inference, _ = self.amp.Evaluate(images)
+            _, items = crit.forward(None, data)
+            loss_sum = items if loss_sum is None else loss_sum + items
+            output, _ = self.engine.non_max_suppression(inference["boxes"], conf_thres, iou_thres, max_det=max_det, nc=nc, rotated=True)
+            bi = np.asarray(data["batch_idx"], np.float32).reshape(-1)
+            cl = np.asarray(data["cls"], np.float32).reshape(-1)
+            bb = np.asarray(data["bboxes"], np.float32).reshape(-1, 5)
+            for b, rows in enumerate(output):
+                sel = bi == b
+                gt = np.concatenate((bb[sel, :4] * np.array([W, H, W, H], np.float32), bb[sel, 4:5]), 1).astype(np.float32)   # Obber.cs:108
+                pred = np.concatenate((rows[:, :4], rows[:, 6:7]), 1).astype(np.float32)                                      # Obber.cs:102
+                iou = self.engine.batch_probiou(gt, pred) if len(gt) and len(pred) else np.zeros((len(gt), len(pred)), np.float32)
+                tps.append(self.engine.match_predictions(rows[:, 5], cl[sel], iou))
+                confs.append(rows[:, 4]); pcls.append(rows[:, 5]); tcls.append(cl[sel])
+        if not tps:
+            return np.zeros(4, np.float32), (0.0, 0.0, 0.0, 0.0)
+        stats = M.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls))
+        return loss_sum, M.val_summary(stats)
+
+
+class KeyPoint:
+    __slots__ = ("X", "Y", "VisibilityScore")
+
+    def __init__(self, x, y, v):
+        self.X, self.Y, self.VisibilityScore = float(x), float(y), float(v)
+
+
+class PoseDetector(Detector):
+    """Models/PoseDetector.cs: ImagePredict (:39-98) = eval forward (pred carries the decoded keypoints) + NMS, result = the
+    truncated box + KeyPoints (visibility 2.0 for 2-D keypoints); Val (:100-200) = eval forward + v8PoseLoss, NMS (conf 0.01, IoU
+    0.7), box_iou matching and Metrics.kpt_iou (area = w * h * 0.53) matching -> ap_per_class twice."""
+
+    def ImagePredict(self, image_chw_u8, predict_threshold=0.25, iou_threshold=0.5):
+        x = pad_to_32(np.asarray(image_chw_u8, np.float32))[None]
+        assert x.shape[2:] == (self.model.height, self.model.width), "create the model with the padded image size"
+        inference, _ = self.amp.Evaluate(x)
+        output, _ = self.engine.non_max_suppression(inference["boxes"], predict_threshold, iou_threshold, nc=self.model.nc)
+        D = self.model.kpt_dim
+        results = []
+        for r in output[0]:
+            res = YoloResult(r)
+            kp = r[6:].reshape(-1, D)
+            res.KeyPoints = [KeyPoint(k[0], k[1], k[2] if D == 3 else 2.0) for k in kp]
+            results.append(res)
+        return results
+
+    def Val(self, batches, conf_thres=0.01, iou_thres=0.7, max_det=300):
+        from .model import v8PoseLoss
+        crit = v8PoseLoss(self.model)
+        tps, tpps, confs, pcls, tcls = [], [], [], [], []
+        loss_sum = None
+        nc, K, D = self.model.nc, self.model.kpt_num, self.model.kpt_dim
+        for data in batches:
+            if np.asarray(data["batch_idx"]).size < 1:
+                continue
+            images = np.ascontiguousarray(data["images"], np.float32)
+            B, _, H, W = images.shape
+            inference, _ = self.amp.Evaluate(images)
+            _, items = crit.forward(None, data)
+            loss_sum = items if loss_sum is None else loss_sum + items
+            output, _ = self.engine.non_max_suppression(inference["boxes"], conf_thres, iou_thres, max_det=max_det, nc=nc)
+            bi = np.asarray(data["batch_idx"], np.float32).reshape(-1)
+            cl = np.asarray(data["cls"], np.float32).reshape(-1)
+            bb = np.asarray(data["bboxes"], np.float32).reshape(-1, 4)
+            kp = np.asarray(data["keypoints"], np.float32).reshape(len(bi), K, -1)
+            if kp.shape[2] == 2:                                   # PoseDetector.cs:144-148: "seen" column of ones
+                kp = np.concatenate((kp, np.ones(kp.shape[:2] + (1,), np.float32)), 2)
+            for b, rows in enumerate(output):
+                sel = bi == b
+                gt = bb[sel] * np.array([W, H, W, H], np.float32)
+                gt_xyxy = np.concatenate((gt[:, :2] - gt[:, 2:] / 2, gt[:, :2] + gt[:, 2:] / 2), 1).astype(np.float32)
+                tps.append(self.engine.match_predictions(rows[:, 5], cl[sel], self.engine.box_iou(gt_xyxy, rows[:, :4])))
+                gk = (kp[sel] * np.array([W, H, 1.0], np.float32)).astype(np.float32)                       # PoseDetector.cs:153-155
+                area = ((gt_xyxy[:, 2] - gt_xyxy[:, 0]) * (gt_xyxy[:, 3] - gt_xyxy[:, 1]) * np.float32(0.53)).astype(np.float32)
+                oks = self.engine.kpt_iou(gk, rows[:, 6:].reshape(-1, K, D), area)
+                tpps.append(self.engine.match_predictions(rows[:, 5], cl[sel], oks))
+                confs.append(rows[:, 4]); pcls.append(rows[:, 5]); tcls.append(cl[sel])
+        if not tps:
+            return np.zeros(5, np.float32), (0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 0.0)
+        conf, pc, tc = np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls)
+        box = M.val_summary(M.ap_per_class(np.concatenate(tps), conf, pc, tc))
+        pose = M.val_summary(M.ap_per_class(np.concatenate(tpps), conf, pc, tc))
+        return loss_sum, box, pose
