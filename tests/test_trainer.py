@@ -65,6 +65,43 @@ def test_trainer_two_epochs_gpu(tmp_path):
     m.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["obb", "pose", "segment"])
+def test_trainer_other_tasks_gpu(tmp_path, task):
+    """The same loop with the task's own criterion and validator (Obber / PoseDetector / Segmenter): loss items of the task's
+    length, falling on a fixed batch; Val returns the box metrics (+ mask / pose metrics)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import yolo_oracle as O
+    from yolosharp_amd import Engine
+    from yolosharp_amd import model as M
+    eng = Engine(0)
+    B, H, W = 8, 128, 128
+    nc = {"obb": 15, "pose": 1, "segment": 80}[task]
+    m = {"obb": M.Yolov8Obb, "pose": M.Yolov8Pose, "segment": M.Yolov8Segment}[task](eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="bf16")
+    m.init_weights(1)
+    if task == "obb":
+        tb = O.synthetic_obb_batch(B, H, W, nc, seed=1, kmax=4)
+    else:
+        tb = O.synthetic_batch(B, H, W, nc, seed=1, kmax=4)
+        if task == "pose":
+            tb["keypoints"] = O.synthetic_keypoints(tb)
+        else:
+            tb["masks"] = O.synthetic_masks(tb, B, H // 4, W // 4)
+    data = {k: v.numpy() for k, v in tb.items()}
+    data["images"] = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
+    tr = T.Trainer(m, epochs=2, nb=6, out_dir=str(tmp_path), lr0=2e-3, warmup_bias_lr=2e-3)
+    hist = tr.fit(lambda: [data] * 6, lambda: [data])
+    n_items = {"obb": 4, "pose": 5, "segment": 5}[task]
+    assert hist[0]["train_loss"].shape == (n_items,) and np.all(np.isfinite(hist[1]["train_loss"]))
+    # 12 warm-up steps at <= 12 % of lr0: the plumbing is what is tested here (descent itself: test_obb_pose / test_segment train steps)
+    assert hist[1]["train_loss"].sum() < 1.01 * hist[0]["train_loss"].sum()
+    assert hist[1]["val_loss"].shape == (n_items,) and len(hist[1]["metrics"]) == 4
+    assert ("metrics2" in hist[1]) == (task != "obb")
+    assert os.path.exists(os.path.join(str(tmp_path), "weights", "last.bin"))
+    m.close()
+
+
 def test_empty_batches_do_not_advance_the_warmup_index():
     """TrainEpoch's `continue` on an empty batch skips its i++ (YoloBaseTaskModel.cs:322-325,349); the epoch returns the SUM of
     the per-step loss items, and zeros when no step ran."""

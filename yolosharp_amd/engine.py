@@ -11,6 +11,7 @@ Everything numeric runs in libyolosharp_hip.so (hand-written HIP, gfx950).  nump
 boundary as plain fp32 host pointers; torch is not involved in the data path.
 """
 import ctypes as C
+import sys
 import numpy as np
 
 from . import _lib
@@ -38,6 +39,8 @@ class Engine:
             self.ctx = C.c_void_p()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone and destruction order is arbitrary
+            return
         try:
             self.close()
         except Exception:

@@ -9,6 +9,7 @@ All arithmetic happens in libyolosharp_hip.so; these classes only marshal plain 
 reference's call order (forward -> criterion -> backward -> optimizer.step -> zero_grad).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -46,6 +47,8 @@ class Yolov8:
             self.handle = C.c_void_p()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():      # interpreter teardown: the HIP runtime may already be gone and destruction order is arbitrary
+            return
         try:
             self.close()
         except Exception:

@@ -75,7 +75,12 @@ class Trainer:
     def __init__(self, model, epochs, nb, out_dir=None, segment=False, **sched):
         self.model, self.epochs, self.out_dir = model, epochs, out_dir
         self.amp = AMPWrapper(model)
-        self.crit = v8SegmentationLoss(model) if segment else v8DetectionLoss(model)
+        # criterion and validator of the model's task (YoloBaseTaskModel's subclasses Detector / Segmenter / Obber / PoseDetector)
+        from . import detector as D
+        from .model import v8OBBLoss, v8PoseLoss
+        task = 1 if segment else getattr(model, "TASK", 0)
+        self.crit = {0: v8DetectionLoss, 1: v8SegmentationLoss, 2: v8OBBLoss, 3: v8PoseLoss}[task](model)
+        self.validator = {0: D.Detector, 1: D.Segmenter, 2: D.Obber, 3: D.PoseDetector}[task]
         self.sched = LrSchedule(model.nc, epochs, nb, **sched)
         self.best_fitness = -float("inf")
 
@@ -91,7 +96,7 @@ class Trainer:
             items_sum = items if items_sum is None else items_sum + items
             i += 1
         self.steps_run = i
-        n_items = 5 if isinstance(self.crit, v8SegmentationLoss) else 3
+        n_items = getattr(self.crit, "N_ITEMS", 3)
         return items_sum if items_sum is not None else np.zeros(n_items, np.float32)
 
     def fit(self, train_batches, val_batches=None):
@@ -101,9 +106,11 @@ class Trainer:
             tr = self.train_epoch(train_batches(), epoch)
             self.sched.end_epoch()
             rec = {"epoch": epoch, "train_loss": tr, "lr": list(self.sched.lrs)}
-            if val_batches is not None and not isinstance(self.crit, v8SegmentationLoss):
-                vloss, metrics = Detector(self.model).Val(val_batches())
+            if val_batches is not None:
+                vloss, metrics, *more = self.validator(self.model).Val(val_batches())   # Segmenter / PoseDetector add mask / pose metrics
                 rec.update(val_loss=vloss, metrics=metrics)
+                if more:
+                    rec.update(metrics2=more[0])
                 fitness = -float(np.sum(vloss))
                 if self.out_dir:
                     os.makedirs(os.path.join(self.out_dir, "weights"), exist_ok=True)
