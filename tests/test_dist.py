@@ -70,7 +70,7 @@ def test_gradsync_world2_gloo():
         assert mx > 0
 
 
-def _engine_worker(rank, world, port, q, emu_path):
+def _engine_worker(rank, world, port, q, emu_path, task="detect"):
     """One rank of the data-parallel step on the interpreter build: ENGINE forward / loss / segmented backward, GradSync's
     bucketed SUM all-reduce overlapped per segment (gloo), AdamW, zero_grad -- dist.train_step_dp, the loop bench.py runs."""
     sys.path.insert(0, ROOT)
@@ -79,28 +79,37 @@ def _engine_worker(rank, world, port, q, emu_path):
     from oracle import yolo_oracle as O
     from yolosharp_amd import Engine
     from yolosharp_amd import dist as ysd
-    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    from yolosharp_amd.model import Yolov8, Yolov8Pose, v8DetectionLoss, v8PoseLoss
     torch.manual_seed(0)
     nc, H, W, Bl = 4, 64, 64, 2
-    ref = O.Yolov8(nc=nc, size="n").train()
+    pose = task == "pose"      # Pose n: 51-wide towers padded inside -> the flat gradient buffer carries zero rows on every rank
+    ref = (O.Yolov8Pose if pose else O.Yolov8)(nc=nc, size="n").train()
+    ocrit = O.v8PoseLoss(nc) if pose else O.v8DetectionLoss(nc)
     sd0 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
     x_all = torch.rand(world * Bl, 3, H, W, generator=torch.Generator().manual_seed(1))
     batch_all = O.synthetic_batch(world * Bl, H, W, nc, seed=2, kmax=3)
+    if pose:
+        batch_all["keypoints"] = O.synthetic_keypoints(batch_all)
 
     def shard(r):
         lo, hi = r * Bl, (r + 1) * Bl
         sel = (batch_all["batch_idx"] >= lo) & (batch_all["batch_idx"] < hi)
-        return x_all[lo:hi], {"batch_idx": batch_all["batch_idx"][sel] - lo, "cls": batch_all["cls"][sel], "bboxes": batch_all["bboxes"][sel]}
+        out = {"batch_idx": batch_all["batch_idx"][sel] - lo, "cls": batch_all["cls"][sel], "bboxes": batch_all["bboxes"][sel]}
+        if pose:
+            out["keypoints"] = batch_all["keypoints"][sel]
+        return x_all[lo:hi], out
 
     eng = Engine(lib_path=emu_path)
-    m = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=Bl, dtype="f32")
+    m = (Yolov8Pose if pose else Yolov8)(eng, nc=nc, size="n", height=H, width=W, max_batch=Bl, dtype="f32")
     m.load_state_dict({k: v.numpy() for k, v in sd0.items()})
     m.train()
-    crit = v8DetectionLoss(m)
+    crit = (v8PoseLoss if pose else v8DetectionLoss)(m)
     x, b = shard(rank)
     d_img = eng.to_device(x.numpy())
     nb = {k: v.numpy() for k, v in b.items()}
     d_lab = (eng.to_device(nb["batch_idx"]), eng.to_device(nb["cls"]), eng.to_device(nb["bboxes"]), len(nb["batch_idx"]))
+    if pose:
+        d_lab = d_lab + (eng.to_device(np.ascontiguousarray(nb["keypoints"], np.float32)),)
     gptr, gn = m.grad_buffer()
     flat = ysd.host_view(gptr.value, gn)
     sync = ysd.GradSync(flat, [m.segment_grad_range(s) for s in range(m.num_segments())])
@@ -117,7 +126,7 @@ def _engine_worker(rank, world, port, q, emu_path):
         ref.load_state_dict(sd0); ref.zero_grad()
         xs, bs = shard(r)
         _, preds = ref(xs)
-        loss, _ = O.v8DetectionLoss(nc)(preds, bs)
+        loss, _ = ocrit(preds, bs)
         loss.sum().backward()
         g = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
         want = g if want is None else {n: want[n] + g[n] for n in g}
@@ -138,14 +147,15 @@ def _engine_worker(rank, world, port, q, emu_path):
     dist.destroy_process_group()
 
 
-def test_train_step_dp_world2_engine_gloo(emu_lib_path):
+@pytest.mark.parametrize("task", ["detect", "pose"])
+def test_train_step_dp_world2_engine_gloo(emu_lib_path, task):
     """the data-parallel step driven end to end by the ENGINE (interpreter build) over gloo, world size 2:
     the segment-overlapped all-reduced gradient equals the oracle's global-batch gradient under per-shard BN, and after AdamW
     both ranks hold bit-identical weights (two steps)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, emu_lib_path)) for r in range(2)]
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, emu_lib_path, task)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(2)]

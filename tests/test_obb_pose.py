@@ -400,3 +400,33 @@ def test_kpt_iou(backend, engine, K, D):
     tp = engine.match_predictions(np.zeros(m, np.float32), np.zeros(n, np.float32), got)      # the second match of PoseDetector.cs:158
     assert np.array_equal(tp, O.match_predictions(torch.zeros(m), torch.zeros(n), torch.from_numpy(want)).numpy())
     assert engine.kpt_iou(np.zeros((0, K, 3), np.float32), k2.numpy(), np.zeros(0, np.float32)).shape == (0, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+@pytest.mark.parametrize("task", ["Obb", "Pose"])
+def test_fp8_mode_train_steps(backend, engine, task):
+    """dtype = fp8 on the extra heads: the wide 3x3 layers run the fp8 MFMA kernels, the cv4 towers (51-wide padded inputs, 1-channel
+    output) stay bf16; items finite and close to the bf16 engine's on the first step, loss falling."""
+    from yolosharp_amd import model as M
+    nc, B, H, W = (15, 4, 320, 320) if task == "Obb" else (1, 4, 320, 320)
+    x = np.random.default_rng(3).random((B, 3, H, W), dtype=np.float32)
+    tb = O.synthetic_obb_batch(B, H, W, nc, seed=1, kmax=6) if task == "Obb" else O.synthetic_batch(B, H, W, nc, seed=1, kmax=6)
+    if task == "Pose":
+        tb["keypoints"] = O.synthetic_keypoints(tb)
+    nb = {k: v.numpy() for k, v in tb.items()}
+    first = {}
+    for dt in ("bf16", "fp8"):
+        m = getattr(M, f"Yolov8{task}")(engine, nc=nc, size="s", height=H, width=W, max_batch=B, dtype=dt)
+        m.init_weights(5)
+        amp = M.AMPWrapper(m, lr=2e-3)
+        crit = (M.v8OBBLoss if task == "Obb" else M.v8PoseLoss)(m)
+        hist = []
+        for _ in range(5):
+            loss, items = amp.TrainStep(x, nb, crit)
+            assert np.isfinite(items).all(), (dt, items)
+            hist.append(items)
+        first[dt] = hist[1]                       # step 2: the first step of the fp8 engine still runs bf16 kernels (scale bootstrap)
+        assert hist[-1].sum() < hist[0].sum(), (dt, hist[0], hist[-1])
+        m.close()
+    assert np.allclose(first["fp8"], first["bf16"], rtol=0.1, atol=0.05), first
