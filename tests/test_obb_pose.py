@@ -109,6 +109,15 @@ def test_head_full_resolution_f32(backend, engine, task, family, size):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", ["gpu"])
+def test_other_sizes_f32(backend, engine):
+    """Pose l: cv4 towers are 64 wide (no padding branch); Obb m: c4 = 48."""
+    for task, size in (("Pose", "l"), ("Obb", "m")):
+        m, _, _ = _head_parity(engine, task, 8, size, 2, 320, 320, 1e-3, nc=2)
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
 @pytest.mark.parametrize("task", ["Obb", "Pose"])
 def test_head_bf16_tracks_f32(backend, engine, task):
     from yolosharp_amd import model as M
