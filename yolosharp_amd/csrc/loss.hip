@@ -17,6 +17,7 @@
 #include "ys_kernels.h"
 
 #define LS_THREADS 256
+#define TAL_REG_N 33        // assigner top-k: metrics per thread kept in registers (33 * 256 = 8448 >= the 8400 anchors of 640x640)
 #define CIOU_EPS 1e-7f
 
 // ------------------------------------------------------------------ dual numbers (value + N partials)
@@ -312,6 +313,39 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   }
   __syncthreads();
   // select_topk_candidates (Tal.cs:144-168): 10 largest align values; ties -> lowest anchor index
+  if (a.A <= TAL_REG_N * LS_THREADS) {
+    // every BASELINE shape (A = 8400 <= 33 * 256): a thread's metrics (anchors tid + j * 256) stay in registers for the ten rounds --
+    // one batch of independent loads instead of a reload per round; a taken entry becomes -2
+    float val[TAL_REG_N];
+#pragma unroll
+    for (int j = 0; j < TAL_REG_N; j++) { const int ai = tid + j * LS_THREADS; val[j] = ai < a.A ? alr[ai] : -3.f; }
+    for (int k = 0; k < a.topk; k++) {
+      float bv = -1.f;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < TAL_REG_N; j++) if (val[j] > bv) { bv = val[j]; bi = tid + j * LS_THREADS; }   // increasing index: strict '>' keeps the lowest among equals
+      for (int m = 32; m >= 1; m >>= 1) {
+        const float ov_ = __shfl_xor(bv, m);
+        const int oi = __shfl_xor(bi, m);
+        if (ov_ > bv || (ov_ == bv && oi < bi)) { bv = ov_; bi = oi; }
+      }
+      if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+      __syncthreads();
+      float fv = s_v[0]; int fi = s_i[0];
+      for (int wv = 1; wv < LS_THREADS / 64; wv++)
+        if (s_v[wv] > fv || (s_v[wv] == fv && s_i[wv] < fi)) { fv = s_v[wv]; fi = s_i[wv]; }
+      if (fi < a.A) {
+        if (tid == 0 && valid && (s_ingt[fi >> 5] & (1u << (fi & 31)))) mp[fi] = 1;     // mask_topk * mask_in_gts * mask_gt (Tal.cs:99)
+        const int js = fi / LS_THREADS;
+        if (fi - js * LS_THREADS == tid) {
+#pragma unroll
+          for (int j = 0; j < TAL_REG_N; j++) val[j] = (j == js) ? -2.f : val[j];
+        }
+      }
+      __syncthreads();                                            // s_v / s_i are rewritten by the next round
+    }
+    return;
+  }
   for (int k = 0; k < a.topk; k++) {
     float bv = -1.f;
     int bi = 0x7fffffff;
