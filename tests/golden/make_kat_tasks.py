@@ -99,3 +99,30 @@ out["obb"] = {"nc": nc, "batch_idx": batch_idx, "cls": cls, "bboxes": bboxes, "b
 with open(os.path.join(HERE, "kat_tasks.json"), "w") as f:
     json.dump(out, f)
 print("wrote kat_tasks.json", os.path.getsize(os.path.join(HERE, "kat_tasks.json")), "bytes")
+
+# ------------------------------------------------------------------ segment (mask term on the detection case of kat_loss.json)
+nm, mh, mw = 32, H // 4, W // 4      # Head.Segment: nm = 32 prototypes at H/4 x W/4 (Head.cs:238-252)
+nc = det["nc"]
+_, _, dtg = K.detection_loss(det["boxes"], det["scores"], det["batch_idx"], det["cls"], det["bboxes"], H, W, nc)
+coeff = [[[rng.gauss(0.0, 1.0) for _ in range(A)] for _ in range(nm)] for _ in range(B)]
+proto = [[[[rng.gauss(0.0, 0.8) for _ in range(mw)] for _ in range(mh)] for _ in range(nm)] for _ in range(B)]
+masks = [[[0.0] * mw for _ in range(mh)] for _ in range(B)]
+slots = [[i for i, bi in enumerate(det["batch_idx"]) if int(bi) == b] for b in range(B)]
+for b in range(B):                                   # overlap-encoded ids: later labels painted on top (YoloDataset.cs:265-267)
+    for slot, i in enumerate(slots[b]):
+        bb = det["bboxes"][i]
+        for r in range(mh):
+            for c in range(mw):
+                u, v = (c + 0.5) / mw, (r + 0.5) / mh
+                if ((u - bb[0]) / (bb[2] / 2)) ** 2 + ((v - bb[1]) / (bb[3] / 2)) ** 2 <= 1.0:
+                    masks[b][r][c] = float(slot + 1)
+seg = K.seg_term(coeff, proto, dtg, masks, H, W)
+seg_trunc = K.seg_term(coeff, proto, dtg, masks, H, W, trunc_crop=True)
+assert seg > 0 and abs(seg - seg_trunc) > 1e-6, (seg, seg_trunc)      # the two crop branches differ on this case (fractional box edges)
+dc = K.fd_grad(coeff, lambda: K.seg_term(coeff, proto, dtg, masks, H, W) * B)
+dp = [K.fd_grad(proto[b], lambda: K.seg_term(coeff, proto, dtg, masks, H, W) * B) for b in range(B)]
+print("seg item", seg, "cpu-crop branch", seg_trunc)
+out["segment"] = {"nm": nm, "coeff": coeff, "proto": proto, "masks": masks, "item": seg, "item_trunc": seg_trunc, "dcoeff": dc, "dproto": dp}
+with open(os.path.join(HERE, "kat_tasks.json"), "w") as f:
+    json.dump(out, f)
+print("wrote kat_tasks.json", os.path.getsize(os.path.join(HERE, "kat_tasks.json")), "bytes")

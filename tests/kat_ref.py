@@ -12,6 +12,8 @@ oracle and the HIP kernels (tests/test_kat.py) on small hand-built cases:
   pose_loss       Utils/Loss.cs:870-1071    (KeypointLoss :169-188: OKS sigmas, kpt_loss_factor, visibility BCE; gains 12 / 1)
   obb_loss        Utils/Loss.cs:486-684     (2-px filter, RotatedTaskAlignedAssigner Tal.cs:260-310 incl. the in-place thin-box
                                              widening, probiou box term, rbox2dist DFL targets, angle term)
+  seg_term        Utils/Loss.cs:786-863     (mask term: einsum coeff . proto, BCE vs the overlap-encoded ids, both Ops.crop_mask
+                                             branches (Ops.cs:421-447), mean / normalised area, / foreground count, gain 7.5)
   probiou         Utils/Metrics.cs:137-160,264-283
   bn_train_stats  Modules/Convs.cs:41-48    (biased batch variance in the normalisation, unbiased in running_var, momentum 0.03)
 
@@ -426,3 +428,42 @@ def obb_loss(boxes, scores, angle_logit, batch_idx, cls, bboxes5, H, W, nc, reg_
             l_ang += math.exp(-(lar ** 2) / 9.0) * math.sin(2.0 * wrapped) ** 2 * w
     items = [7.5 * l_box / tss, 0.5 * l_cls, 1.5 * l_dfl / tss, 1.0 * l_ang / tss]
     return items, sum(items) * B, targets
+
+
+# ----------------------------------------------------------------------------- v8SegmentationLoss mask term (Loss.cs:786-863), scalar
+def seg_term(coeff, proto, targets, masks, H, W, trunc_crop=False):
+    """coeff [B][nm][A] mask coefficients, proto [B][nm][mh][mw], masks [B][mh][mw] overlap-encoded instance ids (id = slot + 1),
+    targets = the detection assignment.  Returns the mask item with the gain 7.5 applied (Loss.cs:777): for every foreground anchor the
+    BCE of (coeff . proto) against (masks == slot + 1), cropped to the target box in mask units (Ops.crop_mask: x1 <= col < x2 in the
+    float form :437-447, C# int truncation + slices in the CPU form :421-435 when trunc_crop), mean over ALL mask pixels, divided by the
+    normalised box area; summed and divided by the number of foreground anchors."""
+    B = len(coeff)
+    nm, mh, mw = len(proto[0]), len(proto[0][0]), len(proto[0][0][0])
+    n_fg = sum(sum(1 for f in t[0] if f) for t in targets)
+    if n_fg == 0:
+        return 0.0
+    total = 0.0
+    for b in range(B):
+        fg, gt_idx, _, tbox = targets[b]
+        entries = [a for a in range(len(fg)) if fg[a]]
+        n_rows = len(entries)
+        for a in entries:
+            nb = (tbox[a][0] / W, tbox[a][1] / H, tbox[a][2] / W, tbox[a][3] / H)           # Loss.cs:808-809
+            area = (nb[2] - nb[0]) * (nb[3] - nb[1])                                        # xyxy2xywh(...)[2:].prod (Loss.cs:812)
+            x1, y1, x2, y2 = nb[0] * mw, nb[1] * mh, nb[2] * mw, nb[3] * mh                  # Loss.cs:815
+            if trunc_crop and n_rows < 50:
+                cols = range(max(int(x1), 0), min(int(x2), mw)) if int(x2) >= 0 else range(0)
+                rows = range(max(int(y1), 0), min(int(y2), mh)) if int(y2) >= 0 else range(0)
+                inside = lambda r, c: r in rows and c in cols
+            else:
+                inside = lambda r, c: (c >= x1) and (c < x2) and (r >= y1) and (r < y2)
+            s = 0.0
+            for r in range(mh):
+                for c in range(mw):
+                    if not inside(r, c):
+                        continue
+                    z = sum(coeff[b][k][a] * proto[b][k][r][c] for k in range(nm))          # einsum "in,nhw->ihw" (Loss.cs:790)
+                    t = 1.0 if masks[b][r][c] == gt_idx[a] + 1 else 0.0                     # Loss.cs:826
+                    s += bce_logits(z, t)
+            total += s / (mh * mw) / area                                                   # .mean(1, 2) / area (Loss.cs:792)
+    return 7.5 * total / n_fg                                                               # Loss.cs:861, gain :777

@@ -5,7 +5,7 @@ that shares nothing with oracle/yolo_oracle.py (no torch, no autograd).  tests/g
 hand-built case (tests/golden/make_kat.py).  Here both the ATen oracle AND the HIP kernels are checked against those answers:
 CIoU, DFL incl. both clamps, TAL (double-claimed anchor, zero-metric ties, tiny-box inflation, padded GT row), the three loss
 items, d(loss)/d(boxes, scores), and BatchNorm's batch / running statistics (momentum 0.03, unbiased running_var).
-tests/golden/kat_tasks.json (make_kat_tasks.py) does the same for v8PoseLoss and v8OBBLoss: items and finite-difference gradients
+tests/golden/kat_tasks.json (make_kat_tasks.py) does the same for v8PoseLoss, v8OBBLoss and the mask term of v8SegmentationLoss: items and finite-difference gradients
 w.r.t. the keypoint outputs, the box / class logits and the angle logit."""
 import json
 import os
@@ -146,6 +146,10 @@ def test_task_kat_file_reproduces():
     items, total, tg = K.obb_loss(o["boxes"], o["scores"], o["angle_logit"], o["batch_idx"], o["cls"], o["bboxes"], t["H"], t["W"], o["nc"])
     assert np.allclose(items, o["items"], rtol=1e-12) and abs(total - o["total"]) < 1e-9
     assert [[bool(v) for v in x[0]] for x in tg] == o["fg"] and [x[1] for x in tg] == o["gt_idx"]
+    g = t["segment"]
+    _, _, dtg = K.detection_loss(k["boxes"], k["scores"], k["batch_idx"], k["cls"], k["bboxes"], t["H"], t["W"], k["nc"])
+    assert abs(K.seg_term(g["coeff"], g["proto"], dtg, g["masks"], t["H"], t["W"]) - g["item"]) < 1e-9
+    assert abs(K.seg_term(g["coeff"], g["proto"], dtg, g["masks"], t["H"], t["W"], trunc_crop=True) - g["item_trunc"]) < 1e-9
     same = K.probiou((3.0, 4.0, 6.0, 2.0, 0.3), (3.0, 4.0, 6.0, 2.0, 0.3))        # identical boxes: bd = 0.5 log(1 + eps') -> clamp(eps)
     assert abs(same - (1.0 - np.sqrt(1.0 - np.exp(-1e-7) + 1e-7))) < 1e-6
     assert abs(K.probiou((0, 0, 4, 2, 0.0), (1, 0, 4, 2, 0.0)) - K.probiou((0, 0, 2, 4, np.pi / 2), (1, 0, 2, 4, np.pi / 2))) < 1e-12
@@ -220,6 +224,55 @@ def test_engine_task_losses_match_kat(backend, engine):
     assert np.allclose(loss.sum(), o["total"], rtol=1e-3)
     for key in ("dboxes", "dscores", "dangle"):
         want = np.array(o[key])
+        got = m.get_output(key)
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (key, np.abs(got - want).max(), np.abs(want).max())
+    m.close()
+
+
+def _seg_case():
+    g = TASKS["segment"]
+    bx, sc, batch = _case()
+    batch["masks"] = np.array(g["masks"], np.float32)
+    return bx, sc, np.array(g["coeff"], np.float64), np.array(g["proto"], np.float64), batch
+
+
+def test_oracle_matches_segment_kat():
+    """ATen-CPU v8SegmentationLoss mask term vs the independent fp64 answers: both Ops.crop_mask branches, autograd vs finite differences."""
+    t, g, k = TASKS, TASKS["segment"], KAT
+    B, H, W = t["B"], t["H"], t["W"]
+    bx, sc, cf, pr, batch = _seg_case()
+    for dt, tol in ((torch.float64, 1e-7), (torch.float32, 2e-4)):
+        feats = [torch.zeros(B, 1, H // s, W // s, dtype=dt) for s in (8, 16, 32)]
+        for branch, want in ((False, g["item"]), (True, g["item_trunc"])):
+            coeff = torch.tensor(cf, dtype=dt, requires_grad=True)
+            proto = torch.tensor(pr, dtype=dt, requires_grad=True)
+            preds = {"boxes": torch.tensor(bx, dtype=dt), "scores": torch.tensor(sc, dtype=dt), "mask_coefficient": coeff, "proto": proto, "feats": feats}
+            loss, items = O.v8SegmentationLoss(k["nc"], cpu_crop_branch=branch)(preds, {kk: torch.from_numpy(v) for kk, v in batch.items()})
+            assert abs(float(items[1]) - want) <= max(tol, tol * abs(want)) * 10, (dt, branch, float(items[1]), want)
+            assert np.allclose(items.detach().numpy()[[0, 2, 3]], k["items"], rtol=tol, atol=tol)      # box, cls, dfl
+        loss.sum().backward()   # (the CPU-branch run is the last one: its crop only changes which pixels count)
+        coeff2 = torch.tensor(cf, dtype=dt, requires_grad=True); proto2 = torch.tensor(pr, dtype=dt, requires_grad=True)
+        preds = {"boxes": torch.tensor(bx, dtype=dt), "scores": torch.tensor(sc, dtype=dt), "mask_coefficient": coeff2, "proto": proto2, "feats": feats}
+        O.v8SegmentationLoss(k["nc"])(preds, {kk: torch.from_numpy(v) for kk, v in batch.items()})[0].sum().backward()
+        for got, key in ((coeff2.grad, "dcoeff"), (proto2.grad, "dproto")):
+            want = np.array(g[key])
+            assert np.abs(got.numpy() - want).max() <= max(tol * 50, 2e-5) * np.abs(want).max(), (dt, key)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_engine_segment_loss_matches_kat(backend, engine):
+    """HIP v8SegmentationLoss on caller-supplied preds vs the independent answers: the mask item in both crop modes, d(coeff), d(proto)."""
+    from yolosharp_amd.model import Yolov8Segment, v8SegmentationLoss
+    t, g, k = TASKS, TASKS["segment"], KAT
+    bx, sc, cf, pr, batch = _seg_case()
+    m = Yolov8Segment(engine, nc=k["nc"], size="n", height=t["H"], width=t["W"], max_batch=t["B"], dtype="f32")
+    for branch, want in ((True, g["item_trunc"]), (False, g["item"])):
+        m.set_preds({"boxes": bx, "scores": sc, "mask_coefficient": cf, "proto": pr})
+        loss, items = v8SegmentationLoss(m, cpu_crop_branch=branch)(None, batch)
+        assert abs(items[1] - want) <= 1e-3 * abs(want), (branch, items, want)
+        assert np.allclose(items[[0, 2, 3]], k["items"], rtol=1e-3, atol=1e-5) and items[4] == 0
+    for key, wk in (("dmask_coefficient", "dcoeff"), ("dproto", "dproto")):
+        want = np.array(g[wk])
         got = m.get_output(key)
         assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (key, np.abs(got - want).max(), np.abs(want).max())
     m.close()
