@@ -276,3 +276,24 @@ def test_engine_segment_loss_matches_kat(backend, engine):
         got = m.get_output(key)
         assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (key, np.abs(got - want).max(), np.abs(want).max())
     m.close()
+
+
+def test_oracle_adamw_matches_torch_optimizer():
+    """The oracle's AdamW restatement (used to check ys_optim_adamw_step) against PyTorch's own torch.optim.AdamW -- the optimizer
+    semantics TorchSharp mirrors (decoupled decay, bias corrections, eps outside the corrected sqrt): three steps, three groups."""
+    g = torch.Generator().manual_seed(0)
+    names = ["model.0.conv.weight", "model.0.bn.weight", "model.0.bn.bias", "model.22.cv2.0.2.bias"]
+    params = {n: torch.randn(7, 5, generator=g, dtype=torch.float64) for n in names}
+    ref = {n: torch.nn.Parameter(p.clone()) for n, p in params.items()}
+    lrs = [3e-3, 1e-3, 2e-3]                                      # groups: bias, conv weight, bn weight
+    opt = torch.optim.AdamW([{"params": [ref[n]], "lr": lrs[O.param_group_of(n)]} for n in names], betas=(0.9, 0.999), eps=1e-8,
+                            weight_decay=5e-4)
+    state = {}
+    for step in range(1, 4):
+        grads = {n: torch.randn(7, 5, generator=g, dtype=torch.float64) * (0.1 if "bn" in n else 1.0) for n in names}
+        for n in names:
+            ref[n].grad = grads[n].clone()
+        opt.step()
+        O.adamw_step(params, grads, state, lrs, step=step)
+        for n in names:
+            assert torch.allclose(params[n], ref[n].detach(), rtol=1e-12, atol=1e-14), (step, n)
