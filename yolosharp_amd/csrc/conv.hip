@@ -511,6 +511,7 @@ __host__ __device__ constexpr int p2_reg_group(int mr, int nr, bool tight = fals
 struct P2Args {
   int TH, TW, tiles_x, tiles_y, ntiles, PH, PW;
   int ppb;       // patch pixel pitch (bytes)
+  int prb;       // patch row pitch (bytes) = PW * ppb + row padding (p2_pick_rowpad)
   int wpitch;    // weight row pitch in LDS (16-byte units)
   int nsteps;    // K-steps (32 K each) = ceil(KH*KW*Cin / 32)
   int nsp;       // row length of the q-major offset table [4][nsp]: nsteps rounded up to 4, plus slack for the pipelined over-read
@@ -842,6 +843,91 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #endif
 }
 
+
+// ---- LDS bank model of the K loop's ds_read_b128 fragment reads (MI355X: a wave's b128 read is served in four fixed 16-lane groups
+// over 64 four-byte banks, i.e. 16 slots of 16 bytes; lanes of a group that hit the same slot at different addresses serialise).
+// Lane (li, q) of a patch fragment reads pixel(li) * ppb + q * 16 (+ a tap / channel offset common to the wave), and each group holds
+// eight lanes of quarter q and eight of quarter q + 1.  With an ODD number of slots per pixel (the round-1/2 rule) the eight pixels of
+// one quarter and the eight of the next always collide pairwise: every fragment read cost 8 LDS cycles instead of 4 (measured:
+// SQ_LDS_BANK_CONFLICT = 44 % of LDS-active cycles).  A pitch of 2 (mod 4) slots puts the pixels of a quarter on even slots and the
+// next quarter's on odd ones -> conflict-free for 16 consecutive pixels; a tile row shorter than 16 pixels needs the row pitch
+// adjusted as well, which p2_pick_rowpad searches with this model.  Returns the mean LDS cycles per fragment read (4 = conflict-free).
+static double p2_read_cycles(int cin, int kh, int kw, int sa, int th, int tw, int mr, int nwv, int ppb, int prb) {
+  static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  const int ktot = kh * kw * cin;
+  const int nsteps = cin >= 16 ? 1 : (ktot + 31) / 32;   // cin >= 16: the quarters of a lane group share a tap, so every K-step adds one constant to all lanes -> same pattern
+  long tot = 0, n = 0;
+  for (int wave = 0; wave < nwv; wave++)
+    for (int mf = 0; mf < mr; mf++) {
+      int pb[16];
+      for (int li = 0; li < 16; li++) {
+        const int px = wave * mr * 16 + mf * 16 + li;
+        int ty = px / tw, tx = px - ty * tw;
+        if (ty >= th) { ty = 0; tx = 0; }
+        pb[li] = ty * sa * prb + tx * sa * ppb;
+      }
+      for (int st = 0; st < nsteps; st++) {
+        int qo[4];
+        for (int q = 0; q < 4; q++) {
+          int k0 = st * 32 + q * 8; if (k0 >= ktot) k0 = 0;
+          const int tap = k0 / cin, ch = k0 - tap * cin;
+          const int a = tap / kw, b = tap - a * kw;
+          qo[q] = a * prb + b * ppb + ch * 2;
+        }
+        for (int half = 0; half < 2; half++)
+          for (int g = 0; g < 2; g++) {
+            int addr[16], mx = 1;
+            for (int i = 0; i < 16; i++) { const int l = grp[g][i] + half * 32; addr[i] = pb[l & 15] + qo[l >> 4]; }
+            for (int i = 0; i < 16; i++) {
+              int c = 1;
+              for (int j = 0; j < i; j++) if (addr[j] == addr[i]) { c = 0; break; }       // identical addresses broadcast
+              if (!c) continue;
+              for (int j = i + 1; j < 16; j++) {
+                if (((addr[j] >> 4) & 15) != ((addr[i] >> 4) & 15) || addr[j] == addr[i]) continue;
+                bool dup = false;
+                for (int k = i + 1; k < j; k++) if (addr[k] == addr[j]) { dup = true; break; }
+                if (!dup) c++;
+              }
+              if (c > mx) mx = c;
+            }
+            tot += mx;
+          }
+        n++;
+      }
+    }
+  return n ? (double)tot / (double)n : 4.0;
+}
+// pixel pitch of the bf16 patch: stride 1 -> smallest slot count >= Cin / 8 that is 2 (mod 4); stride 2 (lanes two pixels apart) -> odd.
+// YS_P2_PITCH=0 restores the odd rule everywhere (A/B runs).
+static int p2_pixel_pitch(int cin, int sa) {
+  static const int rule = getenv("YS_P2_PITCH") ? atoi(getenv("YS_P2_PITCH")) : 1;
+  const int cu = cin / 8;
+  if (!rule || sa != 1) return cin * 2 + ((cu & 1) ? 32 : 16);
+  int p = cu;
+  while ((p & 3) != 2) p++;
+  return p * 16;
+}
+// row padding (in 16-byte slots, 0..15) of the patch that minimises the modelled read cycles of the chosen tile within `room` bytes
+static int p2_pick_rowpad(int cin, int kh, int kw, int sa, int th, int tw, int mr, int nwv, int ppb, int pw, int ph, size_t room) {
+  static const int on = getenv("YS_P2_ROWPAD") ? atoi(getenv("YS_P2_ROWPAD")) : 1;
+  if (!on) return 0;
+  static std::map<std::vector<int>, int> cache;
+  static std::mutex mu;
+  const std::vector<int> key = {cin, kh, kw, sa, th, tw, mr, nwv, ppb, pw, ph, (int)(room / (16 * (size_t)(ph > 0 ? ph : 1)) > 15 ? 15 : (int)(room / (16 * (size_t)(ph > 0 ? ph : 1))))};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  double best = p2_read_cycles(cin, kh, kw, sa, th, tw, mr, nwv, ppb, pw * ppb);
+  int pad = 0;
+  for (int r = 1; r < 16 && best > 4.0 + 1e-9; r++) {
+    if ((size_t)ph * r * 16 > room) break;
+    const double c = p2_read_cycles(cin, kh, kw, sa, th, tw, mr, nwv, ppb, pw * ppb + r * 16);
+    if (c < best - 1e-9) { best = c; pad = r; }
+  }
+  cache[key] = pad;
+  return pad;
+}
+
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
 // fp8 variants whose 32-byte fragments fit the 256-register budget without spilling (hipcc -Rpass-analysis=kernel-resource-usage)
 static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
@@ -878,7 +964,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   const int cu = a.Cin / 8;
   P2Args g{};
   g.xbytes = (unsigned)xbytes_l;
-  g.ppb = f8 ? a.Cin + (((a.Cin / 16) & 1) ? 32 : 16) : a.Cin * 2 + ((cu & 1) ? 32 : 16);   // odd number of 16-byte slots per pixel
+  g.ppb = f8 ? a.Cin + (((a.Cin / 16) & 1) ? 32 : 16) : p2_pixel_pitch(a.Cin, a.SA);   // bf16: bank-model rule (p2_pixel_pitch); fp8: odd number of 16-byte slots per pixel
   const int taps = a.KH * a.KW;
   g.nsteps = f8 ? (taps * a.Cin + 127) / 128 : (taps * a.Cin + 31) / 32;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
@@ -892,17 +978,21 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   static const double tileconst = getenv("YS_P2_TILECONST") ? atof(getenv("YS_P2_TILECONST")) : 3000.0;
   static const int nrsplit = getenv("YS_P2_NRSPLIT") ? atoi(getenv("YS_P2_NRSPLIT")) : 1;   // measured 13.00 -> 12.86 ms/step
   const int nsteps4 = (g.nsteps + 3) & ~3;           // resident weight rows are zero-padded to whole register groups (<= 4 K-steps)
+  // weight rows: 16 consecutive rows per fragment read, same lane-group structure as the patch -> a pitch of 2 (mod 4) slots is
+  // conflict-free (the odd pitch was 2-way); fp8 rows (two reads per fragment, quarters two slots apart) keep the odd pitch
+  static const int wrule = getenv("YS_P2_WPITCH") ? atoi(getenv("YS_P2_WPITCH")) : 1;
+  auto wp = [&](int units) { if (f8 || !wrule) return units | 1; int p = units; while ((p & 3) != 2) p++; return p; };
   g.nsp = nsteps4 + 12;                              // + slack: the pipelined loop reads table entries up to two groups ahead
-  if (nrsplit && (size_t)nr * 16 * ((nsteps4 * ups) | 1) * 16 > wresmax && nr % 2 == 0 &&
-      (size_t)(nr / 2) * 16 * ((nsteps4 * ups) | 1) * 16 <= wresmax && nfr % (nr / 2) == 0)
+  if (nrsplit && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr % 2 == 0 &&
+      (size_t)(nr / 2) * 16 * wp(nsteps4 * ups) * 16 <= wresmax && nfr % (nr / 2) == 0)
     nr /= 2;
-  if (f8 && (size_t)nr * 16 * ((nsteps4 * ups) | 1) * 16 > wresmax && nr > 2 && !getenv("YS_P2_F8_ANYTILE")) nr = 2;   // streamed fp8 weights: small register tiles only
+  if (f8 && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr > 2 && !getenv("YS_P2_F8_ANYTILE")) nr = 2;   // streamed fp8 weights: small register tiles only
   const int bn = nr * 16;
-  const size_t wres_bytes = (size_t)bn * ((nsteps4 * ups) | 1) * 16;
+  const size_t wres_bytes = (size_t)bn * wp(nsteps4 * ups) * 16;
   const int wres = wres_bytes <= wresmax ? 1 : 0;
   g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
-  g.wpitch = wres ? ((nsteps4 * ups) | 1) : ((g.kg * ups) | 1);
+  g.wpitch = wres ? wp(nsteps4 * ups) : wp(g.kg * ups);
   const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
   const size_t tab = ((size_t)g.nsp * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
@@ -927,7 +1017,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         int th = npx / tw; if (th > a.Hout) th = a.Hout;
         const int ph = (th - 1) * a.SA + a.KH, pw = (tw - 1) * a.SA + a.KW;
         size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;
-        if (pbytes < (size_t)16 * nt * 4) pbytes = (size_t)16 * nt * 4;   // statistics scratch of p2_stats_flush
+        if (pbytes < (size_t)17 * nt * 4) pbytes = (size_t)17 * nt * 4;   // statistics scratch of p2_stats_flush ([16][NT] lane sums + [P][2 BN] partials)
         const size_t lds = tab + wbytes + pbytes + stat;
         if (f8 && !p2_f8_tile_ok(mr, nr, wres, ph * pw * cu <= 6 * 256 ? 6 : 12)) continue;
         if (lds > budget || ph * pw * cu > npu_max * nt || (size_t)ph * pw * g.ppb > (size_t)8192 * (f8 ? 8 : 16)) continue;   // 13-bit LDS slot field
@@ -950,6 +1040,23 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   }
   if (!p.ok) return p;
   if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
+  p.g.prb = p.g.PW * p.g.ppb;
+  if (!f8) {
+    // row padding of the patch (bank model, p2_pick_rowpad) inside the occupancy class the tile search settled on
+    const int nwv = p.nt / 64;
+    const size_t stat = (size_t)nwv * bn * 2 * 4, stage = (size_t)nwv * (16 * p.mr * (bn + 8) * 2 + 16 * p.mr * 16);
+    size_t floor_b = stage > (size_t)17 * p.nt * 4 ? stage : (size_t)17 * p.nt * 4;
+    const size_t pb0 = (size_t)p.g.PH * p.g.prb;
+    const size_t cap = (p.lds <= 50 * 1024 && p.npu == 6) ? 50 * 1024 : (p.lds <= 76 * 1024 ? 76 * 1024 : 152 * 1024);
+    const size_t base = p.lds - (pb0 > floor_b ? pb0 : floor_b);           // tables + weights + statistics
+    size_t room = cap > base + pb0 ? cap - base - pb0 : 0;
+    if (pb0 + room > (size_t)8192 * 16) room = (size_t)8192 * 16 > pb0 ? (size_t)8192 * 16 - pb0 : 0;   // 13-bit LDS slot field
+    const int pad = p2_pick_rowpad(a.Cin, a.KH, a.KW, a.SA, p.g.TH, p.g.TW, p.mr, nwv, p.g.ppb, p.g.PW, p.g.PH, room);
+    p.g.prb += pad * 16;
+    const size_t pb1 = (size_t)p.g.PH * p.g.prb;
+    p.lds = base + (pb1 > floor_b ? pb1 : floor_b);
+    p.g.off_stat = (int)(p.lds - stat);
+  }
   const int per_cu = (p.lds <= 50 * 1024 && p.npu == 6) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
@@ -968,7 +1075,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   hipGetDevice(&dev);
   const P2Args& g = p.g;
   const bool f8 = a.f8 != 0;
-  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.nsteps, g.nsp, p.mr, p.npu, p.nt, (int)f8};
+  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.prb, g.nsteps, g.nsp, p.mr, p.npu, p.nt, (int)f8};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   const int NT = p.nt;
@@ -981,7 +1088,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
       if (k0 < Ktot) {
         const int tap = k0 / a.Cin, ch = k0 - tap * a.Cin;
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        h[(size_t)qq * g.nsp + st] = (kh * g.PW + kw) * g.ppb + ch * (f8 ? 1 : 2);
+        h[(size_t)qq * g.nsp + st] = kh * g.prb + kw * g.ppb + ch * (f8 ? 1 : 2);
       }
     }
   int* tpx = h.data() + g.nsp * 4;
@@ -991,7 +1098,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
       const int px = wave * (p.mr * 16) + mf * 16 + li;
       int ty = px / g.TW, tx = px - ty * g.TW;
       if (ty >= g.TH) { ty = g.TH; tx = 0; }    // idle lane of a ragged tile: marked by ty == TH, reads pixel (0,0)
-      tpx[(mf * 3 + 0) * NT + tid] = ty < g.TH ? ((ty * a.SA) * g.PW + tx * a.SA) * g.ppb : 0;
+      tpx[(mf * 3 + 0) * NT + tid] = ty < g.TH ? (ty * a.SA) * g.prb + (tx * a.SA) * g.ppb : 0;
       tpx[(mf * 3 + 1) * NT + tid] = ty;
       tpx[(mf * 3 + 2) * NT + tid] = tx;
     }
@@ -1004,7 +1111,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
       if (idx < npatch) {
         const int pix = idx / cu, u = idx - pix * cu;
         const int r = pix / g.PW, cc = pix - r * g.PW;
-        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (f8 ? (unsigned)(((r * g.PW + cc) * g.ppb + u * 8) >> 3) : (unsigned)(((r * g.PW + cc) * g.ppb + u * 16) >> 4));
+        d = ((unsigned)r << 23) | ((unsigned)cc << 13) | (f8 ? (unsigned)((r * g.prb + cc * g.ppb + u * 8) >> 3) : (unsigned)((r * g.prb + cc * g.ppb + u * 16) >> 4));
         go = (r * a.Win + cc) * a.in_ldc + u * 8;
       }
       tpd[(2 * k + 0) * NT + tid] = (int)d;
@@ -1342,4 +1449,19 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
     return conv_launch_dtype<bf16_t>(st, a);
   }
   return conv_launch_dtype<float>(st, a);
+}
+
+// Development aid (tools/dev/p2_plans.py): the P2 plan of a forward convolution geometry as text -- no device needed.
+extern "C" __attribute__((visibility("default"))) int ys_debug_p2_plan(int B, int Hin, int Win, int Cin, int Cout, int k, int s, int in_ldc, char* buf, int cap) {
+  ConvArgs a{};
+  a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = a.KW = k; a.SA = s; a.PAD = k / 2;
+  a.Hout = (Hin + 2 * (k / 2) - k) / s + 1; a.Wout = (Win + 2 * (k / 2) - k) / s + 1;
+  a.in_ldc = in_ldc; a.in_bstride = (long)Hin * Win; a.out_ldc = Cout; a.out_bstride = (long)a.Hout * a.Wout; a.M = B * a.Hout * a.Wout;
+  if (ys_conv_gemm_rows(a)) { snprintf(buf, cap, "gemm"); return 2; }
+  const P2Plan p = conv_p2_plan(a);
+  if (!p.ok) { snprintf(buf, cap, "none"); return 0; }
+  const double cyc = p2_read_cycles(a.Cin, a.KH, a.KW, a.SA, p.g.TH, p.g.TW, p.mr, p.nt / 64, p.g.ppb, p.g.prb);
+  snprintf(buf, cap, "mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%zu ppb%d prb%d(pad%d) wpitch%d readcyc%.2f", p.mr, p.nr, p.wres, p.npu, p.g.TH, p.g.TW,
+           p.gx, p.gy, p.lds, p.g.ppb, p.g.prb, (p.g.prb - p.g.PW * p.g.ppb) / 16, p.g.wpitch, cyc);
+  return 1;
 }

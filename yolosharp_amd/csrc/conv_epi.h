@@ -134,21 +134,36 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
   constexpr int VPP = BN / 8;
   constexpr int PPI = 64 / VPP;
   constexpr int NT = NW * 64;
+  constexpr int NE = NW * PPI;                // lane entries per (sum, channel)
+  constexpr int P = NT / (2 * BN) >= 1 ? NT / (2 * BN) : 1;   // threads sharing one output: the serial chain of NE dependent LDS reads
+  constexpr int LEN = (NE + P - 1) / P;       // (a 3-4 thousand cycle tail of every forward launch) becomes NE / P + P
   const int tid = threadIdx.x;
   ys_barrier_lds();                           // the last tile's epilogue staging (same LDS region) is consumed
 #pragma unroll
   for (int e = 0; e < 8; e++) { scr[e * NT + tid] = s1[e]; scr[(8 + e) * NT + tid] = s2[e]; }
   ys_barrier_lds();
+  float* part = scr + 16 * NT;                // [P][2 * BN]
+  {
+    const int o = tid % (2 * BN), pi = tid / (2 * BN);
+    if (pi < P) {
+      const int which = o / BN, c = o - which * BN;
+      const int cv = c >> 3, e = c & 7;
+      const float* col = scr + (which * 8 + e) * NT + cv;
+      float t = 0.f;
+#pragma unroll 4
+      for (int k = pi * LEN; k < (pi + 1) * LEN && k < NE; k++) {   // lanes cv, cv + VPP, ... of wave 0, then wave 1, ...: lane index = (k / PPI) * 64 + (k % PPI) * VPP
+        const int w = k / PPI, j = k - w * PPI;
+        t += col[w * 64 + j * VPP];
+      }
+      part[pi * 2 * BN + o] = t;
+    }
+  }
+  ys_barrier_lds();
   for (int o = tid; o < 2 * BN; o += NT) {
     const int which = o / BN, c = o - which * BN;
-    const int cv = c >> 3, e = c & 7;
-    const float* col = scr + (which * 8 + e) * NT + cv;
-    float t = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < NW * PPI; k++) {      // lanes cv, cv + VPP, ... of wave 0, then wave 1, ...: lane index = (k / PPI) * 64 + (k % PPI) * VPP
-      const int w = k / PPI, j = k - w * PPI;
-      t += col[w * 64 + j * VPP];
-    }
+    float t = part[o];
+#pragma unroll
+    for (int pi = 1; pi < P; pi++) t += part[pi * 2 * BN + o];      // fixed order -> deterministic
     if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
   }
 }

@@ -533,7 +533,7 @@ int ys_wgrad_splits(const WgradArgs& a, int dtype) {
   return (int)s;
 }
 
-int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad) {
+int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad, int* used_splits) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   if (a.Cin % epl || a.in_ldc % epl || a.in_coff % epl || a.dy_ldc % epl || a.dy_coff % epl) {
     ys_set_error("wgrad: channel counts/strides must be multiples of %d (Cin %d Cout %d)", epl, a.Cin, a.Cout);
@@ -557,7 +557,55 @@ int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, i
     else wgrad_dispatch<float>(st, a, splits);
   }
   const long n = (long)a.Cout * a.KH * a.KW * a.Cin;
+  if (used_splits) { *used_splits = splits; return YS_OK; }
   YS_LAUNCH(wgrad_reduce_kernel, ys_cdiv(n, 32), 512, st, (const float*)a.partial, splits, n, a.Cin, cin_real, grad);
+  return YS_OK;
+}
+
+// The same reduction for a list of layers in ONE launch (the per-layer form was 63 launches of ~6 us + a kernel boundary each per
+// YOLOv8n step, none of them on the dependency chain of the backward pass -- the optimizer is the only reader).  A workgroup finds
+// its layer by binary search over the 32-output block prefix; summation order per output is the per-layer kernel's.
+__global__ void __launch_bounds__(512)
+wgrad_reduce_batched_kernel(const WgRedDesc* __restrict__ descs, int nd) {
+  __shared__ float sred[16][32];
+  int lo = 0, hi = nd - 1;
+  const long blk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].blk0 <= blk) lo = mid; else hi = mid - 1; }
+  const WgRedDesc d = descs[lo];
+  const float* __restrict__ partial = d.partial;
+  const int splits = d.splits;
+  const long n = d.n;
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (blk - d.blk0) * 32 + o;
+  float gprev = 0.f; long gidx = -1;
+  if (sl == 0 && i < n) {
+    const long row = i / d.cin_pad;
+    const int ci = (int)(i - row * d.cin_pad);
+    if (ci < d.cin_real) { gidx = row * d.cin_real + ci; gprev = d.grad[gidx]; }
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 48 < splits; k += 64) {
+      s0 += partial[(long)k * n + i];
+      s1 += partial[(long)(k + 16) * n + i];
+      s2 += partial[(long)(k + 32) * n + i];
+      s3 += partial[(long)(k + 48) * n + i];
+    }
+    for (; k < splits; k += 16) s0 += partial[(long)k * n + i];
+  }
+  sred[sl][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (gidx >= 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += sred[w][o];
+    d.grad[gidx] = gprev + t;
+  }
+}
+int ys_wgrad_reduce_batched_launch(hipStream_t st, const WgRedDesc* descs_dev, int n_desc, long total_blocks) {
+  if (n_desc <= 0 || total_blocks <= 0) return YS_OK;
+  YS_LAUNCH(wgrad_reduce_batched_kernel, (int)total_blocks, 512, st, descs_dev, n_desc);
   return YS_OK;
 }
 

@@ -51,6 +51,8 @@ struct ConvL {
   bool dw = false;       // depthwise 3x3 (groups = channels): weights [9][C] fp32, no MFMA path
   bool f8_fwd = false, f8_bwd = false;   // fp8 mode: forward / dgrad of this layer may run the fp8 kernel (f8.hip recipe)
   int idx = -1, prep_idx = -1;           // own index in ys_model::convs; first PrepDesc (weight-amax slot)
+  long wgp_off = -1; int wgp_splits = 0; // own region of the weight-gradient partial workspace (floats) and the splits it holds; -1 = shared scratch + immediate reduce
+  int red_slot = -1;                     // index into ys_model::red_host (deferred split reduction)
   bool ct = false;       // ConvTranspose2d(k=2,s=2,bias) = four 1x1 phase GEMMs (Proto.upsample, Block.cs:69); weights [4][Cout][Cin]
 };
 
@@ -128,7 +130,10 @@ struct ys_model {
   bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
   float* chan = nullptr; long n_chan = 0;       // per conv: scale, shift, mean, rstd, c1, c2 (6*cout)
   float* stat_partial = nullptr; long n_stat = 0;
-  float* wg_partial = nullptr; long n_wgp = 0;
+  float* wg_partial = nullptr; long n_wgp = 0;   // [shared scratch (ConvTranspose phases) | one region per convolution]
+  // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
+  std::vector<WgRedDesc> red_host, red_uploaded; WgRedDesc* red_dev = nullptr; int red_first[4] = {0, 0, 0, 0};
+  bool defer_wgred = true;
   unsigned char* argmax = nullptr; long n_argmax = 0;
   float* img_dev = nullptr;                      // staging for host images
   float* pred = nullptr;                         // [B][4+nc][A] fp32 (eval)
@@ -839,8 +844,12 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
   YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4));
   YS_TRY(dev_alloc(m, (void**)&m->argmax, (size_t)amax));
-  // wgrad partial workspace: max over layers of splits * |W|
-  long wgp = 0;
+  // wgrad partial workspace: a shared scratch (max over layers of splits * |W|: ConvTranspose phases, immediate reduction) followed by
+  // one region per convolution, so that the split reduction of a whole backward segment can run as ONE launch after it
+  // (YS_WGRED_DEFER=0: per-layer reduction in the shared scratch, the round-2 behaviour)
+  m->defer_wgred = !(getenv("YS_WGRED_DEFER") && atoi(getenv("YS_WGRED_DEFER")) == 0);
+  long wgp = 0, wgp_regions = 0;
+  std::vector<long> need(m->convs.size(), 0);
   for (auto& c : m->convs) {
     if (c.dw) continue;
     WgradArgs a{}; a.Cin = c.cin_pad; a.Cout = c.cout; a.KH = a.KW = c.k; a.M = (int)((long)B * c.Hout * c.Wout);
@@ -852,10 +861,28 @@ int allocate(ys_model* m) {
       else { a.dy_ldc = ob.ldc; a.dy_coff = c.out.coff; a.dy_bstride = ob.rows_per_b; }
     }
     if (c.ct) { a.Hout = c.Hin; a.Wout = c.Win; a.M = (int)((long)B * c.Hin * c.Win); a.dy_rh = 1; }
-    wgp = std::max(wgp, (long)ys_wgrad_splits(a, m->dtype) * c.cout * c.k * c.k * c.cin_pad);
+    const int sp = ys_wgrad_splits(a, m->dtype);
+    need[c.idx] = (long)sp * c.cout * c.k * c.k * c.cin_pad;
+    wgp = std::max(wgp, need[c.idx]);
+    if (m->defer_wgred && !c.ct) { c.wgp_splits = sp; wgp_regions += (need[c.idx] + 63) / 64 * 64; }
   }
-  m->n_wgp = wgp;
-  YS_TRY(dev_alloc(m, (void**)&m->wg_partial, (size_t)wgp * 4));
+  {
+    long off = (wgp + 63) / 64 * 64;
+    // descriptor order = backward-segment order, so that a backward_range call reduces one contiguous run of descriptors
+    for (int seg = 0; seg < 3; seg++) {
+      m->red_first[seg] = (int)m->red_host.size();
+      for (auto& c : m->convs) {
+        if (c.seg != seg || c.dw || c.ct || !m->defer_wgred) continue;
+        c.wgp_off = off; off += (need[c.idx] + 63) / 64 * 64;
+        c.red_slot = (int)m->red_host.size();
+        m->red_host.push_back(WgRedDesc{});
+      }
+    }
+    m->red_first[3] = (int)m->red_host.size();
+    m->n_wgp = off;
+  }
+  YS_TRY(dev_alloc(m, (void**)&m->wg_partial, (size_t)m->n_wgp * 4));
+  if (!m->red_host.empty()) YS_TRY(dev_alloc(m, (void**)&m->red_dev, m->red_host.size() * sizeof(WgRedDesc)));
   const ys_model_desc& d = m->d;
   YS_TRY(dev_alloc(m, (void**)&m->img_dev, (size_t)B * std::max(3, m->blk_c1) * d.height * d.width * 4));
   YS_TRY(dev_alloc(m, (void**)&m->pred, (size_t)B * (4 + d.nc + m->nm) * m->A * 4));
@@ -1198,8 +1225,10 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
     a.KH = a.KW = c.k; a.stride = c.s; a.pad = c.k / 2;
     a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
     a.dy_ldc = dy_ldc; a.dy_coff = dy_coff; a.dy_bstride = dy_bstride; a.M = (int)M;
-    const int splits = ys_wgrad_splits(a, m->dtype);
-    if ((long)splits * c.cout * c.k * c.k * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
+    int splits = ys_wgrad_splits(a, m->dtype);
+    const bool defer = c.wgp_off >= 0;
+    if (defer) { a.partial = m->wg_partial + c.wgp_off; if (splits > c.wgp_splits) splits = c.wgp_splits; }   // own region (sized at max_batch)
+    else if ((long)splits * c.cout * c.k * c.k * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
     hipStream_t sw = st;
     if (m->overlap) {                    // dy is complete on `st`: hand it to the weight-gradient stream
       hipEvent_t ev = m->ev_dy[slot >= 0 ? slot : ys_model::DY_RING];
@@ -1207,7 +1236,13 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
       YS_CHECK_HIP(hipStreamWaitEvent(m->st2, ev, 0));
       sw = m->st2;
     }
-    YS_TRY(ys_wgrad_launch(sw, m->dtype, a, splits, c.cin, m->grads + c.w_off));
+    int used = 0;
+    YS_TRY(ys_wgrad_launch(sw, m->dtype, a, splits, c.cin, m->grads + c.w_off, defer ? &used : nullptr));
+    if (defer) {
+      WgRedDesc& d = m->red_host[c.red_slot];
+      d.partial = a.partial; d.grad = m->grads + c.w_off; d.n = (long)c.cout * c.k * c.k * c.cin_pad; d.splits = used;
+      d.cin_pad = c.cin_pad; d.cin_real = c.cin;
+    }
     if (m->overlap) {
       m->st2_dirty = true;
       if (slot >= 0) { YS_CHECK_HIP(hipEventRecord(m->ev_free[slot], m->st2)); m->slot_busy[slot] = true; }
@@ -1281,6 +1316,21 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
     m->st2_dirty = false;
   }
   if (m->f8 && seg_hi == 2) m->f8_bwd_done = true;     // every gradient maximum of the step is recorded (last segment = stem)
+  {
+    // split reduction of every weight gradient of these segments in one launch (the partial slabs sit in per-layer regions)
+    const int lo = m->red_first[seg_lo], hi = m->red_first[seg_hi + 1];
+    if (hi > lo) {
+      long blk = 0;
+      for (int i = lo; i < hi; i++) { m->red_host[i].blk0 = blk; blk += (m->red_host[i].n + 31) / 32; }
+      if (m->red_uploaded.size() != m->red_host.size()) m->red_uploaded.assign(m->red_host.size(), WgRedDesc{});
+      if (memcmp(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc)) != 0) {   // first step / batch size changed
+        YS_CHECK_HIP(hipMemcpyAsync(m->red_dev + lo, &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc), hipMemcpyHostToDevice, st));
+        YS_CHECK_HIP(hipStreamSynchronize(st));
+        memcpy(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc));
+      }
+      YS_TRY(ys_wgrad_reduce_batched_launch(st, m->red_dev + lo, hi - lo, blk));
+    }
+  }
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;
 }

@@ -74,7 +74,12 @@ int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
-int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad);
+// used_splits != nullptr: the split reduction is left to the caller (ys_wgrad_reduce_batched_launch over the layers of a backward
+// segment); *used_splits = number of partial slabs [Cout][taps][Cin] written to a.partial
+int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad, int* used_splits = nullptr);
+// one launch reducing the partial slabs of several layers: grad[row * cin_real + ci] += sum_s partial[s][row * cin_pad + ci]
+struct WgRedDesc { const float* partial; float* grad; long n; long blk0; int splits, cin_pad, cin_real, pad_; };
+int ys_wgrad_reduce_batched_launch(hipStream_t st, const WgRedDesc* descs_dev, int n_desc, long total_blocks);
 // blocked-GEMM weight-gradient kernel of the wide bf16 layers (conv_wgrad_gemm.hip): pixel splits it wants (0 = not eligible);
 // the launch uses at most `splits` and returns the number used (0 = not eligible, nothing launched)
 int ys_wgrad_gemm_splits(const WgradArgs& a);
