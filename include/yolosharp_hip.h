@@ -153,7 +153,10 @@ YS_API int ys_loss_obb(ys_model* m, const float* batch_idx, const float* cls, co
 /* v8PoseLoss.forward (Utils/Loss.cs:870-1071, KeypointLoss :169-188) for task = YS_POSE models: the detection terms and
  * assignment of ys_loss_detect, then the keypoint location (OKS-style, hyp_pose 12) and visibility (BCE, hyp_kobj 1) terms and
  * d(sum(loss*B))/d(raw kpts).  keypoints: fp32 [n_labels, kpt_num, kpt_dim] normalised like bboxes (x, y[, visibility]), row i
- * belongs to label i (YoloDataset keypoints, batch["keypoints"]).  A Pose model's ys_model_set_preds takes its raw kpts
+ * belongs to label i (YoloDataset keypoints, batch["keypoints"]).  Labels must be grouped by image in collate order (batch_idx
+ * non-decreasing), as YoloDataset's collate produces them: the reference's _select_target_keypoints (Loss.cs:1040-1071) indexes
+ * the keypoint rows by each label's rank within its image and is only defined for that order; host labels are validated
+ * (YS_ERR_INVALID_ARG otherwise), device labels are the caller's responsibility.  A Pose model's ys_model_set_preds takes its raw kpts
  * [B, nk, A] in the mask_coefficient argument; ys_model_get_output("dkpts") returns the gradient. */
 YS_API int ys_loss_pose(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes,
                         int n_labels, const float* keypoints, int on_device);

@@ -191,6 +191,44 @@ def test_crowded_image_more_labels_than_initial_capacity(backend, engine):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_out_of_range_batch_idx_rows_do_not_overflow_staging(backend, engine):
+    """Label rows whose batch_idx lies outside [0, B) are ignored by the criterion (the reference matches `batch_idx == j`,
+    Loss.cs:376-388) but they ARE staged: 70 rows of which 69 point at a missing image used to overrun the gcap * max_batch
+    staging arrays (round-2 advisor finding).  The workspace now grows with the row count; the loss equals the in-range labels'."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    B, H, W, nc = 1, 64, 64, 80
+    ref = make_ref(seed=5)
+    m = Yolov8(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")      # default capacity: 64 rows
+    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(6))
+    rng = np.random.default_rng(11)
+    n = 70
+    wh = rng.uniform(0.1, 0.5, (n, 2)); c = wh / 2 + rng.uniform(0, 1, (n, 2)) * (1 - wh)
+    bidx = np.full(n, 7.0, np.float32); bidx[0] = 0.0
+    nb = {"batch_idx": bidx, "cls": rng.integers(0, nc, n).astype(np.float32), "bboxes": np.concatenate([c, wh], 1).astype(np.float32)}
+    m.train(); ref.train()
+    m.forward(x.numpy(), fetch=False)
+    _, rpreds = ref(x)
+    keep = {k: torch.from_numpy(v[:1].copy()) for k, v in nb.items()}
+    _, ritems = O.v8DetectionLoss(nc)(rpreds, keep)
+    for rows in (n, 5000):
+        big = {k: np.concatenate([v] + [v[1:2]] * (rows - n), 0) if rows > n else v for k, v in nb.items()}
+        _, items = v8DetectionLoss(m)(None, big)
+        assert np.allclose(items, ritems.numpy(), rtol=1e-3, atol=1e-5), (rows, items, ritems)
+    m.close()
+
+
+def test_conv_bn_act_dtype_names():
+    """engine.conv_bn_act accepts the same dtype names as the model classes and rejects anything else with a ValueError."""
+    from yolosharp_amd import engine as E
+    from yolosharp_amd.model import DTYPES
+    for name, code in DTYPES.items():
+        assert E._dtype_code(name) == code
+    with pytest.raises(ValueError):
+        E._dtype_code("half")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_bf16_path_tracks_f32(backend, engine):
     """bf16 is the performance mode: validated against the fp32 oracle within bf16 rounding (eval logits ~1%)."""
     B, H, W, nc = 2, 64, 64, 80

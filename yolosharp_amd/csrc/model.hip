@@ -1705,7 +1705,12 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
     std::vector<int> cnt(m->B, 0);
     int mx = 0;
     for (int i = 0; i < n; i++) { const int b = (int)batch_idx[i]; if (b >= 0 && b < m->B) mx = std::max(mx, ++cnt[b]); }
+    // every label row is staged (rows whose batch_idx lies outside [0, B) are ignored by the kernels, like the reference's
+    // `batch_idx == j` matches): the staging arrays hold gcap * max_batch rows, so n itself bounds the capacity too
+    const int per_rows = (n + m->maxB - 1) / m->maxB;
+    if (per_rows > mx) mx = per_rows;
     if (mx > m->gcap) YS_TRY(alloc_label_ws(m, (mx + 15) / 16 * 16));
+    YS_REQUIRE(n <= m->max_labels, "ys_loss_detect: %d label rows exceed the staging capacity %d", n, m->max_labels);
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_bidx, batch_idx, (size_t)n * 4, hipMemcpyHostToDevice, st));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_cls, cls, (size_t)n * 4, hipMemcpyHostToDevice, st));
     YS_CHECK_HIP(hipMemcpyAsync(m->lab_box, bboxes, (size_t)n * lbytes, hipMemcpyHostToDevice, st));
@@ -1771,6 +1776,10 @@ int ys_loss_obb(ys_model* m, const float* batch_idx, const float* cls, const flo
 int ys_loss_pose(ys_model* m, const float* batch_idx, const float* cls, const float* bboxes, int n, const float* keypoints, int on_device) {
   YS_REQUIRE(m && m->xkind == 3, "ys_loss_pose: model has no Pose head");
   YS_REQUIRE(n == 0 || keypoints, "ys_loss_pose: null keypoints");
+  if (!on_device && batch_idx)                 // keypoint rows are addressed by a label's rank within its image: collate order only
+    for (int i = 1; i < n; i++)
+      YS_REQUIRE(batch_idx[i] >= batch_idx[i - 1], "ys_loss_pose: labels must be grouped by image in collate order (batch_idx[%d] = %g < batch_idx[%d] = %g)",
+                 i, (double)batch_idx[i], i - 1, (double)batch_idx[i - 1]);
   YS_TRY(loss_detect_core(m, batch_idx, cls, bboxes, n, on_device, true));
   m->have_loss = false;
   hipStream_t st = m->ctx->stream;

@@ -203,8 +203,8 @@ int ys_box_iou(ys_ctx* ctx, const float* box1, int n, const float* box2, int m, 
   hipMemcpyAsync(d1, box1, (size_t)n * 16, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d2, box2, (size_t)m * 16, hipMemcpyHostToDevice, st);
   YS_LAUNCH(box_iou_kernel, ys_cdiv((long)n * m, VM_THREADS), VM_THREADS, st, (const float*)d1, n, (const float*)d2, m, eps, d3);
-  hipMemcpyAsync(iou, d3, (size_t)n * m * 4, hipMemcpyDeviceToHost, st);
-  hipError_t e = hipStreamSynchronize(st);
+  hipError_t e = hipMemcpyAsync(iou, d3, (size_t)n * m * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
   hipFree(d1); hipFree(d2); hipFree(d3);
   if (e != hipSuccess) { ys_set_error("ys_box_iou: %s", hipGetErrorString(e)); return YS_ERR_HIP; }
   return YS_OK;
@@ -220,7 +220,7 @@ struct VmStage {
   const void* in(const void* host, size_t bytes) {
     if (on_device || !host) return host;
     void* d = alloc(bytes);
-    if (d && bytes) hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st);
+    if (d && bytes && hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st) != hipSuccess) ok = false;
     return d;
   }
   void* out(void* host, size_t bytes) { return on_device ? host : alloc(bytes); }
@@ -243,7 +243,7 @@ int ys_mask_iou(ys_ctx* ctx, const float* gt_ids, int nl, const uint8_t* pred_ma
   YS_LAUNCH_LDS(mask_iou_kernel, n, VM_THREADS, (size_t)2 * nl * sizeof(int) + 16, st, d_ids, nl, d_pm, n, npix, eps, d_iou);
   YS_CHECK_HIP(hipGetLastError());
   if (!on_device) {
-    hipMemcpyAsync(iou, d_iou, (size_t)nl * n * 4, hipMemcpyDeviceToHost, st);
+    YS_CHECK_HIP(hipMemcpyAsync(iou, d_iou, (size_t)nl * n * 4, hipMemcpyDeviceToHost, st));
     YS_CHECK_HIP(hipStreamSynchronize(st));
   }
   return YS_OK;
@@ -270,7 +270,7 @@ int ys_kpt_iou(ys_ctx* ctx, const float* kpt1, int n, const float* kpt2, int m, 
   YS_LAUNCH(kpt_iou_kernel, ys_cdiv((long)n * m, VM_THREADS), VM_THREADS, st, d1, n, d2, m, da, kpt_num, kpt_dim, ks, eps, d_iou);
   YS_CHECK_HIP(hipGetLastError());
   if (!on_device) {
-    hipMemcpyAsync(iou, d_iou, (size_t)n * m * 4, hipMemcpyDeviceToHost, st);
+    YS_CHECK_HIP(hipMemcpyAsync(iou, d_iou, (size_t)n * m * 4, hipMemcpyDeviceToHost, st));
     YS_CHECK_HIP(hipStreamSynchronize(st));
   }
   return YS_OK;
@@ -291,7 +291,7 @@ int ys_match_predictions(ys_ctx* ctx, const float* pred_cls, int n, const float*
   float* d_best = (float*)sg.alloc((size_t)n * 8);
   if (!sg.ok) { ys_set_error("ys_match_predictions: out of device memory"); return YS_ERR_OOM; }
   YS_LAUNCH(match_iou_kernel, 1, VM_THREADS, st, d_pc, n, d_tc, nl, d_iou, vm_thresholds(), d_best, d_cor);
-  if (!on_device) hipMemcpyAsync(correct, d_cor, (size_t)n * VM_NT, hipMemcpyDeviceToHost, st);
+  if (!on_device) YS_CHECK_HIP(hipMemcpyAsync(correct, d_cor, (size_t)n * VM_NT, hipMemcpyDeviceToHost, st));
   YS_CHECK_HIP(hipStreamSynchronize(st));      // the scratch buffers are released on return
   return YS_OK;
 }
@@ -337,8 +337,8 @@ int ys_val_match_batched(ys_ctx* ctx, const float* rows, const int32_t* count, i
     hipMemsetAsync(d_ovf, 0, 4, st);
     YS_LAUNCH(val_match_kernel, batch, VM_THREADS, st, d_rows, d_cnt, max_det, row_stride, d_bi, d_cl, d_bb, n_labels, img_w, img_h,
               vm_thresholds(), lcap, d_lab, d_best, d_cor, d_ovf);
-    if (!on_device) hipMemcpyAsync(correct, d_cor, ncor, hipMemcpyDeviceToHost, st);
-    hipError_t e = hipStreamSynchronize(st);      // the scratch buffers are released below
+    hipError_t e = on_device ? hipSuccess : hipMemcpyAsync(correct, d_cor, ncor, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // the scratch buffers are released below
     if (e != hipSuccess) { ys_set_error("ys_val_match_batched: %s", hipGetErrorString(e)); rc = YS_ERR_HIP; }
   }
   for (void* p : tmp) hipFree(p);

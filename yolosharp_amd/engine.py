@@ -21,6 +21,16 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_DTYPE_CODES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "float8": 2, 0: 0, 1: 1, 2: 2}   # same names as model.DTYPES
+
+
+def _dtype_code(dtype):
+    try:
+        return _DTYPE_CODES[dtype]
+    except (KeyError, TypeError):
+        raise ValueError("dtype %r: expected one of f32/float32, bf16/bfloat16, fp8/float8 (or the codes 0, 1, 2)" % (dtype,))
+
+
 class Engine:
     """One device context (ys_ctx): owns a HIP stream; not thread-safe (callers serialise)."""
 
@@ -245,7 +255,7 @@ class Engine:
         p = k // 2
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = np.empty((B, Cout, Ho, Wo), np.float32)
-        dt = {"f32": 0, 0: 0, "bf16": 1, 1: 1, "fp8": 2, 2: 2}[dtype]
+        dt = _dtype_code(dtype)
         g = b = rm = rv = None
         if bn is not None:
             g = np.ascontiguousarray(bn["weight"], np.float32)

@@ -389,6 +389,8 @@ class v8OBBLoss(v8SegmentationLoss):
 
 class v8PoseLoss(v8SegmentationLoss):
     """Loss.cs:870-1071.  batch additionally carries "keypoints" [N, kpt_num, kpt_dim] normalised (x, y[, visibility]).
+    Labels must be grouped by image in collate order (batch_idx non-decreasing; the reference's _select_target_keypoints is only
+    defined for that order) -- host labels are validated by the library.
     Returns (loss*B [5], loss_detach [5]) in the order box, pose, kobj, cls, dfl."""
 
     def __init__(self, model):
