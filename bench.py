@@ -7,11 +7,12 @@ Nothing is skipped inside the timed region.  N > 1: one process per GPU (torch.d
 (weak scaling: 64 images per GPU), SUM all-reduce of gradients over RCCL overlapped with the backward segments.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), extended with
-  roofline     -- dominant kernel class (conv_igemm: forward + dgrad implicit-GEMM launches), HBM-bound:
-                  algorithmic bytes of those launches / their HIP-event durations (measured on the engine's stream in
-                  extra untimed steps after the timed region), peak 8000 GB/s
-  cpu_baseline -- the oracle (ATen-CPU restatement of the reference, NOT TorchSharp) timed on this host's cores on a
-                  bounded sample (B=8 train step), rank 0 / N=1 only
+  roofline     -- the DOMINANT KERNEL of the step (largest summed launch time; conv_p2_kernel on config 2, conv_gemm_kernel on
+                  config 5): algorithmic bytes (HBM-bound) or flop (MFMA-bound, by the kernel's own arithmetic intensity against
+                  the ridge) of its launches / their HIP-event durations, measured live on the engine's stream in extra untimed
+                  steps after the timed region (yolosharp_amd/roofline.py); `kernels` lists every convolution kernel the same way
+  cpu_baseline -- the oracle (ATen-CPU restatement of the reference, NOT TorchSharp) timed on this host's cores on bounded
+                  samples, rank 0 / N=1 only: train step (B=8), predict = forward + NMS, NMS boxes/s
   nms          -- secondary metric: NMS boxes/s on [64, 84, 8400] (candidates entering greedy NMS per second)
 """
 import argparse
@@ -52,10 +53,13 @@ def synth_masks(bi, bb, B, mh, mw):
     return masks
 
 
-def cpu_baseline(nc, H, W, sample_b=8):
-    """Oracle (port) train step on the host cores: forward + loss + backward + AdamW, fp32."""
+def cpu_baseline(nc, H, W, sample_b=8, nms_pred=None):
+    """Oracle (port) on the host cores: train step (forward + loss + backward + AdamW, fp32), predict (eval forward + decode +
+    NMS, the reference's Detector.ImagePredict path, Detector.cs:27-72) and NMS alone (Ops.cs:239-371 restated in oracle/nms_ref.c)."""
+    import ctypes as C
     import torch
     from oracle import yolo_oracle as O
+    from yolosharp_amd import build
     torch.manual_seed(0)
     ref = O.Yolov8(nc=nc, size="n").train()
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=5e-4)
@@ -70,8 +74,40 @@ def cpu_baseline(nc, H, W, sample_b=8):
         opt.zero_grad(); loss.sum().backward(); opt.step()
         times.append(time.perf_counter() - t0)
     t = min(times[1:])
-    return {"value": round(sample_b / t, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/yolo_oracle.py (ATen-CPU restatement, not TorchSharp) YOLOv8n fp32 train step, B={sample_b} {H}x{W}, best of 2 after 1 warm-up"}
+    out = {"value": round(sample_b / t, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"oracle/yolo_oracle.py (ATen-CPU restatement, not TorchSharp) YOLOv8n fp32 train step, B={sample_b} {H}x{W}, best of 2 after 1 warm-up"}
+    # ---- predict: eval forward + decode (ATen, all cores) then NMS (plain C, one core) on one image, conf 0.25 / iou 0.45
+    lib = C.CDLL(build.build_oracle())
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def nms_host(p, conf, iou):
+        Bn, Cn, An = p.shape
+        rows = np.zeros((Bn, 300, 6), np.float32); keep = np.zeros((Bn, 300), np.int64); cnt = np.zeros(Bn, np.int32)
+        t0 = time.perf_counter()
+        rc = lib.ys_oracle_nms(vp(p), Bn, Cn, An, C.c_float(conf), C.c_float(iou), 300, 0, 30000, 7680, vp(rows), vp(keep), vp(cnt))
+        assert rc == 0
+        return time.perf_counter() - t0, int(cnt.sum())
+    ref.eval()
+    x1 = torch.rand(1, 3, H, W)
+    tp = []
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.perf_counter()
+            pred, _ = ref(x1)
+            p = np.ascontiguousarray((pred["boxes"] if isinstance(pred, dict) else pred).numpy(), np.float32)
+            nms_host(p, 0.25, 0.45)
+            tp.append(time.perf_counter() - t0)
+    out["predict"] = {"value": round(1.0 / min(tp[1:]), 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                      "sample": f"oracle eval forward + decode (ATen-CPU) + oracle/nms_ref.c, 1x3x{H}x{W}, best of 3 after 1 warm-up (Detector.cs:27-72 path)"}
+    if nms_pred is not None:   # the same synthetic [64, 84, 8400] tensor the device NMS line is quoted on
+        tn, kept = [], 0
+        for it in range(3):
+            dt, kept = nms_host(nms_pred.copy(), 0.25, 0.45)
+            tn.append(dt)
+        ncand = int((nms_pred[:, 4:].max(1) > 0.25).sum())
+        out["nms"] = {"value": round(ncand / min(tn), 1), "unit": "boxes/s", "cores": 1, "kind": "port", "ms": round(min(tn) * 1e3, 2),
+                      "sample": f"oracle/nms_ref.c (Ops.cs:239-371 + torchvision greedy NMS restated in C, single thread) on {list(nms_pred.shape)}, {ncand} candidates, {kept} kept, best of 3"}
+    return out
 
 
 def main():
@@ -187,13 +223,10 @@ def main():
     out = None
     if rank == 0:
         es = 2 if args.dtype in ("bf16", "fp8") else 4      # fp8 mode stores activations in bf16 (f8.hip)
-        if headline:
-            wk = step_work(args.size, nc, H, W, es)
-        else:   # SURVEY.md 8d totals for the other configurations (per image, bf16 bytes scaled by the element size)
-            tab = {(11, "m", "segment"): (1182e6, 339.3e9)}
-            tb, tf = tab.get((args.family, args.size, args.task), (0.0, 0.0))
-            wk = {"train_bytes": tb * es / 2, "train_flop": tf, "igemm_bytes": 0.0, "igemm_launches": 1}
-        # ---- dominant kernel class, HIP events on the engine stream, untimed extra steps
+        wk = step_work(args.size, nc, H, W, es) if headline else None
+        # ---- per-kernel roofline, HIP events on the engine stream around every convolution launch, untimed extra steps
+        from yolosharp_amd import roofline as RL
+        import tempfile
         steps_prof = 2
         eng.kernel_profile(True)
         for _ in range(steps_prof):
@@ -201,34 +234,44 @@ def main():
         eng.synchronize()
         n_ig, ms_ig = eng.kernel_profile_read("conv_igemm")
         n_wg, ms_wg = eng.kernel_profile_read("conv_wgrad")
-        if args.dump_launches:
-            eng.kernel_profile_dump(args.dump_launches)
+        dump = args.dump_launches or os.path.join(tempfile.gettempdir(), f"ys_launches_{os.getpid()}.csv")
+        eng.kernel_profile_dump(dump)
         eng.kernel_profile(False)
-        # class bytes of one step / launches actually made per step (a stride-2 dgrad runs as four phase launches)
-        bytes_per_launch = wk["igemm_bytes"] * B / max(n_ig / steps_prof, 1)
-        avg_ms = ms_ig / max(n_ig, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the timed process)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-            if headline and tj["conv_igemm_class"]["config"] == f"YOLOv8{args.size} B={B} {H}x{W} {args.dtype}":
-                traffic = tj["conv_igemm_class"]["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            traffic = None
-        if not headline:   # no per-class byte table for this graph: report the whole step against the HBM roofline
-            achieved = wk["train_bytes"] * B / (ms * 1e-3) / 1e9
-            bytes_per_launch = wk["train_bytes"] * B
-        kdesc = ("conv_igemm class = every forward + dgrad convolution launch of the step: conv_p2_kernel (< 128 input channels: 3x3 "
-                 "s1/s2, 1x1, dgrad phases; whole-Cin LDS patch) and conv_gemm_kernel (>= 128 input channels: blocked implicit GEMM, "
-                 "LDS-DMA operand staging)") if headline else \
-                "whole training step (all kernels), algorithmic bytes from SURVEY.md 8d"
-        roofline = {"bound": "hbm", "kernel": kdesc, "achieved": round(achieved, 1),
-                    "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "launches_per_step": n_ig // steps_prof, "avg_launch_ms": round(avg_ms, 5),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "class_ms_per_step": {"conv_igemm": round(ms_ig / steps_prof, 3), "conv_wgrad": round(ms_wg / steps_prof, 3)},
-                    "step_algorithmic_GBps": round(wk["train_bytes"] * B / (ms * 1e-3) / 1e9, 1),
-                    "step_TFLOPs": round(wk["train_flop"] * B / (ms * 1e-3) / 1e12, 2)}
+        agg = RL.per_kernel(dump, steps_prof, es)
+        if not args.dump_launches:
+            os.remove(dump)
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        roofline = RL.roofline_of(dom, agg[dom])
+        roofline["what"] = ("dominant kernel = largest summed launch time of the step; achieved = its launches' algorithmic "
+                            + ("bytes" if roofline["bound"] == "hbm" else "flop") + " (launch geometry: input tensor + output tensor once, SURVEY 8d) / their HIP-event durations")
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the timed process): only when
+        # the file was measured on THIS source tree and configuration
+        traffic, traffic_note = None, None
+        cfg_key = f"YOLOv{args.family}{args.size}{'-' + args.task if args.task != 'detect' else ''} B={B} {H}x{W} {args.dtype}"
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+            ent = tj.get("configs", {}).get(cfg_key)
+            if ent is None:
+                traffic_note = "no PMC passes committed for this configuration"
+            elif ent.get("source_sha") != RL.source_sha(ROOT):
+                traffic_note = f"profiles/r03_hbm_traffic.json was measured on source {ent.get('source_sha')}, this tree is {RL.source_sha(ROOT)}: not reported"
+            else:
+                traffic = ent["kernels"][dom.split("<")[0]]["hbm_bytes_per_launch_corrected"]
+        except Exception as e:
+            traffic_note = f"profiles/r03_hbm_traffic.json unreadable ({type(e).__name__})"
+        roofline["traffic"] = traffic
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
+        roofline["kernels"] = {k: {f: v for f, v in RL.roofline_of(k, a).items() if f in ("bound", "achieved", "unit", "frac", "launches_per_step", "avg_launch_ms", "kernel_ms_per_step")}
+                               for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        roofline["class_ms_per_step"] = {"conv_igemm": round(ms_ig / steps_prof, 3), "conv_wgrad": round(ms_wg / steps_prof, 3)}
+        # whole step: SURVEY 8d totals (headline graph: yolosharp_amd/workload.py; other graphs: the launches actually made -- conv units only)
+        step_bytes = wk["train_bytes"] * B if headline else sum(a["bytes"] for a in agg.values())
+        step_flop = wk["train_flop"] * B if headline else sum(a["flop"] for a in agg.values())
+        roofline["step_algorithmic_GBps"] = round(step_bytes / (ms * 1e-3) / 1e9, 1)
+        roofline["step_frac"] = round(step_bytes / (ms * 1e-3) / 1e9 / RL.HBM_PEAK_GBS, 4)
+        roofline["step_TFLOPs"] = round(step_flop / (ms * 1e-3) / 1e12, 2)
+        roofline["step_mfma_frac"] = round(step_flop / (ms * 1e-3) / 1e12 / RL.MFMA_PEAK_TF["fp8" if args.dtype == "fp8" else ("bf16" if args.dtype == "bf16" else "f32")], 4)
         gname = f"YOLOv{args.family}{args.size}" + {"segment": "-seg", "obb": "-obb", "pose": "-pose"}.get(args.task, "")
         out = {"metric": f"train images/sec {gname} {W}x{H} bs={B}/GPU", "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -251,6 +294,7 @@ def main():
                         "what": "eval forward + decode to pred [B,4+nc(+nm),A], inputs resident in HBM"}
         model.train()
         # ---- secondary metric: NMS boxes/s on [64, 84, 8400]
+        nms_pred_host = None
         if not args.no_nms and nc == 80:      # the NMS line is quoted on the COCO-80 shape
             prng = np.random.default_rng(3)
             A = 8400
@@ -258,6 +302,7 @@ def main():
             sc = 1 / (1 + np.exp(-prng.normal(-3, 1.5, (64, nc, A))))
             sc[:, :, prng.random(A) < 0.92] *= 0.05                      # ~8 % of anchors pass conf 0.25
             pred = np.concatenate([c, wh, sc], 1).astype(np.float32)
+            nms_pred_host = pred
             ncand = int(((pred[:, 4:].max(1)) > 0.25).sum())
             d_pred = eng.malloc(pred.nbytes)
             d_rows = eng.malloc(64 * 300 * 6 * 4); d_keep = eng.malloc(64 * 300 * 8); d_cnt = eng.malloc(64 * 4)
@@ -275,7 +320,7 @@ def main():
             out["nms"] = {"boxes_per_s": round(ncand / tn, 1), "candidates": ncand, "ms": round(tn * 1e3, 3),
                           "shape": [64, 84, A], "conf": 0.25, "iou": 0.45}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nc, H, W)
+            out["cpu_baseline"] = cpu_baseline(nc, H, W, nms_pred=nms_pred_host)
         else:
             out["cpu_baseline"] = None
         # the JSON line must be the LAST line of rank 0's stdout: libraries (RCCL prints "Librccl path : ..." through C stdio,

@@ -5,7 +5,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "r2", "p2_timeline.txt")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2", "p2_timeline.txt")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 if os.path.exists(out):
     os.remove(out)

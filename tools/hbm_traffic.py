@@ -27,6 +27,13 @@ def load(path, counter):
 
 
 def main(fetch_csv, write_csv, out, config):
+    """config = bench.py's cfg_key, e.g. "YOLOv8n B=64 640x640 bf16".  Merges into `out` (one entry per configuration) and stamps
+    the entry with the sha of the device sources it measured (yolosharp_amd/roofline.py source_sha): bench.py only quotes `traffic`
+    from an entry whose sha equals the running tree's."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from yolosharp_amd.roofline import source_sha
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(f) | set(w)):
@@ -36,12 +43,20 @@ def main(fetch_csv, write_csv, out, config):
                       "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024)}
     n = sum(kernels[k]["launches"] for k in CONV_CLASS if k in kernels)
     tot = sum(kernels[k]["hbm_bytes_per_launch_corrected"] * kernels[k]["launches"] for k in CONV_CLASS if k in kernels)
-    res = {"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "),
-           "conv_igemm_class": {"config": config, "kernels": [k for k in CONV_CLASS if k in kernels], "launches": n,
-                                "hbm_bytes_per_launch_corrected": int(tot / max(n, 1))},
-           "kernels": kernels}
+    total = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in kernels.values())
+    res = {"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "configs": {}}
+    if os.path.exists(out):
+        try:
+            res = json.load(open(out))
+            res.setdefault("configs", {})
+        except Exception:
+            pass
+    res["configs"][config] = {"source_sha": source_sha(root), "traced_launch_bytes_total": int(total),
+                              "conv_igemm_class": {"kernels": [k for k in CONV_CLASS if k in kernels], "launches": n,
+                                                   "hbm_bytes_per_launch_corrected": int(tot / max(n, 1))},
+                              "kernels": kernels}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps(res["conv_igemm_class"]))
+    print(json.dumps({"config": config, "source_sha": res["configs"][config]["source_sha"], "traced_GB": round(total / 1e9, 2)}))
 
 
 if __name__ == "__main__":

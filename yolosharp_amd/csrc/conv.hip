@@ -525,7 +525,8 @@ struct P2Args {
 // runs v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: 128 K per instruction at twice the bf16 MFMA rate, and half
 // the LDS bytes per K (the K loop of this kernel is LDS-bandwidth-bound for small register tiles).  A K-step is then 128 K =
 // four 32-channel pieces (one per lane quarter); Cin % 32 == 0.  The fp32 accumulators are scaled back in the epilogue.
-template <int MR, int NR, int WRES, int NPU, int NT, int F8>
+// RED = 1: dgrad launches that also take the BN-backward sums of the producers whose gradient they complete (conv_epi.h, BnRedSeg)
+template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
 __global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 && !F8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD
 conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   typedef bf16_t T;
@@ -831,11 +832,11 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #pragma unroll
           for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
     }
-    if (!P2_DBG(4)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0, stg, st1, st2);
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0, stg, st1, st2);
     TL_STAMP();
     txi = ntx; tyi = nty; b = nb;
   }
-  if (a.stats) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
   if (F8 && a.amax && blockIdx.y == 0) ys_amax_update(a.amax, amx);
   TL_STAMP();
 #ifdef YS_P2_TIMELINE
@@ -1124,7 +1125,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   return dptr;
 }
 
-template <int MR, int NR, int WRES, int NPU, int NT, int F8>
+template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
   a.dbg = dbg;
@@ -1132,7 +1133,7 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
-    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU, NT, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_p2_kernel<MR, NR, WRES, NPU, NT, F8, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[192] = "";
@@ -1149,7 +1150,7 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
     a.tl = tl_buf;
   }
 #endif
-  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU, NT, F8>), dim3(p.gx, p.gy), NT, p.lds, st, a, p.g, tab);
+  YS_LAUNCH_LDS((conv_p2_kernel<MR, NR, WRES, NPU, NT, F8, RED>), dim3(p.gx, p.gy), NT, p.lds, st, a, p.g, tab);
 #ifdef YS_P2_TIMELINE
   if (tl_path) {
     static unsigned long long h[64 * 64];
@@ -1173,15 +1174,14 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
 }
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
   {
-#define P2F(M_, N_, F_) { \
-    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_>(st, a, p); \
-    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256, F_>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256, F_>(st, a, p); }
-#define P2F8(M_, N_) P2F(M_, N_, 1)
-#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F8(M_, N_) else P2F(M_, N_, 0) }
+#define P2F(M_, N_, F_, R_) { \
+    if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_, R_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_, R_>(st, a, p); \
+    return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256, F_, R_>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256, F_, R_>(st, a, p); }
+#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F(M_, N_, 1, 0) else if (a.nred > 0) P2F(M_, N_, 0, 1) else P2F(M_, N_, 0, 0) }
+    if (a.f8 && a.nred > 0) { ys_set_error("conv p2: the fused BN-backward reduction has no fp8 variant"); return YS_ERR_UNSUPPORTED; }
     P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
 #undef P2
 #undef P2F
-#undef P2F8
   }
   ys_set_error("conv p2: no kernel for NT=%d MR=%d NR=%d", p.nt, p.mr, p.nr);
   return YS_ERR_UNSUPPORTED;
@@ -1389,18 +1389,51 @@ static bool conv_dgrad_s2_phase_args(const ConvArgs& a, int ph, ConvArgs& q) {
   return true;
 }
 
-static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a) {
+// rows_only: no launch, returns the partial rows the fused BN-backward reduction of the four launches would write (0 = a phase runs a
+// kernel without that epilogue); otherwise launches and returns a status
+static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_only = false) {
+  int row0 = a.red_row0;
   for (int ph = 0; ph < 4; ph++) {
     ConvArgs q;
     if (!conv_dgrad_s2_phase_args(a, ph, q)) continue;
-    if (q.f8 && q.x8 && ys_conv_gemm_rows(q)) { const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc; continue; }
+    q.red_row0 = row0;                                                // the phases write disjoint pixels of dx: their statistics rows stack
+    if (q.f8 && q.x8 && ys_conv_gemm_rows(q)) {
+      if (rows_only) return 0;                                        // fp8 kernels carry no fused reduction
+      const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc;
+      continue;
+    }
     P2Plan p2 = conv_p2_plan(q);
+    if (p2.ok && q.f8 && rows_only) return 0;
     if (!p2.ok && q.f8) { q.f8 = 0; p2 = conv_p2_plan(q); }          // no fp8 plan for this shape: bf16 kernel, same result type
-    if (!q.f8 && ys_conv_gemm_rows(q)) { const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc; continue; }
-    if (p2.ok) { const int rc = conv_p2_dispatch(st, q, p2); if (rc != YS_OK) return rc; }
-    else { const int rc = conv_launch_dtype<bf16_t>(st, q); if (rc != YS_OK) return rc; }
+    if (!q.f8 && ys_conv_gemm_rows(q)) {
+      row0 += ys_conv_gemm_rows(q);
+      if (!rows_only) { const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc; }
+      continue;
+    }
+    if (p2.ok) { row0 += p2.gx; if (!rows_only) { const int rc = conv_p2_dispatch(st, q, p2); if (rc != YS_OK) return rc; } }
+    else { if (rows_only) return 0; const int rc = conv_launch_dtype<bf16_t>(st, q); if (rc != YS_OK) return rc; }
   }
-  return YS_OK;
+  return rows_only ? row0 - a.red_row0 : YS_OK;
+}
+
+// mirrors ys_conv_launch's routing (bf16 storage): the fused reduction lives in conv_epi.h, i.e. in conv_p2_kernel and conv_gemm_kernel
+int ys_conv_bnred_rows(const ConvArgs& a, int dtype) {
+  static const bool p2_off = getenv("YS_NO_P2") != nullptr;
+  if (dtype != YS_BF16 || p2_off) return 0;
+  if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_bnred_rows(b, dtype); }
+  const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
+  if (a.f8 && !a.x8 && a.q8 && ys_conv_wants_x8(a)) { ConvArgs b = a; b.x8 = a.q8; return ys_conv_bnred_rows(b, dtype); }
+  if (phases) return conv_dgrad_s2_phases(nullptr, a, true);
+  if (a.f8) {                                   // launches routed to an fp8 kernel have no fused variant
+    if (a.x8 && ys_conv_gemm_rows(a)) return 0;
+    const P2Plan pf = conv_p2_plan(a);
+    if (pf.ok) return 0;
+    ConvArgs b = a; b.f8 = 0;
+    return ys_conv_bnred_rows(b, dtype);
+  }
+  if (ys_conv_gemm_rows(a)) return ys_conv_gemm_rows(a);
+  const P2Plan p2 = conv_p2_plan(a);
+  return p2.ok ? p2.gx : 0;
 }
 
 bool ys_conv_wants_x8(const ConvArgs& a) {

@@ -10,7 +10,20 @@
 // out as full 16-byte vectors -- consecutive lanes cover consecutive channels of one pixel row -- applying the residual /
 // gradient accumulation there, and takes the BN batch statistics per 8-channel column (fixed per lane).  Compared with
 // conv_epilogue the two phases keep few values live, which leaves the registers to the next tile's patch prefetch.
-template <int MR, int NR>
+// destination of one fused BN-backward partial sum: output-view channel c of the launch, `which` = 0 (sum du) / 1 (sum du * y)
+__device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long row) {
+  float* d = nullptr;
+#pragma unroll
+  for (int k = 0; k < YS_BNRED_MAXSEG; k++)     // static indices: the segment table stays in scalar registers
+    if (k < a.nred && c >= a.red[k].c0 && c < a.red[k].c1)
+      d = a.red[k].part + (((long)a.red_row0 + row) * 2 + which) * a.red[k].C + (c - a.red[k].c0 + a.red[k].yc0);
+  return d;
+}
+
+// RED = 1: the dgrad form -- gradient accumulation and the fused BN-backward reduction only (no bias / eval-BN / SiLU / residual:
+// a dgrad launch never carries them), compiled as its own kernel variants so that the forward kernels' register allocation is
+// untouched by the reduction's live values (y vectors, coefficients).
+template <int MR, int NR, int RED = 0>
 __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const long (&orow)[MR], const bool (&pv)[MR],
                                    int n0, char* stg, float (&s1)[8], float (&s2)[8]) {
   typedef bf16_t T;
@@ -22,6 +35,41 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   constexpr int NITER = (NPX + PPI - 1) / PPI;
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
   long* rowtab = (long*)(stg + NPX * PITCH);
+  const int cv = lane % VPP, pl = lane / VPP;
+  const bool active = lane < PPI * VPP;
+  const int c = n0 + cv * 8;
+  if (q == 0) {
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) {
+      rowtab[mf * 16 + li] = pv[mf] ? (orow[mf] * a.out_ldc + a.out_coff) * 2L : -1L;   // byte offset of the pixel row
+      rowtab[NPX + mf * 16 + li] = orow[mf];                                              // row index (residual view, producer's y)
+    }
+  }
+  // ---- fused BN-backward reduction (BnRedSeg): this lane's 8-channel column belongs to at most one producer.  Its y vectors for
+  // all NITER iterations are requested now -- right after the row table, before the accumulators are staged -- so that their
+  // latency overlaps phase 1 (a load issued inside the store loop was one dependent HBM round trip per iteration).
+  const bool red_on = RED != 0 && a.nred > 0;
+  const char* ry = nullptr; const float* rscp = nullptr; const float* rshp = nullptr; int rC = 0, rcol = 0; bool ract = false;
+  uint4 yv[RED ? NITER : 1];
+  float rsc[8], rsh[8];
+  if (RED && red_on) {
+#pragma unroll
+    for (int k = 0; k < YS_BNRED_MAXSEG; k++)
+      if (k < a.nred && active && c >= a.red[k].c0 && c < a.red[k].c1) {
+        ry = (const char*)a.red[k].y; rscp = a.red[k].scale; rshp = a.red[k].shift; rC = a.red[k].C;
+        rcol = c - a.red[k].c0 + a.red[k].yc0; ract = a.red[k].act != 0;
+      }
+    ys_wave_sync();                           // the row table is visible
+#pragma unroll
+    for (int it = 0; it < NITER; it++) {
+      const int px = it * PPI + pl;
+      yv[it] = ys_zero16();
+      if (ry && px < NPX && rowtab[px] >= 0) yv[it] = ys_ld16(ry + (rowtab[NPX + px] * rC + rcol) * 2L);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) { rsc[e] = 0.f; rsh[e] = 0.f; }
+    if (ry) { ys_ldcoef<8>(rscp + rcol, rsc); ys_ldcoef<8>(rshp + rcol, rsh); }
+  }
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
 #pragma unroll
@@ -30,7 +78,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
-      if (!a.scale && a.shift) {             // plain conv bias (heads): added to the fp32 accumulators
+      if (!RED && !a.scale && a.shift) {     // plain conv bias (heads): added to the fp32 accumulators
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int cc = (c + r) < a.Cout ? (c + r) : 0;
@@ -48,19 +96,12 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
       pk.y = ys_pack_bf16x2(v[2], v[3]);
       *(uint2*)(stg + (mf * 16 + li) * PITCH + (nf * 16 + 4 * q) * 2) = pk;
     }
-    if (q == 0) {
-      rowtab[mf * 16 + li] = pv[mf] ? (orow[mf] * a.out_ldc + a.out_coff) * 2L : -1L;   // byte offset of the pixel row
-      rowtab[NPX + mf * 16 + li] = orow[mf];                                              // row index (residual view)
-    }
   }
   ys_wave_sync();
-  const int cv = lane % VPP, pl = lane / VPP;
-  const bool active = lane < PPI * VPP;
-  const int c = n0 + cv * 8;
-  const bool do_stats = a.stats != nullptr;
+  const bool do_stats = !RED && a.stats != nullptr;
   // eval-mode BatchNorm folded into the conv (Convs.cs:48 with running statistics): applied on the wide path to the
   // bf16-rounded conv output -- the same value the training path normalises -- with the lane's 8 coefficients loaded once
-  const bool bn_eval = a.scale != nullptr;
+  const bool bn_eval = !RED && a.scale != nullptr;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
@@ -69,14 +110,13 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     if (a.shift) ys_ldcoef<8>(a.shift + c, sh);
   }
   char* yb = (char*)a.y;
-  const char* rb = (const char*)a.res;
+  const char* rb = RED ? nullptr : (const char*)a.res;
   // Stores go through a buffer descriptor of the output buffer: masked lanes (pixel outside the image, channel tile past Cout,
   // idle lanes of the wave) carry the out-of-range offset and the hardware drops them, so the store is issued unconditionally,
   // NITER times per tile -- a static count the compiler can keep in flight (vmcnt(N)) across the next tile's loads instead of the
   // vmcnt(0) that exec-masked stores forced.  Valid offsets are < 2^31 (checked by the launch plans).
   const ys_rsrcv_t rsY = ys_make_rsrcv(yb, 0x7ffffff0u);
-#pragma unroll 2
-  for (int it = 0; it < NITER; it++) {
+  auto store_iter = [&](const int it) {
     const int px = it * PPI + pl;
     const bool lane_ok = active && px < NPX && c < a.Cout;
     const long rofs = lane_ok ? rowtab[px] : -1L;
@@ -117,9 +157,28 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
           }
           val = ys_pack<T>(f);
         }
+        if (RED && red_on && ry) {
+          // dz as every later reader sees it (bf16-rounded, all contributions in), against the producer's raw output y
+          float g[8], yf[8];
+          ys_unpack<T>(val, g);
+          ys_unpack<T>(yv[RED ? it : 0], yf);
+          if (ract) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) g[e] *= ys_silu_grad(yf[e] * rsc[e] + rsh[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) { s1[e] += g[e]; s2[e] += g[e] * yf[e]; }
+        }
       }
     }
     ys_bufst16(rsY, rofs >= 0 ? (unsigned)(rofs + (long)c * 2L) : YS_BUF_OOB, val);
+  };
+  if (RED) {
+#pragma unroll                                // fully: yv[it] must be a register, not an indexed (scratch) array
+    for (int it = 0; it < NITER; it++) store_iter(it);
+  } else {
+#pragma unroll 2
+    for (int it = 0; it < NITER; it++) store_iter(it);
   }
   ys_wave_sync();
 }
@@ -164,7 +223,8 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
     float t = part[o];
 #pragma unroll
     for (int pi = 1; pi < P; pi++) t += part[pi * 2 * BN + o];      // fixed order -> deterministic
-    if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
+    if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
+    else if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
   }
 }
 
@@ -190,6 +250,7 @@ __device__ inline void conv_stats_flush_grid(const ConvArgs& a, int n0, float (&
     float t = 0.f;
     for (int wm = 0; wm < WM; wm++)
       for (int j = 0; j < PPI; j++) t += col[(wm * WN + wn) * 64 + j * VPP];
-    if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
+    if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
+    else if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
   }
 }

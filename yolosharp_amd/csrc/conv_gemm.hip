@@ -47,7 +47,7 @@ struct GemmArgs {
 // delayed scale, e4m3 or -- for a gradient -- e5m2; the weights as the e4m3 shadow a.w8).  Rows are still 128 B, now 128 K values:
 // one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per tile pair and K-tile, twice the bf16 MFMA rate at the same LDS and
 // L2 bytes per instruction.  The fp32 accumulators are scaled back by a.deq in front of the shared epilogue.
-template <int WM, int WN, int MR, int NR, int F8>
+template <int WM, int WN, int MR, int NR, int F8, int RED = 0>
 __global__ void __launch_bounds__(256, 2)
 conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   typedef bf16_t T;
@@ -231,9 +231,9 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
           for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
     }
     char* stg = sStage + wave * (16 * MR * (NR * 16 + 8) * 2 + 16 * MR * 16);
-    if (!GEMM_DBG(8)) p2_epilogue<MR, NR>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
+    if (!GEMM_DBG(8)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
   }
-  if (a.stats) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
+  if (RED ? a.nred > 0 : a.stats != nullptr) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ host side
@@ -301,7 +301,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   return p;
 }
 
-template <int WM, int WN, int MR, int NR, int F8>
+template <int WM, int WN, int MR, int NR, int F8, int RED = 0>
 static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
 #ifdef YS_GEMM_ABLATE
   a.dbg = getenv("YS_GEMM_DBG") ? atoi(getenv("YS_GEMM_DBG")) : 0;
@@ -310,13 +310,13 @@ static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, MR, NR, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, MR, NR, F8, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[192] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), F8 ? "gemmf8 k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d" : "gemm k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, WM * MR * 16, WN * NR * 16, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
-  YS_LAUNCH_LDS((conv_gemm_kernel<WM, WN, MR, NR, F8>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+  YS_LAUNCH_LDS((conv_gemm_kernel<WM, WN, MR, NR, F8, RED>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
   return YS_OK;
 }
 
@@ -328,7 +328,8 @@ int ys_conv_gemm_rows(const ConvArgs& a) {
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a) {
   const GemmPlan p = conv_gemm_plan(a);
   if (!p.ok) return YS_ERR_UNSUPPORTED;
-#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p));
+  if (a.f8 && a.nred > 0) { ys_set_error("conv gemm: the fused BN-backward reduction has no fp8 variant"); return YS_ERR_UNSUPPORTED; }
+#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : (a.nred > 0 ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
   GM(2, 2, 4, 5) GM(2, 2, 4, 4) GM(4, 1, 4, 5) GM(4, 1, 4, 4)
 #undef GM
   return YS_ERR_UNSUPPORTED;

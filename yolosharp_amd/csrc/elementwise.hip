@@ -535,14 +535,19 @@ int ys_chan_stats_launch(hipStream_t st, int dtype, const void* y, long rows, in
   return YS_OK;
 }
 
-// one workgroup per channel: sums partials; MODE 0 -> BN grads + coefficients, MODE 1 -> bias grad
+// one workgroup per channel: sums partials; MODE 0 -> BN grads + coefficients, MODE 1 -> bias grad.
+// The partial rows of a channel come from the source that covers it (FinSrc): one source = the channel-reduction pass; several =
+// the dgrad launches whose epilogues produced the sums (fused BN-backward reduction, BnRedSeg), each with its own row count.
 template <int MODE>
 __global__ void __launch_bounds__(EW_THREADS)
-chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count, float* __restrict__ g0,
+chan_finalize_kernel(FinSrc src, int C, double count, float* __restrict__ g0,
                      float* __restrict__ g1, float* __restrict__ c1, float* __restrict__ c2,
                      const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd) {
   __shared__ double sbuf[EW_THREADS];
   const int c = blockIdx.x;
+  const float* __restrict__ partial = src.p[0]; int nblk = src.nblk[0];
+#pragma unroll
+  for (int k = 1; k < YS_BNRED_MAXSEG; k++) if (k < src.n && c >= src.c1[k - 1]) { partial = src.p[k]; nblk = src.nblk[k]; }
   float sc = 0.f, mu = 0.f, rs = 0.f, g0p = 0.f, g1p = 0.f;   // tail operands first (see bn_finalize_kernel)
   if (threadIdx.x == 0) {
     g0p = g0[c];
@@ -568,10 +573,15 @@ chan_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double 
     }
   }
 }
+int ys_bn_bwd_finalize_src_launch(hipStream_t st, const FinSrc& src, int C, long count, float* dgamma, float* dbeta, float* c1,
+                                  float* c2, const float* scale, const float* mean, const float* rstd) {
+  YS_LAUNCH((chan_finalize_kernel<0>), C, EW_THREADS, st, src, C, (double)count, dgamma, dbeta, c1, c2, scale, mean, rstd);
+  return YS_OK;
+}
 int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, float* dgamma,
                               float* dbeta, float* c1, float* c2, const float* scale, const float* mean, const float* rstd) {
-  YS_LAUNCH((chan_finalize_kernel<0>), C, EW_THREADS, st, partial, nblk, C, (double)count, dgamma, dbeta, c1, c2, scale, mean, rstd);
-  return YS_OK;
+  FinSrc src{}; src.n = 1; src.p[0] = partial; src.nblk[0] = nblk; src.c1[0] = C;
+  return ys_bn_bwd_finalize_src_launch(st, src, C, count, dgamma, dbeta, c1, c2, scale, mean, rstd);
 }
 
 int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
@@ -585,7 +595,8 @@ int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff
   else
     YS_LAUNCH((chan_reduce_kernel<float, 1>), nb, EW_THREADS, st, (const float*)x, ldc, coff, (const float*)nullptr, rows, Cp, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0, 0, partial, rows_per_b, bstride);
   // partial rows are Cp wide; finalize only the C real channels
-  YS_LAUNCH((chan_finalize_kernel<1>), C, EW_THREADS, st, (const float*)partial, nb, Cp, 1.0, grad, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+  FinSrc src{}; src.n = 1; src.p[0] = partial; src.nblk[0] = nb; src.c1[0] = Cp;
+  YS_LAUNCH((chan_finalize_kernel<1>), C, EW_THREADS, st, src, Cp, 1.0, grad, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   return YS_OK;
 }
 
@@ -593,7 +604,8 @@ template <class T, bool ACT>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C,
                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k2,
-                    const float* __restrict__ k3, T* __restrict__ dy, int small, unsigned* __restrict__ amax) {
+                    const float* __restrict__ k3, T* __restrict__ dy, int small, unsigned* __restrict__ amax,
+                    T* __restrict__ rg, int rg_ldc, int rg_coff) {
   constexpr int EPL = Elem<T>::EPL;
   const int CG = C / EPL;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,6 +617,14 @@ bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* 
     float g[EPL], f[EPL], sc[EPL], sh[EPL], a2[EPL], a3[EPL];
     ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
     ys_unpack<T>(ys_ld16(y + row * C + c), f);
+    if (rg) {     // d(residual input) += dz: the Bottleneck shortcut's share, done here when the reduction pass that used to carry it is fused away
+      float o[EPL];
+      T* rp = rg + row * rg_ldc + rg_coff + c;
+      ys_unpack<T>(ys_ld16(rp), o);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) o[e] += g[e];
+      ys_st16(rp, ys_pack<T>(o));
+    }
     ys_ldcoef<EPL>(scale + c, sc); ys_ldcoef<EPL>(shift + c, sh); ys_ldcoef<EPL>(k2 + c, a2); ys_ldcoef<EPL>(k3 + c, a3);
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
@@ -626,7 +646,7 @@ __global__ void __launch_bounds__(EW_THREADS)
 bn_bwd_apply_q8_kernel(const bf16_t* __restrict__ dz, int dz_ldc, int dz_coff, const bf16_t* __restrict__ y, long rows, int C,
                        const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k2,
                        const float* __restrict__ k3, bf16_t* __restrict__ dy, unsigned char* __restrict__ q8,
-                       const float* __restrict__ qscale, unsigned* __restrict__ amax) {
+                       const float* __restrict__ qscale, unsigned* __restrict__ amax, bf16_t* __restrict__ rg, int rg_ldc, int rg_coff) {
   const int CG = C / 8;
   const long n = rows * CG;
   const float qs = qscale[0];
@@ -636,6 +656,14 @@ bn_bwd_apply_q8_kernel(const bf16_t* __restrict__ dz, int dz_ldc, int dz_coff, c
     float g[8], f[8], sc[8], sh[8], a2[8], a3[8];
     ys_unpack<bf16_t>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
     ys_unpack<bf16_t>(ys_ld16(y + row * C + c), f);
+    if (rg) {
+      float o[8];
+      bf16_t* rp = rg + row * rg_ldc + rg_coff + c;
+      ys_unpack<bf16_t>(ys_ld16(rp), o);
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] += g[e];
+      ys_st16(rp, ys_pack<bf16_t>(o));
+    }
     ys_ldcoef<8>(scale + c, sc); ys_ldcoef<8>(shift + c, sh); ys_ldcoef<8>(k2 + c, a2); ys_ldcoef<8>(k3 + c, a3);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -654,11 +682,11 @@ bn_bwd_apply_q8_kernel(const bf16_t* __restrict__ dz, int dz_ldc, int dz_coff, c
 }
 int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C,
                               const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
-                              void* q8, const float* qscale, unsigned* amax) {
+                              void* q8, const float* qscale, unsigned* amax, void* rg, int rg_ldc, int rg_coff) {
   const long n = rows * (C / 8);
   static const long gcap = getenv("YS_Q8_GRID") ? atol(getenv("YS_Q8_GRID")) : 2048;
   long g = ys_cdiv(n, EW_THREADS * 4L); if (g > gcap) g = gcap; if (g < 1) g = 1;
-#define BQ_LAUNCH(AF) YS_LAUNCH((bn_bwd_apply_q8_kernel<AF>), (int)g, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, k2, k3, (bf16_t*)dy, (unsigned char*)q8, qscale, amax)
+#define BQ_LAUNCH(AF) YS_LAUNCH((bn_bwd_apply_q8_kernel<AF>), (int)g, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, k2, k3, (bf16_t*)dy, (unsigned char*)q8, qscale, amax, (bf16_t*)rg, rg_ldc, rg_coff)
   if (act) BQ_LAUNCH(true); else BQ_LAUNCH(false);
 #undef BQ_LAUNCH
   return YS_OK;
@@ -666,11 +694,11 @@ int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz
 
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
                            int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
-                           unsigned* amax) {
+                           unsigned* amax, void* rg, int rg_ldc, int rg_coff) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
   const int small = n < (1L << 31) ? 1 : 0;
-#define BB_LAUNCH(TT, AF) YS_LAUNCH((bn_bwd_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, scale, shift, k2, k3, (TT*)dy, small, amax)
+#define BB_LAUNCH(TT, AF) YS_LAUNCH((bn_bwd_apply_kernel<TT, AF>), ys_cdiv(n, EW_THREADS), EW_THREADS, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, scale, shift, k2, k3, (TT*)dy, small, amax, (TT*)rg, rg_ldc, rg_coff)
   if (dtype == YS_BF16) { if (act) BB_LAUNCH(bf16_t, true); else BB_LAUNCH(bf16_t, false); }
   else { if (act) BB_LAUNCH(float, true); else BB_LAUNCH(float, false); }
 #undef BB_LAUNCH

@@ -54,6 +54,13 @@ struct ConvL {
   long wgp_off = -1; int wgp_splits = 0; // own region of the weight-gradient partial workspace (floats) and the splits it holds; -1 = shared scratch + immediate reduce
   int red_slot = -1;                     // index into ys_model::red_host (deferred split reduction)
   bool ct = false;       // ConvTranspose2d(k=2,s=2,bias) = four 1x1 phase GEMMs (Proto.upsample, Block.cs:69); weights [4][Cout][Cin]
+  // fused BN-backward reduction (BnRedSeg, ys_kernels.h).  As a consumer: the producers whose dz this layer's dgrad completes
+  // (it is their first reader in forward order = last gradient writer in backward order).  As a producer: where its sums come from.
+  struct RedFeed { int prod; int c0, c1, yc0; long part_off; int rows_cap, rows; };
+  struct RedSrc { int cons, feed; };
+  std::vector<RedFeed> feeds;
+  std::vector<RedSrc> red_src;           // sorted by producer channel
+  bool red_ok = false; int red_seen = 0; // every source is a supported dgrad launch / sources attached in the current backward pass
 };
 
 enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2, OP_ATTN = 3, OP_VCOPY = 4, OP_COPY = 5 };
@@ -134,6 +141,8 @@ struct ys_model {
   // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
   std::vector<WgRedDesc> red_host, red_uploaded; WgRedDesc* red_dev = nullptr; int red_first[4] = {0, 0, 0, 0};
   bool defer_wgred = true;
+  // fused BN-backward reduction: planned per batch size (plan_bnred), partial rows of every (producer, consumer) pair
+  bool bnred_on = true; int bnred_B = -1; float* bnred_part = nullptr; long n_bnred = 0;
   unsigned char* argmax = nullptr; long n_argmax = 0;
   float* img_dev = nullptr;                      // staging for host images
   float* pred = nullptr;                         // [B][4+nc][A] fp32 (eval)
@@ -848,6 +857,7 @@ int allocate(ys_model* m) {
   // one region per convolution, so that the split reduction of a whole backward segment can run as ONE launch after it
   // (YS_WGRED_DEFER=0: per-layer reduction in the shared scratch, the round-2 behaviour)
   m->defer_wgred = !(getenv("YS_WGRED_DEFER") && atoi(getenv("YS_WGRED_DEFER")) == 0);
+  m->bnred_on = !(getenv("YS_BNRED") && atoi(getenv("YS_BNRED")) == 0);           // YS_BNRED=0: every BN backward runs its own reduction pass
   long wgp = 0, wgp_regions = 0;
   std::vector<long> need(m->convs.size(), 0);
   for (auto& c : m->convs) {
@@ -1154,7 +1164,126 @@ static ConvArgs dgrad_args(ys_model* m, const ConvL& c, int B, const void* dy, i
   return a;
 }
 
-int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
+
+// Fused BN-backward reduction, host side.  For every BN Conv unit L find, per output channel, the FIRST op in forward order that
+// reads it: that op's backward is the last writer of the channel's gradient dz.  When all of L's channels are completed by the
+// dgrad launches of plain convolutions (reading them as their input view, not as a residual) whose kernels carry the fused
+// epilogue (ys_conv_bnred_rows), those launches produce L's sums and L's backward skips chan_reduce_kernel.
+static ConvArgs dgrad_args(ys_model* m, const ConvL& c, int B, const void* dy, int dy_ldc, int dy_coff, long dy_bstride);
+static ConvArgs dgrad_plan_args(ys_model* m, const ConvL& c, int B, bool f8) {
+  const Buf& ob = m->bufs[c.out.buf];
+  ConvArgs a = c.bn ? dgrad_args(m, c, B, m->dy_scratch, c.cout, 0, (long)c.Hout * c.Wout)
+                    : dgrad_args(m, c, B, view_ptr(m, ob.grad, ob, c.out_rowoff), ob.ldc, c.out.coff, ob.rows_per_b);
+  if (f8 && m->f8 && c.f8_bwd) {
+    a.f8 = 2; a.w8 = m->wd8_all + c.wd_off; a.qscale = m->f8_scales + 4L * c.idx + 2; a.deq = m->f8_scales + 4L * c.idx + 3; a.q8 = m->q8;
+    if (c.bn && m->q8 && c.cout_ld == c.cout && ys_conv_wants_x8(a)) a.x8 = m->q8;
+  }
+  return a;
+}
+int plan_bnred(ys_model* m, int B) {
+  if (m->bnred_B == B) return YS_OK;
+  m->bnred_B = B;
+  for (auto& c : m->convs) { c.feeds.clear(); c.red_src.clear(); c.red_ok = false; c.red_seen = 0; }
+  // fp8 mode: the fp8 kernels have no fused variant, and mixing fused / unfused units would break the mode's contract that its
+  // scale-less first step is bit-identical to the bf16 model -> every unit keeps its own reduction pass there
+  if (!m->bnred_on || m->dtype != YS_BF16 || m->f8) return YS_OK;
+  const int epl = m->epl;
+  // first reader per (buffer, channel): op index and kind (0 = input of a plain convolution, 1 = residual / unsupported reader)
+  std::vector<std::vector<int>> fop(m->bufs.size()), fkind(m->bufs.size());
+  for (size_t b = 0; b < m->bufs.size(); b++) { fop[b].assign(m->bufs[b].ldc, -1); fkind[b].assign(m->bufs[b].ldc, 1); }
+  auto touch = [&](const View& v, int op, int kind) {
+    for (int ch = v.coff; ch < v.coff + v.C; ch++) {
+      if (fop[v.buf][ch] == -1) { fop[v.buf][ch] = op; fkind[v.buf][ch] = kind; }
+      else if (fop[v.buf][ch] == op) fkind[v.buf][ch] = 1;      // read twice by the same op (input and residual): not fusable
+    }
+  };
+  for (size_t oi = 0; oi < m->ops.size(); oi++) {
+    const Op& op = m->ops[oi];
+    if (op.type == OP_CONV) {
+      const ConvL& x = m->convs[op.conv];
+      touch(x.in, (int)oi, (x.dw || x.ct || x.first) ? 1 : 0);
+      if (x.has_res) touch(x.res, (int)oi, 1);
+    } else {
+      touch(op.in, (int)oi, 1);
+    }
+  }
+  // candidate feeds
+  for (auto& l : m->convs) {
+    if (!l.bn || l.ct || l.cout_ld != l.cout) continue;
+    const Buf& ob = m->bufs[l.out.buf]; (void)ob;
+    bool ok = true;
+    std::vector<ConvL::RedSrc> srcs;
+    std::vector<std::pair<int, ConvL::RedFeed>> add;           // (consumer conv, feed)
+    int ch = l.out.coff;
+    while (ok && ch < l.out.coff + l.out.C) {
+      const int op = fop[l.out.buf][ch];
+      if (op < 0 || fkind[l.out.buf][ch] != 0) { ok = false; break; }
+      int e = ch;
+      while (e < l.out.coff + l.out.C && fop[l.out.buf][e] == op && fkind[l.out.buf][e] == 0) e++;
+      const ConvL& x = m->convs[m->ops[op].conv];
+      ConvL::RedFeed f{};
+      f.prod = l.idx; f.c0 = ch - x.in.coff; f.c1 = e - x.in.coff; f.yc0 = ch - l.out.coff;
+      if (f.c0 % epl || f.c1 % epl || f.yc0 % epl || x.Hin != l.Hout || x.Win != l.Wout) { ok = false; break; }
+      add.push_back({x.idx, f});
+      ch = e;
+    }
+    if (!ok || add.empty() || (int)add.size() > YS_BNRED_MAXSEG) continue;
+    for (auto& pr : add) m->convs[pr.first].feeds.push_back(pr.second);
+    l.red_ok = true;                                           // provisional: consumers are checked below
+  }
+  // consumers: segment capacity and kernel support; a failing consumer disqualifies the producers it would have served
+  bool changed = true;
+  while (changed) {
+    changed = false;
+    for (auto& x : m->convs) {
+      if (x.feeds.empty()) continue;
+      int rows = 0;
+      if ((int)x.feeds.size() <= YS_BNRED_MAXSEG) {
+        ConvArgs a = dgrad_plan_args(m, x, B, false);
+        rows = ys_conv_bnred_rows(a, m->dtype);
+        if (rows > 0 && m->f8) { ConvArgs a8 = dgrad_plan_args(m, x, B, true); const int r8 = ys_conv_bnred_rows(a8, m->dtype); rows = r8 > 0 ? std::max(rows, r8) : 0; }
+      }
+      for (auto& f : x.feeds) f.rows_cap = rows;
+      if (rows == 0) {
+        for (auto& f : x.feeds) m->convs[f.prod].red_ok = false;
+        x.feeds.clear();
+        changed = true;
+      }
+    }
+    for (auto& x : m->convs) {                                  // drop feeds of disqualified producers
+      const size_t n0 = x.feeds.size();
+      x.feeds.erase(std::remove_if(x.feeds.begin(), x.feeds.end(), [&](const ConvL::RedFeed& f) { return !m->convs[f.prod].red_ok; }), x.feeds.end());
+      if (x.feeds.size() != n0) changed = true;
+    }
+  }
+  // partial-row regions and the producers' source lists
+  long off = 0;
+  for (auto& x : m->convs)
+    for (size_t k = 0; k < x.feeds.size(); k++) {
+      ConvL::RedFeed& f = x.feeds[k];
+      f.part_off = off; off += (long)f.rows_cap * 2 * m->convs[f.prod].cout;
+      m->convs[f.prod].red_src.push_back(ConvL::RedSrc{x.idx, (int)k});
+    }
+  for (auto& l : m->convs) {
+    std::sort(l.red_src.begin(), l.red_src.end(), [&](const ConvL::RedSrc& p, const ConvL::RedSrc& q) {
+      return m->convs[p.cons].feeds[p.feed].yc0 < m->convs[q.cons].feeds[q.feed].yc0; });
+    if (l.red_src.empty()) l.red_ok = false;
+  }
+  if (off > m->n_bnred) {
+    if (m->bnred_part) { YS_CHECK_HIP(hipStreamSynchronize(m->ctx->stream)); dev_free_tracked(m, m->bnred_part); m->bnred_part = nullptr; }
+    YS_TRY(dev_alloc(m, (void**)&m->bnred_part, (size_t)off * 4));
+    m->n_bnred = off;
+  }
+  if (getenv("YS_BNRED_LOG")) {
+    int nf = 0, nb = 0;
+    for (auto& l : m->convs) { if (l.bn) nb++; if (l.red_ok) nf++; }
+    fprintf(stderr, "[ys] fused BN-backward reduction: %d of %d BN conv units (B=%d, %.1f MB of partial rows)\n", nf, nb, B, off * 4.0 / 1e6);
+    for (auto& l : m->convs) if (l.bn && !l.red_ok) fprintf(stderr, "[ys]   not fused: %s\n", l.name.c_str());
+  }
+  return YS_OK;
+}
+
+int run_conv_bwd(ys_model* m, ConvL& c, int B) {
   if (c.ct) return run_convT_bwd(m, c, B);
   hipStream_t st = m->ctx->stream;
   const Buf& ib = m->bufs[c.in.buf];
@@ -1177,11 +1306,27 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
         rg = rb.grad; rgl = rb.ldc; rgc = c.res.coff;
       }
     }
-    int nblk = 0;
-    YS_TRY(ys_bn_bwd_reduce_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
-                                   chan_ptr(m, c, 2), chan_ptr(m, c, 3), c.act ? 1 : 0, rg, rgl, rgc, m->stat_partial, &nblk));
-    YS_TRY(ys_bn_bwd_finalize_launch(st, m->stat_partial, nblk, c.cout, M, m->grads + c.g_off, m->grads + c.b_off,
-                                     chan_ptr(m, c, 4), chan_ptr(m, c, 5), chan_ptr(m, c, 0), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
+    // sum(du), sum(du * y): from the epilogues of the dgrad launches that completed dz (fused BN-backward reduction), else a pass of its own
+    const bool fused = c.red_ok && c.red_seen == (int)c.red_src.size() && !c.red_src.empty();
+    c.red_seen = 0;
+    void* rg_apply = nullptr;                    // the shortcut's residual-gradient accumulation rides on the reduction pass; without one, on the apply pass
+    if (fused) {
+      FinSrc src{};
+      src.n = (int)c.red_src.size();
+      for (int k = 0; k < src.n; k++) {
+        const ConvL::RedFeed& f = m->convs[c.red_src[k].cons].feeds[c.red_src[k].feed];
+        src.p[k] = m->bnred_part + f.part_off; src.nblk[k] = f.rows; src.c1[k] = f.yc0 + (f.c1 - f.c0);
+      }
+      YS_TRY(ys_bn_bwd_finalize_src_launch(st, src, c.cout, M, m->grads + c.g_off, m->grads + c.b_off, chan_ptr(m, c, 4), chan_ptr(m, c, 5),
+                                           chan_ptr(m, c, 0), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
+      rg_apply = rg;
+    } else {
+      int nblk = 0;
+      YS_TRY(ys_bn_bwd_reduce_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
+                                     chan_ptr(m, c, 2), chan_ptr(m, c, 3), c.act ? 1 : 0, rg, rgl, rgc, m->stat_partial, &nblk));
+      YS_TRY(ys_bn_bwd_finalize_launch(st, m->stat_partial, nblk, c.cout, M, m->grads + c.g_off, m->grads + c.b_off,
+                                       chan_ptr(m, c, 4), chan_ptr(m, c, 5), chan_ptr(m, c, 0), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
+    }
     void* dyb = m->dy_scratch;
     if (m->overlap && !c.dw) {           // ring slot: wait until the weight-gradient kernel that last read it has finished
       slot = m->dy_next; m->dy_next = (slot + 1) % ys_model::DY_RING;
@@ -1198,10 +1343,10 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
     if (dy_q8) {
       YS_TRY(ys_bn_bwd_apply_q8_launch(st, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), chan_ptr(m, c, 4),
                                        chan_ptr(m, c, 5), c.act ? 1 : 0, dyb, m->q8, m->f8_scales + 4L * c.idx + 2,
-                                       m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS));
+                                       m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS, rg_apply, rgl, rgc));
     } else {
       YS_TRY(ys_bn_bwd_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1),
-                                    chan_ptr(m, c, 4), chan_ptr(m, c, 5), c.act ? 1 : 0, dyb));
+                                    chan_ptr(m, c, 4), chan_ptr(m, c, 5), c.act ? 1 : 0, dyb, nullptr, rg_apply, rgl, rgc));
     }
     dy = dyb; dy_ldc = c.cout; dy_coff = 0;
   } else {
@@ -1265,6 +1410,24 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
       }
     }
     if (c.bn && c.cout_ld != c.cout) { ys_set_error("backward: padded BN conv unsupported"); return YS_ERR_UNSUPPORTED; }
+    if (!c.feeds.empty()) {
+      // this launch completes dz of the producers in c.feeds: its epilogue takes their BN-backward sums (BnRedSeg)
+      const int rows = ys_conv_bnred_rows(a, m->dtype);
+      bool fits = rows > 0;
+      for (auto& f : c.feeds) fits = fits && rows <= f.rows_cap;
+      if (fits) {
+        a.nred = (int)c.feeds.size(); a.red_row0 = 0;
+        for (int k = 0; k < a.nred; k++) {
+          ConvL::RedFeed& f = c.feeds[k];
+          ConvL& l = m->convs[f.prod];
+          BnRedSeg& sg = a.red[k];
+          sg.y = (char*)m->y_all + (size_t)l.y_off * m->es; sg.scale = chan_ptr(m, l, 0); sg.shift = chan_ptr(m, l, 1);
+          sg.part = m->bnred_part + f.part_off; sg.c0 = f.c0; sg.c1 = f.c1; sg.yc0 = f.yc0; sg.C = l.cout; sg.act = l.act ? 1 : 0;
+          f.rows = rows;
+          l.red_seen++;
+        }
+      }
+    }
     YS_TRY(ys_conv_launch(st, m->dtype, a));
   }
   return YS_OK;
@@ -1273,6 +1436,7 @@ int run_conv_bwd(ys_model* m, const ConvL& c, int B) {
 int backward_range(ys_model* m, int seg_lo, int seg_hi) {
   hipStream_t st = m->ctx->stream;
   const int B = m->B;
+  YS_TRY(plan_bnred(m, B));
   for (int i = (int)m->ops.size() - 1; i >= 0; i--) {
     const Op& op = m->ops[i];
     if (op.seg < seg_lo || op.seg > seg_hi) continue;
@@ -1337,6 +1501,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
 
 void reset_grad_state(ys_model* m) {
   for (auto& b : m->bufs) std::fill(b.gw.begin(), b.gw.end(), 0);
+  for (auto& c : m->convs) c.red_seen = 0;
   if (m->is_block) { std::fill(m->bufs[m->blk_out].gw.begin(), m->bufs[m->blk_out].gw.end(), 1); return; }   // the caller's dy
   // the loss wrote the head gradients
   std::fill(m->bufs[m->pd_buf].gw.begin(), m->bufs[m->pd_buf].gw.end(), 1);

@@ -2,6 +2,23 @@
 #pragma once
 #include "ys_hip.h"
 
+// Fused BN-backward reduction (round 3).  When a dgrad launch is the LAST writer of the gradient dz of a BN Conv unit's output
+// (the unit's first consumer in forward order), its epilogue -- which holds the finished dz values -- also accumulates that
+// unit's per-channel sums  sum(du), sum(du * y),  du = dz * SiLU'(scale * y + shift)  (what chan_reduce_kernel<MODE 0> computes
+// in a pass of its own over dz and y): one statistics row per workgroup, like the forward BN statistics.  A segment maps the
+// channels [c0, c1) of the launch's OUTPUT view onto channels [yc0, ...) of one producer.
+#define YS_BNRED_MAXSEG 3
+struct BnRedSeg {
+  const void* y;        // producer's raw conv output, dense [M][C]
+  const float* scale;   // producer's BN scale / shift (forward, training statistics), [C]
+  const float* shift;
+  float* part;          // partial rows [rows][2][C] of this (producer, launch) pair
+  int c0, c1;           // output-view channel range of the launch covered by this producer (multiples of 8)
+  int yc0;              // producer channel of c0
+  int C;                // producer channel count
+  int act;              // producer applies SiLU
+  int pad_;
+};
 struct ConvArgs {
   const void* x;        // input activations (NHWC view)
   const void* w;        // weights [Cout][KH*KW][Cin], storage type T
@@ -37,6 +54,10 @@ struct ConvArgs {
   void* q8;                      // optional scratch of >= B*Hin*Win*Cin bytes: ys_conv_launch quantises the input view into it first
   const void* x8;                // set by ys_conv_launch: the dense [B*Hin*Win][Cin] fp8 image of the input (inside q8)
   unsigned long long* tl;        // triage builds (-DYS_P2_TIMELINE): per-workgroup s_memtime stamps of the tile phases; null otherwise
+  // fused BN-backward reduction (dgrad launches through conv_epi.h only; see BnRedSeg)
+  int nred;                      // segments in use (0 = off)
+  int red_row0;                  // first partial row of this launch (the four phase launches of a stride-2 dgrad stack their rows)
+  BnRedSeg red[YS_BNRED_MAXSEG];
 };
 
 struct WgradArgs {
@@ -70,9 +91,12 @@ int ys_bn_act_apply_q8_launch(hipStream_t st, const void* y, long rows, int C, c
                               const float* qscale, unsigned* amax);
 int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C,
                               const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
-                              void* q8, const float* qscale, unsigned* amax);
+                              void* q8, const float* qscale, unsigned* amax, void* rg = nullptr, int rg_ldc = 0, int rg_coff = 0);
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
+// partial rows a launch of `a` (a dgrad with a.nred segments) writes per segment when every kernel it dispatches to supports the fused
+// BN-backward reduction (conv_p2_kernel / conv_gemm_kernel, incl. the phase launches of a stride-2 dgrad); 0 = not supported
+int ys_conv_bnred_rows(const ConvArgs& a, int dtype);
 int ys_wgrad_splits(const WgradArgs& a, int dtype);
 // used_splits != nullptr: the split reduction is left to the caller (ys_wgrad_reduce_batched_launch over the layers of a backward
 // segment); *used_splits = number of partial slabs [Cout][taps][Cin] written to a.partial
@@ -137,9 +161,14 @@ int ys_bn_bwd_reduce_launch(hipStream_t st, int dtype, const void* dz, int dz_ld
 int ys_bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblk, int C, long count, float* dgamma,
                               float* dbeta, float* k2, float* k3, const float* scale, const float* mean, const float* rstd);
 // pass 2: dy = gamma*rstd*(du - mean(du) - xhat*mean(du*xhat)) = scale*du - k2 - y*k3
+// rg != nullptr: also rg[view] += dz (the residual-input gradient of a Bottleneck shortcut)
 int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows,
                            int C, const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
-                           unsigned* amax = nullptr);
+                           unsigned* amax = nullptr, void* rg = nullptr, int rg_ldc = 0, int rg_coff = 0);
+// finalize reading each channel's partial rows from the source that covers it (fused BN-backward reduction)
+struct FinSrc { const float* p[YS_BNRED_MAXSEG]; int nblk[YS_BNRED_MAXSEG]; int c1[YS_BNRED_MAXSEG]; int n; };
+int ys_bn_bwd_finalize_src_launch(hipStream_t st, const FinSrc& src, int C, long count, float* dgamma, float* dbeta, float* k2,
+                                  float* k3, const float* scale, const float* mean, const float* rstd);
 // column sums of a [rows][ldc] view into grad[C] (+=)   (bias gradients)
 int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
                      long bstride, int C, float* partial, float* grad);
