@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--no-infer", action="store_true", help="skip the eval-forward secondary metric (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) code path even with WORLD_SIZE=1 (self-test)")
+    ap.add_argument("--lib", default="", help="TRIAGE ONLY: load another build of the library (ablation / timeline variants under build/); the JSON line then carries \"triage_lib\"")
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (class,label,us) of the profiled conv launches (triage)")
     args = ap.parse_args()
 
@@ -152,7 +153,7 @@ def main():
 
     nc, H, W, B = {"obb": 15, "pose": 1}.get(args.task, 80), args.imgsz, args.imgsz, args.batch   # DOTA-15 / COCO-person class counts
     stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
-    eng = Engine(local_rank, stream=stream)          # N>1: run on torch's stream so RCCL orders against our kernels
+    eng = Engine(local_rank, stream=stream, lib_path=args.lib or None)   # N>1: run on torch's stream so RCCL orders against our kernels
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
         raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
     seg = args.task == "segment"
@@ -279,6 +280,8 @@ def main():
                "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, {'COCO-80' if nc == 80 else str(nc) + '-class'} synthetic labels" + {"segment": " + instance masks", "obb": " (oriented)", "pose": " + 17x3 keypoints"}.get(args.task, ""),
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
+        if args.lib:
+            out["triage_lib"] = args.lib          # not the product library: never a bench line of record
         # ---- secondary metric: inference images/s = eval forward (BN folded into the conv epilogues) + Detect decode
         model.eval()
         for _ in range(0 if args.no_infer else 3):

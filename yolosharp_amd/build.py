@@ -137,6 +137,10 @@ if __name__ == "__main__":
         build_oracle(True)
     if "timeline" in what:
         build_device(True, variant="tl", defines=["-DYS_P2_TIMELINE"], out=os.path.join(BUILD, "libyolosharp_hip_tl.so"))
+    if "epi0" in what:     # A/B: the LDS-staged 16-byte-store epilogue of rounds 1-2 instead of the direct one
+        build_device(True, variant="epi0", defines=["-DYS_P2_EPI_DIRECT=0"], out=os.path.join(BUILD, "libyolosharp_hip_epi0.so"))
+    if "p2ablate" in what:
+        build_device(True, variant="p2abl", defines=["-DYS_P2_ABLATE"], out=os.path.join(BUILD, "libyolosharp_hip_p2abl.so"))
     if "ablate" in what:
         build_device(True, variant="abl", defines=["-DYS_GEMM_ABLATE"], out=os.path.join(BUILD, "libyolosharp_hip_abl.so"))
     if "abi" in what or len(sys.argv) == 1:

@@ -567,14 +567,20 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   // ---- tile-independent tables, computed once per layer geometry on the host (p2_tables): per-(quarter, K-step) patch
   // offsets (q-major so that a lane fetches the offsets of consecutive K-steps with one LDS read), per-thread pixel offsets,
   // per-thread patch unit descriptors
-  for (int e = tid; e < g.nsp * 4; e += NT) sOff[e] = tab[e];
+  // the offset table goes global -> LDS by DMA as well (nsp 16-byte units, <= 2 requests): the copy through registers made every
+  // workgroup wait out one L2 round trip before it could even request its patch
+  {
+    const ys_rsrc_t rsT = ys_make_rsrc(tab, (unsigned)g.nsp * 16u);
+    if (tid < g.nsp) ys_bufld_lds16(rsT, (unsigned)tid * 16u, 0u, lb + wave * 1024);
+  }
   const int* tpx = tab + g.nsp * 4;
-  int pixbase[MR], pty[MR], ptx[MR];
+  int pixbase[MR], pty[MR], ptx[MR], prow[MR];
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
-    pixbase[mf] = tpx[(mf * 3 + 0) * NT + tid];
-    pty[mf] = tpx[(mf * 3 + 1) * NT + tid];
-    ptx[mf] = tpx[(mf * 3 + 2) * NT + tid];
+    pixbase[mf] = tpx[(mf * 4 + 0) * NT + tid];
+    pty[mf] = tpx[(mf * 4 + 1) * NT + tid];
+    ptx[mf] = tpx[(mf * 4 + 2) * NT + tid];
+    prow[mf] = tpx[(mf * 4 + 3) * NT + tid];    // output row of the lane's pixel relative to the tile's first pixel (epilogue)
   }
   constexpr int KG = P2_KG;                    // K-steps per streamed weight group
   constexpr int GU = KG * UPS;                 // 16-byte units per weight row and group
@@ -619,7 +625,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   unsigned pdesc[NPU];                      // patch row (9 bits) | patch column (10) | LDS offset / 16 (13)
   int goff[NPU];                            // (row * Win + column) * in_ldc + unit * 8
   {
-    const int* tpd = tpx + MR * 3 * NT;
+    const int* tpd = tpx + MR * 4 * NT;
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       pdesc[k] = (unsigned)tpd[(2 * k + 0) * NT + tid];
@@ -678,40 +684,41 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   }
   int ntx = txi, nty = tyi, nb = b;
   unsigned okm_next = 0;
+  TL_STAMP();                                            // tables requested
   if (t_first < t_end) okm_next = pfetch(txi, tyi, b);   // the first patch is in flight while the weights are staged
+  TL_STAMP();                                            // first patch requested
   if (WRES) {
     // resident weights: rows padded with zeros to a multiple of 4 K-steps (the pipelined K loop runs whole register groups).
-    // Loads are issued eight at a time before the first LDS store: the one-load-one-store form was a chain of dependent L2
-    // round trips (measured 6-9 thousand cycles of prologue per workgroup for a 36 KB weight set).
+    // LDS DMA (buffer_load ... lds, 1 KB per wave instruction): all of a wave's requests are in flight at once and no VGPR is
+    // touched.  The register form -- eight loads, then eight LDS stores, per round -- was 4-8 thousand cycles of every workgroup's
+    // ~10 thousand cycle prologue (s_memtime stamps, round 3).  LDS slot j of the weight region is (row j / wpitch, unit j % wpitch);
+    // units past the real K (zero padding of the row, the pitch's spare slots) and rows past Cout carry the out-of-range offset =
+    // zeros.  The region is rounded up to whole 1 KB requests by the plan.
     const int per_row = ((g.nsteps + 3) & ~3) * UPS;
-    const int total = BN * per_row;
-    constexpr int UB = 8;
-    for (int base = tid; base < total; base += NT * UB) {
-      uint4 v[UB];
-      int dst[UB];
-#pragma unroll
-      for (int k = 0; k < UB; k++) {
-        const int idx = base + k * NT;
-        const int n = idx / per_row, u = idx - n * per_row;
-        const bool ok = (bool)((int)(idx < total) & (int)(n0 + n < a.Cout) & (int)(u * (16 / WES) < Ktot));
-        const long off = ok ? (long)(n0 + n) * Ktot * WES + u * 16L : 0L;
-        v[k] = ys_ld16(wb + off);
-        if (!ok) v[k] = ys_zero16();
-        dst[k] = idx < total ? n * g.wpitch + u : -1;
-      }
-#pragma unroll
-      for (int k = 0; k < UB; k++) if (dst[k] >= 0) sW[dst[k]] = v[k];
+    const int nslots = BN * g.wpitch;
+    const ys_rsrc_t rsW = ys_make_rsrc(wb, (unsigned)((long)a.Cout * Ktot * WES));
+    int n = tid / g.wpitch, u = tid - n * g.wpitch;
+    const int dn = NT / g.wpitch, du = NT - dn * g.wpitch;       // one round of the workgroup = NT slots further
+    char* dst = (char*)sW + wave * 1024;
+    for (int j = wave * 64; j < nslots; j += NT) {
+      const bool ok = (bool)((int)(u < per_row) & (int)(u * (16 / WES) < Ktot) & (int)(n0 + n < a.Cout) & (int)!P2_DBG(16));
+      ys_bufld_lds16(rsW, ok ? (unsigned)((long)(n0 + n) * Ktot * WES) + (unsigned)u * 16u : YS_BUF_OOB, 0u, dst);
+      dst += NT * 16;
+      n += dn; u += du;
+      if (u >= g.wpitch) { u -= g.wpitch; n++; }
     }
   }
   TL_STAMP();
   if (P2_DBG(128)) return;                     // ablation: prologue only (tables, resident weights, first patch fetch)
-  float st1[8], st2[8];                        // BN statistics of this workgroup's tiles (per-lane column sums)
+  constexpr int P2_NS = YS_P2_EPI_DIRECT ? 4 * NR : 8;
+  float st1[P2_NS], st2[P2_NS];                // BN statistics of this workgroup's tiles (per-lane column sums)
 #pragma unroll
-  for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
+  for (int e = 0; e < P2_NS; e++) { st1[e] = 0.f; st2[e] = 0.f; }
 
   for (int tile = t_first; tile < t_end; tile += t_step) {
     const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
     TL_STAMP();
+    YS_WAIT_VM0();                            // this tile's patch (and, first tile, the wave's weight DMA) has landed
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
     if (!WRES) wfetch(rwA, 0);
 #pragma unroll
@@ -814,13 +821,16 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     if (WRES) ys_barrier_lds();               // every wave finished reading the patch: it becomes the staging area
     TL_STAMP();
 
-    long orow[MR];
+    // output rows: tile base (scalar) + the lane's table entry -- the 64-bit per-lane form cost ~1-1.5 thousand cycles per tile
+    // (s_memtime stamps, round 3); every row index / byte offset of a P2 launch fits 31 bits (conv_p2_plan)
+    const int rh = a.out_rh ? a.out_rh : a.Wout, rw = a.out_rh ? a.out_rw : 1;
+    const int tbase = b * (int)a.out_bstride + oy0 * rh + ox0 * rw + (int)a.out_r0;
+    int orow[MR];
     bool pv[MR];
 #pragma unroll
     for (int mf = 0; mf < MR; mf++) {
-      const int oy = oy0 + pty[mf], ox = ox0 + ptx[mf];
-      pv[mf] = pty[mf] < g.TH && oy < a.Hout && ox < a.Wout;
-      orow[mf] = (long)b * a.out_bstride + (pv[mf] ? (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox)) : 0);
+      pv[mf] = (bool)((int)(pty[mf] < g.TH) & (int)(oy0 + pty[mf] < a.Hout) & (int)(ox0 + ptx[mf] < a.Wout));
+      orow[mf] = tbase + prow[mf];
     }
     char* stg = sPb + wave * (16 * MR * (BN + 8) * 2 + 16 * MR * 16);
     if (F8) {                                 // back to real units: 1 / (input scale * weight scale)
@@ -832,11 +842,29 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #pragma unroll
           for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
     }
+#if YS_P2_EPI_DIRECT
+    (void)stg;
+#ifdef YS_P2_TIMELINE
+    if (!P2_DBG(4)) p2_epilogue_direct<MR, NR, RED>(a, acc, orow, pv, n0, st1, st2, [&]() { TL_STAMP(); });
+#else
+    if (!P2_DBG(4)) p2_epilogue_direct<MR, NR, RED>(a, acc, orow, pv, n0, st1, st2);
+#endif
+#else
+#ifdef YS_P2_TIMELINE
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); });
+#else
     if (!P2_DBG(4)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0, stg, st1, st2);
+#endif
+#endif
     TL_STAMP();
     txi = ntx; tyi = nty; b = nb;
   }
+  YS_WAIT_VM0();                               // a workgroup without tiles still has its table / weight DMA in flight: it must land before the LDS is released
+#if YS_P2_EPI_DIRECT
+  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush_direct<NR, NWV, 1>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+#else
   if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+#endif
   if (F8 && a.amax && blockIdx.y == 0) ys_amax_update(a.amax, amx);
   TL_STAMP();
 #ifdef YS_P2_TIMELINE
@@ -994,7 +1022,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
   g.wpitch = wres ? wp(nsteps4 * ups) : wp(g.kg * ups);
-  const size_t wbytes = wres ? wres_bytes : (size_t)2 * bn * g.wpitch * 16;
+  const size_t wbytes = wres ? (wres_bytes + 1023) / 1024 * 1024 : (size_t)2 * bn * g.wpitch * 16;   // resident set: whole 1 KB LDS-DMA requests
   const size_t tab = ((size_t)g.nsp * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
   // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed
@@ -1076,12 +1104,13 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
   hipGetDevice(&dev);
   const P2Args& g = p.g;
   const bool f8 = a.f8 != 0;
-  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.prb, g.nsteps, g.nsp, p.mr, p.npu, p.nt, (int)f8};
+  const int rh = a.out_rh ? a.out_rh : a.Wout, rw = a.out_rh ? a.out_rw : 1;
+  std::vector<int> key = {dev, a.Cin, a.KH, a.KW, a.SA, a.Win, a.in_ldc, g.TH, g.TW, g.PH, g.PW, g.ppb, g.prb, g.nsteps, g.nsp, p.mr, p.npu, p.nt, (int)f8, rh, rw};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   const int NT = p.nt;
   const int cu = a.Cin / 8, Ktot = a.KH * a.KW * a.Cin, npatch = g.PH * g.PW * cu;
-  std::vector<int> h((size_t)g.nsp * 4 + (size_t)p.mr * 3 * NT + (size_t)p.npu * 2 * NT, 0);
+  std::vector<int> h((size_t)g.nsp * 4 + (size_t)p.mr * 4 * NT + (size_t)p.npu * 2 * NT, 0);
   for (int qq = 0; qq < 4; qq++)            // q-major: [quarter][K-step]; steps past the last real one keep offset 0 (their weights are zero)
     for (int st = 0; st < g.nsteps; st++) {
       const int kp = f8 ? 32 : 8;             // channels per (K-step, quarter) piece
@@ -1099,12 +1128,13 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
       const int px = wave * (p.mr * 16) + mf * 16 + li;
       int ty = px / g.TW, tx = px - ty * g.TW;
       if (ty >= g.TH) { ty = g.TH; tx = 0; }    // idle lane of a ragged tile: marked by ty == TH, reads pixel (0,0)
-      tpx[(mf * 3 + 0) * NT + tid] = ty < g.TH ? (ty * a.SA) * g.prb + (tx * a.SA) * g.ppb : 0;
-      tpx[(mf * 3 + 1) * NT + tid] = ty;
-      tpx[(mf * 3 + 2) * NT + tid] = tx;
+      tpx[(mf * 4 + 0) * NT + tid] = ty < g.TH ? (ty * a.SA) * g.prb + (tx * a.SA) * g.ppb : 0;
+      tpx[(mf * 4 + 1) * NT + tid] = ty;
+      tpx[(mf * 4 + 2) * NT + tid] = tx;
+      tpx[(mf * 4 + 3) * NT + tid] = ty < g.TH ? ty * rh + tx * rw : 0;
     }
   }
-  int* tpd = tpx + p.mr * 3 * NT;
+  int* tpd = tpx + p.mr * 4 * NT;
   for (int tid = 0; tid < NT; tid++)
     for (int k = 0; k < p.npu; k++) {
       const int idx = tid + NT * k;
@@ -1177,9 +1207,13 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
 #define P2F(M_, N_, F_, R_) { \
     if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_, R_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_, R_>(st, a, p); \
     return p.npu == 6 ? conv_p2_launch_t<M_, N_, 0, 6, 256, F_, R_>(st, a, p) : conv_p2_launch_t<M_, N_, 0, 12, 256, F_, R_>(st, a, p); }
-#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F(M_, N_, 1, 0) else if (a.nred > 0) P2F(M_, N_, 0, 1) else P2F(M_, N_, 0, 0) }
+#define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F(M_, N_, 1, 0) else if (a.nred > 0 || (a.accumulate && YS_P2_EPI_DIRECT)) P2F(M_, N_, 0, 1) else P2F(M_, N_, 0, 0) }
     if (a.f8 && a.nred > 0) { ys_set_error("conv p2: the fused BN-backward reduction has no fp8 variant"); return YS_ERR_UNSUPPORTED; }
+#ifdef YS_P2_ONE          // compile-time triage: a single register tile (seconds instead of minutes per resource-usage experiment)
+    P2(1, 5)
+#else
     P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
+#endif
 #undef P2
 #undef P2F
   }

@@ -10,22 +10,55 @@
 // out as full 16-byte vectors -- consecutive lanes cover consecutive channels of one pixel row -- applying the residual /
 // gradient accumulation there, and takes the BN batch statistics per 8-channel column (fixed per lane).  Compared with
 // conv_epilogue the two phases keep few values live, which leaves the registers to the next tile's patch prefetch.
+// ablation switches of the epilogue (triage builds -DYS_P2_ABLATE, YS_DBG bits): 256 = no global stores, 512 = no statistics /
+// fused-reduction arithmetic, 1024 = phase 1 only (no store loop at all)
+#ifdef YS_P2_ABLATE
+#define EPI_DBG(bit) ((a.dbg & (bit)) != 0)
+#else
+#define EPI_DBG(bit) false
+#endif
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- fragment indices must be constants for the register allocator
+#include <type_traits>
+template <int I, int N, class F> __device__ inline void ys_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ys_static_for<I + 1, N>(f); }
+}
+
+// The segment table of a backward launch, re-read from the kernel-argument segment where it is used.  Read through `a.red[k]` the
+// compiler loads the whole table (36 scalar registers) at kernel entry and keeps it live across the tile loop -- the kernels sit at
+// the SGPR limit, the overflow spills into VGPR lanes and from there into scratch (128-472 bytes per lane in the RED variants).  The
+// laundered pointer makes every use a fresh scalar load inside the epilogue.
+#ifdef YS_EMU_BUILD
+typedef const BnRedSeg* ys_redp_t;
+__device__ inline ys_redp_t ys_red_table(const ConvArgs& a) { return a.red; }
+#else
+typedef const BnRedSeg __attribute__((address_space(4)))* ys_redp_t;
+__device__ inline ys_redp_t ys_red_table(const ConvArgs&) {
+  const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  ys_redp_t p = (ys_redp_t)(ka + offsetof(ConvArgs, red));      // ConvArgs is the first kernel argument of both kernels
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#endif
+
 // destination of one fused BN-backward partial sum: output-view channel c of the launch, `which` = 0 (sum du) / 1 (sum du * y)
 __device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long row) {
   float* d = nullptr;
+  const ys_redp_t rt = ys_red_table(a);
 #pragma unroll
-  for (int k = 0; k < YS_BNRED_MAXSEG; k++)     // static indices: the segment table stays in scalar registers
-    if (k < a.nred && c >= a.red[k].c0 && c < a.red[k].c1)
-      d = a.red[k].part + (((long)a.red_row0 + row) * 2 + which) * a.red[k].C + (c - a.red[k].c0 + a.red[k].yc0);
+  for (int k = 0; k < YS_BNRED_MAXSEG; k++)
+    if (k < a.nred && c >= rt[k].c0 && c < rt[k].c1)
+      d = rt[k].part + (((long)a.red_row0 + row) * 2 + which) * rt[k].C + (c - rt[k].c0 + rt[k].yc0);
   return d;
 }
 
 // RED = 1: the dgrad form -- gradient accumulation and the fused BN-backward reduction only (no bias / eval-BN / SiLU / residual:
 // a dgrad launch never carries them), compiled as its own kernel variants so that the forward kernels' register allocation is
 // untouched by the reduction's live values (y vectors, coefficients).
-template <int MR, int NR, int RED = 0>
-__device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const long (&orow)[MR], const bool (&pv)[MR],
-                                   int n0, char* stg, float (&s1)[8], float (&s2)[8]) {
+struct YsNoStamp { __device__ inline void operator()() const {} };   // timeline hook of triage builds (-DYS_P2_TIMELINE): nothing in the product
+template <int MR, int NR, int RED = 0, class SF = YsNoStamp>
+__device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
+                                   int n0, char* stg, float (&s1)[8], float (&s2)[8], SF stamp = SF()) {
   typedef bf16_t T;
   constexpr int BN = NR * 16;
   constexpr int PITCH = (BN + 8) * 2;         // bytes per staged pixel row
@@ -34,15 +67,15 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   constexpr int PPI = 64 / VPP;                // pixels per wave iteration
   constexpr int NITER = (NPX + PPI - 1) / PPI;
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
-  long* rowtab = (long*)(stg + NPX * PITCH);
+  unsigned* rowtab = (unsigned*)(stg + NPX * PITCH);   // [NPX] byte offset of the pixel row (YS_BUF_OOB = outside), [NPX] row index; views < 2^31 bytes (launch plans)
   const int cv = lane % VPP, pl = lane / VPP;
   const bool active = lane < PPI * VPP;
   const int c = n0 + cv * 8;
   if (q == 0) {
 #pragma unroll
     for (int mf = 0; mf < MR; mf++) {
-      rowtab[mf * 16 + li] = pv[mf] ? (orow[mf] * a.out_ldc + a.out_coff) * 2L : -1L;   // byte offset of the pixel row
-      rowtab[NPX + mf * 16 + li] = orow[mf];                                              // row index (residual view, producer's y)
+      rowtab[mf * 16 + li] = pv[mf] ? ((unsigned)orow[mf] * (unsigned)a.out_ldc + (unsigned)a.out_coff) * 2u : YS_BUF_OOB;
+      rowtab[NPX + mf * 16 + li] = (unsigned)orow[mf];
     }
   }
   // ---- fused BN-backward reduction (BnRedSeg): this lane's 8-channel column belongs to at most one producer.  Its y vectors for
@@ -64,12 +97,13 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     for (int it = 0; it < NITER; it++) {
       const int px = it * PPI + pl;
       yv[it] = ys_zero16();
-      if (ry && px < NPX && rowtab[px] >= 0) yv[it] = ys_ld16(ry + (rowtab[NPX + px] * rC + rcol) * 2L);
+      if (ry && px < NPX && rowtab[px] != YS_BUF_OOB) yv[it] = ys_ld16(ry + ((long)rowtab[NPX + px] * rC + rcol) * 2L);
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) { rsc[e] = 0.f; rsh[e] = 0.f; }
     if (ry) { ys_ldcoef<8>(rscp + rcol, rsc); ys_ldcoef<8>(rshp + rcol, rsh); }
   }
+  stamp();
 #pragma unroll
   for (int mf = 0; mf < MR; mf++) {
 #pragma unroll
@@ -97,8 +131,10 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
       *(uint2*)(stg + (mf * 16 + li) * PITCH + (nf * 16 + 4 * q) * 2) = pk;
     }
   }
+  stamp();
   ys_wave_sync();
-  const bool do_stats = !RED && a.stats != nullptr;
+  stamp();
+  const bool do_stats = !RED && a.stats != nullptr && !EPI_DBG(512);
   // eval-mode BatchNorm folded into the conv (Convs.cs:48 with running statistics): applied on the wide path to the
   // bf16-rounded conv output -- the same value the training path normalises -- with the lane's 8 coefficients loaded once
   const bool bn_eval = !RED && a.scale != nullptr;
@@ -119,10 +155,10 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   auto store_iter = [&](const int it) {
     const int px = it * PPI + pl;
     const bool lane_ok = active && px < NPX && c < a.Cout;
-    const long rofs = lane_ok ? rowtab[px] : -1L;
+    const unsigned rofs = lane_ok ? rowtab[px] : YS_BUF_OOB;
     uint4 val = ys_zero16();
     {
-      if (rofs >= 0) {
+      if (rofs != YS_BUF_OOB) {
         val = *(const uint4*)(stg + px * PITCH + cv * 16);
         float f[8];
         ys_unpack<T>(val, f);
@@ -145,7 +181,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
         if (rb || a.accumulate) {
           float gq[8];
           if (rb) {
-            const long row = rowtab[NPX + px];                                    // eval-only path (Bottleneck shortcut)
+            const long row = (long)rowtab[NPX + px];                              // eval-only path (Bottleneck shortcut)
             ys_unpack<T>(ys_ld16(rb + (row * a.res_ldc + a.res_coff + c) * 2L), gq);
 #pragma unroll
             for (int e = 0; e < 8; e++) f[e] += gq[e];
@@ -157,7 +193,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
           }
           val = ys_pack<T>(f);
         }
-        if (RED && red_on && ry) {
+        if (RED && red_on && ry && !EPI_DBG(512)) {
           // dz as every later reader sees it (bf16-rounded, all contributions in), against the producer's raw output y
           float g[8], yf[8];
           ys_unpack<T>(val, g);
@@ -171,8 +207,9 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
         }
       }
     }
-    ys_bufst16(rsY, rofs >= 0 ? (unsigned)(rofs + (long)c * 2L) : YS_BUF_OOB, val);
+    ys_bufst16(rsY, (rofs != YS_BUF_OOB && !EPI_DBG(256)) ? rofs + (unsigned)c * 2u : YS_BUF_OOB, val);
   };
+  if (EPI_DBG(1024)) { ys_wave_sync(); return; }
   if (RED) {
 #pragma unroll                                // fully: yv[it] must be a register, not an indexed (scratch) array
     for (int it = 0; it < NITER; it++) store_iter(it);
@@ -180,7 +217,224 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 #pragma unroll 2
     for (int it = 0; it < NITER; it++) store_iter(it);
   }
+  stamp();
   ys_wave_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Direct epilogue (round 3, default: YS_P2_EPI_DIRECT = 1).  After the MFMA a lane (li, q) already owns 4 CONSECUTIVE channels
+// (n0 + nf*16 + 4q ..) of pixel mf*16 + li for every (mf, nf) fragment, i.e. 8 contiguous bytes of the bf16 NHWC row.  The staged
+// epilogue above transposes through LDS to reach 16-byte stores: s_memtime stamps put that at 3.0-4.9 thousand cycles per tile
+// (row table ~1k, staging writes 0.5-0.9k, two LDS round trips + the store loop 1.3-2.3k) against 2.5-3.5k for the whole K loop,
+// and phase ablation at 1.8 of conv_p2_kernel's 3.9 ms per YOLOv8n step, of which the stores themselves are 0.43 ms
+// (profiles/README.md, round 3).  Here the accumulators are rounded, reduced into the statistics and stored straight from registers
+// as 8-byte buffer stores -- no LDS, no row table, no wave rendezvous; the four q-lanes of a pixel write one contiguous 32-byte
+// sector per fragment.  Statistics are per-lane sums for the lane's own 4*NR channels (st[nf*4 + r]); the 16 pixel lanes of a DPP row
+// are combined once per launch (p2_stats_flush_direct).
+// RED = 1 (backward form): gradient accumulation and the fused BN-backward reduction, operands prefetched for all fragments before
+// the first is consumed.  RED = 0 (forward / eval form): bias, eval-BN, SiLU, residual, BN statistics (+ an in-loop accumulate for
+// the launches that have no RED variant).
+#ifndef YS_P2_EPI_DIRECT
+#define YS_P2_EPI_DIRECT 0     // measured (round 3, MI355X, config 2): direct 10.93 ms/step, staged 10.65 -- the 8-byte stores lose more at the CU's store-issue limit than the LDS round trip costs
+#endif
+__device__ inline uint2 ys_ld8(const void* p) { return *(const uint2*)p; }
+__device__ inline void ys_unpack4_bf16(const uint2& v, float* f) {
+  f[0] = ys_u2f(v.x << 16); f[1] = ys_u2f(v.x & 0xffff0000u); f[2] = ys_u2f(v.y << 16); f[3] = ys_u2f(v.y & 0xffff0000u);
+}
+template <int MR, int NR, int RED = 0, class SF = YsNoStamp>
+__device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
+                                          int n0, float (&s1)[4 * NR], float (&s2)[4 * NR], SF stamp = SF()) {
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  const ys_rsrcv_t rsY = ys_make_rsrcv(a.y, 0x7ffffff0u);
+  unsigned roff[MR];                           // byte offset of this lane's pixel row in the output view (plans: < 2^31)
+#pragma unroll
+  for (int mf = 0; mf < MR; mf++)
+    roff[mf] = pv[mf] ? ((unsigned)orow[mf] * (unsigned)a.out_ldc + (unsigned)a.out_coff) * 2u : YS_BUF_OOB;
+  if (RED) {
+    // ---- backward form.  Operands of fragment column nf + 1 (old dz, the producer's y, its BN coefficients) are requested before
+    // column nf is consumed: two batches of 4*MR + 8 registers in flight instead of every fragment's (which spilled), one exposed
+    // memory latency per tile instead of one per column.
+    const bool red_on = a.nred > 0 && !EPI_DBG(512);
+    auto issue = [&](auto nfc, uint2 (&b_old)[MR], uint2 (&b_y)[MR], float (&b_sc)[4], float (&b_sh)[4], bool& b_has, bool& b_act) {
+      constexpr int nf = decltype(nfc)::value;
+      const int c = n0 + nf * 16 + 4 * q;
+      const char* ry = nullptr; const float* scp = nullptr; const float* shp = nullptr; int rC = 0, rcol = 0; bool ract = false;
+      const ys_redp_t rt = ys_red_table(a);
+#pragma unroll
+      for (int k = 0; k < YS_BNRED_MAXSEG; k++)
+        if (red_on && k < a.nred && c >= rt[k].c0 && c < rt[k].c1) {
+          ry = (const char*)rt[k].y; rC = rt[k].C; rcol = c - rt[k].c0 + rt[k].yc0; ract = rt[k].act != 0;
+          scp = rt[k].scale + rcol; shp = rt[k].shift + rcol;
+        }
+      b_has = ry != nullptr; b_act = ract;
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++) {
+        const bool ok = (bool)((int)pv[mf] & (int)(c < a.Cout));
+        b_old[mf] = a.accumulate ? ys_bufld8(rsY, ok ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB) : make_uint2(0u, 0u);
+        // unconditional load: a lane without a segment / pixel reads a valid dummy address and is masked when consumed
+        const char* yp = (ry && ok) ? ry + ((long)orow[mf] * rC + rcol) * 2L : (const char*)a.y;
+        b_y[mf] = red_on ? ys_ld8(yp) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) { b_sc[r] = 0.f; b_sh[r] = 0.f; }
+      if (ry) { ys_ldcoef<4>(scp, b_sc); ys_ldcoef<4>(shp, b_sh); }
+    };
+    auto consume = [&](auto nfc, const uint2 (&b_old)[MR], const uint2 (&b_y)[MR], const float (&b_sc)[4], const float (&b_sh)[4], const bool b_has, const bool b_act) {
+      constexpr int nf = decltype(nfc)::value;
+      const int c = n0 + nf * 16 + 4 * q;
+#pragma unroll
+      for (int mf = 0; mf < MR; mf++) {
+        const bool ok = (bool)((int)pv[mf] & (int)(c < a.Cout));
+        float v[4], o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = (c + r < a.Cout) ? acc[mf][nf][r] : 0.f;   // channels past Cout inside the last 4-group stay zero
+        if (a.accumulate) {
+          ys_unpack4_bf16(b_old[mf], o);
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] += o[r];
+        }
+        uint2 pk;
+        pk.x = ys_pack_bf16x2(v[0], v[1]); pk.y = ys_pack_bf16x2(v[2], v[3]);
+        if (b_has) {
+          // dz as every later reader sees it (bf16-rounded, all contributions in), against the producer's raw output y
+          float g[4], yf[4];
+          ys_unpack4_bf16(pk, g);
+          ys_unpack4_bf16(b_y[mf], yf);
+          if (b_act) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) g[r] *= ys_silu_grad(yf[r] * b_sc[r] + b_sh[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) { const float du = ok ? g[r] : 0.f; s1[nf * 4 + r] += du; s2[nf * 4 + r] += ok ? du * yf[r] : 0.f; }
+        }
+        ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+      }
+    };
+    uint2 oldA[MR], yA[MR], oldB[MR], yB[MR];
+    float scA[4], shA[4], scB[4], shB[4];
+    bool hasA = false, actA = false, hasB = false, actB = false;
+    issue(std::integral_constant<int, 0>{}, oldA, yA, scA, shA, hasA, actA);
+    stamp();
+    ys_static_for<0, NR>([&](auto nfc) {
+      constexpr int nf = decltype(nfc)::value;
+      // the scheduling fences keep hipcc from hoisting every column's loads to the top (all batches live at once: spills)
+      if constexpr (nf & 1) {
+        if constexpr (nf + 1 < NR) issue(std::integral_constant<int, nf + 1>{}, oldA, yA, scA, shA, hasA, actA);
+        YS_SCHED_FENCE();
+        consume(nfc, oldB, yB, scB, shB, hasB, actB);
+      } else {
+        if constexpr (nf + 1 < NR) issue(std::integral_constant<int, nf + 1>{}, oldB, yB, scB, shB, hasB, actB);
+        YS_SCHED_FENCE();
+        consume(nfc, oldA, yA, scA, shA, hasA, actA);
+      }
+      YS_SCHED_FENCE();
+    });
+    stamp(); stamp(); stamp();
+    return;
+  }
+  // ---- forward / eval form
+  const bool do_stats = a.stats != nullptr && !EPI_DBG(512);
+  const bool bn_eval = a.scale != nullptr;
+  const bool bias = !a.scale && a.shift;
+  const char* rb = (const char*)a.res;
+  stamp();
+#pragma unroll
+  for (int nf = 0; nf < NR; nf++) {
+    const int c = n0 + nf * 16 + 4 * q;
+    const int cc = c < a.Cout ? c : 0;         // coefficient arrays are padded to a multiple of 4 floats; Cout % 4 == 0 on this path
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bn_eval) ys_ldcoef<4>(a.scale + cc, sc);
+    if (a.shift) ys_ldcoef<4>(a.shift + cc, sh);
+#pragma unroll
+    for (int mf = 0; mf < MR; mf++) {
+      const bool ok = (bool)((int)pv[mf] & (int)(c < a.Cout));
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[mf][nf][r];
+      if (bias) {                              // plain conv bias (heads): added to the fp32 accumulators
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] += sh[r];
+        if (a.act) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = ys_silu(v[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) if (c + r >= a.Cout) v[r] = 0.f;   // channels past Cout inside the last 4-group stay zero (Pose: 51 outputs)
+      uint2 pk;
+      pk.x = ys_pack_bf16x2(v[0], v[1]); pk.y = ys_pack_bf16x2(v[2], v[3]);
+      if (do_stats || bn_eval || rb || a.accumulate) {
+        float f[4];
+        ys_unpack4_bf16(pk, f);                // the rounded conv output: what BN normalises / what the statistics describe
+        if (do_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) { const float t = ok ? f[r] : 0.f; s1[nf * 4 + r] += t; s2[nf * 4 + r] += t * t; }
+        }
+        if (bn_eval) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) f[r] = f[r] * sc[r] + sh[r];
+          if (a.act) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) f[r] = ys_silu(f[r]);
+          }
+        }
+        if (rb || a.accumulate) {
+          float gq[4];
+          if (rb) {                            // eval-only path (Bottleneck shortcut)
+            const char* rp = ok ? rb + ((long)orow[mf] * a.res_ldc + a.res_coff + c) * 2L : rb;
+            ys_unpack4_bf16(ys_ld8(rp), gq);
+#pragma unroll
+            for (int r = 0; r < 4; r++) f[r] += gq[r];
+          }
+          if (a.accumulate) {
+            ys_unpack4_bf16(ys_bufld8(rsY, ok ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB), gq);
+#pragma unroll
+            for (int r = 0; r < 4; r++) f[r] += gq[r];
+          }
+        }
+        if (bn_eval || rb || a.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (c + r >= a.Cout) f[r] = 0.f;
+          pk.x = ys_pack_bf16x2(f[0], f[1]); pk.y = ys_pack_bf16x2(f[2], f[3]);
+        }
+      }
+      ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+    }
+  }
+  stamp(); stamp(); stamp();
+}
+
+// One statistics row per workgroup for the direct layout: lane (li, q) of wave w holds the sums of channels nf*16 + 4q + r over its
+// own pixels.  The 16 pixel lanes of a DPP row are combined in registers (ys_row16_sum: 4 VALU adds per value), lane li == 0 of every
+// row parks its 8*NR totals in LDS ([2][waves][BN] floats), and one thread per (sum, channel) adds the waves' entries in a fixed
+// order.  WM x WN wave grids (conv_gemm_kernel): wave w = wm * WN + wn owns channels wn*NR*16 .. of the tile; WN = 1 for conv_p2_kernel.
+template <int NR, int WM, int WN>
+__device__ inline void p2_stats_flush_direct(const ConvArgs& a, int n0, float (&s1)[4 * NR], float (&s2)[4 * NR], float* scr, long stat_row) {
+  constexpr int BNW = NR * 16, BN = WN * BNW, NT = WM * WN * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave - wm * WN;
+#pragma unroll
+  for (int i = 0; i < 4 * NR; i++) { s1[i] = ys_row16_sum(s1[i]); s2[i] = ys_row16_sum(s2[i]); }
+  ys_barrier_lds();                           // the LDS region's previous use (patch / operand stages) is over
+  if (li == 0) {
+#pragma unroll
+    for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ch = wn * BNW + nf * 16 + 4 * q + r;
+        scr[(0 * WM + wm) * BN + ch] = s1[nf * 4 + r];
+        scr[(1 * WM + wm) * BN + ch] = s2[nf * 4 + r];
+      }
+  }
+  ys_barrier_lds();
+  for (int o = tid; o < 2 * BN; o += NT) {
+    const int which = o / BN, c = o - which * BN;
+    float t = scr[(which * WM) * BN + c];
+#pragma unroll
+    for (int w = 1; w < WM; w++) t += scr[(which * WM + w) * BN + c];
+    if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
+    else if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
+  }
 }
 
 // One statistics row per workgroup: the per-lane column sums gathered over all of its tiles go through LDS ([16][NT] floats in

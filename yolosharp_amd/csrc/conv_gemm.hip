@@ -137,9 +137,10 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int t_end = xcd_order ? (((int)(blockIdx.x & 7) + 1) * t_per_xcd < g.mtiles ? ((int)(blockIdx.x & 7) + 1) * t_per_xcd : g.mtiles) : g.mtiles;
 
-  float st1[8], st2[8];
+  constexpr int NS = YS_P2_EPI_DIRECT ? 4 * NR : 8;
+  float st1[NS], st2[NS];
 #pragma unroll
-  for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
+  for (int e = 0; e < NS; e++) { st1[e] = 0.f; st2[e] = 0.f; }
 
   for (int tile = t_first; tile < t_end; tile += t_step) {
     const int m0 = tile * BM;
@@ -210,7 +211,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     }
     ys_barrier_lds();                         // every wave finished reading the stages: they become the epilogue staging area
 
-    long orow[MR];
+    int orow[MR];                             // row indices / byte offsets of a launch fit 31 bits (conv_gemm_plan)
     bool pv[MR];
 #pragma unroll
     for (int mf = 0; mf < MR; mf++) {
@@ -219,7 +220,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       const int mm = pv[mf] ? m : 0;
       const int b = mm / g.HoWo, rem = mm - b * g.HoWo;
       const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-      orow[mf] = (long)b * a.out_bstride + (a.out_rh ? ((long)oy * a.out_rh + (long)ox * a.out_rw + a.out_r0) : ((long)oy * a.Wout + ox));
+      orow[mf] = b * (int)a.out_bstride + (a.out_rh ? (oy * a.out_rh + ox * a.out_rw + (int)a.out_r0) : (oy * a.Wout + ox));
     }
     if (F8) {                                 // back to real units: 1 / (input scale * weight scale)
       const float dq = a.deq[0];
@@ -231,9 +232,18 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
           for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
     }
     char* stg = sStage + wave * (16 * MR * (NR * 16 + 8) * 2 + 16 * MR * 16);
+#if YS_P2_EPI_DIRECT
+    (void)stg;
+    if (!GEMM_DBG(8)) p2_epilogue_direct<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, st1, st2);
+#else
     if (!GEMM_DBG(8)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
+#endif
   }
+#if YS_P2_EPI_DIRECT
+  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush_direct<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
+#else
   if (RED ? a.nred > 0 : a.stats != nullptr) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
+#endif
 }
 
 // ------------------------------------------------------------------ host side
@@ -329,7 +339,7 @@ int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a) {
   const GemmPlan p = conv_gemm_plan(a);
   if (!p.ok) return YS_ERR_UNSUPPORTED;
   if (a.f8 && a.nred > 0) { ys_set_error("conv gemm: the fused BN-backward reduction has no fp8 variant"); return YS_ERR_UNSUPPORTED; }
-#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : (a.nred > 0 ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
+#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : ((a.nred > 0 || (a.accumulate && YS_P2_EPI_DIRECT)) ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
   GM(2, 2, 4, 5) GM(2, 2, 4, 4) GM(4, 1, 4, 5) GM(4, 1, 4, 4)
 #undef GM
   return YS_ERR_UNSUPPORTED;

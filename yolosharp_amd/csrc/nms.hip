@@ -38,8 +38,9 @@ nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thr
                   int* __restrict__ count, unsigned long long* __restrict__ keys, int keys_stride,
                   float* __restrict__ confs, int* __restrict__ clss) {
   const int b = blockIdx.y;
-  const int a0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-  if (a0 >= A) return;
+  const int a0r = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+  const bool live = a0r < A;                  // lanes past the last anchor run on anchor 0's data and are masked out of every store
+  const int a0 = live ? a0r : 0;              // (no early return: the slot allocation below is a wave-wide operation)
   float* p = pred + (size_t)b * C * A;
   auto ld = [&](int ch, float (&o)[V]) {
     if (V == 4) { const float4 q = *(const float4*)(p + (size_t)ch * A + a0); o[0] = q.x; o[V > 1 ? 1 : 0] = q.y; o[V > 2 ? 2 : 0] = q.z; o[V > 3 ? 3 : 0] = q.w; }
@@ -58,7 +59,7 @@ nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thr
       const float hw = w[v] / 2.0f, hh = h[v] / 2.0f;
       x1[v] = cx[v] - hw; y1[v] = cy[v] - hh; x2[v] = cx[v] + hw; y2[v] = cy[v] + hh;
     }
-    st(0, x1); st(1, y1); st(2, x2); st(3, y2);
+    if (live) { st(0, x1); st(1, y1); st(2, x2); st(3, y2); }
   }
   float best[V];
   int bi[V];
@@ -66,6 +67,15 @@ nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thr
 #pragma unroll
   for (int v = 0; v < V; v++) bi[v] = 0;
   int c = 1;
+  for (; c + 15 < nc; c += 16) {              // 16 class channels (16 KB per wave) in flight per trip
+    float q[16][V];
+#pragma unroll
+    for (int k = 0; k < 16; k++) ld(4 + c + k, q[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+#pragma unroll
+      for (int v = 0; v < V; v++) if (q[k][v] > best[v]) { best[v] = q[k][v]; bi[v] = c + k; }
+  }
   for (; c + 7 < nc; c += 8) {
     float q[8][V];
 #pragma unroll
@@ -81,16 +91,29 @@ nms_filter_kernel(float* __restrict__ pred, int C, int A, int nc, float conf_thr
 #pragma unroll
     for (int v = 0; v < V; v++) if (v0[v] > best[v]) { best[v] = v0[v]; bi[v] = c; }
   }
+  // Candidate slots: ONE returning atomic per wave (the per-candidate form was up to V dependent device-scope round trips per
+  // lane at the tail of a streaming kernel).  Slot order inside the image is irrelevant: the sort that follows is a total order
+  // (score, then anchor index).
+  const int lane = threadIdx.x & 63;
+  unsigned long long bal[V];
+  int total = 0;
+#pragma unroll
+  for (int v = 0; v < V; v++) { bal[v] = __ballot(live && best[v] > conf_thres); total += __popcll(bal[v]); }
+  if (total == 0) return;                     // wave-uniform
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&count[b], total);
+  base = __shfl(base, 0);
 #pragma unroll
   for (int v = 0; v < V; v++) {
-    if (best[v] > conf_thres) {
+    if (live && best[v] > conf_thres) {
       const int a = a0 + v;
-      const int slot = atomicAdd(&count[b], 1);
+      const int slot = base + __popcll(bal[v] & ((1ull << lane) - 1ull));
       const unsigned bits = ys_f2u(best[v]);  // best > conf >= 0 -> positive float, bit pattern monotone
       keys[(size_t)b * keys_stride + slot] = ((unsigned long long)(~bits) << 32) | (unsigned)a;
       confs[(size_t)b * A + a] = best[v];
       clss[(size_t)b * A + a] = bi[v];
     }
+    base += __popcll(bal[v]);
   }
 }
 

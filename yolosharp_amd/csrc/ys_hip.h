@@ -567,4 +567,42 @@ __device__ inline void ys_bufst16(const ys_rsrcv_t& r, unsigned voff, const uint
 #endif
 }
 
+// 8-byte forms (the direct epilogue of conv_epi.h: a lane owns 4 consecutive bf16 channels of a pixel after the MFMA)
+__device__ inline uint2 ys_bufld8(const ys_rsrcv_t& r, unsigned voff) {
+#ifdef YS_EMU_BUILD
+  uint2 v; v.x = 0u; v.y = 0u;
+  if ((unsigned long long)voff + 8ull <= (unsigned long long)r.bytes) memcpy(&v, r.base + voff, 8);
+  return v;
+#else
+  typedef unsigned ys_u32x2 __attribute__((ext_vector_type(2)));
+  const ys_u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0);
+  uint2 v; v.x = q[0]; v.y = q[1];
+  return v;
+#endif
+}
+__device__ inline void ys_bufst8(const ys_rsrcv_t& r, unsigned voff, const uint2& v) {
+#ifdef YS_EMU_BUILD
+  if ((unsigned long long)voff + 8ull <= (unsigned long long)r.bytes) memcpy((char*)r.base + voff, &v, 8);
+#else
+  typedef unsigned ys_u32x2 __attribute__((ext_vector_type(2)));
+  ys_u32x2 q; q[0] = v.x; q[1] = v.y;
+  __builtin_amdgcn_raw_buffer_store_b64(q, r, (int)voff, 0, 0);
+#endif
+}
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane of the row: xor-1, xor-2 butterflies by quad_perm,
+// then row_half_mirror and row_mirror -- four VALU adds, no LDS crossbar, a fixed tree (deterministic).  The interpreter's xor
+// butterfly (1, 2, 4, 8) adds the same pairs, so both builds produce identical bits.
+__device__ inline float ys_row16_sum(float v) {
+#ifdef YS_EMU_BUILD
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+#else
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+#endif
+}
+
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
