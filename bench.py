@@ -229,10 +229,12 @@ def main():
         from yolosharp_amd import roofline as RL
         import tempfile
         steps_prof = 2
+        model.set_overlap(False)   # per-kernel durations: every kernel alone on the chip (the timed region ran with the weight-gradient stream on)
         eng.kernel_profile(True)
         for _ in range(steps_prof):
             local_step()        # rank 0 only: no collective may be issued here (the other ranks are already at the final barrier)
         eng.synchronize()
+        model.set_overlap(True)
         n_ig, ms_ig = eng.kernel_profile_read("conv_igemm")
         n_wg, ms_wg = eng.kernel_profile_read("conv_wgrad")
         dump = args.dump_launches or os.path.join(tempfile.gettempdir(), f"ys_launches_{os.getpid()}.csv")
@@ -243,7 +245,7 @@ def main():
             os.remove(dump)
         dom = max(agg, key=lambda k: agg[k]["ms"])
         roofline = RL.roofline_of(dom, agg[dom])
-        roofline["what"] = ("dominant kernel = largest summed launch time of the step; achieved = its launches' algorithmic "
+        roofline["what"] = ("dominant kernel = largest summed launch time of the step (profile steps run with the second weight-gradient stream off, every kernel alone on the chip); achieved = its launches' algorithmic "
                             + ("bytes" if roofline["bound"] == "hbm" else "flop") + " (launch geometry: input tensor + output tensor once, SURVEY 8d) / their HIP-event durations")
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the timed process): only when
         # the file was measured on THIS source tree and configuration

@@ -176,6 +176,11 @@ YS_API int ys_model_backward_segment(ys_model* m, int seg);
 /* [offset,count) (in floats) of the flat gradient buffer completed by segment `seg`. */
 YS_API int ys_model_segment_grad_range(ys_model* m, int seg, int64_t* offset, int64_t* count);
 YS_API int ys_model_zero_grad(ys_model* m);
+/* Weight-gradient kernels of a backward pass run on a second stream, concurrently with the BatchNorm-backward / input-gradient chain
+ * of the following layers (default on; results are identical either way -- every reduction has a fixed order).  on = 0 runs
+ * everything on the context stream (per-kernel profiling: co-running kernels time-slice the CUs and inflate each other's durations).
+ * No reference counterpart (TorchSharp's autograd engine schedules its own streams). */
+YS_API int ys_model_set_overlap(ys_model* m, int on);
 /* flat fp32 device buffers (all parameters / all gradients, same order) for collectives. */
 YS_API int ys_model_grad_buffer(ys_model* m, float** dptr, int64_t* count);
 YS_API int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count);
@@ -328,6 +333,31 @@ YS_API int ys_block_forward(ys_model* block, const float* x_nchw, int on_device,
 /* autograd of the last training-mode forward: given dy (shape of y) accumulates parameter gradients (read with
  * ys_model_get_grad) and writes dx (shape of x; may be NULL). */
 YS_API int ys_block_backward(ys_model* block, const float* dy_nchw, int on_device, float* dx_nchw);
+
+/* ---- the heads as standalone modules (Detect / Segment handles; round 3).
+ * Modules/Head.cs:8-236 Detect, :238-374 Segment, :376-482 Obb, :484-606 Pose: the three neck feature maps in, the criterion's
+ * `preds` (training) / the decoded predictions (eval) out.  The handle is a ys_model without a backbone: the state_dict surface
+ * (module-relative names "cv2.0.0.conv.weight", "cv3...", "dfl.conv.weight", "proto...", "cv4..."; Head.cs registration order),
+ * ys_model_set_training, ys_model_get_output ("boxes", "scores", "pred", "mask_coefficient", "proto", "kpts", "angle" and their
+ * "d..." gradients), ys_loss_detect / _segment / _obb / _pose, ys_model_zero_grad and the optimizer calls work on it unchanged. */
+typedef struct ys_head_desc {
+  int32_t family;        /* ys_family: YS_YOLOV8 = Detect(legacy: 3x3 cls tower), YS_YOLOV11 = depthwise + 1x1 cls tower (Head.cs:50) */
+  int32_t task;          /* ys_task: which head */
+  int32_t nc, reg_max;
+  int32_t ch[3];         /* channels of P3, P4, P5 (multiples of 4 for f32, 8 for bf16) */
+  int32_t height, width; /* INPUT IMAGE size (multiple of 32): level i sees [height / s_i, width / s_i], s = 8, 16, 32 (Head.cs:43) */
+  int32_t max_batch, dtype;
+  int32_t kpt_num, kpt_dim;   /* YS_POSE (0 = 17 x 3) */
+} ys_head_desc;
+YS_API int ys_head_create(ys_ctx* ctx, const ys_head_desc* desc, ys_model** out);
+/* x[i]: fp32 NCHW [batch, ch[i], height / s_i, width / s_i], host arrays (on_device = 0) or device pointers (1) */
+YS_API int ys_head_forward(ys_model* head, const float* const x[3], int on_device, int batch);
+/* Gradients of the head outputs supplied by the caller instead of a ys_loss_* call: [B, 4*reg_max, A], [B, nc, A], the task's
+ * extra output ([B, nm | 1 | nk, A]; NULL for Detect) and the prototypes ([B, nm, mh, mw]; Segment only); fp32 host arrays. */
+YS_API int ys_head_set_grads(ys_model* head, const float* dboxes, const float* dscores, const float* dextra, const float* dproto);
+/* autograd of the last training-mode ys_head_forward from the gradients the criterion (or ys_head_set_grads) left on the head outputs:
+ * accumulates the parameter gradients and writes dx[i] (shape of x[i]; entries / the array may be NULL). */
+YS_API int ys_head_backward(ys_model* head, int on_device, float* const dx[3]);
 
 /* device memory helpers for hosts without a HIP binding of their own */
 YS_API int ys_device_malloc(ys_ctx* ctx, size_t bytes, void** dptr);

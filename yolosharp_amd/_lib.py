@@ -30,6 +30,12 @@ class BlockDesc(C.Structure):
                 ("height", C.c_int32), ("width", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32)]
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [("family", C.c_int32), ("task", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("ch", C.c_int32 * 3),
+                ("height", C.c_int32), ("width", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
+                ("kpt_num", C.c_int32), ("kpt_dim", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/yolosharp_hip.h
 PROTOTYPES = {
     "ys_last_error": (C.c_char_p, []),
@@ -72,6 +78,11 @@ PROTOTYPES = {
     "ys_model_backward_segment": (C.c_int, [C.c_void_p, C.c_int]),
     "ys_model_segment_grad_range": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_i64_p]),
     "ys_model_zero_grad": (C.c_int, [C.c_void_p]),
+    "ys_model_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_head_create": (C.c_int, [C.c_void_p, C.POINTER(HeadDesc), C.POINTER(C.c_void_p)]),
+    "ys_head_forward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "ys_head_set_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ys_head_backward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ys_model_grad_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
     "ys_model_param_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
     "ys_dist_unique_id": (C.c_int, [C.c_void_p]),

@@ -104,6 +104,7 @@ struct ys_model {
   int dfl_after_conv = -1;   // the DFL weight registers right after Detect's cv2/cv3 (Head.cs:52-56), before Segment's proto/cv4
   int in_buf = -1, pd_buf = -1, ps_buf = -1;
   bool is_block = false; int blk_out = -1, blk_c1 = 3, blk_c2 = 0;   // standalone block handle (ys_block_create)
+  bool is_head = false; int head_in[3] = {-1, -1, -1}, head_ch[3] = {0, 0, 0};   // standalone head handle (ys_head_create): P3 / P4 / P5 input buffers
   int ld_pd = 0, ld_ps = 0;
   // flat fp32 parameter state
   long n_params = 0, n_params_real = 0;          // flat length incl. the zero rows of padded towers / the reference's parameter count
@@ -132,7 +133,7 @@ struct ys_model {
   // weight gradients run on a second stream, concurrently with the BN-backward / dgrad chain of the following layers
   // (both mostly latency-bound); dy lives in a ring of DY_RING buffers guarded by events
   static constexpr int DY_RING = 4;
-  bool overlap = false; hipStream_t st2 = nullptr;
+  bool overlap = false, overlap_built = false; hipStream_t st2 = nullptr;   // overlap_built: second stream / dy ring exist; overlap: in use (ys_model_set_overlap)
   void* dy_ring[DY_RING] = {nullptr}; hipEvent_t ev_dy[DY_RING + 1] = {nullptr}, ev_free[DY_RING] = {nullptr}, ev_join = nullptr;
   bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
   float* chan = nullptr; long n_chan = 0;       // per conv: scale, shift, mean, rstd, c1, c2 (6*cout)
@@ -840,7 +841,12 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, &m->dy_scratch, (size_t)dy_max * m->es));
   // measured on MI355X (YOLOv8n B=64): +1.4 % step throughput, but both streams' kernels fill the CUs' LDS, so they mostly
   // time-slice and every per-kernel duration inflates; off by default (YS_OVERLAP=1 enables it)
-  m->overlap = getenv("YS_OVERLAP") != nullptr && atoi(getenv("YS_OVERLAP")) != 0;
+  // Round 3: on by default.  With the split reduction deferred to one launch per segment the weight-gradient kernels are independent
+  // of everything until the segment ends, and both chains are latency-bound: measured 10.50 -> 10.30 ms/step (+2 %) on config 2
+  // (round 2, before the deferral: +1.4 %).  Co-running kernels time-slice the CUs, so PER-KERNEL durations inflate (conv class +7 %):
+  // bench.py switches the overlap off (ys_model_set_overlap) for its per-kernel profile steps.  YS_OVERLAP=0 disables it.
+  m->overlap = !(getenv("YS_OVERLAP") != nullptr && atoi(getenv("YS_OVERLAP")) == 0);
+  m->overlap_built = m->overlap;
   if (m->overlap) {
     YS_CHECK_HIP(hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking));
     for (int k = 0; k < ys_model::DY_RING; k++) {
@@ -1701,7 +1707,7 @@ int ys_model_set_training(ys_model* m, int training) {
 
 int ys_model_forward(ys_model* m, const float* images, int on_device, int batch) {
   YS_REQUIRE(m && images, "ys_model_forward: null argument");
-  YS_REQUIRE(!m->is_block, "ys_model_forward: this handle is a block (use ys_block_forward / ys_block_backward)");
+  YS_REQUIRE(!m->is_block && !m->is_head, "ys_model_forward: this handle is a block / head (use ys_block_forward or ys_head_forward)");
   YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_forward: batch %d outside (0, %d]", batch, m->maxB);
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
@@ -1722,7 +1728,7 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
 // right up to the model's (H, W) -> / 255 -> the NHWC input buffer, in one kernel (no fp32 image is materialised).
 int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int batch, int h, int w) {
   YS_REQUIRE(m && images, "ys_model_forward_u8: null argument");
-  YS_REQUIRE(!m->is_block, "ys_model_forward_u8: this handle is a block (use ys_block_forward / ys_block_backward)");
+  YS_REQUIRE(!m->is_block && !m->is_head, "ys_model_forward_u8: this handle is a block / head (use ys_block_forward or ys_head_forward)");
   YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_model_forward_u8: batch %d outside (0, %d]", batch, m->maxB);
   YS_REQUIRE(h > 0 && w > 0 && h <= m->d.height && w <= m->d.width, "ys_model_forward_u8: image %dx%d does not fit the model's %dx%d", h, w, m->d.height, m->d.width);
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -2046,6 +2052,17 @@ int ys_model_segment_grad_range(ys_model* m, int seg, int64_t* offset, int64_t* 
   return YS_OK;
 }
 
+int ys_model_set_overlap(ys_model* m, int on) {
+  YS_REQUIRE(m, "null model");
+  if (m->st2_dirty) {                     // drain the weight-gradient stream before the mode changes
+    YS_CHECK_HIP(hipEventRecord(m->ev_join, m->st2));
+    YS_CHECK_HIP(hipStreamWaitEvent(m->ctx->stream, m->ev_join, 0));
+    m->st2_dirty = false;
+  }
+  m->overlap = on != 0 && m->overlap_built;
+  return YS_OK;
+}
+
 int ys_model_zero_grad(ys_model* m) {
   YS_REQUIRE(m, "null model");
   YS_CHECK_HIP(hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, m->ctx->stream));
@@ -2185,6 +2202,116 @@ int ys_block_backward(ys_model* m, const float* dy, int on_device, float* dx) {
     float* dst = on_device ? dx : m->img_dev;
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, ib.grad, ib.ldc, 0, B, m->blk_c1, ib.rows_per_b, dst));
     if (!on_device) YS_CHECK_HIP(hipMemcpyAsync(dx, m->img_dev, nx * 4, hipMemcpyDeviceToHost, st));
+  }
+  YS_CHECK_HIP(hipStreamSynchronize(st));
+  return YS_OK;
+}
+
+
+// ---- heads as standalone modules (Head.cs:8-236 Detect, :238-374 Segment, :376-482 Obb, :484-606 Pose): three input buffers + add_detect
+int ys_head_create(ys_ctx* ctx, const ys_head_desc* hd, ys_model** out) {
+  YS_REQUIRE(ctx && hd && out, "ys_head_create: null argument");
+  YS_REQUIRE(hd->dtype == YS_F32 || hd->dtype == YS_BF16 || hd->dtype == YS_FP8, "ys_head_create: dtype %d unsupported", hd->dtype);
+  YS_REQUIRE((hd->family == YS_YOLOV8 || hd->family == YS_YOLOV11) && hd->task >= YS_DETECT && hd->task <= YS_POSE, "ys_head_create: family %d task %d", hd->family, hd->task);
+  YS_REQUIRE(hd->nc > 0 && hd->reg_max > 1 && hd->reg_max <= 32, "ys_head_create: nc=%d reg_max=%d", hd->nc, hd->reg_max);
+  YS_REQUIRE(hd->height > 0 && hd->width > 0 && hd->height % 32 == 0 && hd->width % 32 == 0, "ys_head_create: image size %dx%d must be a positive multiple of 32", hd->height, hd->width);
+  YS_REQUIRE(hd->max_batch > 0, "ys_head_create: max_batch %d", hd->max_batch);
+  YS_CHECK_HIP(hipSetDevice(ctx->device));
+  ys_model* m = new ys_model();
+  m->f8 = hd->dtype == YS_FP8;
+  const int store = m->f8 ? YS_BF16 : hd->dtype;
+  m->ctx = ctx; m->dtype = store; m->epl = store == YS_BF16 ? 8 : 4; m->es = store == YS_BF16 ? 2 : 4;
+  m->maxB = hd->max_batch; m->is_head = true;
+  m->d = ys_model_desc{}; m->d.family = hd->family; m->d.task = hd->task; m->d.nc = hd->nc; m->d.reg_max = hd->reg_max;
+  m->d.height = hd->height; m->d.width = hd->width; m->d.max_batch = hd->max_batch; m->d.dtype = hd->dtype;
+  m->d.kpt_num = hd->kpt_num; m->d.kpt_dim = hd->kpt_dim;
+  for (int j = 0; j < 64; j++) m->dfl_w[j] = (float)j;
+  int st = YS_OK;
+  int hh[3], ww[3], ch[3];
+  for (int i = 0; i < 3 && st == YS_OK; i++) {
+    hh[i] = hd->height / (8 << i); ww[i] = hd->width / (8 << i); ch[i] = hd->ch[i];
+    if (ch[i] <= 0 || ch[i] % m->epl) { ys_set_error("ys_head_create: ch[%d] = %d must be a positive multiple of %d for this dtype", i, ch[i], m->epl); st = YS_ERR_UNSUPPORTED; break; }
+    m->head_in[i] = new_buf(m, hh[i], ww[i], ch[i]);
+    m->head_ch[i] = ch[i];
+  }
+  m->in_buf = m->head_in[0];
+  if (st == YS_OK) st = add_detect(m, "head", m->head_in, ch, hh, ww, hd->family == YS_YOLOV8, 0);
+  if (st == YS_OK) st = layout_params(m);
+  if (st == YS_OK) {
+    for (auto& t : m->tensors) if (t.name.compare(0, 5, "head.") == 0) t.name.erase(0, 5);   // module-relative names (Detect's own state_dict)
+    int cst = 1;                                                                            // host staging (allocate: B * max(3, blk_c1) * H * W floats)
+    for (int i = 0; i < 3; i++) cst = std::max(cst, (ch[i] + (64 << (2 * i)) - 1) / (64 << (2 * i)));   // ch_i * (H / s_i) * (W / s_i) <= cst * H * W
+    m->blk_c1 = cst;
+    st = allocate(m);
+  }
+  if (st == YS_OK) st = ys_model_init_weights(m, 0);
+  if (st != YS_OK) { ys_model_destroy(m); return st; }
+  *out = m;
+  return YS_OK;
+}
+
+int ys_head_forward(ys_model* m, const float* const x[3], int on_device, int batch) {
+  YS_REQUIRE(m && m->is_head && x && x[0] && x[1] && x[2], "ys_head_forward: null argument or not a head handle");
+  YS_REQUIRE(batch > 0 && batch <= m->maxB, "ys_head_forward: batch %d outside (0, %d]", batch, m->maxB);
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  YsTimer timer(m->ctx, "forward");
+  m->B = batch;
+  for (int i = 0; i < 3; i++) {
+    const Buf& ib = m->bufs[m->head_in[i]];
+    const float* src = x[i];
+    if (!on_device) {
+      YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, x[i], (size_t)batch * m->head_ch[i] * ib.rows_per_b * 4, hipMemcpyHostToDevice, st));
+      src = m->img_dev;
+    }
+    YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, m->head_ch[i], ib.H, ib.W, ib.ldc, ib.act));
+    if (!on_device) YS_CHECK_HIP(hipStreamSynchronize(st));          // the staging buffer is reused by the next level
+  }
+  YS_TRY(forward_impl(m, batch));
+  m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;
+  return YS_OK;
+}
+
+int ys_head_set_grads(ys_model* m, const float* dboxes, const float* dscores, const float* dextra, const float* dproto) {
+  YS_REQUIRE(m && m->is_head && dboxes && dscores, "ys_head_set_grads: null argument or not a head handle");
+  YS_REQUIRE(m->have_fwd && m->fwd_training, "ys_head_set_grads: needs a training-mode ys_head_forward first");
+  YS_REQUIRE(!m->segment || (dextra && dproto), "ys_head_set_grads: a Segment head needs dmask_coefficient and dproto");
+  YS_REQUIRE(m->xkind < 2 || dextra, "ys_head_set_grads: an Obb / Pose head needs the gradient of its angle logits / keypoints");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const int B = m->B;
+  struct Item { const float* src; int buf; int C; long rows; } items[4] = {
+    {dboxes, m->pd_buf, 4 * m->d.reg_max, m->A}, {dscores, m->ps_buf, m->d.nc, m->A},
+    {m->segment || m->xkind >= 2 ? dextra : nullptr, m->mc_buf, m->nm, m->A}, {m->segment ? dproto : nullptr, m->pr_buf, m->nm, (long)m->mh * m->mw}};
+  for (const Item& it : items) {
+    if (!it.src) continue;
+    const Buf& b = m->bufs[it.buf];
+    const size_t cnt = (size_t)B * it.C * it.rows;
+    YS_REQUIRE((long)cnt <= m->n_out_stage, "ys_head_set_grads: staging buffer too small");
+    YS_CHECK_HIP(hipMemcpyAsync(m->out_stage, it.src, cnt * 4, hipMemcpyHostToDevice, st));
+    YS_TRY(ys_pack_input_launch(st, m->dtype, m->out_stage, B, it.C, 1, (int)it.rows, b.ldc, b.grad));
+    YS_CHECK_HIP(hipStreamSynchronize(st));   // out_stage is reused by the next item
+  }
+  m->have_loss = true; m->have_seg_loss = true;
+  return YS_OK;
+}
+
+int ys_head_backward(ys_model* m, int on_device, float* const dx[3]) {
+  YS_REQUIRE(m && m->is_head, "ys_head_backward: not a head handle");
+  YS_REQUIRE(m->have_loss && m->fwd_training, "ys_head_backward: needs a training-mode ys_head_forward and a criterion (ys_loss_*) or ys_head_set_grads first");
+  YS_REQUIRE(!m->segment || m->have_seg_loss, "ys_head_backward: the Segment head needs ys_loss_segment (mask gradients)");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  YsTimer timer(m->ctx, "backward");
+  reset_grad_state(m);
+  YS_TRY(backward_range(m, 0, 2));
+  for (int i = 0; i < 3 && dx; i++) {
+    if (!dx[i]) continue;
+    const Buf& ib = m->bufs[m->head_in[i]];
+    const size_t n = (size_t)m->B * m->head_ch[i] * ib.rows_per_b;
+    float* dst = on_device ? dx[i] : m->img_dev;
+    YS_TRY(ys_unpack_nchw_launch(st, m->dtype, ib.grad, ib.ldc, 0, m->B, m->head_ch[i], ib.rows_per_b, dst));
+    if (!on_device) { YS_CHECK_HIP(hipMemcpyAsync(dx[i], m->img_dev, n * 4, hipMemcpyDeviceToHost, st)); YS_CHECK_HIP(hipStreamSynchronize(st)); }
   }
   YS_CHECK_HIP(hipStreamSynchronize(st));
   return YS_OK;

@@ -202,6 +202,10 @@ class Yolov8:
         Engine.dist_init); ends with the engine stream ordered after the last all-reduce."""
         _lib.check(self.lib, self.lib.ys_model_backward_allreduce(self.handle))
 
+    def set_overlap(self, on=True):
+        """Weight-gradient kernels on a second stream (default on); off for per-kernel profiling.  Results are identical."""
+        _lib.check(self.lib, self.lib.ys_model_set_overlap(self.handle, int(bool(on))))
+
     def zero_grad(self):
         _lib.check(self.lib, self.lib.ys_model_zero_grad(self.handle))
 
