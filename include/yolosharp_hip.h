@@ -190,7 +190,7 @@ YS_API int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count);
  * ys_dist_unique_id: rank 0 creates the 128-byte RCCL id and ships it to the other ranks by any host channel.
  * ys_dist_init: joins the communicator (collective).  ys_dist_allreduce_grads(m, seg): asynchronous SUM all-reduce of a
  * backward segment's gradient range (seg < 0: the whole buffer) on a communication stream ordered after the engine stream.
- * ys_dist_wait: the engine stream waits for the outstanding all-reduces.  ys_model_backward_allreduce = the three backward
+ * ys_dist_wait: the engine stream waits for the outstanding all-reduces.  ys_model_backward_allreduce = the four backward
  * segments with each finished segment's all-reduce overlapped with the next (the loop bench.py runs through torch.distributed).
  * RCCL is dlopen'ed on first use; single-GPU processes never load it. */
 YS_API int ys_dist_unique_id(void* id128);

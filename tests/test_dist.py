@@ -167,6 +167,62 @@ def test_train_step_dp_world2_engine_gloo(emu_lib_path, task):
         assert same and finite, rank
 
 
+def test_train_step_dp_world4_engine_gloo(emu_lib_path):
+    """The same end-to-end data-parallel step with FOUR ranks (round-2 verdict item 8): global batch 8 sharded 2 per rank, four
+    backward segments, all-reduced gradient equal to the oracle's under per-shard BN, bit-identical weights on all ranks.
+    Unmeasured on hardware: the development boxes have one GPU (gloo on CPU tensors here)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 4, port, q, emu_lib_path, "detect")) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, worst, same, finite in res:
+        assert worst < 2e-3, (rank, worst)
+        assert same and finite, rank
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from yolosharp_amd.dist import GradSync
+    g = torch.Generator().manual_seed(10 + rank)
+    flat = torch.randn(1000, generator=g)
+    local = flat.clone()
+    sync = GradSync(flat, [(0, 300), (300, 700)], compress="bf16")
+    sync.allreduce_segment(0); sync.allreduce_segment(1); sync.wait()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(t.bfloat16().float() for t in gathered)
+    results = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(results, flat)
+    q.put((rank, float((flat - expect).abs().max() / expect.abs().max()), all(torch.equal(results[0], t) for t in results[1:])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_bf16_exchange_world2_gloo():
+    """compress="bf16": the exchanged values are the bf16 roundings, the result is identical on every rank and within bf16
+    accumulation rounding of the fp32 sum of those roundings."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, same in res:
+        assert err < 1e-2 and same, (rank, err, same)
+
+
 def test_gradsync_single_process_is_identity():
     from yolosharp_amd.dist import GradSync
     g = torch.arange(10, dtype=torch.float32)
@@ -176,7 +232,8 @@ def test_gradsync_single_process_is_identity():
 
 
 def test_segment_ranges_cover_flat_buffer(emu_lib_path):
-    """The engine's backward segments partition the flat gradient buffer (head, neck, backbone)."""
+    """The engine's backward segments partition the flat gradient buffer (head, neck, late backbone, stem); the stem -- whose
+    all-reduce is the exposed one -- is the smallest (round-2 verdict item 8: <= 1/4 of the buffer)."""
     from yolosharp_amd import Engine
     from yolosharp_amd.model import Yolov8
     eng = Engine(lib_path=emu_lib_path)
@@ -186,6 +243,7 @@ def test_segment_ranges_cover_flat_buffer(emu_lib_path):
     assert ranges[0][0] == 0 and sum(c for _, c in ranges) == n == m.num_params()
     for (o1, c1), (o2, _) in zip(ranges, ranges[1:]):
         assert o1 + c1 == o2
+    assert len(ranges) == 4 and ranges[-1][1] * 4 <= n and ranges[-1][1] == min(c for _, c in ranges), ranges
     m.close()
 
 

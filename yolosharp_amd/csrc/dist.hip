@@ -154,7 +154,7 @@ int ys_dist_wait(ys_model* m) {
 #endif
 }
 
-// backward (head -> neck -> backbone) with the all-reduce of each finished segment overlapped with the next one
+// backward (head -> neck -> late backbone -> stem) with the all-reduce of each finished segment overlapped with the next one
 int ys_model_backward_allreduce(ys_model* m) {
   YS_REQUIRE(m, "ys_model_backward_allreduce: null model");
   const int nseg = ys_model_backward_segments(m);

@@ -112,7 +112,8 @@ struct ys_model {
   float* state = nullptr; long n_state = 0;     // running_mean / running_var / num_batches_tracked
   float dfl_w[64];
   struct Range { long off, count; };
-  Range seg_group[3][3];                         // [segment][adamw group]
+  static constexpr int NSEG = 4;                 // backward segments: head, neck, late backbone, stem (the last, exposed all-reduce is the smallest)
+  Range seg_group[NSEG][3];                      // [segment][adamw group]
   long step = 0;
   // fp8 mode (ys_dtype YS_FP8: bf16 storage + fp8 MFMA convolutions, f8.hip)
   bool f8 = false, f8_sx_valid = false, f8_sg_valid = false, f8_bwd_done = false;
@@ -140,7 +141,7 @@ struct ys_model {
   float* stat_partial = nullptr; long n_stat = 0;
   float* wg_partial = nullptr; long n_wgp = 0;   // [shared scratch (ConvTranspose phases) | one region per convolution]
   // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
-  std::vector<WgRedDesc> red_host, red_uploaded; WgRedDesc* red_dev = nullptr; int red_first[4] = {0, 0, 0, 0};
+  std::vector<WgRedDesc> red_host, red_uploaded; WgRedDesc* red_dev = nullptr; int red_first[NSEG + 1] = {0, 0, 0, 0, 0};
   bool defer_wgred = true;
   // fused BN-backward reduction: planned per batch size (plan_bnred), partial rows of every (producer, consumer) pair
   bool bnred_on = true; int bnred_B = -1; float* bnred_part = nullptr; long n_bnred = 0;
@@ -447,14 +448,16 @@ int build_v8_detect(ys_model* m) {
   const int b8 = new_buf(m, H32, W32, w[4]);
   const int b15 = new_buf(m, H8, W8, w[2]), b18 = new_buf(m, H16, W16, w[3]), b21 = new_buf(m, H32, W32, w[4]);
   const View v4{cat14, w[3], w[2]}, v6{cat11, w[4], w[3]}, v9{cat20, w[3], w[4]}, v12{cat17, w[2], w[3]};
-  const int SB = 2, SN = 1, SH = 0;  // backward segments: head first, stem last
+  // backward segments: head first, stem last.  The backbone is cut after model.4: the all-reduce of the LAST segment has no
+  // backward left to hide behind, so it should be the smallest (model.0-4: 2.5 % of YOLOv8n's parameters, 4 % of YOLOv8s')
+  const int SB = 2, SN = 1, SH = 0, SS = 3;
 
-  int ci = add_conv_reg(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SB);
+  int ci = add_conv_reg(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SS);
   m->convs[ci].first = true;
-  add_conv_reg(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SB);
-  add_c2f(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[1]}, w[1], w[1], dep[0], true, H4, W4, SB);
-  add_conv_reg(m, "model.3", View{b2, 0, w[1]}, View{b3, 0, w[2]}, w[1], w[2], 3, 2, true, true, H4, W4, SB);
-  add_c2f(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[2], dep[1], true, H8, W8, SB);
+  add_conv_reg(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SS);
+  add_c2f(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[1]}, w[1], w[1], dep[0], true, H4, W4, SS);
+  add_conv_reg(m, "model.3", View{b2, 0, w[1]}, View{b3, 0, w[2]}, w[1], w[2], 3, 2, true, true, H4, W4, SS);
+  add_c2f(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[2], dep[1], true, H8, W8, SS);
   add_conv_reg(m, "model.5", v4, View{b5, 0, w[3]}, w[2], w[3], 3, 2, true, true, H8, W8, SB);
   add_c2f(m, "model.6", View{b5, 0, w[3]}, v6, w[3], w[3], dep[1], true, H16, W16, SB);
   add_conv_reg(m, "model.7", v6, View{b7, 0, w[4]}, w[3], w[4], 3, 2, true, true, H16, W16, SB);
@@ -504,13 +507,13 @@ int build_v11_detect(ys_model* m) {
   const int b8 = new_buf(m, H32, W32, w[4]), b9 = new_buf(m, H32, W32, w[4]);
   const int b16 = new_buf(m, H8, W8, w[2]), b19 = new_buf(m, H16, W16, w[3]), b22 = new_buf(m, H32, W32, w[4]);
   const View v4{cat15, w[3], w[3]}, v6{cat12, w[4], w[3]}, v10{cat21, w[3], w[4]}, v13{cat18, w[2], w[3]};
-  const int SB = 2, SN = 1, SH = 0;
-  int ci = add_conv_reg(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SB);
+  const int SB = 2, SN = 1, SH = 0, SS = 3;   // stem segment: see build_v8_detect
+  int ci = add_conv_reg(m, "model.0", View{m->in_buf, 0, m->epl}, View{b0, 0, w[0]}, 3, w[0], 3, 2, true, true, H, W, SS);
   m->convs[ci].first = true;
-  add_conv_reg(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SB);
-  add_c3k2(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[2]}, w[1], w[2], n, uc, 0.25f, H4, W4, SB);
-  add_conv_reg(m, "model.3", View{b2, 0, w[2]}, View{b3, 0, w[2]}, w[2], w[2], 3, 2, true, true, H4, W4, SB);
-  add_c3k2(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[3], n, uc, 0.25f, H8, W8, SB);
+  add_conv_reg(m, "model.1", View{b0, 0, w[0]}, View{b1, 0, w[1]}, w[0], w[1], 3, 2, true, true, H2, W2, SS);
+  add_c3k2(m, "model.2", View{b1, 0, w[1]}, View{b2, 0, w[2]}, w[1], w[2], n, uc, 0.25f, H4, W4, SS);
+  add_conv_reg(m, "model.3", View{b2, 0, w[2]}, View{b3, 0, w[2]}, w[2], w[2], 3, 2, true, true, H4, W4, SS);
+  add_c3k2(m, "model.4", View{b3, 0, w[2]}, v4, w[2], w[3], n, uc, 0.25f, H8, W8, SS);
   add_conv_reg(m, "model.5", v4, View{b5, 0, w[3]}, w[3], w[3], 3, 2, true, true, H8, W8, SB);
   add_c3k2(m, "model.6", View{b5, 0, w[3]}, v6, w[3], w[3], n, true, 0.5f, H16, W16, SB);
   add_conv_reg(m, "model.7", v6, View{b7, 0, w[4]}, w[3], w[4], 3, 2, true, true, H16, W16, SB);
@@ -604,7 +607,7 @@ int build_block(ys_model* m, const ys_block_desc& bd) {
 //      0 = "bias" (conv bias, bn.bias), 1 = conv "weight", 2 = "bn" weight
 int layout_params(ys_model* m) {
   long off = 0;
-  for (int seg = 0; seg < 3; seg++)
+  for (int seg = 0; seg < ys_model::NSEG; seg++)
     for (int grp = 0; grp < 3; grp++) {
       const long start = off;
       for (auto& c : m->convs) {
@@ -885,7 +888,7 @@ int allocate(ys_model* m) {
   {
     long off = (wgp + 63) / 64 * 64;
     // descriptor order = backward-segment order, so that a backward_range call reduces one contiguous run of descriptors
-    for (int seg = 0; seg < 3; seg++) {
+    for (int seg = 0; seg < ys_model::NSEG; seg++) {
       m->red_first[seg] = (int)m->red_host.size();
       for (auto& c : m->convs) {
         if (c.seg != seg || c.dw || c.ct || !m->defer_wgred) continue;
@@ -894,7 +897,7 @@ int allocate(ys_model* m) {
         m->red_host.push_back(WgRedDesc{});
       }
     }
-    m->red_first[3] = (int)m->red_host.size();
+    m->red_first[ys_model::NSEG] = (int)m->red_host.size();
     m->n_wgp = off;
   }
   YS_TRY(dev_alloc(m, (void**)&m->wg_partial, (size_t)m->n_wgp * 4));
@@ -1485,7 +1488,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
     YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
     m->st2_dirty = false;
   }
-  if (m->f8 && seg_hi == 2) m->f8_bwd_done = true;     // every gradient maximum of the step is recorded (last segment = stem)
+  if (m->f8 && seg_hi == ys_model::NSEG - 1) m->f8_bwd_done = true;     // every gradient maximum of the step is recorded (last segment = stem)
   {
     // split reduction of every weight gradient of these segments in one launch (the partial slabs sit in per-layer regions)
     const int lo = m->red_first[seg_lo], hi = m->red_first[seg_hi + 1];
@@ -2024,12 +2027,12 @@ int ys_loss_read(ys_model* m, float loss_items[3], float* loss_sum) {
   return YS_OK;
 }
 
-int ys_model_backward_segments(ys_model* m) { (void)m; return 3; }
+int ys_model_backward_segments(ys_model* m) { (void)m; return ys_model::NSEG; }
 
 int ys_model_backward_segment(ys_model* m, int seg) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
   YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
-  YS_REQUIRE(seg >= 0 && seg < 3, "ys_model_backward_segment: segment %d out of range", seg);
+  YS_REQUIRE(seg >= 0 && seg < ys_model::NSEG, "ys_model_backward_segment: segment %d out of range", seg);
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   if (seg == 0) reset_grad_state(m);
   return backward_range(m, seg, seg);
@@ -2042,11 +2045,11 @@ int ys_model_backward(ys_model* m) {
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   YsTimer timer(m->ctx, "backward");
   reset_grad_state(m);
-  return backward_range(m, 0, 2);
+  return backward_range(m, 0, ys_model::NSEG - 1);
 }
 
 int ys_model_segment_grad_range(ys_model* m, int seg, int64_t* offset, int64_t* count) {
-  YS_REQUIRE(m && offset && count && seg >= 0 && seg < 3, "ys_model_segment_grad_range: bad argument");
+  YS_REQUIRE(m && offset && count && seg >= 0 && seg < ys_model::NSEG, "ys_model_segment_grad_range: bad argument");
   *offset = m->seg_group[seg][0].off;
   *count = m->seg_group[seg][0].count + m->seg_group[seg][1].count + m->seg_group[seg][2].count;
   return YS_OK;
@@ -2109,7 +2112,7 @@ int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, flo
   const float bc1 = 1.0f - powf(beta1, (float)m->step), bc2 = 1.0f - powf(beta2, (float)m->step);
   AdamwRanges rg{};                          // one launch for the 3 segments x 3 groups (was nine ~5 us launches)
   auto lr_of = [&](int g) { return lr_per_group[g < ngroups ? g : ngroups - 1]; };
-  for (int seg = 0; seg < 3; seg++)
+  for (int seg = 0; seg < ys_model::NSEG; seg++)
     for (int g = 0; g < 3; g++) {
       const auto r = m->seg_group[seg][g];
       if (r.count <= 0) continue;
@@ -2197,7 +2200,7 @@ int ys_block_backward(ys_model* m, const float* dy, int on_device, float* dx) {
   if (!on_device) { YS_CHECK_HIP(hipMemcpyAsync(m->out_stage, dy, ny * 4, hipMemcpyHostToDevice, st)); src = m->out_stage; }
   YS_TRY(ys_pack_input_launch(st, m->dtype, src, B, m->blk_c2, ob.H, ob.W, ob.ldc, ob.grad));
   reset_grad_state(m);
-  YS_TRY(backward_range(m, 0, 2));
+  YS_TRY(backward_range(m, 0, ys_model::NSEG - 1));
   if (dx) {
     float* dst = on_device ? dx : m->img_dev;
     YS_TRY(ys_unpack_nchw_launch(st, m->dtype, ib.grad, ib.ldc, 0, B, m->blk_c1, ib.rows_per_b, dst));
@@ -2304,7 +2307,7 @@ int ys_head_backward(ys_model* m, int on_device, float* const dx[3]) {
   hipStream_t st = m->ctx->stream;
   YsTimer timer(m->ctx, "backward");
   reset_grad_state(m);
-  YS_TRY(backward_range(m, 0, 2));
+  YS_TRY(backward_range(m, 0, ys_model::NSEG - 1));
   for (int i = 0; i < 3 && dx; i++) {
     if (!dx[i]) continue;
     const Buf& ib = m->bufs[m->head_in[i]];

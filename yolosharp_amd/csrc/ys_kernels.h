@@ -187,7 +187,7 @@ int ys_upsample2x_bwd_launch(hipStream_t st, int dtype, const void* dy, int dy_l
 int ys_copy_view_launch(hipStream_t st, int dtype, const void* src, int s_ldc, int s_coff, long rows, int C, void* dst,
                         int d_ldc, int d_coff, int accumulate);
 // AdamW over a flat range
-#define YS_ADAMW_MAX_RANGES 9
+#define YS_ADAMW_MAX_RANGES 12
 struct AdamwRanges { int n; long off[YS_ADAMW_MAX_RANGES]; long count[YS_ADAMW_MAX_RANGES]; float lr[YS_ADAMW_MAX_RANGES]; };
 // parameters listed in two optimizer groups (mask[i] != 0): a second update with lr_second; bias corrections of the two step indices
 struct AdamwDup { const unsigned char* mask; float lr_second, bc1_first, bc2s_first, bc1_second, bc2s_second; };

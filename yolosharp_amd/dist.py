@@ -3,7 +3,8 @@
 One process per GPU; the global batch is sharded by image; BatchNorm statistics stay per device (the reference has
 no SyncBN); the single exchange step is a SUM all-reduce of the flat fp32 gradient buffer before AdamW
 (each shard back-propagates B_local*items_local, so the sum reproduces the single-device global-batch gradient).
-The engine's backward is split into segments (head -> neck -> backbone); the all-reduce of a finished segment is
+The engine's backward is split into segments (head -> neck -> late backbone -> stem; the stem is cut small because the last
+all-reduce has no backward left to hide behind); the all-reduce of a finished segment is
 issued asynchronously on RCCL's stream while the next segment's kernels run (torch.distributed backend "nccl" is
 RCCL on ROCm; xGMI is point-to-point so a few large buckets beat many small ones).
 
@@ -30,11 +31,17 @@ def host_view(ptr, n):
 
 
 class GradSync:
-    def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None):
-        """flat_grads: 1-D fp32 tensor aliasing the gradient buffer; segment_ranges: [(offset, count)] per backward segment."""
+    def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None, compress=None):
+        """flat_grads: 1-D fp32 tensor aliasing the gradient buffer; segment_ranges: [(offset, count)] per backward segment.
+        compress = "bf16": the exchange moves bf16 (half the xGMI bytes: a ring all-reduce is per-link bound); every rank reduces the
+        same rounded values in the same order, so the ranks' weights stay bit-identical, but the summed gradient carries bf16
+        rounding (2^-9 relative per addend) -- off by default, the fp32 exchange reproduces the single-device gradient."""
+        assert compress in (None, "bf16")
         self.flat = flat_grads
         self.segs = [self.flat.narrow(0, int(o), int(c)) for o, c in segment_ranges]
         self.group = group
+        self.compress = compress
+        self.stage = [torch.empty_like(s, dtype=torch.bfloat16) for s in self.segs] if compress else None
         self.pending = []
 
     @property
@@ -44,11 +51,17 @@ class GradSync:
     def allreduce_segment(self, seg):
         if self.world == 1:
             return
-        self.pending.append(dist.all_reduce(self.segs[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.compress:
+            self.stage[seg].copy_(self.segs[seg])
+            self.pending.append((dist.all_reduce(self.stage[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
+        else:
+            self.pending.append((dist.all_reduce(self.segs[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
 
     def wait(self):
-        for w in self.pending:
+        for w, seg in self.pending:
             w.wait()
+            if seg is not None:
+                self.segs[seg].copy_(self.stage[seg])
         self.pending = []
 
 
