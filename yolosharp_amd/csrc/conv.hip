@@ -1432,8 +1432,9 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_onl
     if (!conv_dgrad_s2_phase_args(a, ph, q)) continue;
     q.red_row0 = row0;                                                // the phases write disjoint pixels of dx: their statistics rows stack
     if (q.f8 && q.x8 && ys_conv_gemm_rows(q)) {
-      if (rows_only) return 0;                                        // fp8 kernels carry no fused reduction
-      const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc;
+      if (rows_only && q.f8 != 2) return 0;                           // only the e5m2-input (dgrad) form of the fp8 GEMM kernel carries the fused reduction
+      row0 += ys_conv_gemm_rows(q);
+      if (!rows_only) { const int rc = ys_conv_gemm_launch(st, q); if (rc != YS_OK) return rc; }
       continue;
     }
     P2Plan p2 = conv_p2_plan(q);
@@ -1458,8 +1459,8 @@ int ys_conv_bnred_rows(const ConvArgs& a, int dtype) {
   const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
   if (a.f8 && !a.x8 && a.q8 && ys_conv_wants_x8(a)) { ConvArgs b = a; b.x8 = a.q8; return ys_conv_bnred_rows(b, dtype); }
   if (phases) return conv_dgrad_s2_phases(nullptr, a, true);
-  if (a.f8) {                                   // launches routed to an fp8 kernel have no fused variant
-    if (a.x8 && ys_conv_gemm_rows(a)) return 0;
+  if (a.f8) {                                   // fp8 routing: the blocked-GEMM kernel has a fused variant for e5m2 (dgrad) input, conv_p2_kernel<F8> has none
+    if (a.x8 && ys_conv_gemm_rows(a)) return a.f8 == 2 ? ys_conv_gemm_rows(a) : 0;
     const P2Plan pf = conv_p2_plan(a);
     if (pf.ok) return 0;
     ConvArgs b = a; b.f8 = 0;

@@ -338,8 +338,9 @@ int ys_conv_gemm_rows(const ConvArgs& a) {
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a) {
   const GemmPlan p = conv_gemm_plan(a);
   if (!p.ok) return YS_ERR_UNSUPPORTED;
-  if (a.f8 && a.nred > 0) { ys_set_error("conv gemm: the fused BN-backward reduction has no fp8 variant"); return YS_ERR_UNSUPPORTED; }
-#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : ((a.nred > 0 || (a.accumulate && YS_P2_EPI_DIRECT)) ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
+  if (a.f8 == 1 && a.nred > 0) { ys_set_error("conv gemm: the fused BN-backward reduction belongs to dgrad launches (e5m2 input)"); return YS_ERR_UNSUPPORTED; }
+  // RED variants: bf16 and e5m2-input (fp8-mode dgrad) launches that carry BN-backward segments
+#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? (a.nred > 0 ? conv_gemm_launch_t<A_, B_, C_, D_, 2, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p)) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : ((a.nred > 0 || (a.accumulate && YS_P2_EPI_DIRECT)) ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
   GM(2, 2, 4, 5) GM(2, 2, 4, 4) GM(4, 1, 4, 5) GM(4, 1, 4, 4)
 #undef GM
   return YS_ERR_UNSUPPORTED;

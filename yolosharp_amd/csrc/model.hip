@@ -1193,9 +1193,9 @@ int plan_bnred(ys_model* m, int B) {
   if (m->bnred_B == B) return YS_OK;
   m->bnred_B = B;
   for (auto& c : m->convs) { c.feeds.clear(); c.red_src.clear(); c.red_ok = false; c.red_seen = 0; }
-  // fp8 mode: the fp8 kernels have no fused variant, and mixing fused / unfused units would break the mode's contract that its
-  // scale-less first step is bit-identical to the bf16 model -> every unit keeps its own reduction pass there
-  if (!m->bnred_on || m->dtype != YS_BF16 || m->f8) return YS_OK;
+  // fp8 mode: a producer is fused only when its consumers' dgrads carry the fused epilogue under BOTH routings (the scale-less
+  // first step runs the bf16 kernels, later steps the fp8 ones): conv_gemm_kernel<e5m2> has the variant, conv_p2_kernel<F8> does not
+  if (!m->bnred_on || m->dtype != YS_BF16) return YS_OK;
   const int epl = m->epl;
   // first reader per (buffer, channel): op index and kind (0 = input of a plain convolution, 1 = residual / unsupported reader)
   std::vector<std::vector<int>> fop(m->bufs.size()), fkind(m->bufs.size());
