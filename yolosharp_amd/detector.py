@@ -6,6 +6,7 @@ been created with (height, width) = the padded image size: the reference pads bo
 before dividing by 255 (Detector.cs:35-41), this does the same."""
 import numpy as np
 
+from . import _lib
 from . import metrics as M
 from .model import AMPWrapper, v8DetectionLoss
 
@@ -57,32 +58,57 @@ class Detector:
 
     def Val(self, batches, conf_thres=0.1, iou_thres=0.7, max_det=300):
         """batches: iterable of dicts (images [B,3,H,W] in [0,1], batch_idx, cls, bboxes).  Returns
-        (mean loss items, (P, R, mAP50, mAP50-95)) like Detector.Val (:76-154)."""
+        (SUM over batches of the loss items, (P, R, mAP50, mAP50-95)) like Detector.Val (Detector.cs:76-154; :126 adds the items up).
+        The predictions never leave the device between the eval forward, NMS and the matching (ys_model_pred_device ->
+        ys_nms_batched -> ys_val_match_batched, all on device pointers); only the kept rows, their count and the `correct`
+        matrix come back per batch, for the epoch-level ap_per_class on the host."""
         crit = v8DetectionLoss(self.model)
+        eng, m = self.engine, self.model
         tps, confs, pcls, tcls = [], [], [], []
         loss_sum, count = None, 0
-        for data in batches:
-            if np.asarray(data["batch_idx"]).size < 1:          # Detector.cs:91-94
-                continue
-            images = np.ascontiguousarray(data["images"], np.float32)
-            B = images.shape[0]
-            # eval forward, then the criterion on the eval-mode preds (Detector.cs:95-97): one forward serves loss and NMS
-            inference, _ = self.amp.Evaluate(images)
-            _, items = crit.forward(None, data)
-            loss_sum = items if loss_sum is None else loss_sum + items
-            pred = inference["boxes"]
-            nc = self.model.nc
-            rows = np.zeros((B, max_det, pred.shape[1] - nc + 2), np.float32)
-            output, _ = self.engine.non_max_suppression(pred, conf_thres, iou_thres, max_det=max_det, nc=nc)
-            cnt = np.array([len(o) for o in output], np.int32)
-            for b, o in enumerate(output):
-                rows[b, :len(o)] = o
-            correct = self.engine.val_match(rows, cnt, data, images.shape[3], images.shape[2])
-            bi = np.asarray(data["batch_idx"]).reshape(-1)
-            for b in range(B):
-                tps.append(correct[b]); confs.append(rows[b, :cnt[b], 4]); pcls.append(rows[b, :cnt[b], 5])
-                tcls.append(np.asarray(data["cls"], np.float32).reshape(-1)[bi == b])
-            count += B
+        nc = m.nc
+        Cc = 4 + nc + m.NM
+        stride = Cc - nc + 2
+        d_rows = d_keep = d_cnt = d_cor = None
+        cap_b = 0
+        try:
+            for data in batches:
+                if np.asarray(data["batch_idx"]).size < 1:          # Detector.cs:91-94
+                    continue
+                images = np.ascontiguousarray(data["images"], np.float32)
+                B = images.shape[0]
+                # eval forward, then the criterion on the eval-mode preds (Detector.cs:95-97): one forward serves loss and NMS
+                m.eval()
+                m.forward(images, fetch=False)
+                _, items = crit.forward(None, data)
+                loss_sum = items if loss_sum is None else loss_sum + items
+                if B > cap_b:
+                    for p_ in (d_rows, d_keep, d_cnt, d_cor):
+                        if p_ is not None:
+                            eng.free(p_)
+                    d_rows, d_keep = eng.malloc(B * max_det * stride * 4), eng.malloc(B * max_det * 8)
+                    d_cnt, d_cor = eng.malloc(B * 4), eng.malloc(B * max_det * 10)
+                    cap_b = B
+                eng.nms_device(m.pred_device(), B, Cc, m.A, conf_thres, iou_thres, max_det, nc, d_rows, d_keep, d_cnt)
+                bi = np.ascontiguousarray(np.asarray(data["batch_idx"], np.float32).reshape(-1))
+                cl = np.ascontiguousarray(np.asarray(data["cls"], np.float32).reshape(-1))
+                bb = np.ascontiguousarray(np.asarray(data["bboxes"], np.float32).reshape(-1, 4))
+                d_lab = [eng.to_device(a) for a in (bi, cl, bb)]
+                _lib.check(eng.lib, eng.lib.ys_val_match_batched(eng.ctx, d_rows, d_cnt, 1, B, max_det, stride, d_lab[0], d_lab[1], d_lab[2],
+                                                                 bi.shape[0], float(images.shape[3]), float(images.shape[2]), d_cor))
+                rows = eng.from_device(d_rows, (B, max_det, stride), np.float32)
+                cnt = eng.from_device(d_cnt, (B,), np.int32)
+                cor = eng.from_device(d_cor, (B, max_det, 10), np.uint8)
+                for p_ in d_lab:
+                    eng.free(p_)
+                for b in range(B):
+                    tps.append(cor[b, :cnt[b]].astype(bool)); confs.append(rows[b, :cnt[b], 4]); pcls.append(rows[b, :cnt[b], 5])
+                    tcls.append(cl[bi == b])
+                count += B
+        finally:
+            for p_ in (d_rows, d_keep, d_cnt, d_cor):
+                if p_ is not None:
+                    eng.free(p_)
         if not tps:
             return np.zeros(3, np.float32), (0.0, 0.0, 0.0, 0.0)
         stats = M.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls))
