@@ -227,6 +227,27 @@ def test_pose_loss_two_dim_keypoints_from_preds(backend, engine):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_pose_loss_refuses_labels_out_of_collate_order(backend, engine):
+    """Keypoint rows are addressed by a label's rank within its image (Loss.cs:1040-1071 `arange - offsets[batch_idx]`), which is
+    only defined for labels grouped by image in collate order: host labels that are not are refused (round-2 advisor finding)."""
+    from yolosharp_amd import YsError
+    from yolosharp_amd.model import Yolov8Pose, v8PoseLoss
+    m = Yolov8Pose(engine, nc=1, size="n", height=32, width=32, max_batch=2, dtype="f32")
+    m.init_weights(3)
+    m.forward(np.random.default_rng(0).random((2, 3, 32, 32), np.float32), fetch=False)
+    bb = np.array([[0.5, 0.5, 0.4, 0.4]] * 3, np.float32)
+    kp = np.random.default_rng(1).random((3, 17, 3)).astype(np.float32)
+    good = {"batch_idx": np.array([0, 0, 1], np.float32), "cls": np.zeros(3, np.float32), "bboxes": bb, "keypoints": kp}
+    _, items = v8PoseLoss(m)(None, good)
+    assert np.isfinite(items).all()
+    bad = dict(good, batch_idx=np.array([1, 0, 0], np.float32))
+    with pytest.raises(YsError) as ei:
+        v8PoseLoss(m)(None, bad)
+    assert ei.value.status == 1 and "collate order" in str(ei.value)
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_pose_loss_without_labels(backend, engine):
     """No foreground anchor: pose = kobj = 0, zero keypoint gradients (the `fg_mask.sum() > 0` guard, Loss.cs:945)."""
     from yolosharp_amd.model import Yolov8Pose, v8PoseLoss

@@ -1069,6 +1069,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
   }
   if (!p.ok) return p;
   if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
+  // three workgroups per CU (TIGHT register variants) when three footprints fit the 160 KB: YS_P2_LDS3 = the per-workgroup limit in bytes
+  static const size_t lds3 = getenv("YS_P2_LDS3") ? (size_t)atol(getenv("YS_P2_LDS3")) : (size_t)50 * 1024;
   p.g.prb = p.g.PW * p.g.ppb;
   if (!f8) {
     // row padding of the patch (bank model, p2_pick_rowpad) inside the occupancy class the tile search settled on
@@ -1076,7 +1078,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     const size_t stat = (size_t)nwv * bn * 2 * 4, stage = (size_t)nwv * (16 * p.mr * (bn + 8) * 2 + 16 * p.mr * 16);
     size_t floor_b = stage > (size_t)17 * p.nt * 4 ? stage : (size_t)17 * p.nt * 4;
     const size_t pb0 = (size_t)p.g.PH * p.g.prb;
-    const size_t cap = (p.lds <= 50 * 1024 && p.npu == 6) ? 50 * 1024 : (p.lds <= 76 * 1024 ? 76 * 1024 : 152 * 1024);
+    const size_t cap = (p.lds <= lds3 && p.npu == 6) ? lds3 : (p.lds <= 76 * 1024 ? 76 * 1024 : 152 * 1024);
     const size_t base = p.lds - (pb0 > floor_b ? pb0 : floor_b);           // tables + weights + statistics
     size_t room = cap > base + pb0 ? cap - base - pb0 : 0;
     if (pb0 + room > (size_t)8192 * 16) room = (size_t)8192 * 16 > pb0 ? (size_t)8192 * 16 - pb0 : 0;   // 13-bit LDS slot field
@@ -1086,7 +1088,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     p.lds = base + (pb1 > floor_b ? pb1 : floor_b);
     p.g.off_stat = (int)(p.lds - stat);
   }
-  const int per_cu = (p.lds <= 50 * 1024 && p.npu == 6) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
+  const int per_cu = (p.lds <= lds3 && p.npu == 6) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
   if (gx < 1) gx = 1;

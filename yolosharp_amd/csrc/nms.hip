@@ -136,7 +136,7 @@ __device__ inline void nms_bitonic_sort(unsigned long long* k, int np2) {
 // boxes / areas / anchor indices in that order, zero the outputs.  n_sorted[b] = candidates entering the greedy pass.
 __global__ void __launch_bounds__(NMS_THREADS)
 nms_sort_kernel(const float* __restrict__ pred, int C, int A, int nc, int max_det, int max_nms, float max_wh,
-                const int* __restrict__ count, unsigned long long* __restrict__ keys_g, int keys_stride,
+                int* __restrict__ count, unsigned long long* __restrict__ keys_g, int keys_stride,
                 const int* __restrict__ clss, float4* __restrict__ sbox, float* __restrict__ sarea, int* __restrict__ sidx,
                 unsigned char* __restrict__ supp_g, int ncap, int* __restrict__ n_sorted,
                 float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count,
@@ -148,6 +148,8 @@ nms_sort_kernel(const float* __restrict__ pred, int C, int A, int nc, int max_de
   const int row_w = 6 + (C - 4 - nc);
   int n = count[b];
   if (n > A) n = A;
+  __syncthreads();
+  if (tid == 0) count[b] = 0;                 // consumed: the next call's filter starts from zero without a memset launch
   float* orow = out_rows + (size_t)b * max_det * row_w;
   long long* okeep = out_keep + (size_t)b * max_det;
   // outputs of images with nothing kept stay zero / count 0 (Ops.cs:298-299,315-318)
@@ -266,10 +268,17 @@ nms_mask_kernel(const int* __restrict__ n_sorted, const float4* __restrict__ sbo
 #define NMS_LDS_N 1024
 #define NMS_LDS_WORDS (NMS_LDS_N / 64)
 #define NMS_SCAN_LDS ((size_t)NMS_LDS_N * NMS_LDS_WORDS * 8 + 16 * 64 * 20)
+__device__ inline void
+nms_greedy_big_body(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det,
+                    const int* __restrict__ n_sorted, const float* __restrict__ confs, const int* __restrict__ clss,
+                    const float4* __restrict__ sbox, const float* __restrict__ sarea, const int* __restrict__ sidx,
+                    unsigned char* __restrict__ supp_g, int ncap,
+                    float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count);
 __global__ void __launch_bounds__(NMS_THREADS)
 nms_scan_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det, const int* __restrict__ n_sorted,
                 const float4* __restrict__ sbox, const float* __restrict__ sarea, const int* __restrict__ sidx, int ncap,
                 const float* __restrict__ confs, const int* __restrict__ clss, const unsigned long long* __restrict__ mask,
+                unsigned char* __restrict__ supp_g,
                 float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
   YS_DYN_LDS(lds);
   unsigned long long* lmask = (unsigned long long*)lds;                       // [n][nw] (n <= NMS_LDS_N)
@@ -280,7 +289,11 @@ nms_scan_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_
   __shared__ int s_nkept;
   const int b = blockIdx.x;
   const int n = n_sorted[b];
-  if (n <= 0 || n > NMS_MASK_MAX) return;
+  if (n <= 0) return;
+  if (n > NMS_MASK_MAX) {                     // large image: the serial sweep (was a launch of its own, made for every call whatever n)
+    nms_greedy_big_body(pred, C, A, nc, iou_thres, max_det, n_sorted, confs, clss, sbox, sarea, sidx, supp_g, ncap, out_rows, out_keep, out_count);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* p = pred + (size_t)b * C * A;
   const int extra = C - 4 - nc, row_w = 6 + extra;
@@ -361,12 +374,12 @@ nms_scan_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_
 
 // Large images (n > NMS_MASK_MAX, up to max_nms = 30000 candidates: an n x n bit matrix would not pay): the serial sweep, one
 // 1024-thread workgroup per image, workgroup-parallel IoU pass per kept box (O(kept x n)).
-__global__ void __launch_bounds__(NMS_THREADS)
-nms_greedy_big_kernel(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det,
-                      const int* __restrict__ n_sorted, const float* __restrict__ confs, const int* __restrict__ clss,
-                      const float4* __restrict__ sbox, const float* __restrict__ sarea, const int* __restrict__ sidx,
-                      unsigned char* __restrict__ supp_g, int ncap,
-                      float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
+__device__ inline void
+nms_greedy_big_body(const float* __restrict__ pred, int C, int A, int nc, float iou_thres, int max_det,
+                    const int* __restrict__ n_sorted, const float* __restrict__ confs, const int* __restrict__ clss,
+                    const float4* __restrict__ sbox, const float* __restrict__ sarea, const int* __restrict__ sidx,
+                    unsigned char* __restrict__ supp_g, int ncap,
+                    float* __restrict__ out_rows, long long* __restrict__ out_keep, int* __restrict__ out_count) {
   __shared__ int s_red[NMS_THREADS / 64];
   __shared__ int s_cur;
   const int b = blockIdx.x;
@@ -580,10 +593,12 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
     if (ctx->nms_ws) { YS_CHECK_HIP(hipStreamSynchronize(ctx->stream)); YS_CHECK_HIP(hipFree(ctx->nms_ws)); ctx->nms_ws = nullptr; ctx->nms_ws_bytes = 0; }
     YS_CHECK_HIP(hipMalloc(&ctx->nms_ws, off));
     ctx->nms_ws_bytes = off;
+    ctx->nms_count_clean = false;
   }
   char* ws = (char*)ctx->nms_ws;
   int* count = (int*)(ws + o_count);
-  YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));
+  if (!ctx->nms_count_clean) YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));   // new workspace / a call that did not reach its sort kernel
+  ctx->nms_count_clean = false;
   YsKprofScope prof(ctx->stream, "nms");
   static const bool dbg = getenv("YS_NMS_DEBUG") != nullptr;
 #define NMS_DBG(what) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(ctx->stream); hipError_t l_ = hipGetLastError(); fprintf(stderr, "nms %s: sync %d last %d\n", what, (int)e_, (int)l_); } } while (0)
@@ -604,9 +619,10 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
     else YS_LAUNCH((nms_filter_kernel<1, false>), g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
   }
   NMS_DBG("filter");
-  YS_LAUNCH(nms_sort_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, max_det, max_nms, (float)max_wh, (const int*)count,
+  YS_LAUNCH(nms_sort_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, max_det, max_nms, (float)max_wh, count,
             keys, np2, (const int*)clss, sbox, sarea, sidx, supp, ncap, nsort, out_rows, (long long*)out_keep, (int*)out_count, scov);
   NMS_DBG("sort");
+  ctx->nms_count_clean = true;                // nms_sort_kernel zeroes the counters it read (same workspace size B next time, else reallocation below)
   if (rotated) {
     YS_LAUNCH(nms_rot_removed_kernel, dim3(ys_cdiv(ncap, 256), B), 256, ctx->stream, (const int*)nsort, (const float4*)sbox, (const float4*)scov, ncap, iou, supp);
     YS_LAUNCH_LDS(nms_rot_pick_kernel, B, NMS_THREADS, (size_t)max_det * sizeof(int), ctx->stream, (const float*)pred, C, A, nc, max_det, (const int*)nsort,
@@ -626,12 +642,9 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   }
   YS_LAUNCH_LDS(nms_scan_kernel, B, NMS_THREADS, NMS_SCAN_LDS, ctx->stream, (const float*)pred, C, A, nc, iou, max_det, (const int*)nsort,
                 (const float4*)sbox, (const float*)sarea, (const int*)sidx, ncap, (const float*)confs, (const int*)clss,
-                (const unsigned long long*)mask, out_rows, (long long*)out_keep, (int*)out_count);
+                (const unsigned long long*)mask, supp, out_rows, (long long*)out_keep, (int*)out_count);
   NMS_DBG("scan");
-  if (big_possible)
-    YS_LAUNCH(nms_greedy_big_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, iou, max_det, (const int*)nsort,
-              (const float*)confs, (const int*)clss, (const float4*)sbox, (const float*)sarea, (const int*)sidx, supp, ncap,
-              out_rows, (long long*)out_keep, (int*)out_count);
+  (void)big_possible;
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;
 }

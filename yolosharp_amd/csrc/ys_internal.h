@@ -41,6 +41,7 @@ struct ys_ctx {
   // NMS workspace (grown on demand)
   void* nms_ws = nullptr;
   size_t nms_ws_bytes = 0;
+  bool nms_count_clean = false;   // the per-image candidate counters are zero (nms_sort_kernel clears what it consumed)
   // scratch for per-operator entry points
   std::map<std::string, float> last_ms;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
