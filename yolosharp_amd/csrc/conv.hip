@@ -851,9 +851,9 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #endif
 #else
 #ifdef YS_P2_TIMELINE
-    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); });
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, (NPU <= 6 ? 2 : 4)>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); });
 #else
-    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0, stg, st1, st2);
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, (NPU <= 6 ? 2 : 4)>(a, acc, orow, pv, n0, stg, st1, st2);
 #endif
 #endif
     TL_STAMP();

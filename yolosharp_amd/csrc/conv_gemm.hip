@@ -58,6 +58,16 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   constexpr int NBP = BN / 8;                 // B pieces per K-tile in the workgroup
   constexpr int NB = (NBP + 3) / 4;           // per wave (the last one may be absent: BN = 80)
   static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 8 == 0, "tile");
+#ifdef YS_P2_TIMELINE
+  // s_memtime stamps of wave 0 / lane 0 of every 37th workgroup (as conv_p2_kernel): entry, tap table written, then per tile
+  // (addresses done + first K-tile requested, K loop done, epilogue done), last = exit
+  int tl_n = 0;
+  unsigned long long* tl_p = (a.tl && (blockIdx.x % 37) == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? a.tl + (blockIdx.x / 37) * 64 : nullptr;
+#define GTL_STAMP() do { if (tl_p && tl_n < 63) tl_p[1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GTL_STAMP() ((void)0)
+#endif
+  GTL_STAMP();
   YS_DYN_LDS(lds);
   char* lb = (char*)lds;
   GemmTap* sTab = (GemmTap*)lb;                     // [nkt * 8] per K unit: (16-byte unit offset from the tap-(0,0) pixel, kh << 8 | kw) or (0, -1)
@@ -88,6 +98,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     } else { t.x = 0; t.y = -1; }
     sTab[e] = t;
   }
+  GTL_STAMP();
 
   // DMA roles.  Piece p of a stage = rows 8p .. 8p+7 (1 KB, one wave-wide instruction); wave w issues pieces w, w+4, ...  Lane l
   // of a piece lands at row 8p + (l >> 3), slot l & 7, and therefore fetches unit (l & 7) ^ ((row >> 1) & 7) of that row -- the
@@ -156,6 +167,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     }
     ys_barrier_lds();                         // the tap table is written; the previous tile's epilogue staging is consumed
     issue(0, 0);
+    GTL_STAMP();
     f32x4 acc[MR][NR];
 #pragma unroll
     for (int mf = 0; mf < MR; mf++)
@@ -210,6 +222,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       }
     }
     ys_barrier_lds();                         // every wave finished reading the stages: they become the epilogue staging area
+    GTL_STAMP();
 
     int orow[MR];                             // row indices / byte offsets of a launch fit 31 bits (conv_gemm_plan)
     bool pv[MR];
@@ -238,11 +251,16 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #else
     if (!GEMM_DBG(8)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
 #endif
+    GTL_STAMP();
   }
 #if YS_P2_EPI_DIRECT
   if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush_direct<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
 #else
   if (RED ? a.nred > 0 : a.stats != nullptr) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
+#endif
+  GTL_STAMP();
+#ifdef YS_P2_TIMELINE
+  if (tl_p) tl_p[0] = (unsigned long long)tl_n;
 #endif
 }
 
@@ -326,7 +344,35 @@ static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
   char lab[192] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), F8 ? "gemmf8 k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d" : "gemm k%d s%d div1 cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d", a.KH * 10 + a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, WM * MR * 16, WN * NR * 16, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
+#ifdef YS_P2_TIMELINE
+  static unsigned long long* tl_buf = nullptr;
+  const char* tl_path = getenv("YS_P2_TL");
+  if (tl_path) {
+    if (!tl_buf) hipMalloc(&tl_buf, 64 * 64 * 8);
+    hipMemsetAsync(tl_buf, 0, 64 * 64 * 8, st);
+    a.tl = tl_buf;
+  }
+#endif
   YS_LAUNCH_LDS((conv_gemm_kernel<WM, WN, MR, NR, F8, RED>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.g);
+#ifdef YS_P2_TIMELINE
+  if (tl_path) {
+    static unsigned long long h[64 * 64];
+    hipStreamSynchronize(st);
+    hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
+    FILE* f = fopen(tl_path, "a");
+    if (f) {
+      fprintf(f, "# gemm k%d%d s%d cin%d cout%d M%d acc%d tile%dx%d grid%dx%d lds%d mtiles%d nkt%d (stamps: table, then per tile: first request, K loop done, epilogue done; exit)\n", a.KH, a.KW, a.SA, a.Cin, a.Cout, a.M, a.accumulate, WM * MR * 16, WN * NR * 16, p.gx, p.gy, (int)p.lds, p.g.mtiles, p.g.nkt);
+      for (int w = 0; w < 64 && w * 37 < p.gx; w++) {
+        const int n = (int)h[w * 64];
+        if (n <= 0) continue;
+        fprintf(f, "wg%d:", w * 37);
+        for (int i = 1; i < n; i++) fprintf(f, " %llu", h[w * 64 + 1 + i] - h[w * 64 + 1]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   return YS_OK;
 }
 
