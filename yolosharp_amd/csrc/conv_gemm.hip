@@ -13,8 +13,8 @@
 //    9 fragment reads (460 B of LDS per MFMA -- conv_p2_kernel's wide-layer tiles read 1.2 KB per MFMA);
 //  * K in tiles of 64 (one 128-byte line per tile row): both operands go global -> LDS by LDS DMA (global_load_lds_dwordx4),
 //    16 bytes per lane and no VGPRs in between; every lane computes its own source offset into a buffer descriptor, which is where the
-//    implicit-GEMM gather (tap offset; zero padding = an out-of-range offset, the hardware returns zeros) and the bank swizzle live.  Two LDS stages: the DMA of tile k+1 is in flight
-//    while tile k is multiplied, one barrier per K-tile;
+//    implicit-GEMM gather (tap offset; zero padding = an out-of-range offset, the hardware returns zeros) and the bank swizzle live.  2-4 LDS stages (GemmArgs::nstage): the DMA of tiles k+1 .. k+nstage-1 is in flight
+//    while tile k is multiplied (s_waitcnt vmcnt(N) on the wave's own requests), one barrier per K-tile;
 //  * LDS rows are 128 B, so a fragment read (16 rows x 16 B per lane quarter) would hit 2 of 16 bank groups; unit u of row r is
 //    stored at slot u ^ ((r >> 1) & 7) -- applied to the SOURCE address of the DMA and to the ds_read address alike -> conflict-free;
 //  * persistent grid (gx, N-tiles): a workgroup keeps its output-channel tile and walks M-tiles of its XCD's contiguous share, so
@@ -39,6 +39,7 @@ struct GemmArgs {
   int mtiles;       // ceil(M / BM)
   int off_stage;    // LDS byte offset of the two operand stages (the tap table sits at 0)
   int stage_bytes;  // (BM + BN) * 128
+  int nstage;       // LDS stages of the operand pipeline (2..4): tile kt + nstage - 1 is requested while tile kt is multiplied
   int HoWo;
   unsigned abytes;  // bytes of the input view from its first channel to the end of the last image (descriptor range, < 2^31)
 };
@@ -134,6 +135,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     for (int j = 0; j < NB; j++)
       if (wave + 4 * j < NBP) ys_bufld_lds16(rsB, boff[j], (unsigned)kt * 128u, sb + BM * 128 + (wave + 4 * j) * 1024);
   };
+  constexpr int PER = NA + NBP / 4;           // requests per K-tile that EVERY wave issues (BN = 80: two waves issue one more; waiting for fewer is conservative)
 
   // fragment read offsets: row (16-row fragment base + li); bf16: unit (ks * 4 + q) ^ (li >> 1) of K-step ks; fp8: the lane's 32
   // bytes are units 2q and 2q + 1
@@ -166,7 +168,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       } else { aiy[j] = -(1 << 20); aix[j] = 0; abase[j] = 0; }
     }
     ys_barrier_lds();                         // the tap table is written; the previous tile's epilogue staging is consumed
-    issue(0, 0);
+    for (int p = 0; p < g.nstage - 1 && p < g.nkt; p++) issue(p, p);
     GTL_STAMP();
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -174,12 +176,18 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #pragma unroll
       for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
 
+    int stage_cur = 0, stage_next = (g.nstage - 1 < g.nkt ? g.nstage - 1 : g.nkt) % g.nstage;
 #pragma unroll 1
     for (int kt = 0; kt < g.nkt; kt++) {
-      YS_WAIT_VM0();                          // this wave's DMA pieces of tile kt have landed ...
-      ys_barrier_lds();                       // ... everybody's have, and everybody is done reading the other stage
-      if (kt + 1 < g.nkt) issue((kt + 1) & 1, kt + 1);
-      const char* sb = sStage + (kt & 1) * g.stage_bytes;
+      // this wave's DMA pieces of tile kt have landed: at most the requests of the `ahead` younger tiles are still in flight
+      {
+        const int left = g.nkt - 1 - kt, ahead = left < g.nstage - 2 ? left : g.nstage - 2;
+        if (ahead >= 2) ys_wait_vm<2 * PER>(); else if (ahead == 1) ys_wait_vm<PER>(); else YS_WAIT_VM0();
+      }
+      ys_barrier_lds();                       // ... everybody's have, and everybody is done reading tile kt - 1's stage, which is requested next
+      if (kt + g.nstage - 1 < g.nkt) { issue(stage_next, kt + g.nstage - 1); stage_next = stage_next + 1 == g.nstage ? 0 : stage_next + 1; }
+      const char* sb = sStage + stage_cur * g.stage_bytes;
+      stage_cur = stage_cur + 1 == g.nstage ? 0 : stage_cur + 1;
       if (GEMM_DBG(4)) continue;
       if (F8) {
         // 32-byte fragments: the pixel fragments stay live, the weight fragments come in two groups (all at once is 72 registers
@@ -315,14 +323,28 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   const size_t stage2 = (size_t)2 * g.stage_bytes;
   const size_t epi = (size_t)4 * (16 * p.mr * (p.nr * 16 + 8) * 2 + 16 * p.mr * 16);
   if (epi > stage2 || (size_t)16 * 256 * 4 > stage2) return p;
-  p.lds = g.off_stage + stage2;
-  if (p.lds > 160 * 1024) return p;
+  if (g.off_stage + stage2 > 160 * 1024) return p;
   p.gy = ys_cdiv(a.Cout, bn);
+  // Pipeline depth.  Two stages leave a request one K-tile of MFMA time (~500-1300 cycles) to land against ~1600 cycles of memory
+  // latency (s_memtime stamps, round 3: 1600-1750 cycles per K-tile whatever the tile): a second workgroup on the CU covers the gap
+  // when the grid has one; a launch with at most one workgroup per CU (the deep YOLOv8n layers at B = 64: 200 tiles) has nothing
+  // else to run and takes as many stages as the LDS holds instead.  YS_GEMM_STAGES forces a depth (A/B runs).
+  static const int force_st = getenv("YS_GEMM_STAGES") ? atoi(getenv("YS_GEMM_STAGES")) : 0;
+  g.nstage = 2;
+  {
+    int fit = (int)((160 * 1024 - (size_t)g.off_stage) / g.stage_bytes);
+    if (fit > 4) fit = 4;
+    if ((long)g.mtiles * p.gy <= 256 && g.nkt > 2) g.nstage = fit;
+    if (force_st >= 2 && force_st <= 4) g.nstage = force_st < fit ? force_st : fit;
+    if (g.nstage > g.nkt) g.nstage = g.nkt < 2 ? 2 : g.nkt;
+  }
+  p.lds = g.off_stage + (size_t)g.nstage * g.stage_bytes;
   const int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
   long gx = (256L * per_cu) / p.gy;
   gx &= ~7L;                                  // XCD-ordered tile walk needs a multiple of 8
   if (gx < 8) gx = 8;
   if (gx > g.mtiles) gx = g.mtiles;
+  if ((long)g.mtiles * p.gy <= 256) gx = g.mtiles;   // the whole launch fits the chip at one workgroup per CU: one tile each
   p.gx = (int)gx;
   p.g = g;
   p.ok = 1;

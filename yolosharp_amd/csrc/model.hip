@@ -1396,6 +1396,7 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
       WgRedDesc& d = m->red_host[c.red_slot];
       d.partial = a.partial; d.grad = m->grads + c.w_off; d.n = (long)c.cout * c.k * c.k * c.cin_pad; d.splits = used;
       d.cin_pad = c.cin_pad; d.cin_real = c.cin;
+      YS_REQUIRE((c.cin_pad & 3) == 0, "wgrad reduce: input channel pitch must be a multiple of 4");
     }
     if (m->overlap) {
       m->st2_dirty = true;
@@ -1494,7 +1495,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
     const int lo = m->red_first[seg_lo], hi = m->red_first[seg_hi + 1];
     if (hi > lo) {
       long blk = 0;
-      for (int i = lo; i < hi; i++) { m->red_host[i].blk0 = blk; blk += (m->red_host[i].n + 31) / 32; }
+      for (int i = lo; i < hi; i++) { m->red_host[i].blk0 = blk; blk += (m->red_host[i].n + YS_WGRED_OUT_PER_BLOCK - 1) / YS_WGRED_OUT_PER_BLOCK; }
       if (m->red_uploaded.size() != m->red_host.size()) m->red_uploaded.assign(m->red_host.size(), WgRedDesc{});
       if (memcmp(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc)) != 0) {   // first step / batch size changed
         YS_CHECK_HIP(hipMemcpyAsync(m->red_dev + lo, &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc), hipMemcpyHostToDevice, st));

@@ -29,6 +29,14 @@
 #else
 #define YS_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
+// s_waitcnt vmcnt(N), N <= 63 (gfx9 encoding: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt left at "no wait"):
+// at most N of this wave's vector-memory instructions still in flight -- loads and stores retire in issue order.
+template <int N> __device__ inline void ys_wait_vm() {
+#ifndef YS_EMU_BUILD
+  static_assert(N >= 0 && N <= 63, "vmcnt");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+#endif
+}
 
 // Scheduling fence: hipcc's machine scheduler otherwise sinks LDS reads next to their first use (fewer live registers), which
 // serialises every read's latency with the MFMAs; a fence keeps "issue all reads, then all MFMAs" as written.
