@@ -23,6 +23,9 @@
 //  * epilogue, statistics, bias / eval-BN / SiLU, residual and gradient accumulation: the shared wide-store stage (conv_epi.h).
 #include "conv_epi.h"
 #include <atomic>
+#ifndef YS_GEMM_READ_AHEAD
+#define YS_GEMM_READ_AHEAD 0   // measured (round 3, MI355X): no difference -- config 5 bf16 88.51 vs 88.57 ms/step, config 4 32.62 vs 32.71, config 2 10.24 vs 10.22; the K-tile is bound by LDS bytes (operand DMA + fragment reads ~220 KB per K-tile pair and CU), not by the exposed round trip
+#endif
 #include <cstdlib>
 
 // ablation switches for performance triage (YS_GEMM_DBG bits; compiled in only with -DYS_GEMM_ABLATE = `build.py ablate`):
@@ -214,6 +217,27 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
         }
         continue;
       }
+      constexpr bool AHEAD = YS_GEMM_READ_AHEAD && !(WM == 4 && NR == 5 && !RED);   // 256x80 forward: 36 more live registers spill
+      if constexpr (AHEAD) {
+      // both K-steps' fragments are requested before the first MFMA: the second step's LDS round trip runs under the first step's
+      // MFMAs (ds_reads return in order, the compiler waits with lgkmcnt(N)), one exposed round trip per K-tile instead of two
+      uint4 fw[2][NR], fx[2][MR];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int ko = ks ? koff1 : koff0;
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++) fw[ks][nf] = *(const uint4*)(sb + brow0 + nf * 2048 + ko);
+#pragma unroll
+        for (int mf = 0; mf < MR; mf++) fx[ks][mf] = *(const uint4*)(sb + arow0 + mf * 2048 + ko);
+      }
+      YS_SCHED_FENCE();
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int nf = 0; nf < NR; nf++)
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(fw[ks][nf], fx[ks][mf], acc[mf][nf]);
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         const int ko = ks ? koff1 : koff0;
@@ -227,6 +251,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
         for (int nf = 0; nf < NR; nf++)
 #pragma unroll
           for (int mf = 0; mf < MR; mf++) acc[mf][nf] = ys_mma<T>(fw[nf], fx[mf], acc[mf][nf]);
+      }
       }
     }
     ys_barrier_lds();                         // every wave finished reading the stages: they become the epilogue staging area
