@@ -1212,7 +1212,11 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
 #define P2(M_, N_) if (p.mr == M_ && p.nr == N_) { if (a.f8) P2F(M_, N_, 1, 0) else if (a.nred > 0 || (a.accumulate && YS_P2_EPI_DIRECT)) P2F(M_, N_, 0, 1) else P2F(M_, N_, 0, 0) }
     if (a.f8 && a.nred > 0) { ys_set_error("conv p2: the fused BN-backward reduction has no fp8 variant"); return YS_ERR_UNSUPPORTED; }
 #ifdef YS_P2_ONE          // compile-time triage: a single register tile (seconds instead of minutes per resource-usage experiment)
-    P2(1, 5)
+#ifndef YS_P2_ONE_M
+#define YS_P2_ONE_M 1
+#define YS_P2_ONE_N 5
+#endif
+    P2(YS_P2_ONE_M, YS_P2_ONE_N)
 #else
     P2(1, 1) P2(2, 1) P2(4, 1) P2(1, 2) P2(2, 2) P2(4, 2) P2(1, 3) P2(2, 3) P2(4, 3) P2(1, 4) P2(2, 4) P2(4, 4) P2(1, 5) P2(2, 5)
 #endif

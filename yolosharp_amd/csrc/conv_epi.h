@@ -252,9 +252,29 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 // the first is consumed.  RED = 0 (forward / eval form): bias, eval-BN, SiLU, residual, BN statistics (+ an in-loop accumulate for
 // the launches that have no RED variant).
 #ifndef YS_P2_EPI_DIRECT
-#define YS_P2_EPI_DIRECT 0     // measured (round 3, MI355X, config 2): direct 10.93 ms/step, staged 10.65 -- the 8-byte stores lose more at the CU's store-issue limit than the LDS round trip costs
+#define YS_P2_EPI_DIRECT 0     // measured (round 3, MI355X, config 2): staged 10.19-10.21 ms/step; direct with 8-byte stores 10.93 (against 10.65 then); direct with the 16-lane row swap (YS_EPI_SWAP16, 16-byte stores from registers) 10.58-10.60 -- the 4*NR-per-lane statistics and the masked selects cost the 168-register variants more (12-160 B of scratch) than the LDS round trip
+#endif
+#ifndef YS_EPI_SWAP16
+#define YS_EPI_SWAP16 1        // direct epilogue: fragment pairs trade 16-lane rows (v_permlane16_swap_b32) so that every lane stores 16 contiguous bytes
 #endif
 __device__ inline uint2 ys_ld8(const void* p) { return *(const uint2*)p; }
+// v_permlane16_swap_b32 (gfx950): the odd 16-lane rows of `a` trade places with the even rows of `b`:
+//   a' = [a.row0, b.row0, a.row2, b.row2],  b' = [a.row1, b.row1, a.row3, b.row3]      (probe: tools/dev/permlane_swap_probe.hip)
+// With a = lane (li, q)'s four packed channels 4q.. of fragment column n and b = the same of column n + 1, lane q = 0 ends up with
+// channels 0-7 of column n (its own four + q = 1's), q = 1 with channels 0-7 of column n + 1, q = 2 / 3 with channels 8-15: the 8-byte
+// pieces of the MFMA layout become 16-byte pieces of the NHWC row without LDS.
+__device__ inline void ys_row_swap(unsigned& a, unsigned& b) {
+#ifdef YS_EMU_BUILD
+  const int lane = threadIdx.x & 63;
+  const bool odd = (lane >> 4) & 1;
+  const unsigned pa = __shfl(a, lane ^ 16), pb = __shfl(b, lane ^ 16);
+  const unsigned na = odd ? pb : a, nb = odd ? b : pa;
+  a = na; b = nb;
+#else
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+#endif
+}
 __device__ inline void ys_unpack4_bf16(const uint2& v, float* f) {
   f[0] = ys_u2f(v.x << 16); f[1] = ys_u2f(v.x & 0xffff0000u); f[2] = ys_u2f(v.y << 16); f[3] = ys_u2f(v.y & 0xffff0000u);
 }
@@ -267,6 +287,18 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
 #pragma unroll
   for (int mf = 0; mf < MR; mf++)
     roff[mf] = pv[mf] ? ((unsigned)orow[mf] * (unsigned)a.out_ldc + (unsigned)a.out_coff) * 2u : YS_BUF_OOB;
+  // 16-byte stores of two 8-byte pieces A (even-q lanes keep it) and B (odd-q lanes keep it): after the row swap a lane holds 8
+  // consecutive channels starting at c8 = column base + (q >> 1) * 8 of ITS piece; rowE / rowO = byte offset of the pixel row the even /
+  // odd lanes write (YS_BUF_OOB = pixel outside), colE / colO = first channel of the fragment column of A / B.
+  const bool q_odd = (q & 1) != 0;
+  auto store_pair = [&](uint2 A, uint2 B, unsigned rowE, unsigned rowO, int colE, int colO) {
+    ys_row_swap(A.x, B.x);
+    ys_row_swap(A.y, B.y);
+    const unsigned row = q_odd ? rowO : rowE;
+    const int c8 = (q_odd ? colO : colE) + (q >> 1) * 8;
+    ys_bufst16(rsY, (row != YS_BUF_OOB && c8 < a.Cout && !EPI_DBG(256)) ? row + (unsigned)c8 * 2u : YS_BUF_OOB, make_uint4(A.x, A.y, B.x, B.y));
+  };
+  uint2 pkE[MR];                               // even fragment columns wait here for their odd neighbour
   if (RED) {
     // ---- backward form.  Operands of fragment column nf + 1 (old dz, the producer's y, its BN coefficients) are requested before
     // column nf is consumed: two batches of 4*MR + 8 registers in flight instead of every fragment's (which spilled), one exposed
@@ -324,7 +356,14 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
 #pragma unroll
           for (int r = 0; r < 4; r++) { const float du = ok ? g[r] : 0.f; s1[nf * 4 + r] += du; s2[nf * 4 + r] += ok ? du * yf[r] : 0.f; }
         }
-        ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+        if constexpr (!YS_EPI_SWAP16) ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+        else if constexpr ((nf & 1) == 0 && nf + 1 < NR) pkE[mf] = pk;
+        else if constexpr (nf & 1) store_pair(pkE[mf], pk, roff[mf], roff[mf], n0 + (nf - 1) * 16, n0 + nf * 16);
+        else {                                 // last, unpaired column: pixel rows mf / mf + 1 pair up instead
+          if ((mf & 1) == 0 && mf + 1 < MR) pkE[mf] = pk;
+          else if (mf & 1) store_pair(pkE[mf - 1], pk, roff[mf - 1], roff[mf], n0 + nf * 16, n0 + nf * 16);
+          else ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+        }
       }
     };
     uint2 oldA[MR], yA[MR], oldB[MR], yB[MR];
@@ -415,7 +454,14 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
           pk.x = ys_pack_bf16x2(f[0], f[1]); pk.y = ys_pack_bf16x2(f[2], f[3]);
         }
       }
-      ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+      if (!YS_EPI_SWAP16) ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+      else if ((nf & 1) == 0 && nf + 1 < NR) pkE[mf] = pk;
+      else if (nf & 1) store_pair(pkE[mf], pk, roff[mf], roff[mf], n0 + (nf - 1) * 16, n0 + nf * 16);
+      else {                                   // last, unpaired column: pixel rows mf / mf + 1 pair up instead
+        if ((mf & 1) == 0 && mf + 1 < MR) pkE[mf] = pk;
+        else if (mf & 1) store_pair(pkE[mf - 1], pk, roff[mf - 1], roff[mf], n0 + nf * 16, n0 + nf * 16);
+        else ys_bufst8(rsY, (ok && !EPI_DBG(256)) ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB, pk);
+      }
     }
   }
   stamp(); stamp(); stamp();
