@@ -752,11 +752,16 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     YS_WAIT_VM0();                            // (without it -- the epilogue's stores are unconditional now -- the class is 3 % slower: 5.10 -> 5.25 ms)
     if (tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
 
+    // resident weights: the accumulators start as the first K-step's products (MFMA with a zero C operand -- an inline constant, no
+    // registers cleared: 4 * MR * NR v_mov per tile in a kernel whose busiest pipe is the VALU); streamed weights enter the K loop
+    // once per weight group and keep the cleared accumulators
     f32x4 acc[MR][NR];
+    if (!WRES) {
 #pragma unroll
-    for (int mf = 0; mf < MR; mf++)
+      for (int mf = 0; mf < MR; mf++)
 #pragma unroll
-      for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+        for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+    }
 
     // ---- K loop in register groups of G K-steps.  The one-step-at-a-time form (table read -> wait -> operand reads -> wait ->
     // MFMAs) cost ~350 cycles per K-step whatever the number of MFMAs in it (s_memtime stamps: 90-180 cycles per MFMA against 16
@@ -775,11 +780,19 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     // ng register groups starting at table step sbase, weight units from 0 in wbuf
     auto kloop = [&](const uint4* wbuf, int sbase, int ng, auto bf8_tag) {
       constexpr int B_BF8 = decltype(bf8_tag)::value;
-      if (P2_DBG(2)) return;
+      if (P2_DBG(2)) {                          // ablation build only: no K loop, defined accumulators
+        if (WRES) {
+#pragma unroll
+          for (int mf = 0; mf < MR; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
+        }
+        return;
+      }
       int off[G];
       read_offs(off, sbase);
-#pragma unroll 1
-      for (int gi = 0; gi < ng; gi++) {
+      auto group = [&](const int gi, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value != 0;   // the tile's first group: C = 0 for its first K-step
         Frags f;
 #pragma unroll
         for (int gs = 0; gs < G; gs++) {
@@ -800,10 +813,15 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
           for (int nf = 0; nf < NR; nf++)
 #pragma unroll
             for (int mf = 0; mf < MR; mf++) {
-              if (F8) acc[mf][nf] = mfma_scale_16x16x128_f8<B_BF8>(f.w[gs][nf][0], f.w[gs][nf][FU - 1], f.x[gs][mf][0], f.x[gs][mf][FU - 1], acc[mf][nf]);
-              else acc[mf][nf] = ys_mma<T>(f.w[gs][nf][0], f.x[gs][mf][0], acc[mf][nf]);
+              const f32x4 c0 = (FIRST && gs == 0) ? f32x4_zero() : acc[mf][nf];
+              if (F8) acc[mf][nf] = mfma_scale_16x16x128_f8<B_BF8>(f.w[gs][nf][0], f.w[gs][nf][FU - 1], f.x[gs][mf][0], f.x[gs][mf][FU - 1], c0);
+              else acc[mf][nf] = ys_mma<T>(f.w[gs][nf][0], f.x[gs][mf][0], c0);
             }
-      }
+      };
+      int gi0 = 0;
+      if (WRES) { group(0, P2Tag1{}); gi0 = 1; }
+#pragma unroll 1
+      for (int gi = gi0; gi < ng; gi++) group(gi, P2Tag0{});
     };
     const bool in_bf8 = F8 && a.f8 == 2;      // uniform: the input operand is a gradient quantised to e5m2
     if (WRES) {

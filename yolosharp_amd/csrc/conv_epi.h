@@ -122,9 +122,12 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 #pragma unroll
           for (int r = 0; r < 4; r++) v[r] = ys_silu(v[r]);
         }
-      }
+        // padded channels of the output row stay zero.  Only the bias can make them anything else: the weight rows past Cout reach
+        // LDS as zeros (out-of-range DMA / masked fetch), so their accumulators ARE zero -- the four selects per fragment (and the
+        // SGPR pairs holding their lane masks) are not part of the BatchNorm / gradient launches
 #pragma unroll
-      for (int r = 0; r < 4; r++) if (c + r >= a.Cout) v[r] = 0.f;   // padded channels of the output row stay zero
+        for (int r = 0; r < 4; r++) if (c + r >= a.Cout) v[r] = 0.f;
+      }
       uint2 pk;
       pk.x = ys_pack_bf16x2(v[0], v[1]);
       pk.y = ys_pack_bf16x2(v[2], v[3]);
