@@ -485,6 +485,9 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 //  * 256 threads, <= 128 VGPRs: register pressure no longer caps occupancy.
 // Handles forward (stride 1 and 2) and stride-1 dgrad (same gather, flipped weights); DIV = 2 dgrads stay on the old path.
 #include "conv_epi.h"
+#ifndef YS_EPI_BATCH_P2
+#define YS_EPI_BATCH_P2(NPU_) ((NPU_) <= 6 ? 2 : 4)
+#endif
 
 // ablation switches (YS_DBG bits) cost scalar checks in the hot loops: compiled in only for triage builds (-DYS_P2_ABLATE)
 #ifdef YS_P2_ABLATE
@@ -869,9 +872,9 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #endif
 #else
 #ifdef YS_P2_TIMELINE
-    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, (NPU <= 6 ? 2 : 4)>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); });
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_P2(NPU)>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); });
 #else
-    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, (NPU <= 6 ? 2 : 4)>(a, acc, orow, pv, n0, stg, st1, st2);
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_P2(NPU)>(a, acc, orow, pv, n0, stg, st1, st2);
 #endif
 #endif
     TL_STAMP();

@@ -56,7 +56,7 @@ __device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long 
 // a dgrad launch never carries them), compiled as its own kernel variants so that the forward kernels' register allocation is
 // untouched by the reduction's live values (y vectors, coefficients).
 struct YsNoStamp { __device__ inline void operator()() const {} };   // timeline hook of triage builds (-DYS_P2_TIMELINE): nothing in the product
-template <int MR, int NR, int RED = 0, int BMAX = 4, class SF = YsNoStamp>
+template <int MR, int NR, int RED = 0, int BMAX = 4 /* unused: batch depth of the reverted batched store loop */, class SF = YsNoStamp>
 __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
                                    int n0, char* stg, float (&s1)[8], float (&s2)[8], SF stamp = SF()) {
   typedef bf16_t T;
@@ -135,7 +135,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     }
   }
   stamp();
-  ys_wave_sync();
+  ys_wave_sync_lds();                          // the staged rows (written by other lanes of this wave) are IN LDS before the reads below are issued
   stamp();
   const bool do_stats = !RED && a.stats != nullptr && !EPI_DBG(512);
   // eval-mode BatchNorm folded into the conv (Convs.cs:48 with running statistics): applied on the wide path to the
@@ -155,87 +155,77 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   // NITER times per tile -- a static count the compiler can keep in flight (vmcnt(N)) across the next tile's loads instead of the
   // vmcnt(0) that exec-masked stores forced.  Valid offsets are < 2^31 (checked by the launch plans).
   const ys_rsrcv_t rsY = ys_make_rsrcv(yb, 0x7ffffff0u);
-  // The store loop runs in batches of up to four iterations with every memory read of a batch issued before its first use: the row
-  // offsets and the staged vectors (LDS addresses that do not depend on each other -- a lane without a pixel reads slot 0 and
-  // discards it), then, for accumulating launches, the old gradient vectors through the output descriptor (out-of-range offset =
-  // zeros, no exec-masked load).  The one-iteration-at-a-time form was a chain of two dependent LDS round trips (plus one HBM round
-  // trip when accumulating) PER iteration, against an LDS that the CU's other workgroups keep busy with their K loops: s_memtime
-  // stamps put the epilogue of a 128x128 blocked-GEMM tile at 7.6-9.7 thousand cycles of a 22 thousand cycle workgroup (round 3).
-  constexpr int BATCH = NITER < BMAX ? NITER : BMAX;   // BMAX: 2 in the small-patch (NPU = 6) variants of conv_p2_kernel, whose register budget buys a third wave per SIMD
-  auto finish = [&](const int it, const unsigned rofs, uint4 val, const uint4& old) {
+  // One iteration at a time: row offset, then the staged vector, then the store.  (Round 3 tried batches of up to four iterations with
+  // all LDS reads -- and the accumulate operand -- issued up front: 0.3 % faster on config 2, but the blocked-GEMM kernel's BatchNorm sums
+  // then differed from run to run on wide layers (cin400 -> cout160 1x1 at 320x320: one pixel's vectors in ~10^6 read stale, element 1 / 3 / 5
+  // of every vector of that pixel; caught by tests/test_configs.py::test_c5_v8x_1280_bs16_fp8_train_steps, reproducer
+  // tools/dev/determinism_layer.py).  A wait between the staging writes and the reads removed one instance, a full wait plus idle
+  // cycles after the reads lowered the rate of the other but did not remove it -- reverted to this form, which the row-table
+  // dependency serialises: every read is consumed before the next is issued.)
+  auto store_iter = [&](const int it) {
     const int px = it * PPI + pl;
-    if (rofs != YS_BUF_OOB) {
-      float f[8];
-      ys_unpack<T>(val, f);
-      if (do_stats) {
+    const bool lane_ok = active && px < NPX && c < a.Cout;
+    const unsigned rofs = lane_ok ? rowtab[px] : YS_BUF_OOB;
+    uint4 val = ys_zero16();
+    {
+      if (rofs != YS_BUF_OOB) {
+        val = *(const uint4*)(stg + px * PITCH + cv * 16);
+        float f[8];
+        ys_unpack<T>(val, f);
+        if (do_stats) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
-      }
-      if (bn_eval) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) f[e] = f[e] * sc[e] + sh[e];
-        if (a.act) {                        // one uniform branch around the unrolled loop, not one per element
-#pragma unroll
-          for (int e = 0; e < 8; e++) f[e] = ys_silu(f[e]);
+          for (int e = 0; e < 8; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
         }
+        if (bn_eval) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) if (c + e >= a.Cout) f[e] = 0.f;
-        if (!(rb || a.accumulate)) val = ys_pack<T>(f);
-      }
-      if (rb || a.accumulate) {
-        float gq[8];
-        if (rb) {
-          const long row = (long)rowtab[NPX + px];                              // eval-only path (Bottleneck shortcut)
-          ys_unpack<T>(ys_ld16(rb + (row * a.res_ldc + a.res_coff + c) * 2L), gq);
+          for (int e = 0; e < 8; e++) f[e] = f[e] * sc[e] + sh[e];
+          if (a.act) {                        // one uniform branch around the unrolled loop, not one per element
 #pragma unroll
-          for (int e = 0; e < 8; e++) f[e] += gq[e];
+            for (int e = 0; e < 8; e++) f[e] = ys_silu(f[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) if (c + e >= a.Cout) f[e] = 0.f;
+          if (!(rb || a.accumulate)) val = ys_pack<T>(f);
         }
-        if (a.accumulate) {
-          ys_unpack<T>(old, gq);
+        T* yp = (T*)(yb + rofs + c * 2);
+        if (rb || a.accumulate) {
+          float gq[8];
+          if (rb) {
+            const long row = (long)rowtab[NPX + px];                              // eval-only path (Bottleneck shortcut)
+            ys_unpack<T>(ys_ld16(rb + (row * a.res_ldc + a.res_coff + c) * 2L), gq);
 #pragma unroll
-          for (int e = 0; e < 8; e++) f[e] += gq[e];
+            for (int e = 0; e < 8; e++) f[e] += gq[e];
+          }
+          if (a.accumulate) {
+            ys_unpack<T>(ys_ld16(yp), gq);
+#pragma unroll
+            for (int e = 0; e < 8; e++) f[e] += gq[e];
+          }
+          val = ys_pack<T>(f);
         }
-        val = ys_pack<T>(f);
-      }
-      if (RED && red_on && ry && !EPI_DBG(512)) {
-        // dz as every later reader sees it (bf16-rounded, all contributions in), against the producer's raw output y
-        float g[8], yf[8];
-        ys_unpack<T>(val, g);
-        ys_unpack<T>(yv[RED ? it : 0], yf);
-        if (ract) {
+        if (RED && red_on && ry && !EPI_DBG(512)) {
+          // dz as every later reader sees it (bf16-rounded, all contributions in), against the producer's raw output y
+          float g[8], yf[8];
+          ys_unpack<T>(val, g);
+          ys_unpack<T>(yv[RED ? it : 0], yf);
+          if (ract) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) g[e] *= ys_silu_grad(yf[e] * rsc[e] + rsh[e]);
+            for (int e = 0; e < 8; e++) g[e] *= ys_silu_grad(yf[e] * rsc[e] + rsh[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) { s1[e] += g[e]; s2[e] += g[e] * yf[e]; }
         }
-#pragma unroll
-        for (int e = 0; e < 8; e++) { s1[e] += g[e]; s2[e] += g[e] * yf[e]; }
       }
     }
     ys_bufst16(rsY, (rofs != YS_BUF_OOB && !EPI_DBG(256)) ? rofs + (unsigned)c * 2u : YS_BUF_OOB, val);
   };
   if (EPI_DBG(1024)) { ys_wave_sync(); return; }
-#pragma unroll                                // fully: the batch arrays (and yv[it]) must be registers, not indexed (scratch) arrays
-  for (int it0 = 0; it0 < NITER; it0 += BATCH) {
-    unsigned rofs[BATCH];
-    uint4 val[BATCH], old[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; j++) {
-      const int px = (it0 + j) * PPI + pl;
-      const bool lane_ok = active && px < NPX && c < a.Cout && it0 + j < NITER;
-      const int pxs = px < NPX ? px : 0;
-      const unsigned r = rowtab[pxs];
-      val[j] = *(const uint4*)(stg + pxs * PITCH + cv * 16);
-      rofs[j] = lane_ok ? r : YS_BUF_OOB;
-    }
-    if (a.accumulate) {
-#pragma unroll
-      for (int j = 0; j < BATCH; j++) old[j] = ys_bufld16(rsY, rofs[j] != YS_BUF_OOB ? rofs[j] + (unsigned)c * 2u : YS_BUF_OOB);
-    } else {
-#pragma unroll
-      for (int j = 0; j < BATCH; j++) old[j] = ys_zero16();
-    }
-#pragma unroll
-    for (int j = 0; j < BATCH; j++)
-      if (it0 + j < NITER) finish(it0 + j, rofs[j], val[j], old[j]);
+  if (RED) {
+#pragma unroll                                // fully: yv[it] must be a register, not an indexed (scratch) array
+    for (int it = 0; it < NITER; it++) store_iter(it);
+  } else {
+#pragma unroll 2
+    for (int it = 0; it < NITER; it++) store_iter(it);
   }
   stamp();
   ys_wave_sync();

@@ -23,6 +23,9 @@
 //  * epilogue, statistics, bias / eval-BN / SiLU, residual and gradient accumulation: the shared wide-store stage (conv_epi.h).
 #include "conv_epi.h"
 #include <atomic>
+#ifndef YS_EPI_BATCH_GEMM
+#define YS_EPI_BATCH_GEMM 4
+#endif
 #ifndef YS_GEMM_READ_AHEAD
 #define YS_GEMM_READ_AHEAD 0   // measured (round 3, MI355X): no difference -- config 5 bf16 88.51 vs 88.57 ms/step, config 4 32.62 vs 32.71, config 2 10.24 vs 10.22; the K-tile is bound by LDS bytes (operand DMA + fragment reads ~220 KB per K-tile pair and CU), not by the exposed round trip
 #endif
@@ -282,7 +285,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
     (void)stg;
     if (!GEMM_DBG(8)) p2_epilogue_direct<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, st1, st2);
 #else
-    if (!GEMM_DBG(8)) p2_epilogue<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
+    if (!GEMM_DBG(8)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_GEMM>(a, acc, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
 #endif
     GTL_STAMP();
   }

@@ -51,6 +51,7 @@ struct ConvL {
   bool dw = false;       // depthwise 3x3 (groups = channels): weights [9][C] fp32, no MFMA path
   bool f8_fwd = false, f8_bwd = false;   // fp8 mode: forward / dgrad of this layer may run the fp8 kernel (f8.hip recipe)
   int idx = -1, prep_idx = -1;           // own index in ys_model::convs; first PrepDesc (weight-amax slot)
+  int lane = 0;          // Detect / Segment / Pose / OBB towers of pyramid level 1 (P4) and 2 (P5): side stream lane (ys_model::lane_st), 0 = main stream
   long wgp_off = -1; int wgp_splits = 0; // own region of the weight-gradient partial workspace (floats) and the splits it holds; -1 = shared scratch + immediate reduce
   int red_slot = -1;                     // index into ys_model::red_host (deferred split reduction)
   bool ct = false;       // ConvTranspose2d(k=2,s=2,bias) = four 1x1 phase GEMMs (Proto.upsample, Block.cs:69); weights [4][Cout][Cin]
@@ -134,6 +135,12 @@ struct ys_model {
   // weight gradients run on a second stream, concurrently with the BN-backward / dgrad chain of the following layers
   // (both mostly latency-bound); dy lives in a ring of DY_RING buffers guarded by events
   static constexpr int DY_RING = 4;
+  // head lanes (round 3): the towers of the three pyramid levels are independent chains (own buffers, own rows of the prediction buffers);
+  // the P4 / P5 chains are short, latency-bound launches (100-400 workgroups) that run beside the P3 chain on two side streams
+  static const int NLANE = 2;
+  hipStream_t lane_st[NLANE] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_lane[NLANE] = {nullptr, nullptr};
+  float* stat_lane[NLANE] = {nullptr, nullptr};   // each lane's own BN-statistics partial rows (conv -> finalize scratch)
+  bool head_lanes = false;
   bool overlap = false, overlap_built = false; hipStream_t st2 = nullptr;   // overlap_built: second stream / dy ring exist; overlap: in use (ys_model_set_overlap)
   void* dy_ring[DY_RING] = {nullptr}; hipEvent_t ev_dy[DY_RING + 1] = {nullptr}, ev_free[DY_RING] = {nullptr}, ev_join = nullptr;
   bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
@@ -354,6 +361,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
   m->ld_ps = (d.nc + m->epl - 1) / m->epl * m->epl;
   m->pd_buf = new_buf(m, 1, m->A, m->ld_pd);
   m->ps_buf = new_buf(m, 1, m->A, m->ld_ps);
+  size_t lane_first = m->convs.size();
   for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
     for (int i = 0; i < 3; i++) {
       const int cm = t == 0 ? c2 : c3;
@@ -373,6 +381,8 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       }
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, cm}, View{ob, 0, co}, cm, co, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
+      if (legacy) for (size_t k = lane_first; k < m->convs.size(); k++) m->convs[k].lane = i;   // level 0 (P3) stays on the main stream; v11 towers hold depthwise units (own launch path): no lanes
+      lane_first = m->convs.size();
     }
   }
   m->dfl_after_conv = m->reg.back();
@@ -394,6 +404,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       add_conv_reg(m, tp + ".1", View{t0, 0, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4}, View{m->mc_buf, 0, nm}, c4, nm, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
+      if (legacy) for (int k = cc - 2; k <= cc; k++) m->convs[k].lane = i;
     }
     m->xkind = 1;
   } else if (d.task == YS_OBB || d.task == YS_POSE) {
@@ -417,6 +428,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       m->convs[k0].cout_real = m->convs[k1].cout_real = c4;
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4p}, View{m->mc_buf, 0, nx}, c4, nx, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
+      if (legacy) for (int k = k0; k <= cc; k++) m->convs[k].lane = i;
     }
   }
   return YS_OK;
@@ -861,6 +873,23 @@ int allocate(ys_model* m) {
   }
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
   YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4));
+  // off by default: measured (round 3, config 2) 10.52-10.55 ms/step with the lanes against 9.98-10.01 without (round 2's variant of the
+  // same experiment: -5.7 %).  The P3 chain's kernels are persistent grids sized to own every CU (2-3 workgroups per CU by LDS); a
+  // side-stream kernel that takes some of those slots turns the big kernel's equal tile shares into a tail.  YS_HEAD_LANES=1 enables it.
+  m->head_lanes = m->overlap_built && getenv("YS_HEAD_LANES") && atoi(getenv("YS_HEAD_LANES")) != 0;
+  if (m->head_lanes) {
+    bool any = false;
+    for (auto& c : m->convs) any = any || c.lane > 0;
+    m->head_lanes = any;
+  }
+  if (m->head_lanes) {
+    YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    for (int l = 0; l < ys_model::NLANE; l++) {
+      YS_CHECK_HIP(hipStreamCreateWithFlags(&m->lane_st[l], hipStreamNonBlocking));
+      YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_lane[l], hipEventDisableTiming));
+      YS_TRY(dev_alloc(m, (void**)&m->stat_lane[l], (size_t)stat_max * 4));
+    }
+  }
   YS_TRY(dev_alloc(m, (void**)&m->argmax, (size_t)amax));
   // wgrad partial workspace: a shared scratch (max over layers of splits * |W|: ConvTranspose phases, immediate reduction) followed by
   // one region per convolution, so that the split reduction of a whole backward segment can run as ONE launch after it
@@ -990,10 +1019,12 @@ static ConvArgs fwd_args(ys_model* m, const ConvL& c, int B) {
 }
 
 // `next`: the convolution that runs right after this one, when it reads exactly the view this one writes (else null)
-int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr) {
+// `lane_st` / `lane_stat`: side stream and statistics scratch of a head lane (forward_impl), null = the context's stream
+int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr, hipStream_t lane_st = nullptr, float* lane_stat = nullptr) {
   if (c.dw) return run_dwconv_fwd(m, c, B);
   if (c.ct) return run_convT_fwd(m, c, B);
-  hipStream_t st = m->ctx->stream;
+  hipStream_t st = lane_st ? lane_st : m->ctx->stream;
+  float* stat_partial = lane_stat ? lane_stat : m->stat_partial;
   const Buf& ib = m->bufs[c.in.buf];
   const Buf& ob = m->bufs[c.out.buf];
   ConvArgs a = fwd_args(m, c, B);
@@ -1013,10 +1044,10 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
   if (c.bn && m->training) {
     void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
-    a.stats = m->stat_partial;
+    a.stats = stat_partial;
     YS_TRY(ys_conv_launch(st, m->dtype, a));
     const int gm = ys_conv_grid_m(a, m->dtype);
-    YS_TRY(ys_bn_finalize_launch(st, m->stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
+    YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
                                  m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
                                  chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
     const void* res = nullptr; int rl = 0, rc = 0;
@@ -1064,6 +1095,9 @@ int forward_impl(ys_model* m, int B) {
     m->eval_coeffs_dirty = false;
   }
   m->q8_fwd_ready = -1;
+  // head lanes: training forward in bf16 / f32 storage with the overlap switch on (bench.py's per-kernel profile steps switch it off)
+  const bool lanes_on = m->head_lanes && m->overlap && m->training && !m->f8;
+  bool forked = false;
   for (size_t oi = 0; oi < m->ops.size(); oi++) {
     const Op& op = m->ops[oi];
     const Buf& ib = m->bufs[op.in.buf];
@@ -1076,7 +1110,16 @@ int forward_impl(ys_model* m, int B) {
         if (nc.in.buf == cc.out.buf && nc.in.coff == cc.out.coff && nc.in.C == cc.out.C && nc.cin_pad == cc.cout && nc.cin == cc.cout &&
             nc.Hin == cc.Hout && nc.Win == cc.Wout) next = &nc;
       }
-      YS_TRY(run_conv_fwd(m, cc, B, next));
+      if (lanes_on && cc.lane > 0 && !cc.dw && !cc.ct) {
+        if (!forked) {                           // everything the towers read (the neck outputs) is complete on the main stream here
+          YS_CHECK_HIP(hipEventRecord(m->ev_fork, st));
+          for (int l = 0; l < ys_model::NLANE; l++) YS_CHECK_HIP(hipStreamWaitEvent(m->lane_st[l], m->ev_fork, 0));
+          forked = true;
+        }
+        YS_TRY(run_conv_fwd(m, cc, B, nullptr, m->lane_st[cc.lane - 1], m->stat_lane[cc.lane - 1]));
+      } else {
+        YS_TRY(run_conv_fwd(m, cc, B, next));
+      }
     } else if (op.type == OP_MAXPOOL) {
       YS_TRY(ys_maxpool5_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc,
                                     op.out.coff, m->training ? m->argmax + op.aux_off : nullptr));
@@ -1088,6 +1131,12 @@ int forward_impl(ys_model* m, int B) {
       YS_TRY(ys_attn_v_copy_launch(st, m->dtype, ib.act, ob.act, (long)B * op.H * op.W, ib.ldc, op.heads, op.kd, op.hd, ob.ldc, 0));
     } else if (op.type == OP_COPY) {
       YS_TRY(ys_copy_view_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, (long)B * op.H * op.W, op.in.C, ob.act, ob.ldc, op.out.coff, 0));
+    }
+  }
+  if (forked) {                            // join: the loss / decode read every level's rows
+    for (int l = 0; l < ys_model::NLANE; l++) {
+      YS_CHECK_HIP(hipEventRecord(m->ev_lane[l], m->lane_st[l]));
+      YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_lane[l], 0));
     }
   }
   if (m->f8) m->f8_sx_valid = true;        // every fp8 candidate has recorded an input maximum (bootstrap pass or its own kernel)
@@ -1580,6 +1629,11 @@ int ys_model_destroy(ys_model* m) {
     if (m->ev_join) hipEventDestroy(m->ev_join);
     hipStreamDestroy(m->st2);
   }
+  for (int l = 0; l < ys_model::NLANE; l++) {
+    if (m->lane_st[l]) { hipStreamSynchronize(m->lane_st[l]); hipStreamDestroy(m->lane_st[l]); }
+    if (m->ev_lane[l]) hipEventDestroy(m->ev_lane[l]);
+  }
+  if (m->ev_fork) hipEventDestroy(m->ev_fork);
   for (void* p : m->allocs) hipFree(p);
   delete m;
   return YS_OK;

@@ -435,6 +435,18 @@ __device__ inline void ys_wave_sync() {
 #endif
 }
 
+// The same ordering point WITH a wait for the wave's outstanding LDS operations: a row staged by ds_write and read back by OTHER
+// lanes of the wave.  Round 3: without the wait (reads issued right behind the writes) the blocked-GEMM kernel's BatchNorm sums
+// differed from run to run on wide layers (cin800 -> cout320 1x1: every rerun; one stale 16-byte vector in ~10^6) -- a bank-
+// conflicted ds_write_b64 had not finished all of its passes when the ds_read_b128 of another lane's row went through.  The
+// one-iteration-at-a-time epilogue had an s_waitcnt lgkmcnt(0) there by accident (the row-table value was consumed first).
+__device__ inline void ys_wave_sync_lds() {
+#ifndef YS_EMU_BUILD
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  ys_wave_sync();
+}
+
 // ---------------------------------------------------------------- LDS transpose read (gfx950 ds_read_b64_tr_b16)
 // Every lane passes the LDS address of 4 contiguous 16-bit elements (8-byte aligned).  Within each 16-lane group the
 // lanes' 16 addresses describe a [4 rows][16 cols] block (lane 4*row + col/4 holds cols 4*(col/4)..+3 of its row; the row
@@ -479,6 +491,15 @@ __device__ inline void ys_lds_tr_wait(uint2& a, uint2& b) {
 // on gfx9-family parts), which would stall on the next tile's global prefetch at every barrier; this one waits for the
 // wave's own LDS operations and leaves global loads in flight.  Use only where no global data is exchanged inside the
 // workgroup across the barrier.
+// s_waitcnt lgkmcnt(0): every LDS (and scalar-memory) operation of this wave has completed.  the anchors tie the wait to the values the
+// reads produce, so that the compiler can move neither the reads below it nor their uses above it.
+__device__ inline void ys_wait_lds_all(uint4& anchor, unsigned& anchor2) {
+#ifndef YS_EMU_BUILD
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(anchor.x), "+v"(anchor.y), "+v"(anchor.z), "+v"(anchor.w), "+v"(anchor2) : : "memory");
+#else
+  (void)anchor; (void)anchor2;
+#endif
+}
 __device__ inline void ys_barrier_lds() {
 #ifdef YS_EMU_BUILD
   __syncthreads();
