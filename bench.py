@@ -144,6 +144,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("YS_BENCH_NO_PG_BARRIER") != "1":   # (triage switch)
+            dist.barrier()   # the communicator (its streams and buffers) exists before the engine creates its own streams: without it the
+                             # engine's two streams ended up serialised (11.6 instead of 10.3 ms/step at one rank)
 
     from yolosharp_amd import Engine
     from yolosharp_amd.model import Yolov8, Yolov11, Yolov8Segment, Yolov11Segment, v8DetectionLoss, v8SegmentationLoss
@@ -152,7 +155,13 @@ def main():
     from yolosharp_amd.workload import step_work
 
     nc, H, W, B = {"obb": 15, "pose": 1}.get(args.task, 80), args.imgsz, args.imgsz, args.batch   # DOTA-15 / COCO-person class counts
-    stream = torch.cuda.current_stream(dev).cuda_stream if distributed else None
+    stream = None
+    if distributed:
+        # a stream of its own (not the legacy default stream, whose implicit synchronisation with every blocking stream serialises the
+        # engine's side streams): torch's current stream for the whole run, so RCCL collectives order against the engine's kernels
+        if os.environ.get("YS_BENCH_NULL_STREAM") != "1":
+            torch.cuda.set_stream(torch.cuda.Stream(dev))
+        stream = torch.cuda.current_stream(dev).cuda_stream
     eng = Engine(local_rank, stream=stream, lib_path=args.lib or None)   # N>1: run on torch's stream so RCCL orders against our kernels
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
         raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
@@ -184,7 +193,7 @@ def main():
     sync = None
     if distributed:
         flat = ysd.device_view(gptr.value, gn, dev)
-        sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())])
+        sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())], model=model)
 
     def local_step():
         model.forward_device(d_img, B)

@@ -173,6 +173,14 @@ YS_API int ys_model_backward(ys_model* m);
  * RCCL all-reduce of a finished gradient bucket while later segments still run. */
 YS_API int ys_model_backward_segments(ys_model* m);
 YS_API int ys_model_backward_segment(ys_model* m, int seg);
+/* The same segment WITHOUT ordering the context stream behind the weight-gradient stream when it ends (ys_model_backward_segment
+ * waits there, which stalls the next segment's kernels for the weight gradients still queued -- measured 1.1 ms of an 11.4 ms
+ * data-parallel step on one MI355X).  The segment's gradients are complete once ys_model_segment_fence's events have fired:
+ * ys_model_segment_fence(m, seg, stream) makes `stream` (a hipStream_t, e.g. the stream the all-reduce is issued on) wait for them.
+ * ys_optim_adamw_step, ys_model_zero_grad, ys_model_get_grad and the next forward order the context stream behind the
+ * weight-gradient stream themselves.  No reference counterpart (single-device autograd, Amp.cs:348). */
+YS_API int ys_model_backward_segment_async(ys_model* m, int seg);
+YS_API int ys_model_segment_fence(ys_model* m, int seg, void* stream);
 /* [offset,count) (in floats) of the flat gradient buffer completed by segment `seg`. */
 YS_API int ys_model_segment_grad_range(ys_model* m, int seg, int64_t* offset, int64_t* count);
 YS_API int ys_model_zero_grad(ys_model* m);

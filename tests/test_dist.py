@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from conftest import BACKENDS
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -245,6 +247,43 @@ def test_segment_ranges_cover_flat_buffer(emu_lib_path):
         assert o1 + c1 == o2
     assert len(ranges) == 4 and ranges[-1][1] * 4 <= n and ranges[-1][1] == min(c for _, c in ranges), ranges
     m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_async_segment_ends_give_the_same_gradients(backend, engine):
+    """ys_model_backward_segment_async + ys_model_segment_fence (a segment ends without the main stream waiting for the
+    weight-gradient stream; the consumer waits on the segment's events) against the synchronous segments and the one-call
+    backward: identical gradients and, after AdamW (which orders itself behind the weight-gradient stream), identical weights."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    from oracle import yolo_oracle as O
+    B, H, W, nc = 2, 64, 64, 6
+    x = np.random.default_rng(5).random((B, 3, H, W), dtype=np.float32)
+    nb = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=6).items()}
+    res = {}
+    for mode in ("whole", "sync", "async"):
+        m = Yolov8(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="bf16")
+        m.init_weights(3); m.train()
+        crit = v8DetectionLoss(m)
+        for it in range(2):
+            m.zero_grad()
+            m.forward(x, fetch=False); crit(None, nb)
+            if mode == "whole":
+                m.backward()
+            else:
+                for seg in range(m.num_segments()):
+                    if mode == "async":
+                        m.backward_segment_async(seg); m.segment_fence(seg, 0)     # stream 0: the fence itself is what is exercised
+                    else:
+                        m.backward_segment(seg)
+            grads = {k: v.copy() for k, v in m.grads().items()}                      # get_grad orders itself behind the weight-gradient stream
+            m.adamw_step([1e-3] * 3)
+        res[mode] = (grads, {k: np.array(v, copy=True) for k, v in m.state_dict().items()})
+        m.close()
+    for mode in ("sync", "async"):
+        for k in res["whole"][0]:
+            assert np.array_equal(res["whole"][0][k], res[mode][0][k]), (mode, k)
+        for k in res["whole"][1]:
+            assert np.array_equal(res["whole"][1][k], res[mode][1][k]), (mode, k)
 
 
 def test_c_abi_dist_needs_device_build():

@@ -260,6 +260,8 @@ hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = 0);
 hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned);
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int);
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "ys_model_backward": (C.c_int, [C.c_void_p]),
     "ys_model_backward_segments": (C.c_int, [C.c_void_p]),
     "ys_model_backward_segment": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_model_backward_segment_async": (C.c_int, [C.c_void_p, C.c_int]),
+    "ys_model_segment_fence": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ys_model_segment_grad_range": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_i64_p]),
     "ys_model_zero_grad": (C.c_int, [C.c_void_p]),
     "ys_model_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),

@@ -133,6 +133,7 @@ int ys_dist_allreduce_grads(ys_model* m, int seg) {
   YS_CHECK_HIP(hipSetDevice(ctx->device));
   YS_CHECK_HIP(hipEventRecord(ctx->dist_ready, ctx->stream));
   YS_CHECK_HIP(hipStreamWaitEvent(ctx->dist_stream, ctx->dist_ready, 0));
+  if (seg >= 0) YS_TRY(ys_model_segment_fence(m, seg, (void*)ctx->dist_stream));   // a segment ended asynchronously: its weight-gradient stream as well
   YS_CHECK_NCCL(g_rccl.AllReduce(g + off, g + off, (size_t)cnt, ncclFloat32, ncclSum, (ncclComm_t)ctx->dist_comm, ctx->dist_stream));
   ctx->dist_pending = true;
   return YS_OK;
@@ -159,7 +160,7 @@ int ys_model_backward_allreduce(ys_model* m) {
   YS_REQUIRE(m, "ys_model_backward_allreduce: null model");
   const int nseg = ys_model_backward_segments(m);
   for (int s = 0; s < nseg; s++) {
-    YS_TRY(ys_model_backward_segment(m, s));
+    YS_TRY(ys_model_backward_segment_async(m, s));   // the engine stream does not wait for the weight-gradient stream at the boundary
     YS_TRY(ys_dist_allreduce_grads(m, s));
   }
   return ys_dist_wait(m);

@@ -141,6 +141,10 @@ struct ys_model {
   hipStream_t lane_st[NLANE] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_lane[NLANE] = {nullptr, nullptr};
   float* stat_lane[NLANE] = {nullptr, nullptr};   // each lane's own BN-statistics partial rows (conv -> finalize scratch)
   bool head_lanes = false;
+  // asynchronous segment ends (data-parallel step): the weight-gradient stream is NOT joined into the main stream when a backward segment
+  // ends; the segment's completion is two events (main stream, weight-gradient stream) a communication stream waits on (ys_model_segment_fence)
+  hipEvent_t ev_seg_m[NSEG] = {nullptr, nullptr, nullptr, nullptr}, ev_seg_w[NSEG] = {nullptr, nullptr, nullptr, nullptr};
+  bool seg_on_st2[NSEG] = {false, false, false, false};
   bool overlap = false, overlap_built = false; hipStream_t st2 = nullptr;   // overlap_built: second stream / dy ring exist; overlap: in use (ys_model_set_overlap)
   void* dy_ring[DY_RING] = {nullptr}; hipEvent_t ev_dy[DY_RING + 1] = {nullptr}, ev_free[DY_RING] = {nullptr}, ev_join = nullptr;
   bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
@@ -863,13 +867,28 @@ int allocate(ys_model* m) {
   m->overlap = !(getenv("YS_OVERLAP") != nullptr && atoi(getenv("YS_OVERLAP")) == 0);
   m->overlap_built = m->overlap;
   if (m->overlap) {
-    YS_CHECK_HIP(hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking));
+    // lowest priority: the weight gradients are off the critical path (the optimizer is their only reader), and a priority class of
+    // its own is a hardware queue of its own -- streams of one class share a handful of queues in creation order, and with the main
+    // stream and this one on the SAME queue nothing overlaps (seen with an eagerly initialised RCCL communicator, whose streams
+    // shifted the assignment: 11.6 instead of 10.2 ms/step).  YS_ST2_PRIO=0: default priority.
+    {
+      int least = 0, greatest = 0;
+      const bool low = !(getenv("YS_ST2_PRIO") && atoi(getenv("YS_ST2_PRIO")) == 0);
+      if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        YS_CHECK_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, least));
+      else
+        YS_CHECK_HIP(hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking));
+    }
     for (int k = 0; k < ys_model::DY_RING; k++) {
       YS_TRY(dev_alloc(m, &m->dy_ring[k], (size_t)dy_max * m->es));
       YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_free[k], hipEventDisableTiming));
     }
     for (int k = 0; k <= ys_model::DY_RING; k++) YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dy[k], hipEventDisableTiming));
     YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  }
+  for (int k = 0; k < ys_model::NSEG; k++) {
+    YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_seg_m[k], hipEventDisableTiming));
+    YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_seg_w[k], hipEventDisableTiming));
   }
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
   YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4));
@@ -1082,8 +1101,10 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
   return YS_OK;
 }
 
+static int join_wgrad_stream(ys_model* m);
 int forward_impl(ys_model* m, int B) {
   hipStream_t st = m->ctx->stream;
+  YS_TRY(join_wgrad_stream(m));              // asynchronous segment ends: the previous step's weight-gradient kernels still read activations / dy slots
   YS_TRY(prep_weights(m));
   if (m->f8)   // delayed scaling: this pass quantises with the maxima the previous passes recorded (consumed and cleared here)
     YS_TRY(ys_f8_scales_launch(st, m->f8_convs, m->n_f8_convs, m->amax_w, m->amax_act, m->amax_dy, m->f8_scales));
@@ -1492,7 +1513,18 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
   return YS_OK;
 }
 
-int backward_range(ys_model* m, int seg_lo, int seg_hi) {
+// the weight-gradient stream has work the main stream has not waited for: order the main stream behind it
+static int join_wgrad_stream(ys_model* m) {
+  if (m->st2 && m->st2_dirty) {
+    YS_CHECK_HIP(hipEventRecord(m->ev_join, m->st2));
+    YS_CHECK_HIP(hipStreamWaitEvent(m->ctx->stream, m->ev_join, 0));
+    m->st2_dirty = false;
+  }
+  return YS_OK;
+}
+
+// async_end: leave the weight-gradient stream unjoined (its split reduction runs there too) and record the segment's completion events
+int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) {
   hipStream_t st = m->ctx->stream;
   const int B = m->B;
   YS_TRY(plan_bnred(m, B));
@@ -1533,11 +1565,12 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
                                         op.in.coff, mode));
     }
   }
-  if (m->overlap && m->st2_dirty) {      // the segment's gradients are complete only when the weight-gradient stream has drained
-    YS_CHECK_HIP(hipEventRecord(m->ev_join, m->st2));
-    YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
-    m->st2_dirty = false;
-  }
+  // the segment's gradients are complete only when the weight-gradient stream has drained: the main stream waits for it here, unless the
+  // caller asked for an asynchronous end -- then the split reduction below goes to that stream as well, nothing on the main stream waits,
+  // and whoever consumes the segment's gradients (the all-reduce) waits on the two events recorded at the end
+  const bool on_st2 = async_end && m->overlap && m->st2_dirty;
+  hipStream_t sr = on_st2 ? m->st2 : st;
+  if (!on_st2) YS_TRY(join_wgrad_stream(m));
   if (m->f8 && seg_hi == ys_model::NSEG - 1) m->f8_bwd_done = true;     // every gradient maximum of the step is recorded (last segment = stem)
   {
     // split reduction of every weight gradient of these segments in one launch (the partial slabs sit in per-layer regions)
@@ -1551,7 +1584,14 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi) {
         YS_CHECK_HIP(hipStreamSynchronize(st));
         memcpy(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc));
       }
-      YS_TRY(ys_wgrad_reduce_batched_launch(st, m->red_dev + lo, hi - lo, blk));
+      YS_TRY(ys_wgrad_reduce_batched_launch(sr, m->red_dev + lo, hi - lo, blk));
+    }
+  }
+  if (async_end) {
+    for (int sgi = seg_lo; sgi <= seg_hi; sgi++) {
+      m->seg_on_st2[sgi] = on_st2;
+      YS_CHECK_HIP(hipEventRecord(m->ev_seg_m[sgi], st));
+      if (on_st2) YS_CHECK_HIP(hipEventRecord(m->ev_seg_w[sgi], m->st2));
     }
   }
   YS_CHECK_HIP(hipGetLastError());
@@ -1634,6 +1674,7 @@ int ys_model_destroy(ys_model* m) {
     if (m->ev_lane[l]) hipEventDestroy(m->ev_lane[l]);
   }
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
+  for (int k = 0; k < ys_model::NSEG; k++) { if (m->ev_seg_m[k]) hipEventDestroy(m->ev_seg_m[k]); if (m->ev_seg_w[k]) hipEventDestroy(m->ev_seg_w[k]); }
   for (void* p : m->allocs) hipFree(p);
   delete m;
   return YS_OK;
@@ -1657,6 +1698,7 @@ int ys_model_tensor_info(ys_model* m, int index, char* name, int name_cap, int32
 }
 
 static int tensor_io(ys_model* m, const char* name, float* host, size_t count, int what /*0 set,1 get,2 get grad*/) {
+  if (what == 2) YS_TRY(join_wgrad_stream(m));   // asynchronous segment ends: gradients are complete once the weight-gradient stream has drained
   YS_REQUIRE(m && name && host, "tensor io: null argument");
   TensorRec* t = find_tensor(m, name);
   YS_REQUIRE(t != nullptr, "unknown tensor '%s'", name);
@@ -2093,6 +2135,25 @@ int ys_model_backward_segment(ys_model* m, int seg) {
   return backward_range(m, seg, seg);
 }
 
+int ys_model_backward_segment_async(ys_model* m, int seg) {
+  YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
+  YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
+  YS_REQUIRE(seg >= 0 && seg < ys_model::NSEG, "ys_model_backward_segment_async: segment %d out of range", seg);
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  if (seg == 0) reset_grad_state(m);
+  return backward_range(m, seg, seg, true);
+}
+
+int ys_model_segment_fence(ys_model* m, int seg, void* stream) {
+  YS_REQUIRE(m && seg >= 0 && seg < ys_model::NSEG, "ys_model_segment_fence: bad argument");
+  YS_REQUIRE(m->ev_seg_m[seg], "ys_model_segment_fence: model not built");
+  YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  YS_CHECK_HIP(hipStreamWaitEvent(s, m->ev_seg_m[seg], 0));
+  if (m->seg_on_st2[seg]) YS_CHECK_HIP(hipStreamWaitEvent(s, m->ev_seg_w[seg], 0));
+  return YS_OK;
+}
+
 int ys_model_backward(ys_model* m) {
   YS_REQUIRE(m && m->have_loss, "ys_model_backward: needs forward + loss first");
   YS_REQUIRE(m->fwd_training, "ys_model_backward: the last forward ran in eval mode (no batch statistics / pre-BN outputs were kept)");
@@ -2123,6 +2184,7 @@ int ys_model_set_overlap(ys_model* m, int on) {
 
 int ys_model_zero_grad(ys_model* m) {
   YS_REQUIRE(m, "null model");
+  YS_TRY(join_wgrad_stream(m));              // asynchronous segment ends: the weight-gradient stream may still be adding into the buffer
   YS_CHECK_HIP(hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, m->ctx->stream));
   return YS_OK;
 }
@@ -2162,6 +2224,7 @@ int ys_optim_set_param_groups(ys_model* m, int mode) {
 int ys_optim_adamw_step(ys_model* m, const float* lr_per_group, int ngroups, float beta1, float beta2, float eps, float wd) {
   YS_REQUIRE(m && lr_per_group && ngroups >= 1, "ys_optim_adamw_step: bad argument");
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
+  YS_TRY(join_wgrad_stream(m));              // asynchronous segment ends (ys_model_backward_segment_async): every gradient is in before the update
   YsTimer timer(m->ctx, "optim");
   m->step += 1;
   const float bc1 = 1.0f - powf(beta1, (float)m->step), bc2 = 1.0f - powf(beta2, (float)m->step);

@@ -6,9 +6,14 @@ no SyncBN); the single exchange step is a SUM all-reduce of the flat fp32 gradie
 The engine's backward is split into segments (head -> neck -> late backbone -> stem; the stem is cut small because the last
 all-reduce has no backward left to hide behind); the all-reduce of a finished segment is
 issued asynchronously on RCCL's stream while the next segment's kernels run (torch.distributed backend "nccl" is
-RCCL on ROCm; xGMI is point-to-point so a few large buckets beat many small ones).
+RCCL on ROCm; xGMI is point-to-point so a few large buckets beat many small ones).  With the model handle given, a segment ends
+asynchronously: its weight-gradient kernels keep running on the engine's second stream while the next segment starts, and the
+all-reduce -- issued on a communication stream of its own -- waits on the segment's completion events instead of the main stream
+(the synchronous form idled the main stream for the queued weight gradients at every boundary: 11.35 vs 10.2 ms/step at one rank).
 
 The same class runs on CPU tensors with the gloo backend (world_size-2 tests)."""
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -31,7 +36,7 @@ def host_view(ptr, n):
 
 
 class GradSync:
-    def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None, compress=None):
+    def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None, compress=None, model=None):
         """flat_grads: 1-D fp32 tensor aliasing the gradient buffer; segment_ranges: [(offset, count)] per backward segment.
         compress = "bf16": the exchange moves bf16 (half the xGMI bytes: a ring all-reduce is per-link bound); every rank reduces the
         same rounded values in the same order, so the ranks' weights stay bit-identical, but the summed gradient carries bf16
@@ -43,19 +48,31 @@ class GradSync:
         self.compress = compress
         self.stage = [torch.empty_like(s, dtype=torch.bfloat16) for s in self.segs] if compress else None
         self.pending = []
+        # model given + device buffer: the all-reduces are issued on a communication stream that waits for each segment's own completion
+        # events (Model.segment_fence), so the engine's main stream never waits for the weight-gradient stream at a segment boundary
+        self.model = model
+        self.comm = torch.cuda.Stream(device=flat_grads.device) if (model is not None and flat_grads.is_cuda) else None
 
     @property
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @property
+    def async_segments(self):
+        return self.comm is not None
+
     def allreduce_segment(self, seg):
+        if self.comm is not None:
+            self.model.segment_fence(seg, self.comm.cuda_stream)
         if self.world == 1:
             return
-        if self.compress:
-            self.stage[seg].copy_(self.segs[seg])
-            self.pending.append((dist.all_reduce(self.stage[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
-        else:
-            self.pending.append((dist.all_reduce(self.segs[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+        ctx = torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()
+        with ctx:
+            if self.compress:
+                self.stage[seg].copy_(self.segs[seg])
+                self.pending.append((dist.all_reduce(self.stage[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
+            else:
+                self.pending.append((dist.all_reduce(self.segs[seg], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
 
     def wait(self):
         for w, seg in self.pending:
@@ -70,7 +87,10 @@ def train_step_dp(model, crit, sync: GradSync, images_dev, batch, labels_dev, lr
     model.forward_device(images_dev, batch)
     crit.forward_device(*labels_dev)
     for seg in range(model.num_segments()):
-        model.backward_segment(seg)
+        if sync.async_segments:
+            model.backward_segment_async(seg)
+        else:
+            model.backward_segment(seg)
         sync.allreduce_segment(seg)
     sync.wait()
     model.adamw_step(lrs)

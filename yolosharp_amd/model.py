@@ -189,6 +189,14 @@ class Yolov8:
     def backward_segment(self, seg):
         _lib.check(self.lib, self.lib.ys_model_backward_segment(self.handle, seg))
 
+    def backward_segment_async(self, seg):
+        """backward_segment without the wait for the weight-gradient stream at the segment's end (see segment_fence)."""
+        _lib.check(self.lib, self.lib.ys_model_backward_segment_async(self.handle, seg))
+
+    def segment_fence(self, seg, stream_ptr):
+        """Makes the HIP stream `stream_ptr` (int, e.g. torch.cuda.Stream.cuda_stream) wait until segment `seg`'s gradients are complete."""
+        _lib.check(self.lib, self.lib.ys_model_segment_fence(self.handle, seg, C.c_void_p(int(stream_ptr))))
+
     def num_segments(self):
         return self.lib.ys_model_backward_segments(self.handle)
 
