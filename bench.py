@@ -193,7 +193,8 @@ def main():
     sync = None
     if distributed:
         flat = ysd.device_view(gptr.value, gn, dev)
-        sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())], model=model)
+        sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())], model=model,
+                            force_collective=args.force_dist)   # --force-dist: the one-rank group still issues its (identity) all-reduces
 
     def local_step():
         model.forward_device(d_img, B)

@@ -36,7 +36,7 @@ def host_view(ptr, n):
 
 
 class GradSync:
-    def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None, compress=None, model=None):
+    def __init__(self, flat_grads: torch.Tensor, segment_ranges, group=None, compress=None, model=None, force_collective=False):
         """flat_grads: 1-D fp32 tensor aliasing the gradient buffer; segment_ranges: [(offset, count)] per backward segment.
         compress = "bf16": the exchange moves bf16 (half the xGMI bytes: a ring all-reduce is per-link bound); every rank reduces the
         same rounded values in the same order, so the ranks' weights stay bit-identical, but the summed gradient carries bf16
@@ -51,6 +51,7 @@ class GradSync:
         # model given + device buffer: the all-reduces are issued on a communication stream that waits for each segment's own completion
         # events (Model.segment_fence), so the engine's main stream never waits for the weight-gradient stream at a segment boundary
         self.model = model
+        self.force_collective = force_collective     # issue the all-reduce even in a one-rank group (self-test of the RCCL call path)
         self.comm = torch.cuda.Stream(device=flat_grads.device) if (model is not None and flat_grads.is_cuda) else None
 
     @property
@@ -64,7 +65,7 @@ class GradSync:
     def allreduce_segment(self, seg):
         if self.comm is not None:
             self.model.segment_fence(seg, self.comm.cuda_stream)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         ctx = torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()
         with ctx:
