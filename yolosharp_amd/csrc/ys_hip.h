@@ -422,13 +422,17 @@ __device__ inline unsigned long long ys_readlane64(unsigned long long v, int src
 #endif
 }
 
-// wave-level ordering point for LDS traffic that is private to one wave: LDS operations of a wave execute in order on
-// the hardware, so only the compiler must not reorder across it (the interpreter needs a real rendezvous).
+// wave-level ordering point for LDS traffic that is private to one wave (rows written by some lanes, read by others): the wave's
+// outstanding LDS operations complete (s_waitcnt lgkmcnt(0)), and the compiler must not reorder across it (the interpreter needs a
+// real rendezvous).  Rounds 1-2 had no wait here, on the assumption that a wave's LDS operations execute in order; round 3 measured
+// a case where that is not enough (ys_wave_sync_lds below: reads issued right behind bank-conflicted writes of other lanes' rows
+// returned stale data about once per 10^6 vectors), so the wait is part of the primitive now.
 __device__ inline void ys_wave_sync() {
 #ifdef YS_EMU_BUILD
   int z = 0;
   emu::wave_collective(&z, sizeof(z), [](unsigned char (*)[128]) {});
 #else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -440,12 +444,7 @@ __device__ inline void ys_wave_sync() {
 // differed from run to run on wide layers (cin800 -> cout320 1x1: every rerun; one stale 16-byte vector in ~10^6) -- a bank-
 // conflicted ds_write_b64 had not finished all of its passes when the ds_read_b128 of another lane's row went through.  The
 // one-iteration-at-a-time epilogue had an s_waitcnt lgkmcnt(0) there by accident (the row-table value was consumed first).
-__device__ inline void ys_wave_sync_lds() {
-#ifndef YS_EMU_BUILD
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-  ys_wave_sync();
-}
+__device__ inline void ys_wave_sync_lds() { ys_wave_sync(); }   // (the wait moved into ys_wave_sync itself; the name marks the site that showed the defect)
 
 // ---------------------------------------------------------------- LDS transpose read (gfx950 ds_read_b64_tr_b16)
 // Every lane passes the LDS address of 4 contiguous 16-bit elements (8-byte aligned).  Within each 16-lane group the
