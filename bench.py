@@ -159,8 +159,7 @@ def main():
     if distributed:
         # a stream of its own (not the legacy default stream, whose implicit synchronisation with every blocking stream serialises the
         # engine's side streams): torch's current stream for the whole run, so RCCL collectives order against the engine's kernels
-        if os.environ.get("YS_BENCH_NULL_STREAM") != "1":
-            torch.cuda.set_stream(torch.cuda.Stream(dev))
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
         stream = torch.cuda.current_stream(dev).cuda_stream
     eng = Engine(local_rank, stream=stream, lib_path=args.lib or None)   # N>1: run on torch's stream so RCCL orders against our kernels
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
