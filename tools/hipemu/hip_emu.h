@@ -260,6 +260,8 @@ hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = 0);
 hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned);
+#define hipDeviceMallocUncached 0x3
+hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned flags);
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int);
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipStreamDestroy(hipStream_t s);

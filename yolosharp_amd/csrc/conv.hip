@@ -759,7 +759,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     // registers cleared: 4 * MR * NR v_mov per tile in a kernel whose busiest pipe is the VALU); streamed weights enter the K loop
     // once per weight group and keep the cleared accumulators
     f32x4 acc[MR][NR];
-    if (!WRES) {
+    if (!WRES || F8) {                        // (fp8 variants keep the cleared accumulators: peeling their 128-deep first group costs them registers)
 #pragma unroll
       for (int mf = 0; mf < MR; mf++)
 #pragma unroll
@@ -784,7 +784,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
     auto kloop = [&](const uint4* wbuf, int sbase, int ng, auto bf8_tag) {
       constexpr int B_BF8 = decltype(bf8_tag)::value;
       if (P2_DBG(2)) {                          // ablation build only: no K loop, defined accumulators
-        if (WRES) {
+        if (WRES && !F8) {
 #pragma unroll
           for (int mf = 0; mf < MR; mf++)
 #pragma unroll
@@ -822,7 +822,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
             }
       };
       int gi0 = 0;
-      if (WRES) { group(0, P2Tag1{}); gi0 = 1; }
+      if (WRES && !F8) { group(0, P2Tag1{}); gi0 = 1; }
 #pragma unroll 1
       for (int gi = gi0; gi < ng; gi++) group(gi, P2Tag0{});
     };
@@ -886,6 +886,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #else
   if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
 #endif
+  if (!RED && !F8) conv_bn_finalize_ticket<NT>(a, n0, BN, (double*)sPb);
   if (F8 && a.amax && blockIdx.y == 0) ys_amax_update(a.amax, amx);
   TL_STAMP();
 #ifdef YS_P2_TIMELINE
@@ -1374,6 +1375,13 @@ int ys_conv_grid_m(const ConvArgs& a, int dtype) {
     return t.tx * t.ty * a.B;
   }
   return ys_cdiv(a.M, 64 * conv_pick_mr(a.M, a.Cout));
+}
+
+// channel tiles (gridDim.y) of the conv_p2_kernel launch a bf16, non-fp8 forward convolution would get; 0 = another kernel runs it
+int ys_conv_is_p2(const ConvArgs& a) {
+  if (a.f8 || ys_conv_gemm_rows(a)) return 0;
+  const P2Plan p2 = conv_p2_plan(a);
+  return p2.ok ? p2.gy : 0;
 }
 
 template <class T, int MR, int NR>

@@ -141,6 +141,7 @@ struct ys_model {
   hipStream_t lane_st[NLANE] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_lane[NLANE] = {nullptr, nullptr};
   float* stat_lane[NLANE] = {nullptr, nullptr};   // each lane's own BN-statistics partial rows (conv -> finalize scratch)
   bool head_lanes = false;
+  BnFinArgs* fin_dev = nullptr; unsigned* fin_tickets = nullptr; bool bn_ticket = false;   // in-kernel BatchNorm finalize (YS_BN_TICKET=1), table indexed by conv
   // asynchronous segment ends (data-parallel step): the weight-gradient stream is NOT joined into the main stream when a backward segment
   // ends; the segment's completion is two events (main stream, weight-gradient stream) a communication stream waits on (ys_model_segment_fence)
   hipEvent_t ev_seg_m[NSEG] = {nullptr, nullptr, nullptr, nullptr}, ev_seg_w[NSEG] = {nullptr, nullptr, nullptr, nullptr};
@@ -173,9 +174,11 @@ struct ys_model {
 
 namespace {
 
-int dev_alloc(ys_model* m, void** p, size_t bytes, bool zero = true) {
+int dev_alloc(ys_model* m, void** p, size_t bytes, bool zero = true, bool uncached = false) {
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(p, bytes);
+  // uncached (fine-grained, MTYPE UC): stores go to memory and loads come from it whatever XCD issues them -- data workgroups of one
+  // launch hand to each other (statistics rows of the in-kernel BatchNorm finalize) without a cache write-back / invalidate
+  hipError_t e = uncached ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) : hipMalloc(p, bytes);
   if (e != hipSuccess) { ys_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return YS_ERR_OOM; }
   m->allocs.push_back(*p);
   if (zero) { e = hipMemsetAsync(*p, 0, bytes, m->ctx->stream); if (e != hipSuccess) { ys_set_error("hipMemset failed"); return YS_ERR_HIP; } }
@@ -891,10 +894,28 @@ int allocate(ys_model* m) {
     YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_seg_w[k], hipEventDisableTiming));
   }
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4));
+  const bool ticket_uc = getenv("YS_BN_TICKET") && atoi(getenv("YS_BN_TICKET")) == 2;   // 2: statistics rows + tickets in uncached memory, no fences
+  YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4, true, ticket_uc));
   // off by default: measured (round 3, config 2) 10.52-10.55 ms/step with the lanes against 9.98-10.01 without (round 2's variant of the
   // same experiment: -5.7 %).  The P3 chain's kernels are persistent grids sized to own every CU (2-3 workgroups per CU by LDS); a
   // side-stream kernel that takes some of those slots turns the big kernel's equal tile shares into a tail.  YS_HEAD_LANES=1 enables it.
+  m->bn_ticket = getenv("YS_BN_TICKET") && atoi(getenv("YS_BN_TICKET")) != 0;
+  if (m->bn_ticket) {
+    YS_TRY(dev_alloc(m, (void**)&m->fin_tickets, m->convs.size() * 16 * sizeof(unsigned), true, ticket_uc));   // zero-initialised
+    std::vector<BnFinArgs> h(m->convs.size());
+    for (auto& c : m->convs) {
+      BnFinArgs f{};
+      if (c.bn) {
+        f.gamma = m->params + c.g_off; f.beta = m->params + c.b_off;
+        f.run_mean = m->state + c.rm_off; f.run_var = m->state + c.rv_off; f.nbt = m->state + c.nbt_off;
+        f.scale = chan_ptr(m, c, 0); f.shift = chan_ptr(m, c, 1); f.mean = chan_ptr(m, c, 2); f.rstd = chan_ptr(m, c, 3);
+        f.ticket = m->fin_tickets + (size_t)c.idx * 16; f.eps = 1e-3f; f.momentum = 0.03f; f.uncached = ticket_uc ? 1 : 0;
+      }
+      h[c.idx] = f;
+    }
+    YS_TRY(dev_alloc(m, (void**)&m->fin_dev, h.size() * sizeof(BnFinArgs), false));
+    YS_CHECK_HIP(hipMemcpy(m->fin_dev, h.data(), h.size() * sizeof(BnFinArgs), hipMemcpyHostToDevice));
+  }
   m->head_lanes = m->overlap_built && getenv("YS_HEAD_LANES") && atoi(getenv("YS_HEAD_LANES")) != 0;
   if (m->head_lanes) {
     bool any = false;
@@ -1064,9 +1085,12 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
     void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
     a.stats = stat_partial;
+    const int p2_tiles = (m->bn_ticket && m->dtype == YS_BF16 && !a.f8 && !lane_st) ? ys_conv_is_p2(a) : 0;
+    const bool ticket = p2_tiles > 0 && p2_tiles <= 16;     // one arrival counter per channel tile (BnFinArgs::ticket)
+    if (ticket) a.fin = m->fin_dev + c.idx;
     YS_TRY(ys_conv_launch(st, m->dtype, a));
     const int gm = ys_conv_grid_m(a, m->dtype);
-    YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
+    if (!ticket) YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
                                  m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
                                  chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
     const void* res = nullptr; int rl = 0, rc = 0;
