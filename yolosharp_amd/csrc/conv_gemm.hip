@@ -143,9 +143,11 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   };
   constexpr int PER = NA + NBP / 4;           // requests per K-tile that EVERY wave issues (BN = 80: two waves issue one more; waiting for fewer is conservative)
 
-  // fragment read offsets: row (16-row fragment base + li); bf16: unit (ks * 4 + q) ^ (li >> 1) of K-step ks; fp8: the lane's 32
-  // bytes are units 2q and 2q + 1
-  const int koff0 = ((F8 ? 2 * q : q) ^ (li >> 1)) << 4, koff1 = ((F8 ? 2 * q + 1 : 4 + q) ^ (li >> 1)) << 4;
+  // fragment read offsets: row (16-row fragment base + li); bf16: unit (ks * 4 + q) ^ (li >> 1) of K-step ks
+  // fp8: a lane quarter's 32 bytes are units q and 4 + q as well (not 2q, 2q + 1): which 32 of the tile's 128 K values a quarter
+  // multiplies is free as long as both operands agree, and with 2q / 2q + 1 the eight lanes of quarter q + 1 that the LDS serves together
+  // with eight of quarter q landed on the same 16-byte slots (SQ_LDS_BANK_CONFLICT 0.36 of LDS-active cycles in the fp8 kernel, 0.08 in bf16)
+  const int koff0 = (q ^ (li >> 1)) << 4, koff1 = ((4 + q) ^ (li >> 1)) << 4;
   const int arow0 = ((wm * MR) * 16 + li) * 128;
   const int brow0 = BM * 128 + ((wn * NR) * 16 + li) * 128;
 
