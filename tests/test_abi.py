@@ -75,3 +75,16 @@ def test_c_consumer_runs_on_device():
     dev, _ = build.build_abi_smoke()
     rc, out = _run_smoke(dev)
     assert rc == 0 and "abi_smoke OK: device_build=1" in out, out
+
+
+def test_csharp_shim_binds_only_exported_symbols():
+    """bindings/csharp/YoloSharpHip.cs (the P/Invoke file a YoloSharp maintainer drops in): every
+    `static extern` it declares must be a symbol of the header -- there is no dotnet here to compile it, so at least the names are pinned."""
+    txt = open(os.path.join(ROOT, "bindings", "csharp", "YoloSharpHip.cs")).read()
+    names = re.findall(r"static\s+extern\s+[\w\[\]]+\s+(ys_\w+)\s*\(", txt)
+    assert len(names) >= 40
+    declared = set(declared_symbols())
+    unknown = [n for n in names if n not in declared]
+    assert not unknown, unknown
+    for must in ("ys_model_forward", "ys_loss_detect", "ys_model_backward", "ys_optim_adamw_step", "ys_nms_batched", "ys_dist_init"):
+        assert must in names, must

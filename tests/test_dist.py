@@ -344,3 +344,26 @@ def test_bench_force_dist_world1():
     assert a["n_gpus"] == 1 and a["scaling"] == "weak" and a["config"]["parallelism"] == "dp1" and a["value"] > 0
     assert a["roofline"]["bound"] == "hbm" and 0 < a["roofline"]["frac"] < 1
     assert np.allclose(a["loss_items"], b["loss_items"], rtol=1e-5)          # SUM over one rank: identical training trajectory
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (round-3 verdict: the flag used to be parsed
+    and ignored).  --spawn-probe takes the same re-exec path but joins a gloo group and counts the ranks instead of touching a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-probe"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"probe": True, "n_gpus": 2, "rccl_ranks": 2, "spawned": True}
+
+
+def test_bench_gpus_n_refuses_without_devices():
+    """Without N visible GPUs the N-rank launch must refuse loudly instead of printing a one-rank number (no GPU in the dev container)."""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the refusal path does not apply")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -1722,8 +1722,8 @@ int ys_model_tensor_info(ys_model* m, int index, char* name, int name_cap, int32
 }
 
 static int tensor_io(ys_model* m, const char* name, float* host, size_t count, int what /*0 set,1 get,2 get grad*/) {
-  if (what == 2) YS_TRY(join_wgrad_stream(m));   // asynchronous segment ends: gradients are complete once the weight-gradient stream has drained
   YS_REQUIRE(m && name && host, "tensor io: null argument");
+  if (what == 2) YS_TRY(join_wgrad_stream(m));   // asynchronous segment ends: gradients are complete once the weight-gradient stream has drained
   TensorRec* t = find_tensor(m, name);
   YS_REQUIRE(t != nullptr, "unknown tensor '%s'", name);
   YS_REQUIRE((long)count == t->count, "tensor '%s' has %ld elements, caller passed %zu", name, t->count, count);
@@ -1842,6 +1842,7 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
   }
   YsTimer timer(m->ctx, "forward");
   m->B = batch;
+  YS_TRY(join_wgrad_stream(m));   // the previous backward's weight-gradient kernels (model.0 reads the input buffer) may still run on the second stream
   YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, 3, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
   m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;
@@ -1864,6 +1865,7 @@ int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int b
   }
   YsTimer timer(m->ctx, "forward");
   m->B = batch;
+  YS_TRY(join_wgrad_stream(m));   // as in ys_model_forward: the input buffer is rewritten below
   YS_TRY(ys_pack_input_u8_launch(st, m->dtype, src, batch, 3, h, w, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
   m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;
@@ -2320,6 +2322,7 @@ int ys_block_forward(ys_model* m, const float* x, int on_device, int batch, floa
   const float* src = x;
   if (!on_device) { YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, x, nx * 4, hipMemcpyHostToDevice, st)); src = m->img_dev; }
   m->B = batch;
+  YS_TRY(join_wgrad_stream(m));
   YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, m->blk_c1, ib.H, ib.W, ib.ldc, ib.act));
   YS_TRY(forward_impl(m, batch));
   m->have_fwd = m->training;   // only a training-mode forward keeps what backward needs (pre-BN outputs, batch statistics)
@@ -2402,6 +2405,7 @@ int ys_head_forward(ys_model* m, const float* const x[3], int on_device, int bat
   hipStream_t st = m->ctx->stream;
   YsTimer timer(m->ctx, "forward");
   m->B = batch;
+  YS_TRY(join_wgrad_stream(m));   // the level inputs are rewritten below; the previous backward's weight-gradient kernels read them
   for (int i = 0; i < 3; i++) {
     const Buf& ib = m->bufs[m->head_in[i]];
     const float* src = x[i];

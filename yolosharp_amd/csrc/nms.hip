@@ -594,10 +594,13 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
     YS_CHECK_HIP(hipMalloc(&ctx->nms_ws, off));
     ctx->nms_ws_bytes = off;
     ctx->nms_count_clean = false;
+    ctx->nms_count_clean_B = 0;
   }
   char* ws = (char*)ctx->nms_ws;
   int* count = (int*)(ws + o_count);
-  if (!ctx->nms_count_clean) YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));   // new workspace / a call that did not reach its sort kernel
+  // new workspace / a call that did not reach its sort kernel / MORE images than the counters known to be zero (a smaller-B call only
+  // cleared its own B counters; with a layout that still fits the old workspace the rest is padding or old key bytes)
+  if (!ctx->nms_count_clean || B > ctx->nms_count_clean_B) YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));
   ctx->nms_count_clean = false;
   YsKprofScope prof(ctx->stream, "nms");
   static const bool dbg = getenv("YS_NMS_DEBUG") != nullptr;
@@ -622,7 +625,8 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   YS_LAUNCH(nms_sort_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, max_det, max_nms, (float)max_wh, count,
             keys, np2, (const int*)clss, sbox, sarea, sidx, supp, ncap, nsort, out_rows, (long long*)out_keep, (int*)out_count, scov);
   NMS_DBG("sort");
-  ctx->nms_count_clean = true;                // nms_sort_kernel zeroes the counters it read (same workspace size B next time, else reallocation below)
+  ctx->nms_count_clean = true;                // nms_sort_kernel zeroes the B counters it read
+  ctx->nms_count_clean_B = B;
   if (rotated) {
     YS_LAUNCH(nms_rot_removed_kernel, dim3(ys_cdiv(ncap, 256), B), 256, ctx->stream, (const int*)nsort, (const float4*)sbox, (const float4*)scov, ncap, iou, supp);
     YS_LAUNCH_LDS(nms_rot_pick_kernel, B, NMS_THREADS, (size_t)max_det * sizeof(int), ctx->stream, (const float*)pred, C, A, nc, max_det, (const int*)nsort,

@@ -42,6 +42,7 @@ struct ys_ctx {
   void* nms_ws = nullptr;
   size_t nms_ws_bytes = 0;
   bool nms_count_clean = false;   // the per-image candidate counters are zero (nms_sort_kernel clears what it consumed)
+  int nms_count_clean_B = 0;      // ... for this many images (a later call with more images clears again)
   // scratch for per-operator entry points
   std::map<std::string, float> last_ms;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -93,14 +93,18 @@ class Detector:
                 bi = np.ascontiguousarray(np.asarray(data["batch_idx"], np.float32).reshape(-1))
                 cl = np.ascontiguousarray(np.asarray(data["cls"], np.float32).reshape(-1))
                 bb = np.ascontiguousarray(np.asarray(data["bboxes"], np.float32).reshape(-1, 4))
-                d_lab = [eng.to_device(a) for a in (bi, cl, bb)]
-                _lib.check(eng.lib, eng.lib.ys_val_match_batched(eng.ctx, d_rows, d_cnt, 1, B, max_det, stride, d_lab[0], d_lab[1], d_lab[2],
-                                                                 bi.shape[0], float(images.shape[3]), float(images.shape[2]), d_cor))
-                rows = eng.from_device(d_rows, (B, max_det, stride), np.float32)
-                cnt = eng.from_device(d_cnt, (B,), np.int32)
-                cor = eng.from_device(d_cor, (B, max_det, 10), np.uint8)
-                for p_ in d_lab:
-                    eng.free(p_)
+                d_lab = []
+                try:                       # the per-batch label buffers are released on the error paths too
+                    for a in (bi, cl, bb):
+                        d_lab.append(eng.to_device(a))
+                    _lib.check(eng.lib, eng.lib.ys_val_match_batched(eng.ctx, d_rows, d_cnt, 1, B, max_det, stride, d_lab[0], d_lab[1], d_lab[2],
+                                                                     bi.shape[0], float(images.shape[3]), float(images.shape[2]), d_cor))
+                    rows = eng.from_device(d_rows, (B, max_det, stride), np.float32)
+                    cnt = eng.from_device(d_cnt, (B,), np.int32)
+                    cor = eng.from_device(d_cor, (B, max_det, 10), np.uint8)
+                finally:
+                    for p_ in d_lab:
+                        eng.free(p_)
                 for b in range(B):
                     tps.append(cor[b, :cnt[b]].astype(bool)); confs.append(rows[b, :cnt[b], 4]); pcls.append(rows[b, :cnt[b], 5])
                     tcls.append(cl[bi == b])

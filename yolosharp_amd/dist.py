@@ -53,6 +53,15 @@ class GradSync:
         self.model = model
         self.force_collective = force_collective     # issue the all-reduce even in a one-rank group (self-test of the RCCL call path)
         self.comm = torch.cuda.Stream(device=flat_grads.device) if (model is not None and flat_grads.is_cuda) else None
+        if self.comm is not None:
+            # wait() orders torch's CURRENT stream behind the all-reduces, and AdamW then runs on the engine's stream: the two must be the
+            # same stream (bench.py: Engine(stream=torch.cuda.current_stream().cuda_stream)), else the optimizer could read gradients the
+            # collective has not finished
+            es = getattr(getattr(model, "engine", None), "stream", None)
+            cur = torch.cuda.current_stream(flat_grads.device).cuda_stream
+            if es is None or int(es) != int(cur):
+                raise RuntimeError("GradSync(model=...): the Engine must run on torch's current stream (create it with "
+                                   "Engine(device, stream=torch.cuda.current_stream(device).cuda_stream) and keep that stream current)")
 
     @property
     def world(self):

@@ -42,6 +42,7 @@ class Engine:
         else:
             _lib.check(self.lib, self.lib.ys_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(self.ctx)))
         self.device = device
+        self.stream = stream          # the caller's HIP stream the context runs on (None: a stream the library created for itself)
 
     def close(self):
         if self.ctx:
