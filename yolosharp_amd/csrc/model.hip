@@ -62,6 +62,10 @@ struct ConvL {
   std::vector<RedFeed> feeds;
   std::vector<RedSrc> red_src;           // sorted by producer channel
   bool red_ok = false; int red_seen = 0; // every source is a supported dgrad launch / sources attached in the current backward pass
+  // Several reference modules executed as ONE convolution (shared-input fusion, add_detect): member k owns output rows
+  // [row0, row0 + rows) of this layer's weight / BN vectors and appears in the state_dict under its own module name.  Empty = one module.
+  struct Member { std::string name; int row0, rows; };
+  std::vector<Member> members;
 };
 
 enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2, OP_ATTN = 3, OP_VCOPY = 4, OP_COPY = 5 };
@@ -235,6 +239,8 @@ void add_c2f(ys_model* m, const std::string& name, View xin, View xout, int c1, 
   for (int i : mids) m->reg.push_back(i);
 }
 
+// registration-list entry of member `mem` of a fused convolution (plain convolutions: the index itself)
+inline int reg_entry(int conv, int mem) { return conv | (mem << 20); }
 int add_conv_reg(ys_model* m, const std::string& name, View in, View out, int cin, int cout, int k, int s, bool bn, bool act,
                  int Hin, int Win, int seg, const View* res = nullptr, bool dw = false) {
   const int i = add_conv(m, name, in, out, cin, cout, k, s, bn, act, Hin, Win, seg, res, dw);
@@ -368,6 +374,17 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
   m->ld_ps = (d.nc + m->epl - 1) / m->epl * m->epl;
   m->pd_buf = new_buf(m, 1, m->A, m->ld_pd);
   m->ps_buf = new_buf(m, 1, m->A, m->ld_ps);
+  // Shared-input fusion (round 4).  cv2[i][0] = Conv(x, c2, 3) and cv3[i][0] = Conv(x, c3, 3) -- and Segment's cv4[i][0] = Conv(x, c4, 3) --
+  // read the SAME x[i] (Head.cs:47-48, 254-259, consumed at :81-82): they run as ONE convolution with Cout = c2 + c3 (+ c4) into one
+  // buffer whose channel slices the second tower layers read.  BatchNorm and SiLU are per channel, so this is exact; the input is
+  // read once in the forward and in the weight gradient, and the input gradient is ONE dgrad with K = 9 (c2 + c3 + c4) instead of an
+  // overwrite followed by read-modify-write accumulations.  The state_dict keeps the reference's module names (ConvL::members).
+  // v11 heads (legacy = false) start their class tower with a depthwise unit: nothing to fuse with there.  YS_HEAD_FUSE=0: one launch each.
+  const int c4s = d.task == YS_SEGMENT ? std::max(ch[0] / 4, 32) : 0;
+  const int cf = c2 + c3 + c4s;
+  bool fuse = legacy && !(getenv("YS_HEAD_FUSE") && atoi(getenv("YS_HEAD_FUSE")) == 0) && (c4s % m->epl) == 0;
+  if (m->f8 && (cf % 32 || c2 % 32 || c3 % 32)) fuse = false;   // fp8 mode: the dgrad of a fused layer must still qualify for the fp8 kernel (K units of 32)
+  int fbuf[3] = {-1, -1, -1}, fconv[3] = {-1, -1, -1};
   size_t lane_first = m->convs.size();
   for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
     for (int i = 0; i < 3; i++) {
@@ -375,11 +392,24 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       const int co = t == 0 ? 4 * d.reg_max : d.nc;
       const int ob = t == 0 ? m->pd_buf : m->ps_buf;
       const std::string tp = hp + (t == 0 ? ".cv2." : ".cv3.") + std::to_string(i);
-      const int t0 = new_buf(m, hh[i], ww[i], cm), t1 = new_buf(m, hh[i], ww[i], cm);
-      if (t == 0 || legacy) {
+      const int t1 = new_buf(m, hh[i], ww[i], cm);
+      if (fuse) {
+        if (t == 0) {
+          fbuf[i] = new_buf(m, hh[i], ww[i], cf);
+          fconv[i] = add_conv(m, tp + ".0+cv3" + (c4s ? "+cv4" : ""), View{pv[i], 0, ch[i]}, View{fbuf[i], 0, cf}, ch[i], cf, 3, 1, true, true, hh[i], ww[i], seg);
+          ConvL& fc = m->convs[fconv[i]];
+          fc.members.push_back({tp + ".0", 0, c2});
+          fc.members.push_back({hp + ".cv3." + std::to_string(i) + ".0", c2, c3});
+          if (c4s) fc.members.push_back({hp + ".cv4." + std::to_string(i) + ".0", c2 + c3, c4s});
+        }
+        m->reg.push_back(reg_entry(fconv[i], t));
+        add_conv_reg(m, tp + ".1", View{fbuf[i], t == 0 ? 0 : c2, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg);
+      } else if (t == 0 || legacy) {
+        const int t0 = new_buf(m, hh[i], ww[i], cm);
         add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 3, 1, true, true, hh[i], ww[i], seg);
         add_conv_reg(m, tp + ".1", View{t0, 0, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg);
       } else {
+        const int t0 = new_buf(m, hh[i], ww[i], cm);
         const int d0 = new_buf(m, hh[i], ww[i], ch[i]), d1 = new_buf(m, hh[i], ww[i], cm);
         add_conv_reg(m, tp + ".0.0", View{pv[i], 0, ch[i]}, View{d0, 0, ch[i]}, ch[i], ch[i], 3, 1, true, true, hh[i], ww[i], seg, nullptr, true);
         add_conv_reg(m, tp + ".0.1", View{d0, 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 1, 1, true, true, hh[i], ww[i], seg);
@@ -406,12 +436,18 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
     m->mc_buf = new_buf(m, 1, m->A, m->ld_mc);
     for (int i = 0; i < 3; i++) {
       const std::string tp = hp + ".cv4." + std::to_string(i);
-      const int t0 = new_buf(m, hh[i], ww[i], c4), t1 = new_buf(m, hh[i], ww[i], c4);
-      add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, c4}, ch[i], c4, 3, 1, true, true, hh[i], ww[i], seg);
-      add_conv_reg(m, tp + ".1", View{t0, 0, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
+      const int t1 = new_buf(m, hh[i], ww[i], c4);
+      if (fuse) {                 // cv4[i][0] ran inside the level's fused first convolution (channels [c2 + c3, c2 + c3 + c4) of its output)
+        m->reg.push_back(reg_entry(fconv[i], 2));
+        add_conv_reg(m, tp + ".1", View{fbuf[i], c2 + c3, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
+      } else {
+        const int t0 = new_buf(m, hh[i], ww[i], c4);
+        add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, c4}, ch[i], c4, 3, 1, true, true, hh[i], ww[i], seg);
+        add_conv_reg(m, tp + ".1", View{t0, 0, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
+      }
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4}, View{m->mc_buf, 0, nm}, c4, nm, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
-      if (legacy) for (int k = cc - 2; k <= cc; k++) m->convs[k].lane = i;
+      if (legacy) for (int k = cc - (fuse ? 1 : 2); k <= cc; k++) m->convs[k].lane = i;
     }
     m->xkind = 1;
   } else if (d.task == YS_OBB || d.task == YS_POSE) {
@@ -647,30 +683,53 @@ int layout_params(ys_model* m) {
   m->n_state = so;
   // state_dict listing: parameters in module REGISTRATION order, then buffers (TorchSharp named_parameters + named_buffers)
   std::vector<int> reg2;
-  std::vector<char> seen(m->convs.size(), 0);
-  for (int i : m->reg) if (!seen[i]) { seen[i] = 1; reg2.push_back(i); }
-  if (reg2.size() != m->convs.size()) { ys_set_error("internal: registration list covers %zu of %zu convs", reg2.size(), m->convs.size()); return YS_ERR_STATE; }
-  for (int i : reg2) {
-    const ConvL& c = m->convs[i];
-    if (c.bn) {
-      if (c.dw) add_tensor(m, c.name + ".conv.weight", 4, i, c.w_off, {c.cout_real, 1, 3, 3}, true);
-      else add_tensor(m, c.name + ".conv.weight", 0, i, c.w_off, {c.cout_real, c.cin, c.k, c.k}, true);
-      add_tensor(m, c.name + ".bn.weight", 1, i, c.g_off, {c.cout_real}, true);
-      add_tensor(m, c.name + ".bn.bias", 1, i, c.b_off, {c.cout_real}, true);
-    } else {
-      if (c.ct) add_tensor(m, c.name + ".weight", 5, i, c.w_off, {c.cin, c.cout, 2, 2}, true);   // ConvTranspose2d: [Cin][Cout][kh][kw]
-      else add_tensor(m, c.name + ".weight", 0, i, c.w_off, {c.cout_real, c.cin, c.k, c.k}, true);
-      add_tensor(m, c.name + ".bias", 1, i, c.g_off, {c.cout_real}, true);
+  {
+    std::vector<int> seen_e;
+    std::vector<int> covered(m->convs.size(), 0);
+    for (int e : m->reg) {
+      if (std::find(seen_e.begin(), seen_e.end(), e) != seen_e.end()) continue;
+      seen_e.push_back(e); reg2.push_back(e);
+      covered[e & 0xfffff] += 1;
     }
-    if (i == m->dfl_after_conv)
+    for (size_t i = 0; i < m->convs.size(); i++) {
+      const int want = m->convs[i].members.empty() ? 1 : (int)m->convs[i].members.size();
+      if (covered[i] != want) { ys_set_error("internal: registration list covers %d of %d modules of conv %zu (%s)", covered[i], want, i, m->convs[i].name.c_str()); return YS_ERR_STATE; }
+    }
+  }
+  // (module name, first output row, rows) of a registration entry
+  auto module_of = [&](int e, std::string& name, int& row0, int& rows) {
+    const ConvL& c = m->convs[e & 0xfffff];
+    if (c.members.empty()) { name = c.name; row0 = 0; rows = c.cout_real; }
+    else { const ConvL::Member& mb = c.members[e >> 20]; name = mb.name; row0 = mb.row0; rows = mb.rows; }
+  };
+  for (int e : reg2) {
+    const int i = e & 0xfffff;
+    const ConvL& c = m->convs[i];
+    std::string nm; int r0, nr;
+    module_of(e, nm, r0, nr);
+    const long wrow = c.dw ? 9 : (long)c.k * c.k * c.cin;
+    if (c.bn) {
+      if (c.dw) add_tensor(m, nm + ".conv.weight", 4, i, c.w_off, {nr, 1, 3, 3}, true);
+      else add_tensor(m, nm + ".conv.weight", 0, i, c.w_off + r0 * wrow, {nr, c.cin, c.k, c.k}, true);
+      add_tensor(m, nm + ".bn.weight", 1, i, c.g_off + r0, {nr}, true);
+      add_tensor(m, nm + ".bn.bias", 1, i, c.b_off + r0, {nr}, true);
+    } else {
+      if (c.ct) add_tensor(m, nm + ".weight", 5, i, c.w_off, {c.cin, c.cout, 2, 2}, true);   // ConvTranspose2d: [Cin][Cout][kh][kw]
+      else add_tensor(m, nm + ".weight", 0, i, c.w_off + r0 * wrow, {nr, c.cin, c.k, c.k}, true);
+      add_tensor(m, nm + ".bias", 1, i, c.g_off + r0, {nr}, true);
+    }
+    if (e == m->dfl_after_conv)
       add_tensor(m, m->head_prefix + ".dfl.conv.weight", 3, -1, 0, {1, m->d.reg_max, 1, 1}, true);   // Block.cs:28-30 (never trained, Head.cs:221)
   }
-  for (int i : reg2) {
+  for (int e : reg2) {
+    const int i = e & 0xfffff;
     const ConvL& c = m->convs[i];
     if (!c.bn) continue;
-    add_tensor(m, c.name + ".bn.running_mean", 2, i, c.rm_off, {c.cout_real}, false);
-    add_tensor(m, c.name + ".bn.running_var", 2, i, c.rv_off, {c.cout_real}, false);
-    add_tensor(m, c.name + ".bn.num_batches_tracked", 2, i, c.nbt_off, {1}, false);
+    std::string nm; int r0, nr;
+    module_of(e, nm, r0, nr);
+    add_tensor(m, nm + ".bn.running_mean", 2, i, c.rm_off + r0, {nr}, false);
+    add_tensor(m, nm + ".bn.running_var", 2, i, c.rv_off + r0, {nr}, false);
+    add_tensor(m, nm + ".bn.num_batches_tracked", 2, i, c.nbt_off, {1}, false);   // members of a fused unit share the counter: they always step together
   }
   return YS_OK;
 }
@@ -1770,9 +1829,10 @@ static int tensor_io(ys_model* m, const char* name, float* host, size_t count, i
     // OIHW at the edge <-> [Cout][taps][Cin] inside
     const ConvL& c = m->convs[t->conv];
     const int taps = c.k * c.k;
+    const int rows = (int)t->shape[0];      // the module's own rows (a member of a fused convolution owns a row range)
     std::vector<float> tmp(count);
     if (what == 0) {
-      for (int co = 0; co < c.cout_real; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
+      for (int co = 0; co < rows; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
         tmp[((size_t)co * taps + tp) * c.cin + ci] = host[((size_t)co * c.cin + ci) * taps + tp];
       YS_CHECK_HIP(hipMemcpyAsync(dev, tmp.data(), count * 4, hipMemcpyHostToDevice, st));
       YS_CHECK_HIP(hipStreamSynchronize(st));
@@ -1780,7 +1840,7 @@ static int tensor_io(ys_model* m, const char* name, float* host, size_t count, i
     } else {
       YS_CHECK_HIP(hipMemcpyAsync(tmp.data(), dev, count * 4, hipMemcpyDeviceToHost, st));
       YS_CHECK_HIP(hipStreamSynchronize(st));
-      for (int co = 0; co < c.cout_real; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
+      for (int co = 0; co < rows; co++) for (int ci = 0; ci < c.cin; ci++) for (int tp = 0; tp < taps; tp++)
         host[((size_t)co * c.cin + ci) * taps + tp] = tmp[((size_t)co * taps + tp) * c.cin + ci];
     }
   } else {
