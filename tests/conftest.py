@@ -29,6 +29,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The `-m "not gpu"` suite runs every kernel through the test interpreter (minutes per model-level test on one core): spread it over the
+    cores with pytest-xdist when it is installed and the caller did not choose a worker count.  The `-m gpu` suite stays in ONE process:
+    its tests share the device and some of them time kernels."""
+    opt = config.option
+    if not hasattr(opt, "numprocesses") or opt.numprocesses is not None or os.environ.get("YS_TEST_SERIAL") == "1":
+        return None
+    if "not gpu" not in (getattr(opt, "markexpr", "") or ""):
+        return None
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    n = min(8, os.cpu_count() or 1)
+    if n > 1:
+        opt.numprocesses = n
+    return None
+
+
 BACKENDS = ["emu", pytest.param("gpu", marks=pytest.mark.gpu)]
 
 

@@ -529,9 +529,10 @@ struct P2Args {
 // the LDS bytes per K (the K loop of this kernel is LDS-bandwidth-bound for small register tiles).  A K-step is then 128 K =
 // four 32-channel pieces (one per lane quarter); Cin % 32 == 0.  The fp32 accumulators are scaled back in the epilogue.
 // RED = 1: dgrad launches that also take the BN-backward sums of the producers whose gradient they complete (conv_epi.h, BnRedSeg)
+// The kernel body takes its workgroup index and grid size as arguments (vbx of vgx): conv_p2_kernel passes blockIdx.x / gridDim.x,
+// conv_p2_group_kernel (below) the workgroup's index inside the problem its blockIdx.x range belongs to.
 template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
-__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 && !F8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD
-conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
+__device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g, const int* __restrict__ tab, const int vbx, const int vgx) {
   typedef bf16_t T;
   constexpr int WES = F8 ? 1 : 2;             // bytes per weight element
   constexpr int UPS = F8 ? 8 : 4;             // 16-byte LDS units per weight row and K-step
@@ -542,7 +543,7 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   // s_memtime stamps of wave 0 / lane 0 of every 37th workgroup: [slot 0] entry, [1] prologue issued, then per tile
   // (top, patch in LDS, MFMA loop done, epilogue done), last = exit.  64 slots per recorded workgroup.
   int tl_n = 0;
-  unsigned long long* tl_p = (a.tl && (blockIdx.x % 37) == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? a.tl + (blockIdx.x / 37) * 64 : nullptr;
+  unsigned long long* tl_p = (a.tl && (vbx % 37) == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? a.tl + (vbx / 37) * 64 : nullptr;
 #define TL_STAMP() do { if (tl_p && tl_n < 63) tl_p[1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TL_STAMP() ((void)0)
@@ -638,11 +639,11 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   // Tile order.  Workgroup i runs on XCD i % 8 (round-robin dispatch); when the grid is a multiple of 8 each XCD walks its own
   // contiguous eighth of the tile list, so the tiles resident on an XCD at any time are spatial neighbours and their shared
   // halo rows hit that XCD's L2.  Otherwise plain interleaving.  Tile coordinates advance incrementally (no per-tile divisions).
-  const bool xcd_order = (gridDim.x & 7) == 0 && !P2_DBG(32);
+  const bool xcd_order = (vgx & 7) == 0 && !P2_DBG(32);
   const int t_per_xcd = (g.ntiles + 7) >> 3;
-  const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int t_end = xcd_order ? (((int)(blockIdx.x & 7) + 1) * t_per_xcd < g.ntiles ? ((int)(blockIdx.x & 7) + 1) * t_per_xcd : g.ntiles) : g.ntiles;
+  const int t_step = xcd_order ? (vgx >> 3) : vgx;
+  const int t_first = xcd_order ? (vbx & 7) * t_per_xcd + (vbx >> 3) : vbx;
+  const int t_end = xcd_order ? (((vbx & 7) + 1) * t_per_xcd < g.ntiles ? ((vbx & 7) + 1) * t_per_xcd : g.ntiles) : g.ntiles;
   int stx, sty, sb;
   {
     const int G = t_step;
@@ -882,9 +883,9 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
   }
   YS_WAIT_VM0();                               // a workgroup without tiles still has its table / weight DMA in flight: it must land before the LDS is released
 #if YS_P2_EPI_DIRECT
-  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush_direct<NR, NWV, 1>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush_direct<NR, NWV, 1>(a, n0, st1, st2, (float*)sPb, (long)vbx);
 #else
-  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)blockIdx.x);
+  if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)vbx);
 #endif
   if (!RED && !F8) conv_bn_finalize_ticket<NT>(a, n0, BN, (double*)sPb);
   if (F8 && a.amax && blockIdx.y == 0) ys_amax_update(a.amax, amx);
@@ -892,6 +893,33 @@ conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
 #ifdef YS_P2_TIMELINE
   if (tl_p) tl_p[0] = (unsigned long long)tl_n;
 #endif
+}
+
+template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
+__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 && !F8 ? 3 : 2)))   // TIGHT variants: 3 waves / SIMD
+conv_p2_kernel(ConvArgs a, P2Args g, const int* __restrict__ tab) {
+  conv_p2_body<MR, NR, WRES, NPU, NT, F8, RED>(a, g, tab, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- grouped (multi-problem) launch.  Several INDEPENDENT convolutions that share a kernel variant -- the tower layers of the three
+// pyramid levels of Detect / Segment (Head.cs:81-82: the same module applied to x[0], x[1], x[2] with per-level weights) -- run as ONE
+// persistent grid: workgroups [end[i-1], end[i]) belong to problem i and see themselves as workgroup vbx of a grid of end[i] - end[i-1].
+// The P4 / P5 launches of a YOLOv8n step are 100-400 tiles each, i.e. one latency-bound round of workgroups (12-27 us against a byte
+// floor of 1-4 us); inside the P3 level's grid they are just more tiles.  Side streams were measured twice (-5 %: co-running persistent
+// grids take each other's workgroup slots); one grid with a static split does not have that problem.  Range starts and sizes are
+// multiples of 8 whenever a problem has >= 8 workgroups, so workgroup vbx still runs on XCD vbx % 8 (the tile order relies on it).
+struct P2Prob { ConvArgs a; P2Args g; const int* tab; };
+struct P2Group { int n; int end[YS_GROUP_MAX]; P2Prob p[YS_GROUP_MAX]; };
+template <int MR, int NR, int WRES, int NPU, int NT, int RED>
+__global__ void __launch_bounds__(NT, (NT == 512 ? 4 : (NPU <= 6 && MR * NR <= 8 ? 3 : 2)))
+conv_p2_group_kernel(P2Group grp) {
+  const int bx = (int)blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int k = 0; k + 1 < YS_GROUP_MAX; k++) pi += (int)(k + 1 < grp.n && bx >= grp.end[k]);
+  const int start = pi ? grp.end[pi - 1] : 0;
+  const P2Prob& pr = grp.p[pi];
+  conv_p2_body<MR, NR, WRES, NPU, NT, 0, RED>(pr.a, pr.g, pr.tab, bx - start, grp.end[pi] - start);
 }
 
 
@@ -979,7 +1007,7 @@ static int p2_pick_rowpad(int cin, int kh, int kw, int sa, int th, int tw, int m
   return pad;
 }
 
-struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy; size_t lds; P2Args g; };
+struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy, per_cu; size_t lds; P2Args g; };
 // fp8 variants whose 32-byte fragments fit the 256-register budget without spilling (hipcc -Rpass-analysis=kernel-resource-usage)
 static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
   static const bool any = getenv("YS_P2_F8_ANYTILE") != nullptr;      // triage: accept the spilling variants too
@@ -987,7 +1015,8 @@ static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
   if (wres) return npu == 6 ? !(mr == 4 && nr == 4) : (mr * nr <= 8 && !(mr == 2 && nr == 5));
   return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
 }
-static P2Plan conv_p2_plan(const ConvArgs& a) {
+// force_mr / force_npu (0 = free): grouped launches need every problem on the kernel variant of the group's largest problem
+static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 0) {
   P2Plan p{};
   // 3x3 forward / stride-1 dgrad, 1x1 forward / dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided
   // output-row map)
@@ -1062,6 +1091,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     const size_t stat = (size_t)nwv * bn * 2 * 4;
     const int npu_max = nt == 512 ? 6 : P2_NPU;
     for (int mr = (nt == 512 ? 2 : (nr <= 4 ? 4 : 2)); mr >= 1; mr >>= 1) {
+      if (force_mr && mr != force_mr) continue;
       const int npx = 16 * nwv * mr;
       const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 16);
       for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
@@ -1072,6 +1102,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
         const size_t lds = tab + wbytes + pbytes + stat;
         if (f8 && !p2_f8_tile_ok(mr, nr, wres, ph * pw * cu <= 6 * 256 ? 6 : 12)) continue;
         if (lds > budget || ph * pw * cu > npu_max * nt || (size_t)ph * pw * g.ppb > (size_t)8192 * (f8 ? 8 : 16)) continue;   // 13-bit LDS slot field
+        if (force_npu == 6 && ph * pw * cu > 6 * nt) continue;
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
         const long ntiles = (long)tx * ty * a.B;
         const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + tileconst;
@@ -1084,6 +1115,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
           cur.off_w = (int)tab; cur.off_p = (int)(tab + wbytes); cur.off_stat = (int)(lds - stat);
           p.ok = 1; p.mr = mr; p.nr = nr; p.wres = wres; p.g = cur; p.lds = lds; p.gy = gy; p.nt = nt;
           p.npu = nt == 512 ? 6 : (ph * pw * cu <= 6 * 256 ? 6 : 12);
+          if (force_npu) p.npu = force_npu;
         }
       }
     }
@@ -1111,6 +1143,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a) {
     p.g.off_stat = (int)(p.lds - stat);
   }
   const int per_cu = (p.lds <= lds3 && p.npu == 6) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
+  p.per_cu = per_cu;
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
   if (gx < 1) gx = 1;
@@ -1183,6 +1216,7 @@ template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
   static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
   a.dbg = dbg;
+  a.red_koff = (int)offsetof(ConvArgs, red);       // ConvArgs is the kernel's first argument (conv_epi.h ys_red_table)
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
@@ -1226,7 +1260,14 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
 #endif
   return YS_OK;
 }
+static int conv_p2_group_dispatch(hipStream_t st, const ConvArgs* a, const P2Plan* p, int n, const int* gxs, size_t lds);
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
+  // YS_P2_VIA_GROUP=1: single launches through conv_p2_group_kernel with one problem.  That kernel reads its arguments from the
+  // kernel-argument segment where they are used (dynamically indexed problem array) instead of holding the whole ConvArgs in scalar
+  // registers: hipcc's resource report shows 58-100 SGPRs against the 106-register limit every conv_p2_kernel variant sits at, which
+  // takes the scalar spills (VGPR lanes / scratch) out of several variants and lifts a few to the next occupancy step.
+  static const bool via_group = getenv("YS_P2_VIA_GROUP") && atoi(getenv("YS_P2_VIA_GROUP")) != 0;
+  if (via_group && !a.f8 && !a.fin) { const int gx = p.gx; return conv_p2_group_dispatch(st, &a, &p, 1, &gx, p.lds); }
   {
 #define P2F(M_, N_, F_, R_) { \
     if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_, R_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_, R_>(st, a, p); \
@@ -1247,6 +1288,105 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
   }
   ys_set_error("conv p2: no kernel for NT=%d MR=%d NR=%d", p.nt, p.mr, p.nr);
   return YS_ERR_UNSUPPORTED;
+}
+
+
+// ---- grouped launch of n <= YS_GROUP_MAX independent P2 convolutions on one kernel variant (conv_p2_group_kernel).  Returns YS_OK
+// and the statistics rows (= workgroups) each problem got in rows[], or YS_ERR_UNSUPPORTED when the problems cannot share a variant
+// (the caller then launches them one by one).  row_cap[i] > 0 bounds problem i's workgroups (partial-row regions sized elsewhere).
+template <int MR, int NR, int WRES, int NPU, int NT, int RED>
+static int conv_p2_group_launch_t(hipStream_t st, const ConvArgs* a, const P2Plan* p, int n, const int* gxs, size_t lds) {
+  static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;
+  static std::atomic<unsigned> attr_done{0};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
+    hipFuncSetAttribute((const void*)conv_p2_group_kernel<MR, NR, WRES, NPU, NT, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
+  }
+  P2Group grp{};
+  grp.n = n;
+  int total = 0;
+  char lab[256] = "";
+  for (int i = 0; i < n; i++) {
+    P2Prob& pr = grp.p[i];
+    pr.a = a[i]; pr.a.dbg = dbg; pr.g = p[i].g;
+    pr.a.red_koff = (int)(offsetof(P2Group, p) + (size_t)i * sizeof(P2Prob) + offsetof(P2Prob, a) + offsetof(ConvArgs, red));
+    pr.tab = p2_tables(a[i], p[i]);
+    if (!pr.tab) { ys_set_error("conv p2: cannot allocate the index tables"); return YS_ERR_OOM; }
+    total += gxs[i];
+    grp.end[i] = total;
+  }
+  for (int i = n; i < YS_GROUP_MAX; i++) grp.end[i] = total;
+  if (ys_kprof_enabled()) {
+    int o = snprintf(lab, sizeof(lab), "p2grp%d k%d s%d div1 cin%d cout%d M", n, a[0].KH * 10 + a[0].KW, a[0].SA, a[0].Cin, a[0].Cout);
+    long Msum = 0;
+    for (int i = 0; i < n; i++) Msum += a[i].M;
+    snprintf(lab + o, sizeof(lab) - o, "%ld acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", Msum, a[0].accumulate, NT, MR, NR, WRES, NPU, p[0].g.TH, p[0].g.TW, total, p[0].gy, (int)lds);
+  }
+  YsKprofScope prof(st, "conv_igemm", lab);
+  YS_LAUNCH_LDS((conv_p2_group_kernel<MR, NR, WRES, NPU, NT, RED>), dim3(total, p[0].gy), NT, lds, st, grp);
+  return YS_OK;
+}
+
+// variant dispatch of a grouped launch (n >= 1 problems already planned on ONE variant; gxs = workgroups per problem)
+static int conv_p2_group_dispatch(hipStream_t st, const ConvArgs* a, const P2Plan* p, int n, const int* gxs, size_t lds) {
+  const bool red = a[0].nred > 0 || (a[0].accumulate && YS_P2_EPI_DIRECT);
+#define P2GF(M_, N_, R_) { \
+    if (p[0].wres) return p[0].npu == 6 ? conv_p2_group_launch_t<M_, N_, 1, 6, 256, R_>(st, a, p, n, gxs, lds) : conv_p2_group_launch_t<M_, N_, 1, 12, 256, R_>(st, a, p, n, gxs, lds); \
+    return p[0].npu == 6 ? conv_p2_group_launch_t<M_, N_, 0, 6, 256, R_>(st, a, p, n, gxs, lds) : conv_p2_group_launch_t<M_, N_, 0, 12, 256, R_>(st, a, p, n, gxs, lds); }
+#define P2G(M_, N_) if (p[0].mr == M_ && p[0].nr == N_) { if (red) P2GF(M_, N_, 1) else P2GF(M_, N_, 0) }
+#ifdef YS_P2_ONE
+  P2G(YS_P2_ONE_M, YS_P2_ONE_N)
+#else
+  P2G(1, 1) P2G(2, 1) P2G(4, 1) P2G(1, 2) P2G(2, 2) P2G(4, 2) P2G(1, 3) P2G(2, 3) P2G(4, 3) P2G(1, 4) P2G(2, 4) P2G(4, 4) P2G(1, 5) P2G(2, 5)
+#endif
+#undef P2G
+#undef P2GF
+  ys_set_error("conv p2 group: no kernel for MR=%d NR=%d", p[0].mr, p[0].nr);
+  return YS_ERR_UNSUPPORTED;
+}
+
+int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int* row_cap, int* rows, bool plan_only) {
+  static const bool off = getenv("YS_NO_P2") != nullptr || (getenv("YS_GROUP") && atoi(getenv("YS_GROUP")) == 0);
+  if (off || n < 2 || n > YS_GROUP_MAX) return YS_ERR_UNSUPPORTED;
+  P2Plan p[YS_GROUP_MAX];
+  int big = 0;
+  for (int i = 0; i < n; i++) {
+    const ConvArgs& x = a[i];
+    if (x.f8 || x.fin || ys_conv_gemm_rows(x)) return YS_ERR_UNSUPPORTED;
+    if (ys_conv_dgrad_uses_phases(YS_BF16, x.KH, x.DIVM + 1) && x.KW == x.KH) return YS_ERR_UNSUPPORTED;
+    if (x.Cin != a[0].Cin || x.Cout != a[0].Cout || x.KH != a[0].KH || x.KW != a[0].KW || x.SA != a[0].SA || x.PAD != a[0].PAD ||
+        (x.nred > 0) != (a[0].nred > 0) || (x.accumulate != 0) != (a[0].accumulate != 0) || (x.stats != nullptr) != (a[0].stats != nullptr)) return YS_ERR_UNSUPPORTED;
+    if (x.M > a[big].M) big = i;
+  }
+  p[big] = conv_p2_plan(a[big]);
+  if (!p[big].ok) return YS_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; i++) {
+    if (i == big) continue;
+    p[i] = conv_p2_plan(a[i], p[big].mr, p[big].npu);
+    if (!p[i].ok || p[i].nr != p[big].nr || p[i].wres != p[big].wres || p[i].nt != p[big].nt || p[i].gy != p[big].gy) return YS_ERR_UNSUPPORTED;
+  }
+  // one persistent grid: the slots of the largest LDS footprint's occupancy class, split in proportion to the tile counts
+  size_t lds = 0; int per_cu = 3;
+  long tiles = 0;
+  for (int i = 0; i < n; i++) { lds = lds > p[i].lds ? lds : p[i].lds; per_cu = per_cu < p[i].per_cu ? per_cu : p[i].per_cu; tiles += p[i].g.ntiles; }
+  const long slots = (256L * per_cu) / p[0].gy > 0 ? (256L * per_cu) / p[0].gy : 1;
+  int gxs[YS_GROUP_MAX];
+  long used = 0;
+  for (int i = 0; i < n; i++) {
+    long gx = (slots * p[i].g.ntiles + tiles / 2) / tiles;
+    if (gx >= 8) gx = (gx + 4) / 8 * 8;          // multiples of 8: workgroup vbx keeps running on XCD vbx % 8
+    if (gx < 1) gx = 1;
+    if (gx > p[i].g.ntiles) gx = p[i].g.ntiles;
+    if (row_cap && row_cap[i] > 0 && gx > row_cap[i]) gx = row_cap[i];
+    gxs[i] = (int)gx; used += gx;
+  }
+  // a range that is not a multiple of 8 shifts the XCD phase of the ranges behind it: order the problems so that only the last may be ragged
+  // (ranges of >= 8 workgroups are multiples of 8 unless a cap cut them; a shifted phase only costs L2 locality, never correctness)
+  for (int i = 0; i < n; i++) if (rows) rows[i] = gxs[i];
+  if (plan_only) return YS_OK;
+  return conv_p2_group_dispatch(st, a, p, n, gxs, lds);
 }
 
 // host-side tile choice for the patch kernel: largest pixel tile (64*MR) whose patch fits PATCH_UNITS, shaped to

@@ -33,9 +33,12 @@ typedef const BnRedSeg* ys_redp_t;
 __device__ inline ys_redp_t ys_red_table(const ConvArgs& a) { return a.red; }
 #else
 typedef const BnRedSeg __attribute__((address_space(4)))* ys_redp_t;
-__device__ inline ys_redp_t ys_red_table(const ConvArgs&) {
+__device__ inline ys_redp_t ys_red_table(const ConvArgs& a) {
+  // a.red_koff = byte offset of THIS ConvArgs' segment table inside the launch's kernel-argument segment, set by the host launcher:
+  // offsetof(ConvArgs, red) where ConvArgs is the first kernel argument (conv_p2_kernel, conv_gemm_kernel), the element's offset in the
+  // problem array of a grouped launch (conv_p2_group_kernel)
   const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-  ys_redp_t p = (ys_redp_t)(ka + offsetof(ConvArgs, red));      // ConvArgs is the first kernel argument of both kernels
+  ys_redp_t p = (ys_redp_t)(ka + a.red_koff);
   asm volatile("" : "+s"(p));
   return p;
 }

@@ -383,6 +383,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
 
 template <int WM, int WN, int MR, int NR, int F8, int RED = 0>
 static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
+  a.red_koff = (int)offsetof(ConvArgs, red);       // ConvArgs is the kernel's first argument (conv_epi.h ys_red_table)
 #ifdef YS_GEMM_ABLATE
   a.dbg = getenv("YS_GEMM_DBG") ? atoi(getenv("YS_GEMM_DBG")) : 0;
 #endif

@@ -1146,3 +1146,195 @@ int ys_detect_decode_launch(hipStream_t st, int dtype, const void* pd, int ld_pd
     YS_LAUNCH_LDS((detect_decode_kernel<float>), ys_cdiv(n, DEC_ANCH), EW_THREADS, lds_bytes, st, (const float*)pd, ld_pd, (const float*)ps, ld_ps, B, A, nc, reg_max, nl, lo[0], o1, o2, lw[0], w1, w2, ls[0], s1, s2, pred, pred_C, (const float*)px, ld_px, xkind, nx, kdim);
   return YS_OK;
 }
+
+// ------------------------------------------------------------------ grouped (multi-problem) BatchNorm passes
+// The BN passes of INDEPENDENT Conv units that the planner runs side by side (the tower layers of the three pyramid levels of a
+// head, model.hip run_conv_fwd_group / run_conv_bwd_group) as one launch each: workgroups [end[i-1], end[i]) serve problem i.  The
+// P4 / P5 instances are 5-14 us launch-latency-bound kernels on their own; same arithmetic, same order of operations per element
+// and per channel as the single-problem kernels above (bit-identical results).
+template <class G> __device__ inline int ys_ew_group_pick(const G& g, int bx, int& start) {
+  int pi = 0;
+#pragma unroll
+  for (int k = 0; k + 1 < YS_EW_GROUP_MAX; k++) pi += (int)(k + 1 < g.n && bx >= g.end[k]);
+  start = pi ? g.end[pi - 1] : 0;
+  return pi;
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+bn_finalize_group_kernel(BnFinGroup grp, float eps, float momentum) {
+  __shared__ double sbuf[EW_THREADS];
+  int start;
+  const BnFinProb& p = grp.p[ys_ew_group_pick(grp, (int)blockIdx.x, start)];
+  const int c = (int)blockIdx.x - start, C = p.C;
+  const float* __restrict__ partial = p.partial;
+  float g = 0.f, bt = 0.f, rm0 = 0.f, rv0 = 0.f, nbt0 = 0.f;
+  if (threadIdx.x == 0) { g = p.gamma[c]; bt = p.beta[c]; rm0 = p.run_mean[c]; rv0 = p.run_var[c]; if (c == 0 && p.nbt) nbt0 = p.nbt[0]; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < p.nblk; k += EW_THREADS) {
+    s1 += (double)partial[((long)k * 2 + 0) * C + c];
+    s2 += (double)partial[((long)k * 2 + 1) * C + c];
+  }
+  block_sum2_d(s1, s2, sbuf);
+  if (threadIdx.x == 0) {
+    const double count = p.count;
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    p.scale[c] = g * rstd;
+    p.shift[c] = bt - (float)mean * g * rstd;
+    p.mean[c] = (float)mean;
+    p.rstd[c] = rstd;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    p.run_mean[c] = (1.0f - momentum) * rm0 + momentum * (float)mean;
+    p.run_var[c] = (1.0f - momentum) * rv0 + momentum * (float)unb;
+    if (c == 0 && p.nbt) p.nbt[0] = nbt0 + 1.0f;
+  }
+}
+int ys_bn_finalize_group_launch(hipStream_t st, const BnFinProb* probs, int n, float eps, float momentum) {
+  if (n < 1 || n > YS_EW_GROUP_MAX) { ys_set_error("bn finalize group: %d problems", n); return YS_ERR_INVALID_ARG; }
+  BnFinGroup grp{};
+  grp.n = n;
+  int total = 0;
+  for (int i = 0; i < n; i++) { grp.p[i] = probs[i]; total += probs[i].C; grp.end[i] = total; }
+  for (int i = n; i < YS_EW_GROUP_MAX; i++) grp.end[i] = total;
+  YS_LAUNCH(bn_finalize_group_kernel, total, EW_THREADS, st, grp, eps, momentum);
+  return YS_OK;
+}
+
+template <class T, bool ACT>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_apply_group_kernel(BnApplyGroup grp) {
+  constexpr int EPL = Elem<T>::EPL;
+  int start;
+  const BnApplyProb& p = grp.p[ys_ew_group_pick(grp, (int)blockIdx.x, start)];
+  const int C = p.C, CG = C / EPL;
+  const unsigned iu = (unsigned)((int)blockIdx.x - start) * (unsigned)EW_THREADS + threadIdx.x;     // rows * CG < 2^31 (checked by the launcher)
+  if ((long)iu < p.rows * CG) {
+    const unsigned r = iu / (unsigned)CG;
+    const long row = r; const int c = (int)(iu - r * (unsigned)CG) * EPL;
+    const T* __restrict__ y = (const T*)p.y; const T* __restrict__ res = (const T*)p.res; T* __restrict__ z = (T*)p.z;
+    float f[EPL], rr[EPL], sc[EPL], sh[EPL];
+    ys_unpack<T>(ys_ld16(y + row * C + c), f);
+    if (res) ys_unpack<T>(ys_ld16(res + row * p.res_ldc + p.res_coff + c), rr);
+    ys_ldcoef<EPL>(p.scale + c, sc);
+    ys_ldcoef<EPL>(p.shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      float u = f[e] * sc[e] + sh[e];
+      if (ACT) u = ys_silu(u);
+      if (res) u += rr[e];
+      f[e] = u;
+    }
+    ys_st16(z + row * p.z_ldc + p.z_coff + c, ys_pack<T>(f));
+  }
+}
+int ys_bn_act_apply_group_launch(hipStream_t st, int dtype, const BnApplyProb* probs, int n, int act) {
+  if (n < 1 || n > YS_EW_GROUP_MAX) { ys_set_error("bn apply group: %d problems", n); return YS_ERR_INVALID_ARG; }
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  BnApplyGroup grp{};
+  grp.n = n;
+  long total = 0;
+  for (int i = 0; i < n; i++) {
+    const long nn = probs[i].rows * (probs[i].C / epl);
+    if (nn >= (1L << 31)) { ys_set_error("bn apply group: problem too large"); return YS_ERR_UNSUPPORTED; }
+    grp.p[i] = probs[i]; total += ys_cdiv(nn, EW_THREADS); grp.end[i] = (int)total;
+  }
+  for (int i = n; i < YS_EW_GROUP_MAX; i++) grp.end[i] = (int)total;
+#define BAG_LAUNCH(TT, AF) YS_LAUNCH((bn_act_apply_group_kernel<TT, AF>), (int)total, EW_THREADS, st, grp)
+  if (dtype == YS_BF16) { if (act) BAG_LAUNCH(bf16_t, true); else BAG_LAUNCH(bf16_t, false); }
+  else { if (act) BAG_LAUNCH(float, true); else BAG_LAUNCH(float, false); }
+#undef BAG_LAUNCH
+  return YS_OK;
+}
+
+// MODE 0 (BN backward) of chan_finalize_kernel for several units at once
+__global__ void __launch_bounds__(EW_THREADS)
+chan_finalize_group_kernel(ChanFinGroup grp) {
+  __shared__ double sbuf[EW_THREADS];
+  int start;
+  const ChanFinProb& p = grp.p[ys_ew_group_pick(grp, (int)blockIdx.x, start)];
+  const int c = (int)blockIdx.x - start, C = p.C;
+  const float* __restrict__ partial = p.src.p[0]; int nblk = p.src.nblk[0];
+#pragma unroll
+  for (int k = 1; k < YS_BNRED_MAXSEG; k++) if (k < p.src.n && c >= p.src.c1[k - 1]) { partial = p.src.p[k]; nblk = p.src.nblk[k]; }
+  float sc = 0.f, mu = 0.f, rs = 0.f, g0p = 0.f, g1p = 0.f;
+  if (threadIdx.x == 0) { g0p = p.g0[c]; sc = p.scale[c]; mu = p.mean[c]; rs = p.rstd[c]; g1p = p.g1[c]; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += EW_THREADS) {
+    s1 += (double)partial[((long)k * 2 + 0) * C + c];
+    s2 += (double)partial[((long)k * 2 + 1) * C + c];
+  }
+  block_sum2_d(s1, s2, sbuf);
+  if (threadIdx.x == 0) {
+    const double count = p.count;
+    s2 = (double)rs * (s2 - (double)mu * s1);
+    p.g0[c] = g0p + (float)s2;
+    p.g1[c] = g1p + (float)s1;
+    const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+    p.c1[c] = sc * (m1 - mu * rs * m2);
+    p.c2[c] = sc * rs * m2;
+  }
+}
+int ys_bn_bwd_finalize_group_launch(hipStream_t st, const ChanFinProb* probs, int n) {
+  if (n < 1 || n > YS_EW_GROUP_MAX) { ys_set_error("bn backward finalize group: %d problems", n); return YS_ERR_INVALID_ARG; }
+  ChanFinGroup grp{};
+  grp.n = n;
+  int total = 0;
+  for (int i = 0; i < n; i++) { grp.p[i] = probs[i]; total += probs[i].C; grp.end[i] = total; }
+  for (int i = n; i < YS_EW_GROUP_MAX; i++) grp.end[i] = total;
+  YS_LAUNCH(chan_finalize_group_kernel, total, EW_THREADS, st, grp);
+  return YS_OK;
+}
+
+template <class T, bool ACT>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_bwd_apply_group_kernel(BnBwdGroup grp) {
+  constexpr int EPL = Elem<T>::EPL;
+  int start;
+  const BnBwdProb& p = grp.p[ys_ew_group_pick(grp, (int)blockIdx.x, start)];
+  const int C = p.C, CG = C / EPL;
+  const unsigned iu = (unsigned)((int)blockIdx.x - start) * (unsigned)EW_THREADS + threadIdx.x;
+  if ((long)iu < p.rows * CG) {
+    const unsigned r = iu / (unsigned)CG;
+    const long row = r; const int c = (int)(iu - r * (unsigned)CG) * EPL;
+    const T* __restrict__ dz = (const T*)p.dz; const T* __restrict__ y = (const T*)p.y; T* __restrict__ dy = (T*)p.dy; T* __restrict__ rg = (T*)p.rg;
+    float g[EPL], f[EPL], sc[EPL], sh[EPL], a2[EPL], a3[EPL];
+    ys_unpack<T>(ys_ld16(dz + row * p.dz_ldc + p.dz_coff + c), g);
+    ys_unpack<T>(ys_ld16(y + row * C + c), f);
+    if (rg) {
+      float o[EPL];
+      T* rp = rg + row * p.rg_ldc + p.rg_coff + c;
+      ys_unpack<T>(ys_ld16(rp), o);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) o[e] += g[e];
+      ys_st16(rp, ys_pack<T>(o));
+    }
+    ys_ldcoef<EPL>(p.scale + c, sc); ys_ldcoef<EPL>(p.shift + c, sh); ys_ldcoef<EPL>(p.k2 + c, a2); ys_ldcoef<EPL>(p.k3 + c, a3);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      const float u = f[e] * sc[e] + sh[e];
+      const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];
+      f[e] = sc[e] * du - a2[e] - f[e] * a3[e];
+    }
+    ys_st16(dy + row * C + c, ys_pack<T>(f));
+  }
+}
+int ys_bn_bwd_apply_group_launch(hipStream_t st, int dtype, const BnBwdProb* probs, int n, int act) {
+  if (n < 1 || n > YS_EW_GROUP_MAX) { ys_set_error("bn backward apply group: %d problems", n); return YS_ERR_INVALID_ARG; }
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  BnBwdGroup grp{};
+  grp.n = n;
+  long total = 0;
+  for (int i = 0; i < n; i++) {
+    const long nn = probs[i].rows * (probs[i].C / epl);
+    if (nn >= (1L << 31)) { ys_set_error("bn backward apply group: problem too large"); return YS_ERR_UNSUPPORTED; }
+    grp.p[i] = probs[i]; total += ys_cdiv(nn, EW_THREADS); grp.end[i] = (int)total;
+  }
+  for (int i = n; i < YS_EW_GROUP_MAX; i++) grp.end[i] = (int)total;
+#define BBG_LAUNCH(TT, AF) YS_LAUNCH((bn_bwd_apply_group_kernel<TT, AF>), (int)total, EW_THREADS, st, grp)
+  if (dtype == YS_BF16) { if (act) BBG_LAUNCH(bf16_t, true); else BBG_LAUNCH(bf16_t, false); }
+  else { if (act) BBG_LAUNCH(float, true); else BBG_LAUNCH(float, false); }
+#undef BBG_LAUNCH
+  return YS_OK;
+}

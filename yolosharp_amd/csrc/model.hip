@@ -66,6 +66,12 @@ struct ConvL {
   // [row0, row0 + rows) of this layer's weight / BN vectors and appears in the state_dict under its own module name.  Empty = one module.
   struct Member { std::string name; int row0, rows; };
   std::vector<Member> members;
+  // Level-parallel execution of the head (round 4): `stage` orders the head's ops stage-major (all pyramid levels of one tower layer next
+  // to each other); ops of one `group` (>= 0) are consecutive in ys_model::ops, mutually independent, and run as grouped launches
+  // (run_conv_fwd_group / run_conv_bwd_group).  Grouped units own their statistics rows and dy buffer (no shared scratch between problems).
+  int stage = -1, group = -1;
+  long gstat_off = -1;                   // floats into ys_model::stat_group
+  void* dy_own = nullptr;
 };
 
 enum OpType { OP_CONV = 0, OP_MAXPOOL = 1, OP_UPSAMPLE = 2, OP_ATTN = 3, OP_VCOPY = 4, OP_COPY = 5 };
@@ -155,6 +161,7 @@ struct ys_model {
   bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
   float* chan = nullptr; long n_chan = 0;       // per conv: scale, shift, mean, rstd, c1, c2 (6*cout)
   float* stat_partial = nullptr; long n_stat = 0;
+  float* stat_group = nullptr;                  // statistics rows of the grouped head stages (one region per unit, ConvL::gstat_off)
   float* wg_partial = nullptr; long n_wgp = 0;   // [shared scratch (ConvTranspose phases) | one region per convolution]
   // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
   std::vector<WgRedDesc> red_host, red_uploaded; WgRedDesc* red_dev = nullptr; int red_first[NSEG + 1] = {0, 0, 0, 0, 0};
@@ -385,6 +392,8 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
   bool fuse = legacy && !(getenv("YS_HEAD_FUSE") && atoi(getenv("YS_HEAD_FUSE")) == 0) && (c4s % m->epl) == 0;
   if (m->f8 && (cf % 32 || c2 % 32 || c3 % 32)) fuse = false;   // fp8 mode: the dgrad of a fused layer must still qualify for the fp8 kernel (K units of 32)
   int fbuf[3] = {-1, -1, -1}, fconv[3] = {-1, -1, -1};
+  const size_t op0 = m->ops.size();
+  auto tag = [&](int idx, int tower, int depth) { m->convs[idx].stage = tower * 4 + depth; };   // towers: 0 cv2, 1 cv3, 2 proto, 3 cv4
   size_t lane_first = m->convs.size();
   for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
     for (int i = 0; i < 3; i++) {
@@ -401,13 +410,14 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
           fc.members.push_back({tp + ".0", 0, c2});
           fc.members.push_back({hp + ".cv3." + std::to_string(i) + ".0", c2, c3});
           if (c4s) fc.members.push_back({hp + ".cv4." + std::to_string(i) + ".0", c2 + c3, c4s});
+          tag(fconv[i], 0, 0);
         }
         m->reg.push_back(reg_entry(fconv[i], t));
-        add_conv_reg(m, tp + ".1", View{fbuf[i], t == 0 ? 0 : c2, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg);
+        tag(add_conv_reg(m, tp + ".1", View{fbuf[i], t == 0 ? 0 : c2, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg), t, 1);
       } else if (t == 0 || legacy) {
         const int t0 = new_buf(m, hh[i], ww[i], cm);
-        add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 3, 1, true, true, hh[i], ww[i], seg);
-        add_conv_reg(m, tp + ".1", View{t0, 0, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg);
+        tag(add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, cm}, ch[i], cm, 3, 1, true, true, hh[i], ww[i], seg), t, 0);
+        tag(add_conv_reg(m, tp + ".1", View{t0, 0, cm}, View{t1, 0, cm}, cm, cm, 3, 1, true, true, hh[i], ww[i], seg), t, 1);
       } else {
         const int t0 = new_buf(m, hh[i], ww[i], cm);
         const int d0 = new_buf(m, hh[i], ww[i], ch[i]), d1 = new_buf(m, hh[i], ww[i], cm);
@@ -418,6 +428,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       }
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, cm}, View{ob, 0, co}, cm, co, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
+      tag(cc, t, 2);
       if (legacy) for (size_t k = lane_first; k < m->convs.size(); k++) m->convs[k].lane = i;   // level 0 (P3) stays on the main stream; v11 towers hold depthwise units (own launch path): no lanes
       lane_first = m->convs.size();
     }
@@ -432,21 +443,26 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
     m->ld_mc = (nm + m->epl - 1) / m->epl * m->epl;
     m->ld_pr = m->ld_mc;
     m->mh = 2 * hh[0]; m->mw = 2 * ww[0];
-    m->pr_buf = add_proto(m, hp + ".proto", View{pv[0], 0, ch[0]}, ch[0], npr, nm, hh[0], ww[0], seg);
+    {
+      const size_t pc0 = m->convs.size();
+      m->pr_buf = add_proto(m, hp + ".proto", View{pv[0], 0, ch[0]}, ch[0], npr, nm, hh[0], ww[0], seg);
+      for (size_t k = pc0; k < m->convs.size(); k++) m->convs[k].stage = 2 * 4 + (int)(k - pc0);   // a chain: one unit per stage
+    }
     m->mc_buf = new_buf(m, 1, m->A, m->ld_mc);
     for (int i = 0; i < 3; i++) {
       const std::string tp = hp + ".cv4." + std::to_string(i);
       const int t1 = new_buf(m, hh[i], ww[i], c4);
       if (fuse) {                 // cv4[i][0] ran inside the level's fused first convolution (channels [c2 + c3, c2 + c3 + c4) of its output)
         m->reg.push_back(reg_entry(fconv[i], 2));
-        add_conv_reg(m, tp + ".1", View{fbuf[i], c2 + c3, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
+        tag(add_conv_reg(m, tp + ".1", View{fbuf[i], c2 + c3, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg), 4, 1);
       } else {
         const int t0 = new_buf(m, hh[i], ww[i], c4);
-        add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, c4}, ch[i], c4, 3, 1, true, true, hh[i], ww[i], seg);
-        add_conv_reg(m, tp + ".1", View{t0, 0, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg);
+        tag(add_conv_reg(m, tp + ".0", View{pv[i], 0, ch[i]}, View{t0, 0, c4}, ch[i], c4, 3, 1, true, true, hh[i], ww[i], seg), 4, 0);
+        tag(add_conv_reg(m, tp + ".1", View{t0, 0, c4}, View{t1, 0, c4}, c4, c4, 3, 1, true, true, hh[i], ww[i], seg), 4, 1);
       }
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4}, View{m->mc_buf, 0, nm}, c4, nm, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
+      tag(cc, 4, 2);
       if (legacy) for (int k = cc - (fuse ? 1 : 2); k <= cc; k++) m->convs[k].lane = i;
     }
     m->xkind = 1;
@@ -471,7 +487,28 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       m->convs[k0].cout_real = m->convs[k1].cout_real = c4;
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4p}, View{m->mc_buf, 0, nx}, c4, nx, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
+      tag(k0, 4, 0); tag(k1, 4, 1); tag(cc, 4, 2);
       if (legacy) for (int k = k0; k <= cc; k++) m->convs[k].lane = i;
+    }
+  }
+  // Level-parallel schedule (v8 heads; YS_GROUP=0 keeps the level-major order and single launches): the head's ops stage-major -- the same
+  // tower layer of P3, P4, P5 next to each other -- and every stage of >= 2 units is one group.  Units of a stage read and write disjoint
+  // buffers (per-level towers, per-level rows of the prediction buffers); a stage only depends on earlier stages of its own tower and on
+  // the (fused) first layers, which sort first.
+  const bool group_on = legacy && !(getenv("YS_GROUP") && atoi(getenv("YS_GROUP")) == 0) && !m->f8;
+  if (group_on) {
+    bool all = true;
+    for (size_t k = op0; k < m->ops.size(); k++) all = all && m->ops[k].type == OP_CONV && m->convs[m->ops[k].conv].stage >= 0;
+    if (all) {
+      std::stable_sort(m->ops.begin() + op0, m->ops.end(), [&](const Op& x, const Op& y) { return m->convs[x.conv].stage < m->convs[y.conv].stage; });
+      int gid = 0;
+      for (size_t k = op0; k < m->ops.size();) {
+        size_t e = k + 1;
+        while (e < m->ops.size() && m->convs[m->ops[e].conv].stage == m->convs[m->ops[k].conv].stage) e++;
+        const ConvL& c0 = m->convs[m->ops[k].conv];
+        if (e - k >= 2 && (int)(e - k) <= YS_GROUP_MAX && !c0.dw && !c0.ct) { for (size_t j = k; j < e; j++) m->convs[m->ops[j].conv].group = gid; gid++; }
+        k = e;
+      }
     }
   }
   return YS_OK;
@@ -952,6 +989,17 @@ int allocate(ys_model* m) {
     YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_seg_m[k], hipEventDisableTiming));
     YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_seg_w[k], hipEventDisableTiming));
   }
+  {
+    // grouped head stages: every unit keeps its own statistics rows (conv -> grouped finalize) and its own dy (BN backward -> wgrad / dgrad)
+    long gst = 0;
+    for (auto& c : m->convs) {
+      if (c.group < 0) continue;
+      const long M = (long)B * c.Hout * c.Wout;
+      c.gstat_off = gst; gst += (2L * ys_cdiv(M, 64) * 2 * c.cout_ld + 63) / 64 * 64;
+      if (c.bn) YS_TRY(dev_alloc(m, &c.dy_own, (size_t)M * c.cout_ld * m->es));
+    }
+    if (gst) YS_TRY(dev_alloc(m, (void**)&m->stat_group, (size_t)gst * 4));
+  }
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
   const bool ticket_uc = getenv("YS_BN_TICKET") && atoi(getenv("YS_BN_TICKET")) == 2;   // 2: statistics rows + tickets in uncached memory, no fences
   YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4, true, ticket_uc));
@@ -1184,6 +1232,56 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
   return YS_OK;
 }
 
+// ---- grouped forward of n independent Conv units / plain convolutions of one head stage (ConvL::group): one grouped convolution
+// launch when the problems share a kernel variant (same channels and taps: the .1 / .2 tower layers of the three levels), else one
+// launch each; then ONE BatchNorm finalize and ONE BN + SiLU apply launch for the whole stage.  Same arithmetic as run_conv_fwd.
+int run_conv_fwd_group(ys_model* m, ConvL* const* cs, int n, int B) {
+  hipStream_t st = m->ctx->stream;
+  bool ok = n >= 2 && n <= YS_GROUP_MAX && !m->f8 && !m->bn_ticket;
+  for (int i = 0; i < n && ok; i++) {
+    const ConvL& c = *cs[i];
+    ok = !c.dw && !c.ct && !c.has_res && c.gstat_off >= 0 && c.bn == cs[0]->bn && c.act == cs[0]->act;
+  }
+  if (!ok) { for (int i = 0; i < n; i++) YS_TRY(run_conv_fwd(m, *cs[i], B)); return YS_OK; }
+  ConvArgs a[YS_GROUP_MAX];
+  int rows[YS_GROUP_MAX] = {0, 0, 0};
+  const bool bn_train = cs[0]->bn && m->training;
+  for (int i = 0; i < n; i++) {
+    const ConvL& c = *cs[i];
+    const Buf& ob = m->bufs[c.out.buf];
+    a[i] = fwd_args(m, c, B);
+    if (bn_train) {
+      a[i].y = (char*)m->y_all + (size_t)c.y_off * m->es; a[i].out_ldc = c.cout; a[i].out_coff = 0; a[i].out_bstride = (long)c.Hout * c.Wout;
+      a[i].vec_ok = (c.cout % 4 == 0);
+      a[i].stats = m->stat_group + c.gstat_off;
+    } else {
+      a[i].y = view_ptr(m, ob.act, ob, c.out_rowoff);
+      a[i].out_ldc = ob.ldc; a[i].out_coff = c.out.coff; a[i].out_bstride = ob.rows_per_b;
+      a[i].vec_ok = ((ob.ldc % 4 == 0) && (c.out.coff % 4 == 0)) ? 1 : 0;
+      if (c.bn) { a[i].scale = chan_ptr(m, c, 0); a[i].shift = chan_ptr(m, c, 1); a[i].act = c.act ? 1 : 0; }
+      else a[i].shift = m->params + c.g_off;  // conv bias
+    }
+  }
+  int rc = m->dtype == YS_BF16 ? ys_conv_p2_group_launch(st, a, n, nullptr, rows) : YS_ERR_UNSUPPORTED;
+  if (rc == YS_ERR_UNSUPPORTED) {
+    for (int i = 0; i < n; i++) { YS_TRY(ys_conv_launch(st, m->dtype, a[i])); rows[i] = ys_conv_grid_m(a[i], m->dtype); }
+  } else if (rc != YS_OK) return rc;
+  if (!bn_train) return YS_OK;
+  BnFinProb fp[YS_GROUP_MAX];
+  BnApplyProb ap[YS_GROUP_MAX];
+  for (int i = 0; i < n; i++) {
+    const ConvL& c = *cs[i];
+    const Buf& ob = m->bufs[c.out.buf];
+    const long M = a[i].M;
+    fp[i] = BnFinProb{m->stat_group + c.gstat_off, rows[i], c.cout, (double)M, m->params + c.g_off, m->params + c.b_off, m->state + c.rm_off,
+                      m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0), chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)};
+    ap[i] = BnApplyProb{a[i].y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), nullptr, 0, 0, ob.act, ob.ldc, c.out.coff};
+  }
+  YS_TRY(ys_bn_finalize_group_launch(st, fp, n, 1e-3f, 0.03f));
+  YS_TRY(ys_bn_act_apply_group_launch(st, m->dtype, ap, n, cs[0]->act ? 1 : 0));
+  return YS_OK;
+}
+
 static int join_wgrad_stream(ys_model* m);
 int forward_impl(ys_model* m, int B) {
   hipStream_t st = m->ctx->stream;
@@ -1206,6 +1304,15 @@ int forward_impl(ys_model* m, int B) {
     const Op& op = m->ops[oi];
     const Buf& ib = m->bufs[op.in.buf];
     const Buf& ob = m->bufs[op.out.buf];
+    if (op.type == OP_CONV && m->convs[op.conv].group >= 0 && !lanes_on) {
+      // a head stage: the consecutive ops of one group run as grouped launches
+      ConvL* gc[YS_GROUP_MAX]; int gn = 0;
+      const int gid = m->convs[op.conv].group;
+      while (oi + gn < m->ops.size() && gn < YS_GROUP_MAX && m->ops[oi + gn].type == OP_CONV && m->convs[m->ops[oi + gn].conv].group == gid) { gc[gn] = &m->convs[m->ops[oi + gn].conv]; gn++; }
+      YS_TRY(run_conv_fwd_group(m, gc, gn, B));
+      oi += gn - 1;
+      continue;
+    }
     if (op.type == OP_CONV) {
       const ConvL& cc = m->convs[op.conv];
       const ConvL* next = nullptr;               // the very next op, if it is a convolution reading exactly what this one writes
@@ -1445,6 +1552,45 @@ int plan_bnred(ys_model* m, int B) {
   return YS_OK;
 }
 
+// weight gradient of one convolution on stream `sw` (split partials into the layer's own region when the reduction is deferred)
+static int launch_wgrad(ys_model* m, ConvL& c, int B, const void* dy, int dy_ldc, int dy_coff, long dy_bstride, hipStream_t sw) {
+  const Buf& ib = m->bufs[c.in.buf];
+  const long M = (long)B * c.Hout * c.Wout;
+  WgradArgs a{};
+  a.x = ib.act; a.dy = dy; a.partial = m->wg_partial;
+  a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.cin_pad; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.cout;
+  a.KH = a.KW = c.k; a.stride = c.s; a.pad = c.k / 2;
+  a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
+  a.dy_ldc = dy_ldc; a.dy_coff = dy_coff; a.dy_bstride = dy_bstride; a.M = (int)M;
+  int splits = ys_wgrad_splits(a, m->dtype);
+  const bool defer = c.wgp_off >= 0;
+  if (defer) { a.partial = m->wg_partial + c.wgp_off; if (splits > c.wgp_splits) splits = c.wgp_splits; }   // own region (sized at max_batch)
+  else if ((long)splits * c.cout * c.k * c.k * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
+  int used = 0;
+  YS_TRY(ys_wgrad_launch(sw, m->dtype, a, splits, c.cin, m->grads + c.w_off, defer ? &used : nullptr));
+  if (defer) {
+    WgRedDesc& d = m->red_host[c.red_slot];
+    d.partial = a.partial; d.grad = m->grads + c.w_off; d.n = (long)c.cout * c.k * c.k * c.cin_pad; d.splits = used;
+    d.cin_pad = c.cin_pad; d.cin_real = c.cin;
+    YS_REQUIRE((c.cin_pad & 3) == 0, "wgrad reduce: input channel pitch must be a multiple of 4");
+  }
+  return YS_OK;
+}
+
+// the BN-backward segments of the producers whose dz this dgrad launch completes (c.feeds) -> a.red[]; `rows` = partial rows it will write
+static void attach_bnred_feeds(ys_model* m, ConvL& c, ConvArgs& a, int rows) {
+  a.nred = (int)c.feeds.size(); a.red_row0 = 0;
+  for (int k = 0; k < a.nred; k++) {
+    ConvL::RedFeed& f = c.feeds[k];
+    ConvL& l = m->convs[f.prod];
+    BnRedSeg& sg = a.red[k];
+    sg.y = (char*)m->y_all + (size_t)l.y_off * m->es; sg.scale = chan_ptr(m, l, 0); sg.shift = chan_ptr(m, l, 1);
+    sg.part = m->bnred_part + f.part_off; sg.c0 = f.c0; sg.c1 = f.c1; sg.yc0 = f.yc0; sg.C = l.cout; sg.act = l.act ? 1 : 0;
+    f.rows = rows;
+    l.red_seen++;
+  }
+}
+
 int run_conv_bwd(ys_model* m, ConvL& c, int B) {
   if (c.ct) return run_convT_bwd(m, c, B);
   hipStream_t st = m->ctx->stream;
@@ -1526,16 +1672,6 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
   }
   // ---- wgrad
   {
-    WgradArgs a{};
-    a.x = ib.act; a.dy = dy; a.partial = m->wg_partial;
-    a.B = B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.cin_pad; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.cout;
-    a.KH = a.KW = c.k; a.stride = c.s; a.pad = c.k / 2;
-    a.in_ldc = ib.ldc; a.in_coff = c.in.coff; a.in_bstride = ib.rows_per_b;
-    a.dy_ldc = dy_ldc; a.dy_coff = dy_coff; a.dy_bstride = dy_bstride; a.M = (int)M;
-    int splits = ys_wgrad_splits(a, m->dtype);
-    const bool defer = c.wgp_off >= 0;
-    if (defer) { a.partial = m->wg_partial + c.wgp_off; if (splits > c.wgp_splits) splits = c.wgp_splits; }   // own region (sized at max_batch)
-    else if ((long)splits * c.cout * c.k * c.k * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
     hipStream_t sw = st;
     if (m->overlap) {                    // dy is complete on `st`: hand it to the weight-gradient stream
       hipEvent_t ev = m->ev_dy[slot >= 0 ? slot : ys_model::DY_RING];
@@ -1543,14 +1679,7 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
       YS_CHECK_HIP(hipStreamWaitEvent(m->st2, ev, 0));
       sw = m->st2;
     }
-    int used = 0;
-    YS_TRY(ys_wgrad_launch(sw, m->dtype, a, splits, c.cin, m->grads + c.w_off, defer ? &used : nullptr));
-    if (defer) {
-      WgRedDesc& d = m->red_host[c.red_slot];
-      d.partial = a.partial; d.grad = m->grads + c.w_off; d.n = (long)c.cout * c.k * c.k * c.cin_pad; d.splits = used;
-      d.cin_pad = c.cin_pad; d.cin_real = c.cin;
-      YS_REQUIRE((c.cin_pad & 3) == 0, "wgrad reduce: input channel pitch must be a multiple of 4");
-    }
+    YS_TRY(launch_wgrad(m, c, B, dy, dy_ldc, dy_coff, dy_bstride, sw));
     if (m->overlap) {
       m->st2_dirty = true;
       if (slot >= 0) { YS_CHECK_HIP(hipEventRecord(m->ev_free[slot], m->st2)); m->slot_busy[slot] = true; }
@@ -1578,21 +1707,97 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
       const int rows = ys_conv_bnred_rows(a, m->dtype);
       bool fits = rows > 0;
       for (auto& f : c.feeds) fits = fits && rows <= f.rows_cap;
-      if (fits) {
-        a.nred = (int)c.feeds.size(); a.red_row0 = 0;
-        for (int k = 0; k < a.nred; k++) {
-          ConvL::RedFeed& f = c.feeds[k];
-          ConvL& l = m->convs[f.prod];
-          BnRedSeg& sg = a.red[k];
-          sg.y = (char*)m->y_all + (size_t)l.y_off * m->es; sg.scale = chan_ptr(m, l, 0); sg.shift = chan_ptr(m, l, 1);
-          sg.part = m->bnred_part + f.part_off; sg.c0 = f.c0; sg.c1 = f.c1; sg.yc0 = f.yc0; sg.C = l.cout; sg.act = l.act ? 1 : 0;
-          f.rows = rows;
-          l.red_seen++;
-        }
-      }
+      if (fits) attach_bnred_feeds(m, c, a, rows);
     }
     YS_TRY(ys_conv_launch(st, m->dtype, a));
   }
+  return YS_OK;
+}
+
+// ---- grouped backward of one head stage (mirror of run_conv_fwd_group): BN backward finalize + apply as one launch each, the weight
+// gradients handed to the weight-gradient stream behind ONE event, the input gradients as one grouped dgrad launch when the problems
+// share a kernel variant.  Falls back to run_conv_bwd per unit whenever a unit needs something the grouped form does not carry.
+int run_conv_bwd_group(ys_model* m, ConvL* const* cs, int n, int B) {
+  hipStream_t st = m->ctx->stream;
+  bool ok = n >= 2 && n <= YS_GROUP_MAX && !m->f8;
+  for (int i = 0; i < n && ok; i++) {
+    const ConvL& c = *cs[i];
+    ok = !c.dw && !c.ct && !c.has_res && !c.first && c.gstat_off >= 0 && c.bn == cs[0]->bn && c.act == cs[0]->act && (!c.bn || (c.dy_own && c.cout_ld == c.cout));
+    if (ok && c.bn) ok = c.red_ok && c.red_seen == (int)c.red_src.size() && !c.red_src.empty();   // sums already produced by the consumers' dgrads
+  }
+  if (!ok) { for (int i = 0; i < n; i++) YS_TRY(run_conv_bwd(m, *cs[i], B)); return YS_OK; }
+  const void* dy[YS_GROUP_MAX]; int dy_ldc[YS_GROUP_MAX], dy_coff[YS_GROUP_MAX]; long dy_bs[YS_GROUP_MAX];
+  if (cs[0]->bn) {
+    ChanFinProb fp[YS_GROUP_MAX];
+    BnBwdProb bp[YS_GROUP_MAX];
+    for (int i = 0; i < n; i++) {
+      ConvL& c = *cs[i];
+      const Buf& ob = m->bufs[c.out.buf];
+      const long M = (long)B * c.Hout * c.Wout;
+      FinSrc src{};
+      src.n = (int)c.red_src.size();
+      for (int k = 0; k < src.n; k++) {
+        const ConvL::RedFeed& f = m->convs[c.red_src[k].cons].feeds[c.red_src[k].feed];
+        src.p[k] = m->bnred_part + f.part_off; src.nblk[k] = f.rows; src.c1[k] = f.yc0 + (f.c1 - f.c0);
+      }
+      c.red_seen = 0;
+      fp[i] = ChanFinProb{src, c.cout, (double)M, m->grads + c.g_off, m->grads + c.b_off, chan_ptr(m, c, 4), chan_ptr(m, c, 5), chan_ptr(m, c, 0), chan_ptr(m, c, 2), chan_ptr(m, c, 3)};
+      bp[i] = BnBwdProb{ob.grad, ob.ldc, c.out.coff, (char*)m->y_all + (size_t)c.y_off * m->es, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), chan_ptr(m, c, 4), chan_ptr(m, c, 5), c.dy_own, nullptr, 0, 0};
+      dy[i] = c.dy_own; dy_ldc[i] = c.cout; dy_coff[i] = 0; dy_bs[i] = (long)c.Hout * c.Wout;
+    }
+    YS_TRY(ys_bn_bwd_finalize_group_launch(st, fp, n));
+    YS_TRY(ys_bn_bwd_apply_group_launch(st, m->dtype, bp, n, cs[0]->act ? 1 : 0));
+  } else {
+    for (int i = 0; i < n; i++) {
+      ConvL& c = *cs[i];
+      const Buf& ob = m->bufs[c.out.buf];
+      const long M = (long)B * c.Hout * c.Wout;
+      dy[i] = view_ptr(m, ob.grad, ob, c.out_rowoff); dy_ldc[i] = ob.ldc; dy_coff[i] = c.out.coff; dy_bs[i] = ob.rows_per_b;
+      YS_TRY(ys_colsum_launch(st, m->dtype, dy[i], dy_ldc[i], dy_coff[i], M, (long)c.Hout * c.Wout, dy_bs[i], c.cout, m->stat_partial, m->grads + c.g_off));
+    }
+  }
+  // ---- weight gradients: every dy of the stage is complete on `st` here
+  {
+    hipStream_t sw = st;
+    if (m->overlap) {
+      hipEvent_t ev = m->ev_dy[ys_model::DY_RING];
+      YS_CHECK_HIP(hipEventRecord(ev, st));
+      YS_CHECK_HIP(hipStreamWaitEvent(m->st2, ev, 0));
+      sw = m->st2;
+      m->st2_dirty = true;
+    }
+    for (int i = 0; i < n; i++) YS_TRY(launch_wgrad(m, *cs[i], B, dy[i], dy_ldc[i], dy_coff[i], dy_bs[i], sw));
+  }
+  // ---- input gradients
+  ConvArgs a[YS_GROUP_MAX];
+  int cap[YS_GROUP_MAX] = {0, 0, 0}, rows[YS_GROUP_MAX] = {0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    ConvL& c = *cs[i];
+    const int mode = grad_mode(m, c.in);
+    if (mode < 0) { ys_set_error("backward: inconsistent gradient slice state at %s", c.name.c_str()); return YS_ERR_STATE; }
+    a[i] = dgrad_args(m, c, B, dy[i], dy_ldc[i], dy_coff[i], dy_bs[i]);
+    a[i].accumulate = mode;
+    for (auto& f : c.feeds) cap[i] = cap[i] ? std::min(cap[i], f.rows_cap) : f.rows_cap;
+    if (!c.feeds.empty()) { a[i].nred = (int)c.feeds.size(); }   // (segments are attached once the row counts are known)
+  }
+  // a grouped launch needs the segment tables before it starts and its row counts are only known after planning: plan first (dry run)
+  int rc = m->dtype == YS_BF16 ? ys_conv_p2_group_launch(st, a, n, cap, rows, true) : YS_ERR_UNSUPPORTED;
+  if (rc == YS_OK) {
+    for (int i = 0; i < n; i++) { a[i].nred = 0; if (!cs[i]->feeds.empty()) attach_bnred_feeds(m, *cs[i], a[i], rows[i]); }
+    YS_TRY(ys_conv_p2_group_launch(st, a, n, cap, rows));
+  } else if (rc == YS_ERR_UNSUPPORTED) {
+    for (int i = 0; i < n; i++) {
+      ConvL& c = *cs[i];
+      a[i].nred = 0;
+      if (!c.feeds.empty()) {
+        const int r = ys_conv_bnred_rows(a[i], m->dtype);
+        bool fits = r > 0;
+        for (auto& f : c.feeds) fits = fits && r <= f.rows_cap;
+        if (fits) attach_bnred_feeds(m, c, a[i], r);
+      }
+      YS_TRY(ys_conv_launch(st, m->dtype, a[i]));
+    }
+  } else return rc;
   return YS_OK;
 }
 
@@ -1614,7 +1819,15 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) 
   for (int i = (int)m->ops.size() - 1; i >= 0; i--) {
     const Op& op = m->ops[i];
     if (op.seg < seg_lo || op.seg > seg_hi) continue;
-    if (op.type == OP_CONV) {
+    if (op.type == OP_CONV && m->convs[op.conv].group >= 0) {
+      ConvL* gc[YS_GROUP_MAX]; int gn = 0;
+      const int gid = m->convs[op.conv].group;
+      int j = i;
+      while (j >= 0 && gn < YS_GROUP_MAX && m->ops[j].type == OP_CONV && m->convs[m->ops[j].conv].group == gid) { gn++; j--; }
+      for (int k = 0; k < gn; k++) gc[k] = &m->convs[m->ops[i - gn + 1 + k].conv];     // forward (level) order
+      YS_TRY(run_conv_bwd_group(m, gc, gn, B));
+      i -= gn - 1;
+    } else if (op.type == OP_CONV) {
       YS_TRY(run_conv_bwd(m, m->convs[op.conv], B));
     } else if (op.type == OP_ATTN) {
       // d(qkv) = [dq | dk | dv]; the v part already holds the gradient that arrived through pe(v) (OP_VCOPY backward)

@@ -8,6 +8,8 @@
 // in a pass of its own over dz and y): one statistics row per workgroup, like the forward BN statistics.  A segment maps the
 // channels [c0, c1) of the launch's OUTPUT view onto channels [yc0, ...) of one producer.
 #define YS_BNRED_MAXSEG 3
+#define YS_GROUP_MAX 3        // problems of one grouped convolution launch (the three pyramid levels of a head)
+#define YS_EW_GROUP_MAX 9     // problems of one grouped elementwise launch (BN passes of up to three towers x three levels)
 struct BnRedSeg {
   const void* y;        // producer's raw conv output, dense [M][C]
   const float* scale;   // producer's BN scale / shift (forward, training statistics), [C]
@@ -69,6 +71,7 @@ struct ConvArgs {
   // fused BN-backward reduction (dgrad launches through conv_epi.h only; see BnRedSeg)
   int nred;                      // segments in use (0 = off)
   int red_row0;                  // first partial row of this launch (the four phase launches of a stride-2 dgrad stack their rows)
+  int red_koff;                  // set by the launchers: byte offset of `red` in the launch's kernel-argument segment (conv_epi.h ys_red_table)
   BnRedSeg red[YS_BNRED_MAXSEG];
 };
 
@@ -184,6 +187,23 @@ struct FinSrc { const float* p[YS_BNRED_MAXSEG]; int nblk[YS_BNRED_MAXSEG]; int 
 int ys_bn_bwd_finalize_src_launch(hipStream_t st, const FinSrc& src, int C, long count, float* dgamma, float* dbeta, float* k2,
                                   float* k3, const float* scale, const float* mean, const float* rstd);
 // column sums of a [rows][ldc] view into grad[C] (+=)   (bias gradients)
+// ---- grouped (multi-problem) launches: independent Conv units of the same kind side by side in one grid (elementwise.hip, conv.hip)
+struct BnFinProb { const float* partial; int nblk, C; double count; const float *gamma, *beta; float *run_mean, *run_var, *nbt, *scale, *shift, *mean, *rstd; };
+struct BnFinGroup { int n; int end[YS_EW_GROUP_MAX]; BnFinProb p[YS_EW_GROUP_MAX]; };
+struct BnApplyProb { const void* y; long rows; int C; const float *scale, *shift; const void* res; int res_ldc, res_coff; void* z; int z_ldc, z_coff; };
+struct BnApplyGroup { int n; int end[YS_EW_GROUP_MAX]; BnApplyProb p[YS_EW_GROUP_MAX]; };
+struct ChanFinProb { FinSrc src; int C; double count; float *g0, *g1, *c1, *c2; const float *scale, *mean, *rstd; };
+struct ChanFinGroup { int n; int end[YS_EW_GROUP_MAX]; ChanFinProb p[YS_EW_GROUP_MAX]; };
+struct BnBwdProb { const void* dz; int dz_ldc, dz_coff; const void* y; long rows; int C; const float *scale, *shift, *k2, *k3; void* dy; void* rg; int rg_ldc, rg_coff; };
+struct BnBwdGroup { int n; int end[YS_EW_GROUP_MAX]; BnBwdProb p[YS_EW_GROUP_MAX]; };
+int ys_bn_finalize_group_launch(hipStream_t st, const BnFinProb* probs, int n, float eps, float momentum);
+int ys_bn_act_apply_group_launch(hipStream_t st, int dtype, const BnApplyProb* probs, int n, int act);
+int ys_bn_bwd_finalize_group_launch(hipStream_t st, const ChanFinProb* probs, int n);
+int ys_bn_bwd_apply_group_launch(hipStream_t st, int dtype, const BnBwdProb* probs, int n, int act);
+// n <= YS_GROUP_MAX independent P2 convolutions of one shape class as ONE persistent grid; YS_ERR_UNSUPPORTED = launch them one by one.
+// row_cap[i] > 0 bounds problem i's workgroups; rows[i] = workgroups (= statistics / BN-reduction partial rows) problem i got
+// plan_only: no launch, only the row counts (a dgrad's BN-reduction segments need them before the launch)
+int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int* row_cap, int* rows, bool plan_only = false);
 int ys_colsum_launch(hipStream_t st, int dtype, const void* x, int ldc, int coff, long rows, long rows_per_b,
                      long bstride, int C, float* partial, float* grad);
 int ys_colsum_blocks(long rows, int C, int dtype);

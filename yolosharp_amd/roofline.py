@@ -19,6 +19,7 @@ MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0, "f32": 157.3}
 
 KERNELS = {   # label prefix -> (kernel symbol, operand type of its MFMAs)
     "p2": ("conv_p2_kernel", "bf16"), "p2f8": ("conv_p2_kernel<F8>", "fp8"),
+    "p2grp": ("conv_p2_group_kernel", "bf16"),     # grouped launch (label "p2grpN ... M<sum of the problems' pixels>"): same channels and taps for every problem
     "gemm": ("conv_gemm_kernel", "bf16"), "gemmf8": ("conv_gemm_kernel<F8>", "fp8"),
     "direct": ("conv_igemm_kernel", "bf16"), "patch": ("conv3x3_tile_kernel", "bf16"),
     "wgrad_tr": ("conv_wgrad_tr_kernel", "bf16"), "wgemm": ("conv_wgrad_gemm_kernel", "bf16"), "wgrad": ("conv_wgrad_kernel", "bf16"),
@@ -29,9 +30,9 @@ _LAB = re.compile(r"^(\w+) k(\d+) s(\d+) (?:div(\d+) )?cin(\d+) cout(\d+) M(\d+)
 def launch_work(label, elem_bytes=2):
     """(kernel symbol, operand type, algorithmic bytes, flop) of one labelled launch; None for labels without geometry."""
     m = _LAB.match(label)
-    if not m or m.group(1) not in KERNELS:
+    if not m or re.sub(r"(?<=grp)\d+$", "", m.group(1)) not in KERNELS:
         return None
-    kind, k, s, div, cin, cout, M = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4) or 1), int(m.group(5)), int(m.group(6)), int(m.group(7))
+    kind, k, s, div, cin, cout, M = re.sub(r"(?<=grp)\d+$", "", m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4) or 1), int(m.group(5)), int(m.group(6)), int(m.group(7))
     kh, kw = (k // 10, k % 10) if k >= 10 else (k, k)          # "k33" style (conv) or "k3" (wgrad / round-1 kernels)
     sym, op = KERNELS[kind]
     in_px = M * s * s / (div * div)
