@@ -208,10 +208,13 @@ def test_c5_v8x_1280_bf16_tracks_oracle(eng):
     m.close()
 
 
-def test_c5_v8x_1280_bs16_fp8_train_steps(eng):
+def test_c5_v8x_1280_bs16_fp8_train_steps(eng, monkeypatch):
     """BASELINE config 5 AT ITS STATED POINT: YOLOv8x, 1280x1280, batch 16, fp8 MFMA convolution mode (round-2 verdict:
     fp8 was only exercised at 640x640 B=2 / 320x320 under pytest).  Step 0 has no recorded maxima (bf16 kernels, bit-identical to
-    the bf16 model); from step 1 on the fp8 kernels run.  Checks: every loss item finite, the fp8 run is deterministic (two
+    the bf16 model WITH THE SAME LAUNCH SCHEDULE: the fp8 mode neither fuses the shared-input head convolutions of this graph
+    (c2 = 80 is not a multiple of the fp8 kernel's 32-channel K unit) nor groups the towers, so the bf16 comparator is built with
+    YS_HEAD_FUSE=0 YS_GROUP=0 -- a different BatchNorm partial-sum order alone moves a random-init v8x loss by percents);
+    from step 1 on the fp8 kernels run.  Checks: every loss item finite, the fp8 run is deterministic (two
     models, same seed -> identical items at every step), the fp8 loss stays within 5 % of the bf16 model's at every step, and
     AdamW lowers it."""
     from yolosharp_amd.model import Yolov8, v8DetectionLoss
@@ -220,6 +223,8 @@ def test_c5_v8x_1280_bs16_fp8_train_steps(eng):
     nb = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=52, kmax=8).items()}
     hist = {}
     for tag, dt in (("fp8", "fp8"), ("fp8_again", "fp8"), ("bf16", "bf16")):
+        if dt == "bf16":
+            monkeypatch.setenv("YS_HEAD_FUSE", "0"); monkeypatch.setenv("YS_GROUP", "0")
         m = Yolov8(eng, nc=nc, size="x", height=H, width=W, max_batch=B, dtype=dt)
         m.init_weights(7); m.train()
         crit = v8DetectionLoss(m)

@@ -6,7 +6,7 @@
 cd $GRAFT_REPO_ROOT; TAG=${1:-s}; O=gpurun_out/$TAG; mkdir -p $O
 TESTS=${2:--}; AB=${3:-}; PROF=${4:-}
 if [ "$TESTS" != "-" ]; then
-  timeout 1500 python -m pytest $TESTS -x -q -m gpu > $O/tests.txt 2>&1; echo "tests rc=$?"; grep -E "passed|failed|error" $O/tests.txt | tail -3; grep -E "^(FAILED|ERROR)|Error" $O/tests.txt | head -10
+  timeout 1500 python -m pytest $TESTS -q -m gpu ${PYTEST_X:-} > $O/tests.txt 2>&1; echo "tests rc=$?"; grep -E "passed|failed|error" $O/tests.txt | tail -3; grep -E "^(FAILED|ERROR)|Error" $O/tests.txt | head -10
 fi
 for t in $AB; do
   name=${t%%:*}; ev=${t#*:}; ev=${ev//,/ }
