@@ -244,6 +244,50 @@ def test_bf16_path_tracks_f32(backend, engine):
     m.close()
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_stem_reads_fp32_planes_directly_bf16(backend, engine):
+    """model.0 (Conv(3, c, 3, 2): Yolo.cs:43, Convs.cs:36-62) on the bf16 path reads the fp32 NCHW image itself (csrc/conv_stem.hip) --
+    forward, batch statistics and weight gradient -- instead of a packed bf16 NHWC copy.  Checked (a) against the packed-copy path of the
+    same engine (YS_STEM_DIRECT=0 at model creation; same operand rounding, different summation order) on a canvas whose stem output
+    (48 x 80) leaves ragged 8 x 32 tiles, and (b) against the fp32 oracle restricted to that layer with rounding-matched operands."""
+    B, H, W, nc = 2, 96, 160, 80
+    ref = make_ref(seed=3)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(4))
+    batch = O.synthetic_batch(B, H, W, nc, seed=5, kmax=5)
+    from yolosharp_amd.model import v8DetectionLoss
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["YS_STEM_DIRECT"] = mode
+        try:
+            m = build(engine, ref, H, W, B, "bf16")
+        finally:
+            os.environ.pop("YS_STEM_DIRECT", None)
+        m.eval()
+        inf, _ = m.forward(x.numpy())
+        m.train()
+        m.forward(x.numpy())
+        loss, items = v8DetectionLoss(m)(None, {k: v.numpy() for k, v in batch.items()})
+        m.zero_grad(); m.backward()
+        g = m.grads(); sd = m.state_dict()
+        out[mode] = dict(inf=inf["boxes"].copy(), items=np.asarray(items).copy(), gw=g["model.0.conv.weight"].copy(), gg=g["model.0.bn.weight"].copy(),
+                         rm=sd["model.0.bn.running_mean"].copy(), rv=sd["model.0.bn.running_var"].copy())
+        m.close()
+    d, p = out["1"], out["0"]
+    assert relerr(d["inf"], p["inf"]) < 1e-2
+    assert np.allclose(d["items"], p["items"], rtol=2e-2)
+    assert np.allclose(d["rm"], p["rm"], rtol=1e-4, atol=1e-6) and np.allclose(d["rv"], p["rv"], rtol=1e-4, atol=1e-6)
+    assert relerr(d["gw"], p["gw"]) < 3e-2 and relerr(d["gg"], p["gg"]) < 3e-2
+    cos = float((d["gw"] * p["gw"]).sum() / np.sqrt((d["gw"] ** 2).sum() * (p["gw"] ** 2).sum()))
+    assert cos > 0.999, cos
+    # (b) the layer alone: bf16-rounded image and weights, fp32 accumulation, output rounded to bf16 before the statistics
+    w0 = ref.state_dict()["model.0.conv.weight"]
+    y = torch.nn.functional.conv2d(x.bfloat16().float(), w0.bfloat16().float(), stride=2, padding=1).bfloat16().float()
+    mean = y.mean(dim=(0, 2, 3)); var = y.var(dim=(0, 2, 3), unbiased=True)
+    rm0 = ref.state_dict()["model.0.bn.running_mean"]; rv0 = ref.state_dict()["model.0.bn.running_var"]
+    assert np.allclose(d["rm"], (0.97 * rm0 + 0.03 * mean).numpy(), rtol=1e-3, atol=1e-5)
+    assert np.allclose(d["rv"], (0.97 * rv0 + 0.03 * var).numpy(), rtol=1e-3, atol=1e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", ["gpu"])
 def test_full_resolution_parity_f32(backend, engine):

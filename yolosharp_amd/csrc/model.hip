@@ -170,6 +170,8 @@ struct ys_model {
   bool bnred_on = true; int bnred_B = -1; float* bnred_part = nullptr; long n_bnred = 0;
   unsigned char* argmax = nullptr; long n_argmax = 0;
   float* img_dev = nullptr;                      // staging for host images
+  bool stem_on = true;                           // YS_STEM_DIRECT=0 at creation: model.0 reads the packed bf16 copy like every other layer
+  const float* in_f32 = nullptr;                 // the fp32 NCHW image of the current step when model.0 reads it directly (conv_stem.hip); null = the packed input buffer holds it
   float* pred = nullptr;                         // [B][4+nc][A] fp32 (eval)
   float* out_stage = nullptr; long n_out_stage = 0;
   // loss
@@ -1042,6 +1044,7 @@ int allocate(ys_model* m) {
   // one region per convolution, so that the split reduction of a whole backward segment can run as ONE launch after it
   // (YS_WGRED_DEFER=0: per-layer reduction in the shared scratch, the round-2 behaviour)
   m->defer_wgred = !(getenv("YS_WGRED_DEFER") && atoi(getenv("YS_WGRED_DEFER")) == 0);
+  m->stem_on = !(getenv("YS_STEM_DIRECT") && atoi(getenv("YS_STEM_DIRECT")) == 0);
   m->bnred_on = !(getenv("YS_BNRED") && atoi(getenv("YS_BNRED")) == 0);           // YS_BNRED=0: every BN backward runs its own reduction pass
   long wgp = 0, wgp_regions = 0;
   std::vector<long> need(m->convs.size(), 0);
@@ -1153,6 +1156,18 @@ int run_convT_fwd(ys_model* m, const ConvL& c, int B) {
   return YS_OK;
 }
 
+// model.0 of a whole-model handle on the bf16 path, with its own weight-gradient partial region (deferred split reduction)
+static const ConvL* stem_conv(const ys_model* m) {
+  if (!m->stem_on || m->is_block || m->is_head || m->dtype != YS_BF16 || m->bn_ticket || m->convs.empty()) return nullptr;
+  const ConvL& c = m->convs[0];
+  if (!c.first || !c.bn || c.dw || c.ct || c.has_res || c.wgp_off < 0 || c.in.buf != m->in_buf) return nullptr;
+  if (!ys_stem_eligible(m->dtype, c.cin, c.cout, c.k, c.s)) return nullptr;
+  const Buf& ob = m->bufs[c.out.buf];
+  if ((ob.ldc & 3) || (c.out.coff & 3)) return nullptr;
+  return &c;
+}
+static bool stem_direct(const ys_model* m) { return stem_conv(m) != nullptr; }
+
 // geometry / operand part of the forward convolution arguments of layer c
 static ConvArgs fwd_args(ys_model* m, const ConvL& c, int B) {
   const Buf& ib = m->bufs[c.in.buf];
@@ -1174,6 +1189,24 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
   float* stat_partial = lane_stat ? lane_stat : m->stat_partial;
   const Buf& ib = m->bufs[c.in.buf];
   const Buf& ob = m->bufs[c.out.buf];
+  if (c.first && m->in_f32 && !lane_st) {      // model.0 straight from the fp32 image planes (conv_stem.hip)
+    const long Ms = (long)B * c.Hout * c.Wout;
+    const void* wf = (char*)m->wf_all + (size_t)c.wf_off * m->es;
+    if (m->training) {
+      void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
+      int gm = 0;
+      YS_TRY(ys_stem_fwd_launch(st, m->in_f32, B, c.Hin, c.Win, wf, c.cout, y, c.cout, 0, (long)c.Hout * c.Wout, stat_partial, nullptr, nullptr, 0, &gm));
+      YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, Ms, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
+                                   m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
+                                   chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
+      YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, Ms, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, nullptr, 0, 0,
+                                    ob.act, ob.ldc, c.out.coff, nullptr));
+    } else {
+      YS_TRY(ys_stem_fwd_launch(st, m->in_f32, B, c.Hin, c.Win, wf, c.cout, ob.act, ob.ldc, c.out.coff, ob.rows_per_b, nullptr,
+                                chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, nullptr));
+    }
+    return YS_OK;
+  }
   ConvArgs a = fwd_args(m, c, B);
   const long M = a.M;
   const bool vec = (ob.ldc % 4 == 0) && (c.out.coff % 4 == 0);
@@ -1564,6 +1597,14 @@ static int launch_wgrad(ys_model* m, ConvL& c, int B, const void* dy, int dy_ldc
   a.dy_ldc = dy_ldc; a.dy_coff = dy_coff; a.dy_bstride = dy_bstride; a.M = (int)M;
   int splits = ys_wgrad_splits(a, m->dtype);
   const bool defer = c.wgp_off >= 0;
+  if (c.first && m->in_f32 && defer) {     // model.0: x is the fp32 image itself (conv_stem.hip); slabs in the generic split layout
+    int used = 0;
+    YS_TRY(ys_stem_wgrad_launch(sw, m->in_f32, B, c.Hin, c.Win, dy, dy_ldc, dy_coff, dy_bstride, c.cout, m->wg_partial + c.wgp_off, c.wgp_splits, &used));
+    WgRedDesc& d = m->red_host[c.red_slot];
+    d.partial = m->wg_partial + c.wgp_off; d.grad = m->grads + c.w_off; d.n = (long)c.cout * c.k * c.k * c.cin_pad; d.splits = used;
+    d.cin_pad = c.cin_pad; d.cin_real = c.cin;
+    return YS_OK;
+  }
   if (defer) { a.partial = m->wg_partial + c.wgp_off; if (splits > c.wgp_splits) splits = c.wgp_splits; }   // own region (sized at max_batch)
   else if ((long)splits * c.cout * c.k * c.k * c.cin_pad > m->n_wgp) { ys_set_error("wgrad workspace too small"); return YS_ERR_STATE; }
   int used = 0;
@@ -2109,14 +2150,19 @@ int ys_model_forward(ys_model* m, const float* images, int on_device, int batch)
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   const float* src = images;
+  YS_TRY(join_wgrad_stream(m));   // the previous backward's weight-gradient kernels (model.0 reads the input buffer / the staged image) may still run on the second stream
   if (!on_device) {
     YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, images, (size_t)batch * 3 * m->d.height * m->d.width * 4, hipMemcpyHostToDevice, st));
     src = m->img_dev;
   }
   YsTimer timer(m->ctx, "forward");
   m->B = batch;
-  YS_TRY(join_wgrad_stream(m));   // the previous backward's weight-gradient kernels (model.0 reads the input buffer) may still run on the second stream
-  YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, 3, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
+  // model.0 reads the fp32 planes itself when it can (conv_stem.hip): no packed bf16 NHWC copy of the image.  The weight gradient of
+  // this step reads the same planes again, so a device-resident image must stay unchanged until the step's backward has run (the
+  // autograd rule of the reference: Utils/Amp.cs:348 differentiates through the tensor it was handed).
+  m->in_f32 = nullptr;
+  if (stem_direct(m)) m->in_f32 = src;
+  else YS_TRY(ys_pack_input_launch(st, m->dtype, src, batch, 3, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
   m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;
   return YS_OK;
@@ -2133,12 +2179,14 @@ int ys_model_forward_u8(ys_model* m, const uint8_t* images, int on_device, int b
   hipStream_t st = m->ctx->stream;
   const unsigned char* src = images;
   if (!on_device) {
+    YS_TRY(join_wgrad_stream(m)); // the staging buffer may be the fp32 image the previous step's model.0 weight gradient still reads
     YS_CHECK_HIP(hipMemcpyAsync(m->img_dev, images, (size_t)batch * 3 * h * w, hipMemcpyHostToDevice, st));
     src = (const unsigned char*)m->img_dev;
   }
   YsTimer timer(m->ctx, "forward");
   m->B = batch;
   YS_TRY(join_wgrad_stream(m));   // as in ys_model_forward: the input buffer is rewritten below
+  m->in_f32 = nullptr;            // uint8 planes: the packed input buffer is the layer's input
   YS_TRY(ys_pack_input_u8_launch(st, m->dtype, src, batch, 3, h, w, m->d.height, m->d.width, m->epl, m->bufs[m->in_buf].act));
   YS_TRY(forward_impl(m, batch));
   m->have_fwd = true; m->fwd_training = m->training; m->have_loss = false; m->have_seg_loss = false;

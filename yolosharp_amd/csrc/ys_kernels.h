@@ -108,6 +108,14 @@ int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz
                               const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
                               void* q8, const float* qscale, unsigned* amax, void* rg = nullptr, int rg_ldc = 0, int rg_coff = 0);
 int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
+// model.0 read straight from the fp32 NCHW image (conv_stem.hip): forward (training: raw output + statistics rows; eval: folded BatchNorm
+// + SiLU) and weight gradient (partial slabs [Cout][9][8] in the generic kernel's split layout)
+bool ys_stem_eligible(int dtype, int cin, int cout, int k, int s);
+int ys_stem_fwd_rows(int B, int Hout, int Wout);
+int ys_stem_fwd_launch(hipStream_t st, const float* x, int B, int H, int W, const void* wf, int Cout, void* y, int out_ldc, int out_coff,
+                       long out_bstride, float* stats, const float* scale, const float* shift, int act, int* rows);
+int ys_stem_wgrad_launch(hipStream_t st, const float* x, int B, int H, int W, const void* dy, int dy_ldc, int dy_coff, long dy_bstride,
+                         int Cout, float* partial, int max_splits, int* used);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
 int ys_conv_is_p2(const ConvArgs& a);
 // partial rows a launch of `a` (a dgrad with a.nred segments) writes per segment when every kernel it dispatches to supports the fused

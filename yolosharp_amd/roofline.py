@@ -22,6 +22,7 @@ KERNELS = {   # label prefix -> (kernel symbol, operand type of its MFMAs)
     "p2grp": ("conv_p2_group_kernel", "bf16"),     # grouped launch (label "p2grpN ... M<sum of the problems' pixels>"): same channels and taps for every problem
     "gemm": ("conv_gemm_kernel", "bf16"), "gemmf8": ("conv_gemm_kernel<F8>", "fp8"),
     "direct": ("conv_igemm_kernel", "bf16"), "patch": ("conv3x3_tile_kernel", "bf16"),
+    "stem": ("stem_fwd_kernel", "bf16"), "wstem": ("stem_wgrad_kernel", "bf16"),   # model.0 straight from the fp32 NCHW image (conv_stem.hip)
     "wgrad_tr": ("conv_wgrad_tr_kernel", "bf16"), "wgemm": ("conv_wgrad_gemm_kernel", "bf16"), "wgrad": ("conv_wgrad_kernel", "bf16"),
 }
 _LAB = re.compile(r"^(\w+) k(\d+) s(\d+) (?:div(\d+) )?cin(\d+) cout(\d+) M(\d+)")
@@ -38,7 +39,9 @@ def launch_work(label, elem_bytes=2):
     in_px = M * s * s / (div * div)
     cin_alg = 3 if (cin == 8 and kh == 3 and s == 2) else cin   # the stem's 3 input channels are padded to 8 in memory
     flop = 2.0 * M * cout * cin_alg * kh * kw / (div * div)
-    if kind.startswith("w"):                                    # weight gradient: reads x (in_px * cin) and dy (M * cout)
+    if kind in ("stem", "wstem"):                               # the image is fp32 in HBM (the boundary's own tensor), the output / dy bf16
+        byt = in_px * cin_alg * 4 + M * cout * elem_bytes
+    elif kind.startswith("w"):                                  # weight gradient: reads x (in_px * cin) and dy (M * cout)
         byt = (in_px * cin_alg + M * cout) * elem_bytes
     else:
         byt = (in_px * cin_alg + M * cout) * elem_bytes
