@@ -110,6 +110,83 @@ def test_block_parity_bf16_gpu(engine, backend, case):
     _block_parity(engine, case, "bf16", 4, 4e-2, 8e-2, scale=2)
 
 
+# ---- bf16 against the ROUNDING-MATCHED oracle (tests/bf16_ref.py: fp32 arithmetic with a bf16 round trip at every point where the engine
+# stores a tensor).  This is the tight bf16 parity statement: a block's train-mode forward is bit-identical to that reference up to
+# isolated one-ulp flips (summation order inside a convolution), its input gradient is within a few bf16 ulps (the engine adds several
+# consumers' contributions into a bf16 buffer one at a time -- 25-65 % of the elements round differently by one ulp -- and BatchNorm
+# backward amplifies that through the block), and the parameter gradients (fp32) agree to cosine 0.9998 / 1.5 % of their maximum.
+# A whole YOLOv8n at random initialisation amplifies one-ulp flips by ~2x per block (measured: running-mean updates differ by 1e-5 after
+# model.2 and 2e-2 after model.21, head outputs by 7 % rms), so tight model-level bf16 bounds do not exist; the block level is where the
+# implementation can be pinned.
+BF16_CASES = {
+    "conv3": (lambda: O.Conv(32, 32, 3, 1), "Conv", dict(c1=32, c2=32, k=3, s=1), 32),
+    "conv3s2": (lambda: O.Conv(32, 64, 3, 2), "Conv", dict(c1=32, c2=64, k=3, s=2), 32),
+    "conv1_noact": (lambda: O.Conv(64, 32, 1, 1, act=False), "Conv", dict(c1=64, c2=32, k=1, s=1, act=False), 64),
+    "bneck_sc": (lambda: O.Bottleneck(32, 32, True, e=0.5), "Bottleneck", dict(c1=32, c2=32, shortcut=True, e=0.5), 32),
+    "c2f_sc": (lambda: O.C2f(32, 32, 2, True), "C2f", dict(c1=32, c2=32, n=2, shortcut=True), 32),
+    "c2f": (lambda: O.C2f(48, 32, 1, False), "C2f", dict(c1=48, c2=32, n=1, shortcut=False), 48),
+    "sppf": (lambda: O.SPPF(32, 32), "SPPF", dict(c1=32, c2=32), 32),
+    "c2f_wide": (lambda: O.C2f(256, 256, 1, True), "C2f", dict(c1=256, c2=256, n=1, shortcut=True), 256),   # blocked-GEMM kernels (>= 128 channels)
+}
+
+
+def _block_bf16_matched(engine, case, B, H, W):
+    from yolosharp_amd import blocks
+    import bf16_ref as R
+    make_ref, cls, kw, c1 = BF16_CASES[case]
+    torch.manual_seed(11)
+    ref = make_ref()
+    _randomise(ref, 5)
+    blk = getattr(blocks, cls)(engine, **kw, height=H, width=W, max_batch=B, dtype="bf16")
+    blk.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    x = torch.randn(B, c1, H, W, generator=torch.Generator().manual_seed(3))
+    blk.train(); ref.train()
+    y = blk.forward(x.numpy())
+    xr = R.bf16r(x).requires_grad_(True)
+    with R.bf16_storage(ref):
+        ry = ref(R.rste(xr))
+    rya = ry.detach().numpy()
+    flips = float((y != rya).mean())
+    assert flips <= 2e-3, ("forward differs from the rounding-matched oracle in more than isolated flips", flips)
+    R.check_elem(y, rya, case + " forward", max_out=2e-3, out_mult=4.0)      # and a flip is one ulp, not garbage
+    dy = R.bf16r(torch.randn(ry.shape, generator=torch.Generator().manual_seed(4)))
+    blk.zero_grad()
+    dx = blk.backward(dy.numpy())
+    ry.backward(dy)
+    single = cls == "Conv"
+    R.check_elem(dx, xr.grad.numpy(), case + " dx", max_out=2e-3 if single else 0.15, out_mult=4.0 if single else 16.0)
+    g = blk.grads()
+    gmax = max(float(p.grad.abs().max()) for _, p in ref.named_parameters())
+    for k, p in ref.named_parameters():
+        a, b = g[k].astype(np.float64).ravel(), p.grad.numpy().astype(np.float64).ravel()
+        assert np.abs(a - b).max() <= 1.5e-2 * np.abs(b).max() + 2e-3 * gmax, (k, np.abs(a - b).max(), np.abs(b).max(), gmax)
+        if np.abs(b).max() > 1e-2 * gmax:
+            assert float(a @ b) / np.sqrt(float(a @ a) * float(b @ b)) > 0.9998, k
+    sd = blk.state_dict()
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            assert np.allclose(sd[k], v.numpy(), rtol=2e-4, atol=2e-5), k     # statistics of bit-identical y: fp32 summation order only
+    blk.close()
+
+
+@pytest.mark.parametrize("case", ["conv3", "conv3s2", "conv1_noact", "bneck_sc", "c2f_sc", "c2f", "sppf"])
+@pytest.mark.parametrize("backend", ["emu"])
+def test_block_bf16_rounding_matched_emu(engine, backend, case):
+    _block_bf16_matched(engine, case, 2, 24, 24)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(BF16_CASES))
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_block_bf16_rounding_matched_gpu(engine, backend, case):
+    """The same statement on the MI355X at sizes where the persistent grids walk several tiles per workgroup (80 x 80, B = 8; the
+    256-channel case at 20 x 20 is a P5 C2f of YOLOv8n)."""
+    if case == "c2f_wide":
+        _block_bf16_matched(engine, case, 8, 20, 20)
+    else:
+        _block_bf16_matched(engine, case, 8, 80, 80)
+
+
 @pytest.mark.parametrize("backend", ["emu"])
 def test_c2psa_bf16_emu(engine, backend):
     """bf16 C2PSA (attention forward / backward, depthwise pe conv) against the fp32 oracle module; the fp32 runs above are the

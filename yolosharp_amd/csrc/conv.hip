@@ -495,6 +495,9 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 #else
 #define P2_DBG(bit) false
 #endif
+#ifndef YS_P2_COUNTED_WAIT
+#define YS_P2_COUNTED_WAIT 1   // 0: the tile loop opens with s_waitcnt vmcnt(0) (rounds 1-3; A/B build)
+#endif
 #ifndef P2_KG
 #define P2_KG 2            // K-steps (32 K each) per streamed weight group
 #endif
@@ -545,8 +548,14 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   int tl_n = 0;
   unsigned long long* tl_p = (a.tl && (vbx % 37) == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? a.tl + (vbx / 37) * 64 : nullptr;
 #define TL_STAMP() do { if (tl_p && tl_n < 63) tl_p[1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+#ifdef YS_P2_TIMELINE_FINE
+#define TL_STAMP2() TL_STAMP()
+#else
+#define TL_STAMP2() ((void)0)
+#endif
 #else
 #define TL_STAMP() ((void)0)
+#define TL_STAMP2() ((void)0)
 #endif
   TL_STAMP();
   constexpr int NWU = WRES ? 1 : (BN * P2_KG * UPS + NT - 1) / NT;   // streamed weight units per thread
@@ -719,11 +728,24 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
 #pragma unroll
   for (int e = 0; e < P2_NS; e++) { st1[e] = 0.f; st2[e] = 0.f; }
 
+  // Counted waits (round 4).  vmcnt counts loads AND stores on this part and retires them in issue order.  The tile loop used to open
+  // with s_waitcnt vmcnt(0): besides the prefetched patch that also drained the previous tile's output stores, which a CU retires at
+  // 7-10 bytes per clock -- about two thousand cycles for a 16 KB tile, every tile, with nothing of this workgroup overlapping it (the
+  // "patch in LDS" phase of the round-3 stamps: 3.4-3.6 thousand cycles whatever the epilogue form).  The patch loads are issued BEFORE
+  // the epilogue, so "at most NST operations outstanding", NST = the epilogue's store instructions per wave (a static count: the stores
+  // are unconditional, masked lanes carry the out-of-range offset), means the patch has landed while the stores keep draining under the
+  // LDS writes, the next prefetch and the K loop.  Anything else the epilogue issued (accumulate / residual / y loads) only makes the
+  // number outstanding larger, i.e. the wait longer -- never too short.  The weight / table DMA (inline asm, invisible to the
+  // compiler) is waited for once, in front of the loop.
+  constexpr int NST = (YS_P2_EPI_DIRECT || !YS_P2_COUNTED_WAIT) ? 0 : p2_epi_stores(MR, NR);
+  YS_WAIT_VM0();
   for (int tile = t_first; tile < t_end; tile += t_step) {
     const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
     TL_STAMP();
-    YS_WAIT_VM0();                            // this tile's patch (and, first tile, the wave's weight DMA) has landed
+    ys_wait_vm<NST>();                        // this tile's patch has landed (the previous tile's stores may still be in flight)
+    TL_STAMP2();
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
+    TL_STAMP2();
     if (!WRES) wfetch(rwA, 0);
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
@@ -753,7 +775,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     advance(ntx, nty, nb);
     // everything older (the patch just consumed, the previous epilogue's conditional loads / stores) has already been waited
     // for above; saying so explicitly resets the compiler's "may still be in flight" state for the accumulator registers
-    YS_WAIT_VM0();                            // (without it -- the epilogue's stores are unconditional now -- the class is 3 % slower: 5.10 -> 5.25 ms)
+    ys_wait_vm<NST>();                        // (without it -- the epilogue's stores are unconditional now -- the class is 3 % slower: 5.10 -> 5.25 ms)
     if (tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
 
     // resident weights: the accumulators start as the first K-step's products (MFMA with a zero C operand -- an inline constant, no

@@ -58,6 +58,11 @@ __device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long 
 // RED = 1: the dgrad form -- gradient accumulation and the fused BN-backward reduction only (no bias / eval-BN / SiLU / residual:
 // a dgrad launch never carries them), compiled as its own kernel variants so that the forward kernels' register allocation is
 // untouched by the reduction's live values (y vectors, coefficients).
+// Store instructions one wave issues per p2_epilogue call (NITER below): the static count behind the tile loop's counted waits --
+// conv_p2_body waits for "all but the last p2_epi_stores() vector-memory operations" at the top of a tile, i.e. for the prefetched
+// patch but NOT for the previous tile's output stores (gfx9-family parts count loads and stores on one in-order vmcnt).
+__host__ __device__ constexpr int p2_epi_stores(int mr, int nr) { return (16 * mr + 64 / (nr * 2) - 1) / (64 / (nr * 2)); }
+template <int M> struct EpiMode { static constexpr int value = M; };
 struct YsNoStamp { __device__ inline void operator()() const {} };   // timeline hook of triage builds (-DYS_P2_TIMELINE): nothing in the product
 template <int MR, int NR, int RED = 0, int BMAX = 4 /* unused: batch depth of the reverted batched store loop */, class SF = YsNoStamp>
 __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
@@ -69,6 +74,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   constexpr int VPP = BN / 8;                  // 16-byte vectors per pixel
   constexpr int PPI = 64 / VPP;                // pixels per wave iteration
   constexpr int NITER = (NPX + PPI - 1) / PPI;
+  static_assert(NITER == p2_epi_stores(MR, NR), "p2_epi_stores");
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
   unsigned* rowtab = (unsigned*)(stg + NPX * PITCH);   // [NPX] byte offset of the pixel row (YS_BUF_OOB = outside), [NPX] row index; views < 2^31 bytes (launch plans)
   const int cv = lane % VPP, pl = lane / VPP;
@@ -140,19 +146,19 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   stamp();
   ys_wave_sync_lds();                          // the staged rows (written by other lanes of this wave) are IN LDS before the reads below are issued
   stamp();
-  const bool do_stats = !RED && a.stats != nullptr && !EPI_DBG(512);
+  const bool do_stats_rt = !RED && a.stats != nullptr && !EPI_DBG(512);
   // eval-mode BatchNorm folded into the conv (Convs.cs:48 with running statistics): applied on the wide path to the
   // bf16-rounded conv output -- the same value the training path normalises -- with the lane's 8 coefficients loaded once
-  const bool bn_eval = !RED && a.scale != nullptr;
+  const bool bn_eval_rt = !RED && a.scale != nullptr;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
-  if (bn_eval && active && c < a.Cout) {     // coefficient arrays are padded to a multiple of 4 floats; Cout % 8 == 0 for BN convs
+  if (bn_eval_rt && active && c < a.Cout) {     // coefficient arrays are padded to a multiple of 4 floats; Cout % 8 == 0 for BN convs
     ys_ldcoef<8>(a.scale + c, sc);
     if (a.shift) ys_ldcoef<8>(a.shift + c, sh);
   }
   char* yb = (char*)a.y;
-  const char* rb = RED ? nullptr : (const char*)a.res;
+  const char* rb_rt = RED ? nullptr : (const char*)a.res;
   // Stores go through a buffer descriptor of the output buffer: masked lanes (pixel outside the image, channel tile past Cout,
   // idle lanes of the wave) carry the out-of-range offset and the hardware drops them, so the store is issued unconditionally,
   // NITER times per tile -- a static count the compiler can keep in flight (vmcnt(N)) across the next tile's loads instead of the
@@ -165,7 +171,15 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   // tools/dev/determinism_layer.py).  A wait between the staging writes and the reads removed one instance, a full wait plus idle
   // cycles after the reads lowered the rate of the other but did not remove it -- reverted to this form, which the row-table
   // dependency serialises: every read is consumed before the next is issued.)
-  auto store_iter = [&](const int it) {
+  // MODE (compile-time view of the run-time flags, so that the common launches get a branch-free, fully unrolled loop -- the compiler
+  // then SEES the NITER stores in a row, which is what lets the tile loop wait with vmcnt(NITER) instead of draining them):
+  //   0 training forward (statistics only), 1 eval BatchNorm (+ SiLU), 2 everything (residual, accumulate), RED always 2
+  auto store_iter = [&](const int it, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const bool do_stats = MODE != 1 && do_stats_rt;
+    const bool bn_eval = MODE != 0 && bn_eval_rt;
+    const char* const rb = MODE == 2 ? rb_rt : nullptr;
+    const bool accum = MODE == 2 && a.accumulate;
     const int px = it * PPI + pl;
     const bool lane_ok = active && px < NPX && c < a.Cout;
     const unsigned rofs = lane_ok ? rowtab[px] : YS_BUF_OOB;
@@ -188,10 +202,10 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
           }
 #pragma unroll
           for (int e = 0; e < 8; e++) if (c + e >= a.Cout) f[e] = 0.f;
-          if (!(rb || a.accumulate)) val = ys_pack<T>(f);
+          if (!(rb || accum)) val = ys_pack<T>(f);
         }
         T* yp = (T*)(yb + rofs + c * 2);
-        if (rb || a.accumulate) {
+        if (rb || accum) {
           float gq[8];
           if (rb) {
             const long row = (long)rowtab[NPX + px];                              // eval-only path (Bottleneck shortcut)
@@ -199,7 +213,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 #pragma unroll
             for (int e = 0; e < 8; e++) f[e] += gq[e];
           }
-          if (a.accumulate) {
+          if (accum) {
             ys_unpack<T>(ys_ld16(yp), gq);
 #pragma unroll
             for (int e = 0; e < 8; e++) f[e] += gq[e];
@@ -223,13 +237,11 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     ys_bufst16(rsY, (rofs != YS_BUF_OOB && !EPI_DBG(256)) ? rofs + (unsigned)c * 2u : YS_BUF_OOB, val);
   };
   if (EPI_DBG(1024)) { ys_wave_sync(); return; }
-  if (RED) {
-#pragma unroll                                // fully: yv[it] must be a register, not an indexed (scratch) array
-    for (int it = 0; it < NITER; it++) store_iter(it);
-  } else {
-#pragma unroll 2
-    for (int it = 0; it < NITER; it++) store_iter(it);
-  }
+  // Fully unrolled (round 4; the forward form used to be `unroll 2`): the compiler then SEES the NITER stores in a row, which is what
+  // lets the tile loop of conv_p2_body wait with vmcnt(NITER) -- behind a rolled loop hipcc only credits the stores of one trip and
+  // puts s_waitcnt vmcnt(2), (1) in front of the patch's LDS writes, i.e. drains half of them again.  (RED: yv[it] must be a register.)
+#pragma unroll
+  for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
   stamp();
   ys_wave_sync();
 }
