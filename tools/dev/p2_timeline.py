@@ -13,7 +13,9 @@ os.environ["YS_P2_TL"] = out
 from yolosharp_amd import Engine
 eng = Engine(0, lib_path=os.path.join(ROOT, "build", "libyolosharp_hip_tl.so"))
 rng = np.random.default_rng(0)
-for (B, Cin, H, W, Cout, k, s) in [(64, 64, 40, 40, 64, 3, 1), (64, 128, 20, 20, 128, 3, 1), (64, 32, 80, 80, 32, 3, 1), (64, 384, 20, 20, 256, 1, 1),
+SHAPES = os.environ.get("YS_TL_SHAPES")
+shapes = [tuple(int(v) for v in t.split(",")) for t in SHAPES.split(";")] if SHAPES else None
+for (B, Cin, H, W, Cout, k, s) in shapes or [(64, 64, 40, 40, 64, 3, 1), (64, 128, 20, 20, 128, 3, 1), (64, 32, 80, 80, 32, 3, 1), (64, 384, 20, 20, 256, 1, 1),
                                    (64, 16, 160, 160, 16, 3, 1), (64, 64, 80, 80, 64, 3, 1), (64, 64, 80, 80, 64, 1, 1), (64, 32, 160, 160, 32, 1, 1)]:
     x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
     w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)

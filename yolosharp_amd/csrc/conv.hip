@@ -495,6 +495,17 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 #else
 #define P2_DBG(bit) false
 #endif
+#ifndef YS_P2_GROUP_COPY
+#define YS_P2_GROUP_COPY 1
+#endif
+#ifndef YS_P2_G1_MIN
+#define YS_P2_G1_MIN 10        // register tiles of >= this many MFMAs per K-step run one K-step per LDS wait (12: two K-steps for the 2 x 5 tile -- spills at 256 registers)
+#endif
+#ifndef YS_P2_RING3
+#define YS_P2_RING3 0          // 1: streamed weights fetched three groups ahead, next patch requested after the K loop.  Built and measured (round 4, same box,
+                               // alternating): grouped head launches 1.00 -> 0.96 ms, plain launches 2.96 -> 3.00 (more spills in the non-grouped variants), step 9.75 = 9.75:
+                               // the K loop of the streamed layers is bound by its LDS round trips per K-step, not by the weight fetch -- off
+#endif
 #ifndef YS_P2_COUNTED_WAIT
 #define YS_P2_COUNTED_WAIT 1   // 0: the tile loop opens with s_waitcnt vmcnt(0) (rounds 1-3; A/B build)
 #endif
@@ -509,7 +520,7 @@ struct P2Tag1 { static constexpr int value = 1; };
 // waves have to cover -- bounded by the fragment registers a group keeps live, 4 * G * (MR + NR): <= 64 in the 256-register
 // variants, <= 32 in the `tight` ones (compiled for three waves per SIMD, 168 registers).  G is 1, 2 or 4 (one table read).
 __host__ __device__ constexpr int p2_reg_group(int mr, int nr, bool tight = false) {
-  const int want = mr * nr >= 10 ? 1 : (mr * nr >= 6 ? 2 : 4);
+  const int want = mr * nr >= YS_P2_G1_MIN ? 1 : (mr * nr >= 6 ? 2 : 4);
   const int cap = (tight ? 8 : 16) / (mr + nr);
   const int g = want < cap ? want : cap;
   return g >= 4 ? 4 : (g >= 2 ? 2 : 1);
@@ -601,24 +612,32 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   constexpr int G0 = F8 ? 1 : p2_reg_group(MR, NR, TIGHT);   // fp8: one K-step is already 128 K (32-byte fragments)
   constexpr int G = (WRES || G0 < KG) ? G0 : KG;   // K-steps per register group of the K loop
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
-  uint4 rwA[NWU];
-  // this thread's (row, unit-in-group) of the streamed weight tile never changes: keep the row pointers, step by group
-  const char* wrow[NWU];
+  // RING3 (round 4): streamed weights are fetched THREE groups ahead (three register sets in rotation, two LDS slots as before).  One
+  // group ahead -- the rounds 1-3 form: fetch at the top of a group, store at its end -- gives the L2 round trip one group's MFMAs to
+  // hide behind (20-32 MFMAs = 320-512 cycles against ~1.5 thousand): s_memtime stamps of the 80 -> 80 and 64 -> 144 3x3 layers of the
+  // Detect towers put their K loop at 21-24 thousand cycles per tile for 3.7 thousand cycles of MFMA.  The next tile's patch is then
+  // requested AFTER the K loop (its registers would not fit next to three weight sets) and lands under the epilogue.
+  constexpr bool RING3 = !WRES && YS_P2_RING3 != 0;
+  uint4 rwA[NWU], rwB[RING3 ? NWU : 1], rwC[RING3 ? NWU : 1];
+  // this thread's (row, unit-in-group) of the streamed weight tile never changes: keep the row's byte offset (32 bits, through a buffer
+  // descriptor of the weight shadow: a unit past the row's real K, a row past Cout or an idle thread carries the out-of-range offset and
+  // arrives as zeros -- no 64-bit row pointers to keep (they were spilled next to three register sets), no select after the load)
+  const ys_rsrcv_t rsWv = ys_make_rsrcv(wb, (unsigned)((long)a.Cout * Ktot * WES));
+  unsigned wro[NWU];
   int wun[NWU];
 #pragma unroll
   for (int k = 0; k < NWU; k++) {
     const int idx = tid + NT * k;
     const int n = idx / GU;
     wun[k] = (idx < BN * GU && n0 + n < a.Cout) ? idx - n * GU : -1;
-    wrow[k] = wb + ((long)(n0 + (wun[k] >= 0 ? n : 0)) * Ktot) * (long)WES;
+    wro[k] = (unsigned)((long)(n0 + (wun[k] >= 0 ? n : 0)) * Ktot * WES);
   }
   auto wfetch = [&](uint4 (&rw)[NWU], int grp) {   // global -> registers: weights of K-steps [grp*KG, grp*KG + KG); unconditional loads
 #pragma unroll
     for (int k = 0; k < NWU; k++) {
       const int u = grp * GU + wun[k];
       const bool ok = (bool)((int)(wun[k] >= 0) & (int)(u * (16 / WES) < Ktot) & (int)!P2_DBG(16));
-      rw[k] = ys_ld16(wrow[k] + (ok ? u * 16 : 0));
-      if (!ok) rw[k] = ys_zero16();
+      rw[k] = ys_bufld16(rsWv, ok ? wro[k] + (unsigned)u * 16u : YS_BUF_OOB);
     }
   };
   auto wstore = [&](const uint4 (&rw)[NWU], int buf) {
@@ -700,6 +719,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   TL_STAMP();                                            // tables requested
   if (t_first < t_end) okm_next = pfetch(txi, tyi, b);   // the first patch is in flight while the weights are staged
   TL_STAMP();                                            // first patch requested
+  if constexpr (RING3) { wfetch(rwA, 0); wfetch(rwB, 1); wfetch(rwC, 2); }
   if (WRES) {
     // resident weights: rows padded with zeros to a multiple of 4 K-steps (the pipelined K loop runs whole register groups).
     // LDS DMA (buffer_load ... lds, 1 KB per wave instruction): all of a wave's requests are in flight at once and no VGPR is
@@ -746,7 +766,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     TL_STAMP2();
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
     TL_STAMP2();
-    if (!WRES) wfetch(rwA, 0);
+    if (!WRES && !RING3) wfetch(rwA, 0);
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       unsigned d = pdesc[k];
@@ -776,7 +796,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     // everything older (the patch just consumed, the previous epilogue's conditional loads / stores) has already been waited
     // for above; saying so explicitly resets the compiler's "may still be in flight" state for the accumulator registers
     ys_wait_vm<NST>();                        // (without it -- the epilogue's stores are unconditional now -- the class is 3 % slower: 5.10 -> 5.25 ms)
-    if (tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
+    if (!RING3 && tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
 
     // resident weights: the accumulators start as the first K-step's products (MFMA with a zero C operand -- an inline constant, no
     // registers cleared: 4 * MR * NR v_mov per tile in a kernel whose busiest pipe is the VALU); streamed weights enter the K loop
@@ -852,6 +872,21 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     const bool in_bf8 = F8 && a.f8 == 2;      // uniform: the input operand is a gradient quantised to e5m2
     if (WRES) {
       if (in_bf8) kloop(sW, 0, (g.nsteps + G - 1) / G, P2Tag1{}); else kloop(sW, 0, (g.nsteps + G - 1) / G, P2Tag0{});
+    } else if constexpr (RING3) {
+      constexpr int NGS = KG / G;               // register groups per streamed weight slot
+      // invariant at a group g = 0 (mod 3): rwA holds group g (already in LDS slot g & 1), rwB group g + 1, rwC group g + 2
+      auto ring_step = [&](uint4 (&rf)[NWU], uint4 (&rs)[NWU], const int grp) {
+        wfetch(rf, grp + 3);                    // unconditional (past the end: zeros); three groups of MFMAs to land
+        if (in_bf8) kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS, P2Tag1{}); else kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS, P2Tag0{});
+        wstore(rs, (grp + 1) & 1);
+        ys_barrier_lds();
+      };
+      int grp = 0;
+#pragma unroll 1
+      for (; grp + 3 <= ngroups; grp += 3) { ring_step(rwA, rwB, grp); ring_step(rwB, rwC, grp + 1); ring_step(rwC, rwA, grp + 2); }
+      if (grp < ngroups) { ring_step(rwA, rwB, grp); if (grp + 1 < ngroups) ring_step(rwB, rwC, grp + 1); }
+      // the next tile: its patch and its first three weight groups are requested now and land under the epilogue
+      if (tile + t_step < t_end) { okm_next = pfetch(ntx, nty, nb); wfetch(rwA, 0); wfetch(rwB, 1); wfetch(rwC, 2); }
     } else {
       constexpr int NGS = KG / G;               // register groups per streamed weight slot
 #pragma unroll 1
@@ -941,7 +976,18 @@ conv_p2_group_kernel(P2Group grp) {
   for (int k = 0; k + 1 < YS_GROUP_MAX; k++) pi += (int)(k + 1 < grp.n && bx >= grp.end[k]);
   const int start = pi ? grp.end[pi - 1] : 0;
   const P2Prob& pr = grp.p[pi];
+#if YS_P2_GROUP_COPY
+  // The problem's arguments are copied into registers once (round 4).  Read in place -- a dynamically indexed slot of the kernel-argument
+  // segment -- hipcc re-loads fields where they are used: 81-109 s_load instructions per variant against 36-44 in conv_p2_kernel, many
+  // of them inside the K loop, and every one is followed by s_waitcnt lgkmcnt(0), which drains the wave's LDS reads as well (the
+  // counter is shared): per-launch records put the grouped 80 -> 80 tower layer at 228 us for 1.31x the pixels of a 113 us single launch.
+  const ConvArgs a = pr.a;
+  const P2Args g = pr.g;
+  const int* const tab = pr.tab;
+  conv_p2_body<MR, NR, WRES, NPU, NT, 0, RED>(a, g, tab, bx - start, grp.end[pi] - start);
+#else
   conv_p2_body<MR, NR, WRES, NPU, NT, 0, RED>(pr.a, pr.g, pr.tab, bx - start, grp.end[pi] - start);
+#endif
 }
 
 
@@ -1329,7 +1375,7 @@ static int conv_p2_group_launch_t(hipStream_t st, const ConvArgs* a, const P2Pla
   P2Group grp{};
   grp.n = n;
   int total = 0;
-  char lab[256] = "";
+  char lab[320] = "";
   for (int i = 0; i < n; i++) {
     P2Prob& pr = grp.p[i];
     pr.a = a[i]; pr.a.dbg = dbg; pr.g = p[i].g;
@@ -1344,7 +1390,8 @@ static int conv_p2_group_launch_t(hipStream_t st, const ConvArgs* a, const P2Pla
     int o = snprintf(lab, sizeof(lab), "p2grp%d k%d s%d div1 cin%d cout%d M", n, a[0].KH * 10 + a[0].KW, a[0].SA, a[0].Cin, a[0].Cout);
     long Msum = 0;
     for (int i = 0; i < n; i++) Msum += a[i].M;
-    snprintf(lab + o, sizeof(lab) - o, "%ld acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", Msum, a[0].accumulate, NT, MR, NR, WRES, NPU, p[0].g.TH, p[0].g.TW, total, p[0].gy, (int)lds);
+    o += snprintf(lab + o, sizeof(lab) - o, "%ld acc%d nt%d mr%d nr%d wres%d npu%d tile%dx%d grid%dx%d lds%d", Msum, a[0].accumulate, NT, MR, NR, WRES, NPU, p[0].g.TH, p[0].g.TW, total, p[0].gy, (int)lds);
+    for (int i = 0; i < n && o < (int)sizeof(lab) - 24; i++) o += snprintf(lab + o, sizeof(lab) - o, " [%dx%d t%d g%d]", p[i].g.TH, p[i].g.TW, p[i].g.ntiles, gxs[i]);
   }
   YsKprofScope prof(st, "conv_igemm", lab);
   YS_LAUNCH_LDS((conv_p2_group_kernel<MR, NR, WRES, NPU, NT, RED>), dim3(total, p[0].gy), NT, lds, st, grp);
@@ -1403,6 +1450,17 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
     if (gx > p[i].g.ntiles) gx = p[i].g.ntiles;
     if (row_cap && row_cap[i] > 0 && gx > row_cap[i]) gx = row_cap[i];
     gxs[i] = (int)gx; used += gx;
+  }
+  // The grid must FIT: rounding every range up to a multiple of 8 made it 520-528 workgroups for 512 slots (776 for 768) on the Detect
+  // towers -- the last 8 wait for a slot, start when the first workgroups leave and then walk their whole tile share alone (round 4,
+  // per-launch records: the grouped 80 -> 80 layer 215 us against 174 us for its three levels launched one by one).  Take the excess
+  // from the largest ranges, 8 at a time (1 at a time below 16).
+  while (used > slots) {
+    int big = 0;
+    for (int i = 1; i < n; i++) if (gxs[i] > gxs[big]) big = i;
+    const int dec = gxs[big] >= 16 ? 8 : 1;
+    if (gxs[big] - dec < 1) break;
+    gxs[big] -= dec; used -= dec;
   }
   // a range that is not a multiple of 8 shifts the XCD phase of the ranges behind it: order the problems so that only the last may be ragged
   // (ranges of >= 8 workgroups are multiples of 8 unless a cap cut them; a shifted phase only costs L2 locality, never correctness)

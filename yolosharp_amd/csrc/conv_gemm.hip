@@ -23,6 +23,13 @@
 //  * epilogue, statistics, bias / eval-BN / SiLU, residual and gradient accumulation: the shared wide-store stage (conv_epi.h).
 #include "conv_epi.h"
 #include <atomic>
+#ifndef YS_GEMM_EPI_DIRECT
+#define YS_GEMM_EPI_DIRECT 0   // 1: this kernel's epilogue goes straight from the accumulator registers (16-byte stores after a 16-lane row swap, conv_epi.h
+                               // p2_epilogue_direct) and the NEXT tile's first operand requests are issued before it (no LDS staging to alias the stages).
+                               // Built and measured in round 4 (same box, alternating, config 2): conv_gemm_kernel 1.23 -> 1.27-1.28 ms/step -- a wave's
+                               // direct store covers 16 pixel rows x 64 B (half lines), the staged form 8 rows x 128 B, and the store path is what this
+                               // epilogue is bound by -- so the staged form stays
+#endif
 #ifndef YS_EPI_BATCH_GEMM
 #define YS_EPI_BATCH_GEMM 4
 #endif
@@ -47,6 +54,7 @@ struct GemmArgs {
   int stage_bytes;  // (BM + BN) * 128
   int nstage;       // LDS stages of the operand pipeline (2..4): tile kt + nstage - 1 is requested while tile kt is multiplied
   int HoWo;
+  YsFastDiv dHoWo, dWout;   // m -> (image, row, column) without integer divisions
   unsigned abytes;  // bytes of the input view from its first channel to the end of the last image (descriptor range, < 2^31)
 };
 
@@ -158,25 +166,36 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
   const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int t_end = xcd_order ? (((int)(blockIdx.x & 7) + 1) * t_per_xcd < g.mtiles ? ((int)(blockIdx.x & 7) + 1) * t_per_xcd : g.mtiles) : g.mtiles;
 
-  constexpr int NS = YS_P2_EPI_DIRECT ? 4 * NR : 8;
+  constexpr int NS = YS_GEMM_EPI_DIRECT ? 4 * NR : 8;
   float st1[NS], st2[NS];
 #pragma unroll
   for (int e = 0; e < NS; e++) { st1[e] = 0.f; st2[e] = 0.f; }
 
-  for (int tile = t_first; tile < t_end; tile += t_step) {
+  // row coordinates of a tile's A pieces + the requests of its first nstage - 1 K-tiles
+  auto open_tile = [&](const int tile) {
     const int m0 = tile * BM;
 #pragma unroll
     for (int j = 0; j < NA; j++) {
       const int m = m0 + 8 * (wave + 4 * j) + rsub;
       if (m < a.M) {
-        const int b = m / g.HoWo, rem = m - b * g.HoWo;
-        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        const int b = (int)ys_fastdiv((unsigned)m, g.dHoWo), rem = m - b * g.HoWo;
+        const int oy = (int)ys_fastdiv((unsigned)rem, g.dWout), ox = rem - oy * a.Wout;
         aiy[j] = oy * a.SA - a.PAD; aix[j] = ox * a.SA - a.PAD - a.pad_w_delta;
         abase[j] = (int)((((long)b * bstride + (long)aiy[j] * a.Win + aix[j]) * ldu) << 4);
       } else { aiy[j] = -(1 << 20); aix[j] = 0; abase[j] = 0; }
     }
-    ys_barrier_lds();                         // the tap table is written; the previous tile's epilogue staging is consumed
+    ys_barrier_lds();                         // the tap table is written; every wave is done with the stages (and, staged epilogue, with the staging area)
     for (int p = 0; p < g.nstage - 1 && p < g.nkt; p++) issue(p, p);
+  };
+  // Direct epilogue (YS_GEMM_EPI_DIRECT): a tile is OPENED before the previous tile's epilogue runs -- its first K-tiles are in flight
+  // while the accumulators are rounded, reduced into the statistics and stored (~8 thousand cycles per 128 x 128 tile in the round-3
+  // stamps, during which the operand pipeline was empty, and then another DMA round trip before the first MFMA).  The epilogue's stores
+  // are younger than those requests, so the first waits of the next K loop also wait for them -- which the staged form did anyway.
+  constexpr bool EARLY = YS_GEMM_EPI_DIRECT != 0;
+  if (EARLY && t_first < t_end) open_tile(t_first);
+  for (int tile = t_first; tile < t_end; tile += t_step) {
+    const int m0 = tile * BM;
+    if (!EARLY) open_tile(tile);
     GTL_STAMP();
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -259,8 +278,9 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       }
       }
     }
-    ys_barrier_lds();                         // every wave finished reading the stages: they become the epilogue staging area
     GTL_STAMP();
+    if (EARLY) { if (tile + t_step < t_end) open_tile(tile + t_step); }   // (its barrier: every wave finished reading this tile's stages)
+    else ys_barrier_lds();                    // every wave finished reading the stages: they become the epilogue staging area
 
     int orow[MR];                             // row indices / byte offsets of a launch fit 31 bits (conv_gemm_plan)
     bool pv[MR];
@@ -269,8 +289,8 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
       const int m = m0 + (wm * MR + mf) * 16 + li;
       pv[mf] = m < a.M;
       const int mm = pv[mf] ? m : 0;
-      const int b = mm / g.HoWo, rem = mm - b * g.HoWo;
-      const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+      const int b = (int)ys_fastdiv((unsigned)mm, g.dHoWo), rem = mm - b * g.HoWo;
+      const int oy = (int)ys_fastdiv((unsigned)rem, g.dWout), ox = rem - oy * a.Wout;
       orow[mf] = b * (int)a.out_bstride + (a.out_rh ? (oy * a.out_rh + ox * a.out_rw + (int)a.out_r0) : (oy * a.Wout + ox));
     }
     if (F8) {                                 // back to real units: 1 / (input scale * weight scale)
@@ -283,7 +303,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
           for (int r = 0; r < 4; r++) acc[mf][nf][r] *= dq;
     }
     char* stg = sStage + wave * (16 * MR * (NR * 16 + 8) * 2 + 16 * MR * 16);
-#if YS_P2_EPI_DIRECT
+#if YS_GEMM_EPI_DIRECT
     (void)stg;
     if (!GEMM_DBG(8)) p2_epilogue_direct<MR, NR, RED>(a, acc, orow, pv, n0 + wn * NR * 16, st1, st2);
 #else
@@ -291,7 +311,7 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #endif
     GTL_STAMP();
   }
-#if YS_P2_EPI_DIRECT
+#if YS_GEMM_EPI_DIRECT
   if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush_direct<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
 #else
   if (RED ? a.nred > 0 : a.stats != nullptr) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sStage, (long)blockIdx.x);
@@ -340,6 +360,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   g.nkt = (int)((Ktot + (f8 ? 127 : 63)) / (f8 ? 128 : 64));
   g.mtiles = ys_cdiv(a.M, bm);
   g.HoWo = a.Hout * a.Wout;
+  g.dHoWo = ys_fastdiv_make((unsigned)g.HoWo); g.dWout = ys_fastdiv_make((unsigned)a.Wout);
   {
     const long pix = f8 ? (long)a.B * a.Hin * a.Win : ((long)(a.B - 1) * a.in_bstride + (long)a.Hin * a.Win);
     const long ab = f8 ? pix * a.Cin : (pix * a.in_ldc - a.in_coff) * 2L;
@@ -439,7 +460,7 @@ int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a) {
   if (!p.ok) return YS_ERR_UNSUPPORTED;
   if (a.f8 == 1 && a.nred > 0) { ys_set_error("conv gemm: the fused BN-backward reduction belongs to dgrad launches (e5m2 input)"); return YS_ERR_UNSUPPORTED; }
   // RED variants: bf16 and e5m2-input (fp8-mode dgrad) launches that carry BN-backward segments
-#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? (a.nred > 0 ? conv_gemm_launch_t<A_, B_, C_, D_, 2, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p)) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : ((a.nred > 0 || (a.accumulate && YS_P2_EPI_DIRECT)) ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
+#define GM(A_, B_, C_, D_) if (p.wm == A_ && p.wn == B_ && p.mr == C_ && p.nr == D_) return a.f8 == 2 ? (a.nred > 0 ? conv_gemm_launch_t<A_, B_, C_, D_, 2, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 2>(st, a, p)) : (a.f8 ? conv_gemm_launch_t<A_, B_, C_, D_, 1>(st, a, p) : ((a.nred > 0 || (a.accumulate && YS_GEMM_EPI_DIRECT)) ? conv_gemm_launch_t<A_, B_, C_, D_, 0, 1>(st, a, p) : conv_gemm_launch_t<A_, B_, C_, D_, 0>(st, a, p)));
   GM(2, 2, 4, 5) GM(2, 2, 4, 4) GM(4, 1, 4, 5) GM(4, 1, 4, 4)
 #undef GM
   return YS_ERR_UNSUPPORTED;

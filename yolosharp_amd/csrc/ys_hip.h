@@ -634,3 +634,26 @@ __device__ inline float ys_row16_sum(float v) {
 }
 
 static inline int ys_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Division of 0 <= n < 2^31 by a launch-constant divisor 1 <= d < 2^31 as one multiply-high and one shift (the tile loops of the blocked
+// GEMM kernels turned every output row index into (image, row, column) with two integer divisions -- ~45 VALU instructions each,
+// 16-24 of them per tile and thread: ~3 thousand cycles in front of a tile's first request).  For d >= 2: l = ceil(log2 d),
+// mul = ceil(2^(31 + l) / d) < 2^32, n / d = (n * mul) >> (31 + l): the error term n * e / 2^(31 + l) stays below 1 / d for n < 2^31.
+struct YsFastDiv { unsigned mul, sh, d; };
+static inline YsFastDiv ys_fastdiv_make(unsigned d) {
+  YsFastDiv f; f.d = d; f.mul = 0; f.sh = 0;
+  if (d >= 2) {
+    unsigned l = 0; while ((1ull << l) < d) l++;
+    f.mul = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    f.sh = l - 1;
+  }
+  return f;
+}
+__host__ __device__ inline unsigned ys_fastdiv(unsigned n, const YsFastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(YS_EMU_BUILD)
+  const unsigned q = __umulhi(n, f.mul) >> f.sh;
+#else
+  const unsigned q = (unsigned)(((unsigned long long)n * f.mul) >> 32) >> f.sh;
+#endif
+  return f.d == 1 ? n : q;
+}
