@@ -1084,7 +1084,7 @@ static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
   return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
 }
 // force_mr / force_npu (0 = free): grouped launches need every problem on the kernel variant of the group's largest problem
-static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 0) {
+static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 0, bool want_full = true) {
   P2Plan p{};
   // 3x3 forward / stride-1 dgrad, 1x1 forward / dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided
   // output-row map)
@@ -1175,7 +1175,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
         const long ntiles = (long)tx * ty * a.B;
         const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + tileconst;
         const double cost = (double)tx * ty * per_tile;
-        const bool full = ntiles * gy >= 512;
+        const bool full = !want_full || ntiles * gy >= 512;   // (a small member of a grouped launch does not have to fill the chip by itself: cheapest tiles)
         if ((full && !best_full) || (full == best_full && cost < best)) {
           best = cost; best_full = full;
           P2Args cur = g;
@@ -1200,7 +1200,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
     const size_t stat = (size_t)nwv * bn * 2 * 4, stage = (size_t)nwv * (16 * p.mr * (bn + 8) * 2 + 16 * p.mr * 16);
     size_t floor_b = stage > (size_t)17 * p.nt * 4 ? stage : (size_t)17 * p.nt * 4;
     const size_t pb0 = (size_t)p.g.PH * p.g.prb;
-    const size_t cap = (p.lds <= lds3 && p.npu == 6) ? lds3 : (p.lds <= 76 * 1024 ? 76 * 1024 : 152 * 1024);
+    const size_t cap = (p.lds <= lds3 && p.npu == 6 && p.mr * p.nr <= 8) ? lds3 : (p.lds <= 76 * 1024 ? 76 * 1024 : 152 * 1024);
     const size_t base = p.lds - (pb0 > floor_b ? pb0 : floor_b);           // tables + weights + statistics
     size_t room = cap > base + pb0 ? cap - base - pb0 : 0;
     if (pb0 + room > (size_t)8192 * 16) room = (size_t)8192 * 16 > pb0 ? (size_t)8192 * 16 - pb0 : 0;   // 13-bit LDS slot field
@@ -1210,7 +1210,11 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
     p.lds = base + (pb1 > floor_b ? pb1 : floor_b);
     p.g.off_stat = (int)(p.lds - stat);
   }
-  const int per_cu = (p.lds <= lds3 && p.npu == 6) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
+  // three per CU needs the TIGHT register variant too (conv_p2_kernel's launch bounds: NPU <= 6, MR * NR <= 8, bf16 -- 168 registers): the
+  // 4 x 3, 2 x 5 and 4 x 4 tiles compile to 189-236 registers, i.e. two waves per SIMD, and a 768-workgroup grid of theirs left 256
+  // workgroups waiting for a slot (round 4: the same pathology as the grouped launches' rounding)
+  const bool tight_regs = p.npu == 6 && p.mr * p.nr <= 8 && !f8;
+  const int per_cu = (p.lds <= lds3 && tight_regs) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
   p.per_cu = per_cu;
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
@@ -1433,7 +1437,7 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
   if (!p[big].ok) return YS_ERR_UNSUPPORTED;
   for (int i = 0; i < n; i++) {
     if (i == big) continue;
-    p[i] = conv_p2_plan(a[i], p[big].mr, p[big].npu);
+    p[i] = conv_p2_plan(a[i], p[big].mr, p[big].npu, false);
     if (!p[i].ok || p[i].nr != p[big].nr || p[i].wres != p[big].wres || p[i].nt != p[big].nt || p[i].gy != p[big].gy) return YS_ERR_UNSUPPORTED;
   }
   // one persistent grid: the slots of the largest LDS footprint's occupancy class, split in proportion to the tile counts
