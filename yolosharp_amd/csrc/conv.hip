@@ -499,7 +499,11 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 #define YS_P2_GROUP_COPY 1
 #endif
 #ifndef YS_P2_G1_MIN
-#define YS_P2_G1_MIN 10        // register tiles of >= this many MFMAs per K-step run one K-step per LDS wait (12: two K-steps for the 2 x 5 tile -- spills at 256 registers)
+#define YS_P2_G1_MIN 12        // register tiles of >= this many MFMAs per K-step run one K-step per LDS wait (12: two K-steps for the 2 x 5 tile -- spills at 256 registers)
+#endif
+#ifndef YS_P2_LATE_PFETCH
+#define YS_P2_LATE_PFETCH 0    // 1: streamed-weight dgrad variants request the next patch inside the epilogue and run two K-steps per LDS wait (2 x 5 tile).
+                               // Built, verified and measured (round 4, same box, alternating): grouped head launches 0.68 -> 0.67 ms, step 9.51 = 9.51 -- off
 #endif
 #ifndef YS_P2_RING3
 #define YS_P2_RING3 0          // 1: streamed weights fetched three groups ahead, next patch requested after the K loop.  Built and measured (round 4, same box,
@@ -507,7 +511,12 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
                                // the K loop of the streamed layers is bound by its LDS round trips per K-step, not by the weight fetch -- off
 #endif
 #ifndef YS_P2_COUNTED_WAIT
-#define YS_P2_COUNTED_WAIT 1   // 0: the tile loop opens with s_waitcnt vmcnt(0) (rounds 1-3; A/B build)
+#define YS_P2_COUNTED_WAIT 0   // 1: the tile loop opens with s_waitcnt vmcnt(N), N = the epilogue's stores.  UNSAFE, kept only as the record of the experiment:
+                               // it assumes that stores and loads retire in issue order on the shared counter.  They do not -- a store is acknowledged by
+                               // the L2 long before an older HBM load returns -- so "at most N outstanding" can hold with N patch loads still in flight
+                               // (a counted wait is only sound when N counts LOADS issued after the one waited for; loads are ordered among themselves).
+                               // Every parity test passed (the patch was requested ~7 thousand cycles earlier); the 4-step determinism test of config 5
+                               // (two YOLOv8x 1280 x 1280 models, same seed) caught it: different losses at step 0.
 #endif
 #ifndef P2_KG
 #define P2_KG 2            // K-steps (32 K each) per streamed weight group
@@ -519,8 +528,8 @@ struct P2Tag1 { static constexpr int value = 1; };
 // G K-steps share one LDS wait: about 16 MFMAs per group, so that a group's MFMA time matches the LDS round trip the SIMD's other
 // waves have to cover -- bounded by the fragment registers a group keeps live, 4 * G * (MR + NR): <= 64 in the 256-register
 // variants, <= 32 in the `tight` ones (compiled for three waves per SIMD, 168 registers).  G is 1, 2 or 4 (one table read).
-__host__ __device__ constexpr int p2_reg_group(int mr, int nr, bool tight = false) {
-  const int want = mr * nr >= YS_P2_G1_MIN ? 1 : (mr * nr >= 6 ? 2 : 4);
+__host__ __device__ constexpr int p2_reg_group(int mr, int nr, bool tight = false, bool late = false) {
+  const int want = mr * nr >= (late ? YS_P2_G1_MIN : 10) ? 1 : (mr * nr >= 6 ? 2 : 4);
   const int cap = (tight ? 8 : 16) / (mr + nr);
   const int g = want < cap ? want : cap;
   return g >= 4 ? 4 : (g >= 2 ? 2 : 1);
@@ -609,7 +618,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   constexpr int KG = P2_KG;                    // K-steps per streamed weight group
   constexpr int GU = KG * UPS;                 // 16-byte units per weight row and group
   constexpr bool TIGHT = NT == 256 && NPU <= 6 && MR * NR <= 8 && !F8;                    // 168-register variants
-  constexpr int G0 = F8 ? 1 : p2_reg_group(MR, NR, TIGHT);   // fp8: one K-step is already 128 K (32-byte fragments)
+  constexpr int G0 = F8 ? 1 : p2_reg_group(MR, NR, TIGHT, !WRES && RED != 0 && YS_P2_LATE_PFETCH != 0 && !YS_P2_RING3);   // fp8: one K-step is already 128 K (32-byte fragments)
   constexpr int G = (WRES || G0 < KG) ? G0 : KG;   // K-steps per register group of the K loop
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
   // RING3 (round 4): streamed weights are fetched THREE groups ahead (three register sets in rotation, two LDS slots as before).  One
@@ -618,6 +627,10 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   // Detect towers put their K loop at 21-24 thousand cycles per tile for 3.7 thousand cycles of MFMA.  The next tile's patch is then
   // requested AFTER the K loop (its registers would not fit next to three weight sets) and lands under the epilogue.
   constexpr bool RING3 = !WRES && YS_P2_RING3 != 0;
+  // LATE (round 4): streamed-weight variants request the next tile's patch after the K loop (it lands under the epilogue) -- the 48
+  // registers of a 12-unit patch are then free during the K loop, which pays for two K-steps of fragments per LDS wait (YS_P2_G1_MIN)
+  // (dgrad variants only: the forward variants' epilogue -- bias, eval BatchNorm, residual paths -- leaves no room and spilled the patch)
+  constexpr bool LATE = RING3 || (!WRES && !F8 && RED != 0 && YS_P2_LATE_PFETCH != 0);
   uint4 rwA[NWU], rwB[RING3 ? NWU : 1], rwC[RING3 ? NWU : 1];
   // this thread's (row, unit-in-group) of the streamed weight tile never changes: keep the row's byte offset (32 bits, through a buffer
   // descriptor of the weight shadow: a unit past the row's real K, a row past Cout or an idle thread carries the out-of-range offset and
@@ -796,7 +809,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     // everything older (the patch just consumed, the previous epilogue's conditional loads / stores) has already been waited
     // for above; saying so explicitly resets the compiler's "may still be in flight" state for the accumulator registers
     ys_wait_vm<NST>();                        // (without it -- the epilogue's stores are unconditional now -- the class is 3 % slower: 5.10 -> 5.25 ms)
-    if (!RING3 && tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
+    if (!LATE && tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
 
     // resident weights: the accumulators start as the first K-step's products (MFMA with a zero C operand -- an inline constant, no
     // registers cleared: 4 * MR * NR v_mov per tile in a kernel whose busiest pipe is the VALU); streamed weights enter the K loop
@@ -886,15 +899,19 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
       for (; grp + 3 <= ngroups; grp += 3) { ring_step(rwA, rwB, grp); ring_step(rwB, rwC, grp + 1); ring_step(rwC, rwA, grp + 2); }
       if (grp < ngroups) { ring_step(rwA, rwB, grp); if (grp + 1 < ngroups) ring_step(rwB, rwC, grp + 1); }
       // the next tile: its patch and its first three weight groups are requested now and land under the epilogue
-      if (tile + t_step < t_end) { okm_next = pfetch(ntx, nty, nb); wfetch(rwA, 0); wfetch(rwB, 1); wfetch(rwC, 2); }
+      if (tile + t_step < t_end) { wfetch(rwA, 0); wfetch(rwB, 1); wfetch(rwC, 2); }
     } else {
       constexpr int NGS = KG / G;               // register groups per streamed weight slot
 #pragma unroll 1
       for (int grp = 0; grp < ngroups; grp++) {
         wfetch(rwA, grp + 1);                   // unconditional (past the end: zeros); lands during this group's MFMAs
+        if (grp < 3) TL_STAMP2();               // (fine timeline: weight fetch issued / K-steps done / weights stored / barrier passed, first three groups)
         if (in_bf8) kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS, P2Tag1{}); else kloop(sW + (grp & 1) * BN * g.wpitch, grp * KG, NGS, P2Tag0{});
+        if (grp < 3) TL_STAMP2();
         wstore(rwA, (grp + 1) & 1);
+        if (grp < 3) TL_STAMP2();
         ys_barrier_lds();
+        if (grp < 3) TL_STAMP2();
       }
     }
     if (WRES) ys_barrier_lds();               // every wave finished reading the patch: it becomes the staging area
@@ -929,10 +946,14 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     if (!P2_DBG(4)) p2_epilogue_direct<MR, NR, RED>(a, acc, orow, pv, n0, st1, st2);
 #endif
 #else
+    // LATE: the next tile's patch is requested inside the epilogue, right after the accumulators have been staged (their registers are
+    // free then; requested straight after the K loop the forward variants spilled five patch units to scratch -- each spill a wait
+    // for its own load, five exposed HBM round trips per tile)
+    auto late_fetch = [&]() { if (LATE && tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb); };
 #ifdef YS_P2_TIMELINE
-    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_P2(NPU)>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); });
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_P2(NPU)>(a, acc, orow, pv, n0, stg, st1, st2, [&]() { TL_STAMP(); }, late_fetch);
 #else
-    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_P2(NPU)>(a, acc, orow, pv, n0, stg, st1, st2);
+    if (!P2_DBG(4)) p2_epilogue<MR, NR, RED, YS_EPI_BATCH_P2(NPU)>(a, acc, orow, pv, n0, stg, st1, st2, YsNoStamp(), late_fetch);
 #endif
 #endif
     TL_STAMP();

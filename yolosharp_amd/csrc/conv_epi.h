@@ -64,9 +64,11 @@ __device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long 
 __host__ __device__ constexpr int p2_epi_stores(int mr, int nr) { return (16 * mr + 64 / (nr * 2) - 1) / (64 / (nr * 2)); }
 template <int M> struct EpiMode { static constexpr int value = M; };
 struct YsNoStamp { __device__ inline void operator()() const {} };   // timeline hook of triage builds (-DYS_P2_TIMELINE): nothing in the product
-template <int MR, int NR, int RED = 0, int BMAX = 4 /* unused: batch depth of the reverted batched store loop */, class SF = YsNoStamp>
+// after_stage: called once the accumulators have been rounded into the staging rows (they are dead from there on) -- conv_p2_body's
+// streamed-weight variants request the next tile's patch there, into the registers the accumulators just freed
+template <int MR, int NR, int RED = 0, int BMAX = 4 /* unused: batch depth of the reverted batched store loop */, class SF = YsNoStamp, class AF = YsNoStamp>
 __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
-                                   int n0, char* stg, float (&s1)[8], float (&s2)[8], SF stamp = SF()) {
+                                   int n0, char* stg, float (&s1)[8], float (&s2)[8], SF stamp = SF(), AF after_stage = AF()) {
   typedef bf16_t T;
   constexpr int BN = NR * 16;
   constexpr int PITCH = (BN + 8) * 2;         // bytes per staged pixel row
@@ -145,6 +147,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
   }
   stamp();
   ys_wave_sync_lds();                          // the staged rows (written by other lanes of this wave) are IN LDS before the reads below are issued
+  after_stage();
   stamp();
   const bool do_stats_rt = !RED && a.stats != nullptr && !EPI_DBG(512);
   // eval-mode BatchNorm folded into the conv (Convs.cs:48 with running statistics): applied on the wide path to the
@@ -237,11 +240,13 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     ys_bufst16(rsY, (rofs != YS_BUF_OOB && !EPI_DBG(256)) ? rofs + (unsigned)c * 2u : YS_BUF_OOB, val);
   };
   if (EPI_DBG(1024)) { ys_wave_sync(); return; }
-  // Fully unrolled (round 4; the forward form used to be `unroll 2`): the compiler then SEES the NITER stores in a row, which is what
-  // lets the tile loop of conv_p2_body wait with vmcnt(NITER) -- behind a rolled loop hipcc only credits the stores of one trip and
-  // puts s_waitcnt vmcnt(2), (1) in front of the patch's LDS writes, i.e. drains half of them again.  (RED: yv[it] must be a register.)
-#pragma unroll
-  for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
+  if (RED) {
+#pragma unroll                                // fully: yv[it] must be a register, not an indexed (scratch) array
+    for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
+  } else {
+#pragma unroll 2
+    for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
+  }
   stamp();
   ys_wave_sync();
 }
