@@ -168,7 +168,10 @@ def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
 
 
 @pytest.mark.parametrize("backend", [pytest.param("gpu", marks=pytest.mark.gpu)])
-@pytest.mark.parametrize("case", [(16, 800, 160, 160, 320, 1), (2, 400, 320, 320, 160, 1), (4, 64, 160, 160, 64, 3)])
+@pytest.mark.parametrize("case", [(16, 800, 160, 160, 320, 1), (2, 400, 320, 320, 160, 1), (4, 64, 160, 160, 64, 3),
+                                  # round 4: the two layers on which the packed-FP32 statistics of an unrolled epilogue differed in 3-6 of 6 reruns
+                                  # (128 x 160 tile of the blocked-GEMM kernel, ~10 tiles per workgroup); and a YOLOv11m-seg (config 4) shape
+                                  (16, 400, 320, 320, 160, 1), (16, 160, 320, 320, 160, 3), (32, 256, 80, 80, 256, 3)])
 def test_wide_bn_layer_reruns_are_bit_identical(backend, engine, case):
     """Run-to-run bit identity of Conv + BN(train) + SiLU at sizes where a workgroup of the persistent grid walks several tiles
     (blocked-GEMM kernel: K not a multiple of the K-tile; the whole-Cin patch kernel for the third case).  Round 3: a batched form
@@ -183,7 +186,7 @@ def test_wide_bn_layer_reruns_are_bit_identical(backend, engine, case):
     x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
     w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
     outs = []
-    for _ in range(12 if B >= 16 else 4):
+    for _ in range(10 if B >= 16 else 4):
         bn = {"weight": np.ones(Cout, np.float32), "bias": np.zeros(Cout, np.float32),
               "running_mean": np.zeros(Cout, np.float32), "running_var": np.ones(Cout, np.float32)}
         y = engine.conv_bn_act(x, w, k, 1, bn=bn, act=True, training=True, dtype="bf16")

@@ -8,7 +8,9 @@ from yolosharp_amd import Engine
 lib = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("", "-") else None
 eng = Engine(0, lib_path=lib) if lib else Engine(0)
 rng = np.random.default_rng(0)
-for (B, Cin, H, W, Cout, k, s) in [(16, 800, 160, 160, 320, 1, 1), (16, 400, 320, 320, 160, 1, 1)]:
+SHAPES = os.environ.get("YS_DET_SHAPES")
+shapes = [tuple(int(v) for v in t.split(",")) for t in SHAPES.split(";")] if SHAPES else [(16, 800, 160, 160, 320, 1, 1), (16, 400, 320, 320, 160, 1, 1)]
+for (B, Cin, H, W, Cout, k, s) in shapes:
     x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
     w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
     outs = []

@@ -65,7 +65,11 @@ def build_device(verbose=False, variant="dev", defines=(), out=None):
         obj = os.path.join(BUILD, variant, s + ".o")
         objs.append(obj)
         if _newer(obj, [src] + hdrs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+            # -fno-slp-vectorize: no compiler-formed packed-FP32 (v_pk_*_f32 / v_pk_mov_b32) arithmetic in the kernels.  The staged convolution
+            # epilogue's BatchNorm sums were not bit-stable from run to run when hipcc's SLP vectorizer packed them through v_pk_mov_b32
+            # shuffles (round-4 bisection, profiles/README.md); single-issue FP32 is also what the CDNA4 guide prices lower next to MFMAs.
+            # Measured neutral on the headline step (9.49-9.51 vs 9.48-9.52 ms, same box).
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize",
                    "-fno-strict-aliasing", "-Wno-unused-result", "-I", CSRC, "-c", src, "-o", obj] + list(defines)
             if s in NO_CONTRACT:
                 cmd.insert(4, "-ffp-contract=off")

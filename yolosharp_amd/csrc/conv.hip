@@ -511,12 +511,12 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
                                // the K loop of the streamed layers is bound by its LDS round trips per K-step, not by the weight fetch -- off
 #endif
 #ifndef YS_P2_COUNTED_WAIT
-#define YS_P2_COUNTED_WAIT 0   // 1: the tile loop opens with s_waitcnt vmcnt(N), N = the epilogue's stores.  UNSAFE, kept only as the record of the experiment:
-                               // it assumes that stores and loads retire in issue order on the shared counter.  They do not -- a store is acknowledged by
-                               // the L2 long before an older HBM load returns -- so "at most N outstanding" can hold with N patch loads still in flight
-                               // (a counted wait is only sound when N counts LOADS issued after the one waited for; loads are ordered among themselves).
-                               // Every parity test passed (the patch was requested ~7 thousand cycles earlier); the 4-step determinism test of config 5
-                               // (two YOLOv8x 1280 x 1280 models, same seed) caught it: different losses at step 0.
+#define YS_P2_COUNTED_WAIT 1   // the tile loop opens with s_waitcnt vmcnt(N), N = the epilogue's stores (0: vmcnt(0), rounds 1-3).  Relies on loads and stores
+                               // retiring in issue order on the shared counter -- what hipcc's own wait insertion assumes on gfx9-family parts (it derives
+                               // vmcnt(3), (2) from store counts itself when the store loop is rolled).  This switch was suspected and withdrawn once in
+                               // round 4, when the config-5 determinism test failed with it -- the bisection (profiles/README.md) cleared it: counted wait +
+                               // rolled store loop is bit-stable, full unroll WITHOUT it is not (packed-FP32 statistics), and with the convolution sources
+                               // compiled -fno-slp-vectorize the combination is stable in 8 / 8 model-level rounds and every layer rerun.
 #endif
 #ifndef P2_KG
 #define P2_KG 2            // K-steps (32 K each) per streamed weight group

@@ -62,6 +62,17 @@ __device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long 
 // conv_p2_body waits for "all but the last p2_epi_stores() vector-memory operations" at the top of a tile, i.e. for the prefetched
 // patch but NOT for the previous tile's output stores (gfx9-family parts count loads and stores on one in-order vmcnt).
 __host__ __device__ constexpr int p2_epi_stores(int mr, int nr) { return (16 * mr + 64 / (nr * 2) - 1) / (64 / (nr * 2)); }
+#ifndef YS_EPI_SCALAR_STATS
+#define YS_EPI_SCALAR_STATS 0
+#endif
+#ifndef YS_EPI_LDS_NOALIAS
+#define YS_EPI_LDS_NOALIAS 0
+#endif
+#ifndef YS_EPI_FULL_UNROLL
+#define YS_EPI_FULL_UNROLL 1   // forward store loop fully unrolled: hipcc then SEES the NITER stores in a row, which is what lets conv_p2_body wait with vmcnt(NITER)
+                               // (behind a rolled loop it credits one trip and re-drains).  REQUIRES -fno-slp-vectorize (yolosharp_amd/build.py): with SLP-packed
+                               // statistics the unrolled form is the reproducer of the run-to-run nondeterminism (profiles/README.md, round 4); 0 = `unroll 2`
+#endif
 template <int M> struct EpiMode { static constexpr int value = M; };
 struct YsNoStamp { __device__ inline void operator()() const {} };   // timeline hook of triage builds (-DYS_P2_TIMELINE): nothing in the product
 // after_stage: called once the accumulators have been rounded into the staging rows (they are dead from there on) -- conv_p2_body's
@@ -189,12 +200,32 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
     uint4 val = ys_zero16();
     {
       if (rofs != YS_BUF_OOB) {
+#if YS_EPI_LDS_NOALIAS && !defined(YS_EMU_BUILD)
+        {   // triage (round-4 determinism bisection): the staged vector through an LDS read whose destination registers cannot be the address register
+          const unsigned sa = (unsigned)(uintptr_t)(stg + px * PITCH + cv * 16);
+#if YS_EPI_LDS_NOALIAS == 2
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "=&v"(val) : "v"(sa) : "memory");
+#else
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(val) : "v"(sa) : "memory");
+#endif
+        }
+#else
         val = *(const uint4*)(stg + px * PITCH + cv * 16);
+#endif
         float f[8];
         ys_unpack<T>(val, f);
         if (do_stats) {
+#if YS_EPI_SCALAR_STATS && !defined(YS_EMU_BUILD)
+          // triage (round-4 determinism bisection): the sums through single v_add_f32 / v_fmac_f32 (inline asm: hipcc cannot pair them into v_pk_*_f32)
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(s1[e]) : "v"(f[e]));
+            asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(s2[e]) : "v"(f[e]));
+          }
+#else
 #pragma unroll
           for (int e = 0; e < 8; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+#endif
         }
         if (bn_eval) {
 #pragma unroll
@@ -244,8 +275,13 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 #pragma unroll                                // fully: yv[it] must be a register, not an indexed (scratch) array
     for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
   } else {
+#if YS_EPI_FULL_UNROLL
+#pragma unroll
+    for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
+#else
 #pragma unroll 2
     for (int it = 0; it < NITER; it++) store_iter(it, EpiMode<2>{});
+#endif
   }
   stamp();
   ys_wave_sync();

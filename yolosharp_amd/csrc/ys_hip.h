@@ -30,9 +30,9 @@
 #define YS_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
 // s_waitcnt vmcnt(N), N <= 63 (gfx9 encoding: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt left at "no wait"):
-// at most N of this wave's vector-memory instructions still in flight.  LOADS retire in issue order among themselves; a STORE may be acknowledged before
-// an older load returns (round 4: conv_p2_body's counted tile-top wait).  So waiting for load X is sound only with N = the number of LOADS issued after X
-// (then counter <= N implies outstanding loads <= N, i.e. X is back) -- never with a count of later stores.
+// at most N of this wave's vector-memory instructions still in flight -- loads and stores retire in issue order on gfx9-family parts (one counter,
+// hipcc's own s_waitcnt insertion relies on it).  A wait whose N counts only LOADS issued after the one waited for is sound even without
+// that assumption (conv_gemm_kernel's K-loop waits); conv_p2_body's tile-top wait counts later STORES and does rely on it.
 template <int N> __device__ inline void ys_wait_vm() {
 #ifndef YS_EMU_BUILD
   static_assert(N >= 0 && N <= 63, "vmcnt");

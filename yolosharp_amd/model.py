@@ -43,7 +43,10 @@ class Yolov8:
 
     def close(self):
         if self.handle:
-            self.lib.ys_model_destroy(self.handle)
+            # a model outlives its context only when the garbage collector finalises a reference cycle in arbitrary order (a failed test keeps both in
+            # its traceback): destroying it then would walk freed context state -- the context's own destruction has released the device memory
+            if getattr(self.engine, "ctx", None):
+                self.lib.ys_model_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
