@@ -313,17 +313,23 @@ def main():
         # the file was measured on THIS source tree and configuration
         traffic, traffic_note = None, None
         cfg_key = f"YOLOv{args.family}{args.size}{'-' + args.task if args.task != 'detect' else ''} B={B} {H}x{W} {args.dtype}"
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
-            ent = tj.get("configs", {}).get(cfg_key)
-            if ent is None:
-                traffic_note = "no PMC passes committed for this configuration"
-            elif ent.get("source_sha") != RL.source_sha(ROOT):
-                traffic_note = f"profiles/r03_hbm_traffic.json was measured on source {ent.get('source_sha')}, this tree is {RL.source_sha(ROOT)}: not reported"
-            else:
-                traffic = ent["kernels"][dom.split("<")[0]]["hbm_bytes_per_launch_corrected"]
-        except Exception as e:
-            traffic_note = f"profiles/r03_hbm_traffic.json unreadable ({type(e).__name__})"
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True)   # newest round first
+        for tf in tfiles:
+            tname = "profiles/" + os.path.basename(tf)
+            try:
+                ent = json.load(open(tf)).get("configs", {}).get(cfg_key)
+                if ent is None:
+                    traffic_note = traffic_note or "no PMC passes committed for this configuration"
+                elif ent.get("source_sha") != RL.source_sha(ROOT):
+                    traffic_note = f"{tname} was measured on source {ent.get('source_sha')}, this tree is {RL.source_sha(ROOT)}: not reported"
+                    break
+                else:
+                    traffic = ent["kernels"][dom.split("<")[0]]["hbm_bytes_per_launch_corrected"]
+                    traffic_note = None
+                    break
+            except Exception as e:
+                traffic_note = f"{tname} unreadable ({type(e).__name__})"
         roofline["traffic"] = traffic
         if traffic_note:
             roofline["traffic_note"] = traffic_note
