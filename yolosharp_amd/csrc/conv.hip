@@ -486,7 +486,7 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
 // Handles forward (stride 1 and 2) and stride-1 dgrad (same gather, flipped weights); DIV = 2 dgrads stay on the old path.
 #include "conv_epi.h"
 #ifndef YS_EPI_BATCH_P2
-#define YS_EPI_BATCH_P2(NPU_) ((NPU_) <= 6 ? 2 : 4)
+#define YS_EPI_BATCH_P2(NPU_) 4
 #endif
 
 // ablation switches (YS_DBG bits) cost scalar checks in the hot loops: compiled in only for triage builds (-DYS_P2_ABLATE)

@@ -62,6 +62,9 @@ __device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long 
 // conv_p2_body waits for "all but the last p2_epi_stores() vector-memory operations" at the top of a tile, i.e. for the prefetched
 // patch but NOT for the previous tile's output stores (gfx9-family parts count loads and stores on one in-order vmcnt).
 __host__ __device__ constexpr int p2_epi_stores(int mr, int nr) { return (16 * mr + 64 / (nr * 2) - 1) / (64 / (nr * 2)); }
+#ifndef YS_EPI_ACC_PREFETCH
+#define YS_EPI_ACC_PREFETCH 1   // 1: the dgrad (RED) variants; 2: every variant that may accumulate (measured equal: forward variants do not accumulate in a training step)
+#endif
 #ifndef YS_EPI_SCALAR_STATS
 #define YS_EPI_SCALAR_STATS 0
 #endif
@@ -77,7 +80,7 @@ template <int M> struct EpiMode { static constexpr int value = M; };
 struct YsNoStamp { __device__ inline void operator()() const {} };   // timeline hook of triage builds (-DYS_P2_TIMELINE): nothing in the product
 // after_stage: called once the accumulators have been rounded into the staging rows (they are dead from there on) -- conv_p2_body's
 // streamed-weight variants request the next tile's patch there, into the registers the accumulators just freed
-template <int MR, int NR, int RED = 0, int BMAX = 4 /* unused: batch depth of the reverted batched store loop */, class SF = YsNoStamp, class AF = YsNoStamp>
+template <int MR, int NR, int RED = 0, int BMAX = 4 /* most store-loop iterations whose accumulate operands are requested ahead */, class SF = YsNoStamp, class AF = YsNoStamp>
 __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
                                    int n0, char* stg, float (&s1)[8], float (&s2)[8], SF stamp = SF(), AF after_stage = AF()) {
   typedef bf16_t T;
@@ -124,6 +127,23 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
 #pragma unroll
     for (int e = 0; e < 8; e++) { rsc[e] = 0.f; rsh[e] = 0.f; }
     if (ry) { ys_ldcoef<8>(rscp + rcol, rsc); ys_ldcoef<8>(rshp + rcol, rsh); }
+  }
+  // ---- gradient accumulation (dgrad into a view that already holds another consumer's contribution): the old values of all NITER
+  // iterations are requested here too (round 4).  Loaded inside the store loop each iteration was load -> s_waitcnt vmcnt(0) -> add ->
+  // store, i.e. NITER dependent memory round trips per tile, each also draining the previous iteration's store: accumulate launches ran
+  // 1.15-1.9x their overwrite twins (per-launch records: 3x3 32 -> 32 at 160 x 160: 40.6 us against 26.6).  Every lane re-reads exactly the
+  // 16 bytes it will overwrite, so the order of load and store per address is program order.
+  constexpr bool ACC_PRE = (RED != 0 || YS_EPI_ACC_PREFETCH == 2) && YS_EPI_ACC_PREFETCH != 0 && NITER <= BMAX;   // BMAX: what the caller's register budget affords (conv_p2: 4 vectors; conv_gemm: all)
+  uint4 ov[ACC_PRE ? NITER : 1];
+  if (ACC_PRE && a.accumulate) {
+    const ys_rsrcv_t rsO = ys_make_rsrcv(a.y, 0x7ffffff0u);
+    if (!red_on) ys_wave_sync();              // (the reduction path above has already made the row table visible)
+#pragma unroll
+    for (int it = 0; it < NITER; it++) {
+      const int px = it * PPI + pl;
+      const unsigned ro = (active && px < NPX && c < a.Cout) ? rowtab[px] : YS_BUF_OOB;
+      ov[it] = ys_bufld16(rsO, ro != YS_BUF_OOB ? ro + (unsigned)c * 2u : YS_BUF_OOB);
+    }
   }
   stamp();
 #pragma unroll
@@ -248,7 +268,7 @@ __device__ inline void p2_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], cons
             for (int e = 0; e < 8; e++) f[e] += gq[e];
           }
           if (accum) {
-            ys_unpack<T>(ys_ld16(yp), gq);
+            if constexpr (ACC_PRE) ys_unpack<T>(ov[ACC_PRE ? it : 0], gq); else ys_unpack<T>(ys_ld16(yp), gq);
 #pragma unroll
             for (int e = 0; e < 8; e++) f[e] += gq[e];
           }

@@ -31,7 +31,7 @@
                                // epilogue is bound by -- so the staged form stays
 #endif
 #ifndef YS_EPI_BATCH_GEMM
-#define YS_EPI_BATCH_GEMM 4
+#define YS_EPI_BATCH_GEMM 16
 #endif
 #ifndef YS_GEMM_READ_AHEAD
 #define YS_GEMM_READ_AHEAD 0   // measured (round 3, MI355X): no difference -- config 5 bf16 88.51 vs 88.57 ms/step, config 4 32.62 vs 32.71, config 2 10.24 vs 10.22; the K-tile is bound by LDS bytes (operand DMA + fragment reads ~220 KB per K-tile pair and CU), not by the exposed round trip
