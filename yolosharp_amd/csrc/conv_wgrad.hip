@@ -203,8 +203,11 @@ wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, int c
 //   TAPS == 1: 4 waves split the 32-pixel K-blocks and are combined through LDS at the end.
 // K order inside a tile is the tile-local pixel index p = ty*TW + tx for both operands; pixels outside the image (or the
 // tile's 32-pixel rounding) read a zero dy row.  Partials go to partial[blockIdx.x][Cout][taps][Cin] (fixed-order reduce).
+#ifndef YS_WG_TWO_MAX
+#define YS_WG_TWO_MAX 2        // 9-wave weight-gradient tiles of up to this many MFMA fragments run two workgroups per CU (96 registers).  4 measured (round 4): the 2 x 2 tile spills 32 B and the 32 -> 32 layers go 29.4 -> 42.0 us (400 partial slabs instead of 229) -- stays 2
+#endif
 template <int MRA, int NRB, int TAPS>
-__global__ void __launch_bounds__(TAPS == 9 ? 576 : 256)
+__global__ void __launch_bounds__(TAPS == 9 ? 576 : 256, (TAPS == 9 && MRA * NRB <= YS_WG_TWO_MAX) ? 5 : 1)   // small 9-wave tiles: 96 registers = two workgroups per CU
 conv_wgrad_tr_kernel(WgradArgs a) {
   constexpr int NT = TAPS == 9 ? 576 : 256;
   constexpr int NW = NT / 64;
@@ -442,7 +445,7 @@ static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   const int gy = ys_cdiv(a.Cout, cot) * ys_cdiv(a.Cin, cit);
   const long ntiles = (long)p.tx * p.ty * a.B;
   int per_cu = (int)((150 * 1024) / p.lds);
-  const int per_cu_max = k3 ? (p.mra * p.nrb <= 2 ? 2 : 1) : 4;   // 9-wave workgroups are register-limited to 1-2 per CU
+  const int per_cu_max = k3 ? (p.mra * p.nrb <= YS_WG_TWO_MAX ? 2 : 1) : 4;   // 9-wave workgroups are register-limited to 1-2 per CU (launch bounds of conv_wgrad_tr_kernel)
   if (per_cu > per_cu_max) per_cu = per_cu_max;
   if (per_cu < 1) per_cu = 1;
   long gx = (256L * per_cu) / gy;
