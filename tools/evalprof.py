@@ -1,5 +1,5 @@
 import numpy as np, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); os.chdir(sys.path[0])
 from yolosharp_amd import Engine
 from yolosharp_amd.model import Yolov8
 eng = Engine(0)
