@@ -348,7 +348,11 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   // kernel falls back to 2 x 22-pixel tiles whose patch every output-channel column re-reads (64 -> 128 at 80 x 80: 71 us, 9.4x its floor)
   static const int s2_min_cin = getenv("YS_GEMM_S2_MIN_CIN") ? atoi(getenv("YS_GEMM_S2_MIN_CIN")) : 64;
   const bool s2_narrow = k3 && a.SA == 2 && a.Cin >= s2_min_cin && !f8;
-  if ((a.Cin < min_cin && !s2_narrow) || Ktot < min_k || a.Cout < 64 || a.M < min_m) return p;
+  // ... and stride-1 3x3 layers with 64 <= Cin < 128 whose output is wide (the fused Detect / Segment tower input, 64 -> 144): the patch kernel streams
+  // 166 KB of weights per 256-pixel tile there
+  static const int wide_cout = getenv("YS_GEMM_WIDE_COUT") ? atoi(getenv("YS_GEMM_WIDE_COUT")) : 128;
+  const bool wide_out = k3 && a.SA == 1 && a.Cin >= 64 && a.Cout >= wide_cout && !f8;
+  if ((a.Cin < min_cin && !s2_narrow && !wide_out) || Ktot < min_k || a.Cout < 64 || a.M < min_m) return p;
   // output-channel tile: least padding first, then the widest (most reuse of the A tile)
   static const int cand[4][4] = {{2, 2, 4, 5}, {2, 2, 4, 4}, {4, 1, 4, 5}, {4, 1, 4, 4}};   // WM, WN, MR, NR
   int best = -1; long best_pad = 0;
