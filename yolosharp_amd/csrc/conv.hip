@@ -510,6 +510,13 @@ conv3x3_tile_kernel(ConvArgs a, int ntiles, int nchunks, int wres, int wpitch, i
                                // alternating): grouped head launches 1.00 -> 0.96 ms, plain launches 2.96 -> 3.00 (more spills in the non-grouped variants), step 9.75 = 9.75:
                                // the K loop of the streamed layers is bound by its LDS round trips per K-step, not by the weight fetch -- off
 #endif
+#ifndef YS_P2_DMA_RING
+#define YS_P2_DMA_RING 1       // 1: streamed bf16 weights go global -> LDS by DMA into a ring of three group slots, two groups ahead (no registers, no ds_write,
+                               // no wait for the fetch inside the group) -- see DMAW in conv_p2_body
+#endif
+#ifndef YS_P2_DMA_G2
+#define YS_P2_DMA_G2 1
+#endif
 #ifndef YS_P2_COUNTED_WAIT
 #define YS_P2_COUNTED_WAIT 1   // the tile loop opens with s_waitcnt vmcnt(N), N = the epilogue's stores (0: vmcnt(0), rounds 1-3).  Relies on loads and stores
                                // retiring in issue order on the shared counter -- what hipcc's own wait insertion assumes on gfx9-family parts (it derives
@@ -619,7 +626,10 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   constexpr int GU = KG * UPS;                 // 16-byte units per weight row and group
   constexpr bool TIGHT = NT == 256 && NPU <= 6 && MR * NR <= 8 && !F8;                    // 168-register variants
   constexpr int G0 = F8 ? 1 : p2_reg_group(MR, NR, TIGHT, !WRES && RED != 0 && YS_P2_LATE_PFETCH != 0 && !YS_P2_RING3);   // fp8: one K-step is already 128 K (32-byte fragments)
-  constexpr int G = (WRES || G0 < KG) ? G0 : KG;   // K-steps per register group of the K loop
+  // streamed bf16 weights by DMA leave the dgrad variants (no bias / BatchNorm / residual epilogue paths) room for both K-steps of a weight
+  // group per LDS wait: with two waves per SIMD the one-step form is a chain of two LDS round trips per 10-16 MFMAs
+  constexpr bool DMAW_G2 = !WRES && !F8 && NT == 256 && !YS_P2_RING3 && YS_P2_DMA_RING != 0 && RED != 0 && MR * NR <= 12 && YS_P2_DMA_G2 != 0;   // (4 x 4: spills)
+  constexpr int G = DMAW_G2 ? KG : ((WRES || G0 < KG) ? G0 : KG);   // K-steps per register group of the K loop
   const int ngroups = WRES ? 1 : (g.nsteps + KG - 1) / KG;
   // RING3 (round 4): streamed weights are fetched THREE groups ahead (three register sets in rotation, two LDS slots as before).  One
   // group ahead -- the rounds 1-3 form: fetch at the top of a group, store at its end -- gives the L2 round trip one group's MFMAs to
@@ -631,6 +641,15 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   // registers of a 12-unit patch are then free during the K loop, which pays for two K-steps of fragments per LDS wait (YS_P2_G1_MIN)
   // (dgrad variants only: the forward variants' epilogue -- bias, eval BatchNorm, residual paths -- leaves no room and spilled the patch)
   constexpr bool LATE = RING3 || (!WRES && !F8 && RED != 0 && YS_P2_LATE_PFETCH != 0);
+  // DMAW (round 4): streamed bf16 weights by LDS DMA.  A weight group (KG = 2 K-steps = 64 K = 128 bytes per output channel) is BN rows of
+  // eight 16-byte units; a wave instruction moves eight rows (1 KB), lane l -> row l / 8, LDS unit l % 8, which holds the row's logical unit
+  // (l % 8) ^ ((row / 2) % 8) -- the blocked-GEMM kernel's swizzle: the K loop's fragment reads (16 rows x 4 units) are conflict-free.  Three
+  // slots: at group g the workgroup waits for its own requests of g (issued two groups earlier), meets at ONE barrier, requests g + 2 into
+  // the slot group g - 1 was read from, and multiplies.  The register form costs 12 registers, three ds_write_b128 and -- the expensive
+  // part -- a wait for loads issued only one group (~1 thousand cycles) earlier, per thread and group.
+  constexpr bool DMAW = !WRES && !F8 && NT == 256 && !RING3 && YS_P2_DMA_RING != 0;
+  constexpr int NBP = BN / 8;                  // 1 KB requests per weight group
+  constexpr int NPW = (NBP + NWV - 1) / NWV;   // ... per wave (the last round may be partial)
   uint4 rwA[NWU], rwB[RING3 ? NWU : 1], rwC[RING3 ? NWU : 1];
   // this thread's (row, unit-in-group) of the streamed weight tile never changes: keep the row's byte offset (32 bits, through a buffer
   // descriptor of the weight shadow: a unit past the row's real K, a row past Cout or an idle thread carries the out-of-range offset and
@@ -660,6 +679,36 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
       if (idx < BN * GU) { const int n = idx / GU; sW[(buf * BN + n) * g.wpitch + (idx - n * GU)] = rw[k]; }
     }
   };
+
+#ifdef YS_EMU_BUILD
+  const int wvu = wave;
+#else
+  const int wvu = __builtin_amdgcn_readfirstlane(wave);
+#endif
+  const int nmine = DMAW ? (NBP - wvu + NWV - 1) / NWV : 0;     // requests of this wave per weight group
+  const int kunits = Ktot >> 3;
+  const ys_rsrc_t rsWd = ys_make_rsrc(wb, (unsigned)((long)a.Cout * Ktot * WES));
+  unsigned dro[DMAW ? NPW : 1];
+  int dun[DMAW ? NPW : 1];
+  if constexpr (DMAW) {
+#pragma unroll
+    for (int j = 0; j < NPW; j++) {
+      const int row = (wvu + NWV * j) * 8 + (lane >> 3);
+      dun[j] = (lane & 7) ^ ((row >> 1) & 7);
+      dro[j] = (row < BN && n0 + row < a.Cout) ? (unsigned)((long)(n0 + row) * Ktot * 2) + (unsigned)dun[j] * 16u : YS_BUF_OOB;
+    }
+  }
+  auto wdma = [&](int grp, int slot) {           // weight group grp -> ring slot; units past the row's real K, rows past Cout: zeros
+    if constexpr (DMAW) {
+#pragma unroll
+      for (int j = 0; j < NPW; j++)
+        if (wvu + NWV * j < NBP) {
+          const bool ok = (bool)((int)(grp * 8 + dun[j] < kunits) & (int)!P2_DBG(16));
+          ys_bufld_lds16(rsWd, ok ? dro[j] : YS_BUF_OOB, (unsigned)grp * 128u, (char*)sW + slot * (BN * 128) + (wvu + NWV * j) * 1024);
+        }
+    }
+  };
+  const int wko0 = (q ^ ((li >> 1) & 3)) * 16 + ((((li >> 1) & 7) >> 2) << 6);   // ring slot: byte offset of (K-step 0, quarter q) in this lane's rows
 
   // ---- patch of a tile: global -> registers (all loads back-to-back); the NEXT tile's patch is in flight while the
   // current one is consumed, so every resident workgroup always has a whole patch outstanding (HBM needs ~40 KB per CU
@@ -779,7 +828,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
     TL_STAMP2();
     ys_barrier_lds();                         // previous tile's epilogue staging (patch region) and tables are settled
     TL_STAMP2();
-    if (!WRES && !RING3) wfetch(rwA, 0);
+    if (!WRES && !RING3 && !DMAW) wfetch(rwA, 0);
 #pragma unroll
     for (int k = 0; k < NPU; k++) {
       unsigned d = pdesc[k];
@@ -802,14 +851,16 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
         if (d != 0xffffffffu && !P2_DBG(8)) *(uint4*)(sPb + ((d & 8191u) << 4)) = rp[k];     // padding units arrived as zeros
       }
     }
-    if (!WRES) wstore(rwA, 0);
+    if (!WRES && !DMAW) wstore(rwA, 0);
     ys_barrier_lds();
     TL_STAMP();
     advance(ntx, nty, nb);
     // everything older (the patch just consumed, the previous epilogue's conditional loads / stores) has already been waited
     // for above; saying so explicitly resets the compiler's "may still be in flight" state for the accumulator registers
     ys_wait_vm<NST>();                        // (without it -- the epilogue's stores are unconditional now -- the class is 3 % slower: 5.10 -> 5.25 ms)
-    if (!LATE && tile + t_step < t_end) okm_next = pfetch(ntx, nty, nb);
+    const bool more = tile + t_step < t_end;
+    if constexpr (DMAW) { wdma(0, 0); if (ngroups > 1) wdma(1, 1); }   // BEFORE the patch requests: the first groups' waits then leave the patch in flight
+    if (!LATE && more) okm_next = pfetch(ntx, nty, nb);
 
     // resident weights: the accumulators start as the first K-step's products (MFMA with a zero C operand -- an inline constant, no
     // registers cleared: 4 * MR * NR v_mov per tile in a kernel whose busiest pipe is the VALU); streamed weights enter the K loop
@@ -858,7 +909,10 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
 #pragma unroll
           for (int nf = 0; nf < NR; nf++)
 #pragma unroll
-            for (int h = 0; h < FU; h++) f.w[gs][nf][h] = wbuf[(nf * 16 + li) * g.wpitch + ((gi * G + gs) * 4 + q) * FU + h];
+            for (int h = 0; h < FU; h++) {
+              if constexpr (DMAW) f.w[gs][nf][h] = *(const uint4*)((const char*)wbuf + (nf * 16 + li) * 128 + (wko0 ^ (((gi * G + gs) & 1) << 6)));
+              else f.w[gs][nf][h] = wbuf[(nf * 16 + li) * g.wpitch + ((gi * G + gs) * 4 + q) * FU + h];
+            }
 #pragma unroll
           for (int mf = 0; mf < MR; mf++)
 #pragma unroll
@@ -900,6 +954,25 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
       if (grp < ngroups) { ring_step(rwA, rwB, grp); if (grp + 1 < ngroups) ring_step(rwB, rwC, grp + 1); }
       // the next tile: its patch and its first three weight groups are requested now and land under the epilogue
       if (tile + t_step < t_end) { wfetch(rwA, 0); wfetch(rwB, 1); wfetch(rwC, 2); }
+    } else if constexpr (DMAW) {
+      constexpr int NGS = KG / G;
+      // Counted waits: vmcnt(N) with N = the requests of THIS wave known to be younger than group grp's -- group grp + 1's (issued one
+      // iteration earlier) and, for the first two groups, the next tile's patch (NPU unconditional loads issued after the prologue's two
+      // groups).  Anything else in flight (older stores, spills) only makes the wait stricter.
+      int slot = 0;
+#pragma unroll 1
+      for (int grp = 0; grp < ngroups; grp++) {
+        ys_wait_vm_dyn((grp + 1 < ngroups ? nmine : 0) + ((grp < 2 && more && !LATE) ? NPU : 0));
+        if (grp < 3) TL_STAMP2();
+        ys_barrier_lds();                       // group grp is in LDS for every wave; nobody still reads the slot of group grp - 1
+        if (grp < 3) TL_STAMP2();
+        int s2 = slot + 2; if (s2 >= 3) s2 -= 3;
+        if (grp + 2 < ngroups) wdma(grp + 2, s2);
+        if (in_bf8) kloop(sW + slot * (BN * 8), grp * KG, NGS, P2Tag1{}); else kloop(sW + slot * (BN * 8), grp * KG, NGS, P2Tag0{});
+        if (grp < 3) TL_STAMP2();
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      ys_barrier_lds();                         // every wave finished reading the patch: it becomes the staging area
     } else {
       constexpr int NGS = KG / G;               // register groups per streamed weight slot
 #pragma unroll 1
@@ -1162,7 +1235,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   g.kg = wres ? g.nsteps : P2_KG;     // conv_p2_kernel::KG
   if (!wres && g.kg > g.nsteps) g.kg = g.nsteps;
   g.wpitch = wres ? wp(nsteps4 * ups) : wp(g.kg * ups);
-  const size_t wbytes = wres ? (wres_bytes + 1023) / 1024 * 1024 : (size_t)2 * bn * g.wpitch * 16;   // resident set: whole 1 KB LDS-DMA requests
+  const bool dmaw = !wres && !f8 && YS_P2_DMA_RING != 0;   // conv_p2_body::DMAW (every streamed bf16 variant has 256 threads): three ring slots of bn 128-byte rows
+  const size_t wbytes = wres ? (wres_bytes + 1023) / 1024 * 1024 : (dmaw ? (size_t)3 * bn * 128 : (size_t)2 * bn * g.wpitch * 16);   // resident set: whole 1 KB LDS-DMA requests
   const size_t tab = ((size_t)g.nsp * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
   // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed

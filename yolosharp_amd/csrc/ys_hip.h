@@ -40,6 +40,20 @@ template <int N> __device__ inline void ys_wait_vm() {
 #endif
 }
 
+// the same with a wave-uniform run-time count (0..15; larger counts wait as for 15, i.e. longer than asked)
+__device__ inline void ys_wait_vm_dyn(int n) {
+#ifndef YS_EMU_BUILD
+  switch (__builtin_amdgcn_readfirstlane(n)) {
+    case 0: ys_wait_vm<0>(); break; case 1: ys_wait_vm<1>(); break; case 2: ys_wait_vm<2>(); break; case 3: ys_wait_vm<3>(); break;
+    case 4: ys_wait_vm<4>(); break; case 5: ys_wait_vm<5>(); break; case 6: ys_wait_vm<6>(); break; case 7: ys_wait_vm<7>(); break;
+    case 8: ys_wait_vm<8>(); break; case 9: ys_wait_vm<9>(); break; case 10: ys_wait_vm<10>(); break; case 11: ys_wait_vm<11>(); break;
+    case 12: ys_wait_vm<12>(); break; case 13: ys_wait_vm<13>(); break; case 14: ys_wait_vm<14>(); break; default: ys_wait_vm<15>(); break;
+  }
+#else
+  (void)n;
+#endif
+}
+
 // Scheduling fence: hipcc's machine scheduler otherwise sinks LDS reads next to their first use (fewer live registers), which
 // serialises every read's latency with the MFMAs; a fence keeps "issue all reads, then all MFMAs" as written.
 #ifdef YS_EMU_BUILD
