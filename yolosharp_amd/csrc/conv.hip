@@ -1311,6 +1311,9 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   const bool tight_regs = p.npu == 6 && p.mr * p.nr <= 8 && !f8;
   const int per_cu = (p.lds <= lds3 && tight_regs) ? 3 : (p.lds <= 76 * 1024 ? 2 : 1);
   p.per_cu = per_cu;
+  // (measured, round 4: a 168-register variant that LDS limits to two workgroups per CU anyway is NOT better off on the 12-unit variant of the
+  // same tile with 2-4 K-steps per LDS wait: config 2 patch-kernel time 2.58 -> 2.65 ms, config 5 6.8 -> 6.9 -- the K loop of these tiles is
+  // bound by LDS read bandwidth / issue, not by the exposed wait)
   long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
   if (gx < 1) gx = 1;
