@@ -24,6 +24,10 @@ FWD_CASES = [
     (2, 16, 18, 36, 16, 3, 2, True, False, True, True),
     (1, 40, 23, 17, 80, 3, 1, True, False, True, False),
     (3, 64, 21, 21, 64, 3, 2, False, True, False, True),
+    # streamed weights through the LDS-DMA ring (conv.hip DMAW): training epilogue, a last weight group that is only partly real
+    # (K = 720 -> 11.25 groups; K = 648 -> 10.125), an output-channel column whose rows run past Cout (96 = 64 + 32)
+    (2, 80, 19, 13, 80, 3, 1, True, False, True, True),
+    (1, 72, 10, 37, 96, 3, 1, True, False, True, True),
     # blocked-GEMM kernel of the wide layers (conv_gemm.hip; conftest lowers its size gates): every tile shape, ragged M and N,
     # K not a multiple of the K-tile (taps straddle tiles), stride 2, 1x1, eval epilogue
     (1, 128, 9, 11, 80, 3, 2, True, False, True, True),     # 256x80 tile
@@ -88,6 +92,8 @@ BWD_CASES = [(2, 16, 8, 8, 32, 3, 1), (2, 16, 8, 8, 16, 1, 1), (1, 32, 9, 7, 80,
              # multi-tile images, ragged tile edges, several (cout, cin) channel tiles (LDS-tile wgrad kernel)
              (2, 32, 20, 40, 32, 3, 1), (1, 128, 12, 20, 144, 3, 1), (1, 256, 5, 5, 64, 1, 1), (2, 16, 18, 36, 16, 3, 2),
              (3, 48, 13, 17, 32, 1, 1),
+             # dgrad of a streamed-weight layer (ring + both K-steps of a group per LDS wait), ragged tiles
+             (2, 80, 11, 9, 80, 3, 1),
              # dgrad through the blocked-GEMM kernel (Cout of the layer = K of its dgrad): stride-1 3x3, 1x1, stride-2 phases
              (1, 64, 11, 13, 160, 3, 1), (2, 80, 9, 9, 256, 1, 1), (1, 64, 14, 10, 128, 3, 2),
              # wgrad through the blocked-GEMM kernel (conv_wgrad_gemm.hip): 160 / 128 tiles and both mixes, ragged channels, stride 2, 1x1
