@@ -1527,7 +1527,7 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
     const ConvArgs& x = a[i];
     if (x.f8 || x.fin || ys_conv_gemm_rows(x)) return YS_ERR_UNSUPPORTED;
     if (ys_conv_dgrad_uses_phases(YS_BF16, x.KH, x.DIVM + 1) && x.KW == x.KH) return YS_ERR_UNSUPPORTED;
-    if (x.Cin != a[0].Cin || x.Cout != a[0].Cout || x.KH != a[0].KH || x.KW != a[0].KW || x.SA != a[0].SA || x.PAD != a[0].PAD ||
+    if (x.Cin != a[0].Cin || x.Cout != a[0].Cout || x.SA != a[0].SA || x.PAD != a[0].PAD ||   // (kernel sizes may differ: the four phases of a stride-2 dgrad)
         (x.nred > 0) != (a[0].nred > 0) || (x.accumulate != 0) != (a[0].accumulate != 0) || (x.stats != nullptr) != (a[0].stats != nullptr)) return YS_ERR_UNSUPPORTED;
     if (x.M > a[big].M) big = i;
   }
@@ -1784,6 +1784,22 @@ static bool conv_dgrad_s2_phase_args(const ConvArgs& a, int ph, ConvArgs& q) {
 // kernel without that epilogue); otherwise launches and returns a status
 static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_only = false) {
   int row0 = a.red_row0;
+  // The four phases as ONE persistent grid (conv_p2_group_kernel) when every phase is a bf16 patch-kernel launch of one variant: they read the
+  // same dy tiles -- side by side on an XCD the second to fourth read hit its L2 -- and three launches' fixed costs go.  The 2x2-tap phase
+  // first: the group runs on the variant of its first largest member, and that phase has the largest patch.
+  static const bool grp_on = !(getenv("YS_S2_GROUP") && atoi(getenv("YS_S2_GROUP")) == 0);
+  if (grp_on && !a.f8) {
+    ConvArgs qs[4];
+    int n = 0;
+    for (int ph = 3; ph >= 0; ph--) if (conv_dgrad_s2_phase_args(a, ph, qs[n])) n++; else break;
+    int rows[4];
+    if (n == 4 && ys_conv_p2_group_launch(nullptr, qs, 4, nullptr, rows, true) == YS_OK) {
+      for (int i = 0; i < 4; i++) { qs[i].red_row0 = row0; row0 += rows[i]; }
+      if (rows_only) return row0 - a.red_row0;
+      return ys_conv_p2_group_launch(st, qs, 4, nullptr, rows);
+    }
+    row0 = a.red_row0;
+  }
   for (int ph = 0; ph < 4; ph++) {
     ConvArgs q;
     if (!conv_dgrad_s2_phase_args(a, ph, q)) continue;

@@ -8,7 +8,7 @@
 // in a pass of its own over dz and y): one statistics row per workgroup, like the forward BN statistics.  A segment maps the
 // channels [c0, c1) of the launch's OUTPUT view onto channels [yc0, ...) of one producer.
 #define YS_BNRED_MAXSEG 3
-#define YS_GROUP_MAX 3        // problems of one grouped convolution launch (the three pyramid levels of a head)
+#define YS_GROUP_MAX 4        // problems of one grouped convolution launch (the three pyramid levels of a head; the four phases of a stride-2 dgrad)
 #define YS_EW_GROUP_MAX 9     // problems of one grouped elementwise launch (BN passes of up to three towers x three levels)
 struct BnRedSeg {
   const void* y;        // producer's raw conv output, dense [M][C]
