@@ -1178,7 +1178,7 @@ static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
   return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
 }
 // force_mr / force_npu (0 = free): grouped launches need every problem on the kernel variant of the group's largest problem
-static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 0, bool want_full = true) {
+static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 0, bool want_full = true, int force_nr = 0) {
   P2Plan p{};
   // 3x3 forward / stride-1 dgrad, 1x1 forward / dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided
   // output-row map)
@@ -1229,6 +1229,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
       (size_t)(nr / 2) * 16 * wp(nsteps4 * ups) * 16 <= wresmax && nfr % (nr / 2) == 0)
     nr /= 2;
   if (f8 && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr > 2 && !getenv("YS_P2_F8_ANYTILE")) nr = 2;   // streamed fp8 weights: small register tiles only
+  if (force_nr && force_nr <= nr && nfr % force_nr == 0) nr = force_nr;   // grouped launch: the output-channel split of the group's first member (never wider than this problem's own choice)
   const int bn = nr * 16;
   const size_t wres_bytes = (size_t)bn * wp(nsteps4 * ups) * 16;
   const int wres = wres_bytes <= wresmax ? 1 : 0;
@@ -1525,6 +1526,8 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
   int big = 0;
   for (int i = 0; i < n; i++) {
     const ConvArgs& x = a[i];
+    // (measured, round 4: the stride-2 dgrad phases of the 128- and 256-channel layers, which the blocked-GEMM kernel takes one by one, run as one
+    // patch-kernel grid within noise of the four GEMM launches: 9.01-9.02 -> 8.92-9.00 ms/step; they stay on the GEMM kernel)
     if (x.f8 || x.fin || ys_conv_gemm_rows(x)) return YS_ERR_UNSUPPORTED;
     if (ys_conv_dgrad_uses_phases(YS_BF16, x.KH, x.DIVM + 1) && x.KW == x.KH) return YS_ERR_UNSUPPORTED;
     if (x.Cin != a[0].Cin || x.Cout != a[0].Cout || x.SA != a[0].SA || x.PAD != a[0].PAD ||   // (kernel sizes may differ: the four phases of a stride-2 dgrad)
@@ -1535,7 +1538,7 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
   if (!p[big].ok) return YS_ERR_UNSUPPORTED;
   for (int i = 0; i < n; i++) {
     if (i == big) continue;
-    p[i] = conv_p2_plan(a[i], p[big].mr, p[big].npu, false);
+    p[i] = conv_p2_plan(a[i], p[big].mr, p[big].npu, false, p[big].nr);
     if (!p[i].ok || p[i].nr != p[big].nr || p[i].wres != p[big].wres || p[i].nt != p[big].nt || p[i].gy != p[big].gy) return YS_ERR_UNSUPPORTED;
   }
   // one persistent grid: the slots of the largest LDS footprint's occupancy class, split in proportion to the tile counts
