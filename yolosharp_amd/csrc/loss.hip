@@ -17,6 +17,7 @@
 #include "ys_kernels.h"
 
 #define LS_THREADS 256
+#define TAL_LIST_CAP 8192   // in-box anchors of one (image, box) pair walked through an LDS list (16 KB of 16-bit indices; A <= 65535 on that path)
 #define TAL_REG_N 33        // assigner top-k: metrics per thread kept in registers (33 * 256 = 8448 >= the 8400 anchors of 640x640)
 #define CIOU_EPS 1e-7f
 
@@ -120,14 +121,25 @@ __device__ inline R ciou_xyxy(const R b1[4], const R b2[4]) {
 }
 
 struct AnchorInfo { float ax, ay, stride; };
+// Constant indices into the level tables (kernel arguments): scalar loads the compiler hoists out of the anchor loops.  The round-1 form -- a search loop
+// over a.lvl_off[i], then a.lvl_w[l] with a per-lane l -- compiled to one kernel-argument load + wait per search step and a per-lane global load
+// from the argument segment for every anchor: ~1 us per loop iteration of tal_metrics_kernel (three phases of ~33 iterations at 35 us each).
 __device__ inline AnchorInfo anchor_of(const LossArgs& a, int idx) {
-  int l = 0;
-  for (int i = 1; i < a.nl; i++) if (idx >= a.lvl_off[i]) l = i;
-  const int cell = idx - a.lvl_off[l];
+  int off = a.lvl_off[0], w = a.lvl_w[0], st = a.lvl_stride[0];
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    const bool ge = (bool)((int)(i < a.nl) & (int)(idx >= a.lvl_off[i]));   // offsets increase with the level: the last hit wins
+    off = ge ? a.lvl_off[i] : off; w = ge ? a.lvl_w[i] : w; st = ge ? a.lvl_stride[i] : st;
+  }
+  const int cell = idx - off;                 // < 2^24: float reciprocal + fix-up is exact
+  int y = (int)((float)cell * (1.0f / (float)w));
+  int x = cell - y * w;
+  if (x >= w) { y++; x -= w; }
+  if (x < 0) { y--; x += w; }
   AnchorInfo r;
-  r.ax = (float)(cell % a.lvl_w[l]) + 0.5f;   // Tal.cs:325-326 grid_cell_offset 0.5
-  r.ay = (float)(cell / a.lvl_w[l]) + 0.5f;
-  r.stride = (float)a.lvl_stride[l];
+  r.ax = (float)x + 0.5f;   // Tal.cs:325-326 grid_cell_offset 0.5
+  r.ay = (float)y + 0.5f;
+  r.stride = (float)st;
   return r;
 }
 
@@ -280,8 +292,11 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
     abx = cbx - cax; aby = cby - cay; adx = cdx - cax; ady = cdy - cay;
     nab = abx * abx + aby * aby; nad = adx * adx + ady * ady;
   }
-  for (int ai = tid; ai < a.A; ai += LS_THREADS) {
-    const AnchorInfo an = anchor_of(a, ai);
+  // Two passes (round 4).  The metric of an anchor outside the box is zero, and a box holds ~10 % of the anchors: evaluated inside the anchor loop, every
+  // iteration in which ANY lane of a wave was inside ran the whole CIoU / score path -- two dependent global loads behind an exec-masked branch, i.e. one L2
+  // round trip per iteration, 33 iterations per thread (120 us for ~550 boxes).  Pass 1 is the in-box test alone (bit set, zeros for the anchors outside);
+  // the set is compacted into a list in LDS and pass 2 walks it densely: every lane evaluates an anchor, ~3 iterations per thread.
+  auto in_box = [&](const AnchorInfo& an) -> bool {
     const float px = an.ax * an.stride, py = an.ay * an.stride;   // anchor_points * stride_tensor (Loss.cs:439)
     const float dmin_ = fminf(fminf(px - ix1, py - iy1), fminf(ix2 - px, iy2 - py));
     bool ingt = dmin_ > 1e-9f;                                     // Tal.cs:221
@@ -290,28 +305,81 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
       const float dab = apx * abx + apy * aby, dad = apx * adx + apy * ady;
       ingt = dab >= 0.f && dab <= nab && dad >= 0.f && dad <= nad;
     }
-    float o = 0.f, al = 0.f;
-    if (ingt && valid) {
-      if (ROT) {
-        const float* pb = a.pbox + ((long)b * a.A + ai) * 5;
-        const float p5[5] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride, pb[4]};   // Loss.cs:580-583
-        o = probiou_t<float>(g5, p5);                              // Tal.cs:267-270 (obb1 = gt, obb2 = pred)
-      } else {
-        const float* pb = a.pbox + ((long)b * a.A + ai) * 4;
-        const float p4[4] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride};  // Loss.cs:438
-        o = ciou_xyxy<float>(g4, p4);                              // Tal.cs:141 (box1 = gt, box2 = pred)
-      }
-      o = o > 0.f ? o : 0.f;                                        // .clamp(0)
-      const int cc = cls < 0 ? 0 : (cls >= a.nc ? a.nc - 1 : cls);
-      const float sc = ys_sigmoid(Elem<T>::to_f(((const T*)a.ps)[((long)b * a.A + ai) * a.ld_ps + cc]));
-      al = sqrtf(sc) * powf(o, 6.0f);                               // Tal.cs:134 (alpha 0.5, beta 6)
+    return ingt;
+  };
+  auto metrics = [&](int ai, const AnchorInfo& an, float& o, float& al) {   // an anchor inside a valid box
+    if (ROT) {
+      const float* pb = a.pbox + ((long)b * a.A + ai) * 5;
+      const float p5[5] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride, pb[4]};   // Loss.cs:580-583
+      o = probiou_t<float>(g5, p5);                              // Tal.cs:267-270 (obb1 = gt, obb2 = pred)
+    } else {
+      const float* pb = a.pbox + ((long)b * a.A + ai) * 4;
+      const float p4[4] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride};  // Loss.cs:438
+      o = ciou_xyxy<float>(g4, p4);                              // Tal.cs:141 (box1 = gt, box2 = pred)
     }
-    ovr[ai] = o;
-    alr[ai] = al;
+    o = o > 0.f ? o : 0.f;                                        // .clamp(0)
+    const int cc = cls < 0 ? 0 : (cls >= a.nc ? a.nc - 1 : cls);
+    const float sc = ys_sigmoid(Elem<T>::to_f(((const T*)a.ps)[((long)b * a.A + ai) * a.ld_ps + cc]));
+    al = sqrtf(sc) * powf(o, 6.0f);                               // Tal.cs:134 (alpha 0.5, beta 6)
+  };
+  __shared__ unsigned short s_list[TAL_LIST_CAP];
+  __shared__ int s_wsum[LS_THREADS / 64];
+  __shared__ int s_nin;
+  // pass 1: in-box bits; the anchors outside (and every anchor of an invalid box) get their zeros here
+  for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+    const bool ingt = in_box(anchor_of(a, ai));
+    if (!(ingt && valid)) { ovr[ai] = 0.f; alr[ai] = 0.f; }
     mp[ai] = 0;
     if (ingt) atomicOr(&s_ingt[ai >> 5], 1u << (ai & 31));
   }
   __syncthreads();
+#if defined(TAL_ABLATE) && TAL_ABLATE == 1
+  return;
+#endif
+  if (valid) {
+    // compaction: thread t owns the words [t * wpt, (t + 1) * wpt) -- ascending anchor order in the list, so the result does not depend on timing
+    const int wpt = (nw + LS_THREADS - 1) / LS_THREADS;
+    int cnt = 0;
+    for (int k = 0; k < wpt; k++) { const int wi = tid * wpt + k; if (wi < nw) cnt += __popc(s_ingt[wi]); }
+    int incl = cnt;
+    for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(incl, m); if ((tid & 63) >= m) incl += v; }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - cnt;
+    for (int wv = 0; wv < (tid >> 6); wv++) base += s_wsum[wv];
+    if (tid == LS_THREADS - 1) s_nin = base + cnt;
+    __syncthreads();
+    const int nin = s_nin;
+    if (nin <= TAL_LIST_CAP) {
+      for (int k = 0; k < wpt; k++) {
+        const int wi = tid * wpt + k;
+        unsigned bits = wi < nw ? s_ingt[wi] : 0u;
+        while (bits) { const int bt = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1u; s_list[base++] = (unsigned short)(wi * 32 + bt); }
+      }
+      __syncthreads();
+      // pass 2: dense over the list
+      for (int k = tid; k < nin; k += LS_THREADS) {
+        const int ai = (int)s_list[k];
+        float o, al;
+        metrics(ai, anchor_of(a, ai), o, al);
+        ovr[ai] = o;
+        alr[ai] = al;
+      }
+    } else {                                                       // a box that holds more anchors than the list: the one-pass form
+      for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+        if (s_ingt[ai >> 5] & (1u << (ai & 31))) {
+          float o, al;
+          metrics(ai, anchor_of(a, ai), o, al);
+          ovr[ai] = o;
+          alr[ai] = al;
+        }
+      }
+    }
+  }
+  __syncthreads();                                                  // the top-k rounds read other threads' alr entries (global, same workgroup)
+#if defined(TAL_ABLATE) && TAL_ABLATE == 2
+  return;
+#endif
   // select_topk_candidates (Tal.cs:144-168): 10 largest align values; ties -> lowest anchor index
   if (a.A <= TAL_REG_N * LS_THREADS) {
     // every BASELINE shape (A = 8400 <= 33 * 256): a thread's metrics (anchors tid + j * 256) stay in registers for the ten rounds --
