@@ -768,8 +768,8 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
   if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b, LS_THREADS, st, a);
   else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b, LS_THREADS, st, a);
-  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
-  else YS_LAUNCH((tal_metrics_kernel<T, false>), dim3(a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
+  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
+  else YS_LAUNCH((tal_metrics_kernel<T, false>), dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
   YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);

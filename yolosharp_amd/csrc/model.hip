@@ -2318,6 +2318,7 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   const float *bi = batch_idx, *cl = cls, *bb = bboxes;
+  int host_cmax = 0;                           // host labels: the largest per-image count (0 = unknown)
   if (!on_device && n > 0) {
     // host labels: size the padded GT workspace from the batch itself, like the reference's counts.max() (Loss.cs:376-380)
     std::vector<int> cnt(m->B, 0);
@@ -2325,6 +2326,7 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
     for (int i = 0; i < n; i++) { const int b = (int)batch_idx[i]; if (b >= 0 && b < m->B) mx = std::max(mx, ++cnt[b]); }
     // every label row is staged (rows whose batch_idx lies outside [0, B) are ignored by the kernels, like the reference's
     // `batch_idx == j` matches): the staging arrays hold gcap * max_batch rows, so n itself bounds the capacity too
+    host_cmax = mx > 0 ? mx : 1;
     const int per_rows = (n + m->maxB - 1) / m->maxB;
     if (per_rows > mx) mx = per_rows;
     if (mx > m->gcap) YS_TRY(alloc_label_ws(m, (mx + 15) / 16 * 16));
@@ -2341,6 +2343,7 @@ static int loss_detect_core(ys_model* m, const float* batch_idx, const float* cl
   a.H = m->d.height; a.W = m->d.width; a.nl = m->nl;
   for (int i = 0; i < 4; i++) { a.lvl_off[i] = m->lvl_off[i]; a.lvl_w[i] = m->lvl_w[i]; a.lvl_h[i] = m->lvl_h[i]; a.lvl_stride[i] = m->lvl_stride[i]; }
   a.batch_idx = bi; a.cls = cl; a.bboxes = bb; a.n_labels = n; a.gcap = m->gcap;
+  a.gmax = (host_cmax > 0 && host_cmax < m->gcap) ? host_cmax : m->gcap;
   a.gt_count = m->gt_count; a.gt_box = m->gt_box; a.gt_cls = m->gt_cls; a.pbox = m->pbox; a.ov = m->ov; a.align = m->align;
   a.mpos = m->mpos; a.pos_align = m->pos_align; a.pos_ov = m->pos_ov; a.fg_gt = m->fg_gt; a.tnorm = m->tnorm;
   a.partial = m->loss_partial; a.scalars = m->scalars;

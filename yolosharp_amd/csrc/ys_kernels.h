@@ -275,6 +275,7 @@ struct LossArgs {
   int H, W;            // input image size (imgsz = feats[0].shape[2:]*stride[0])
   int nl;              // levels
   int lvl_off[4], lvl_w[4], lvl_h[4], lvl_stride[4];
+  int gmax;   // largest per-image label count when the host knows it (host labels), else gcap: the (box, image) grid of tal_metrics_kernel
   // labels (device): raw collate arrays
   const float* batch_idx; const float* cls; const float* bboxes; int n_labels;
   int gcap;            // GT capacity per image
