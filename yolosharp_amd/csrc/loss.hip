@@ -307,21 +307,29 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
     }
     return ingt;
   };
-  auto metrics = [&](int ai, const AnchorInfo& an, float& o, float& al) {   // an anchor inside a valid box
+  // an anchor inside a valid box: the operands (predicted box, class logit) are requested first, for several anchors at a time, so that a trip
+  // of the dense loop pays one L2 round trip instead of one per anchor (the largest boxes hold ~3 thousand anchors = 12 trips, and they set the kernel's duration)
+  struct MetIn { float pb[ROT ? 5 : 4]; T ps; };
+  const int cc = cls < 0 ? 0 : (cls >= a.nc ? a.nc - 1 : cls);
+  auto met_load = [&](int ai, MetIn& in) {
+    const float* pb = a.pbox + ((long)b * a.A + ai) * (ROT ? 5 : 4);
+    if (ROT) { for (int e = 0; e < 5; e++) in.pb[e] = pb[e]; }
+    else { const float4 v = *(const float4*)pb; in.pb[0] = v.x; in.pb[1] = v.y; in.pb[2] = v.z; in.pb[3] = v.w; }
+    in.ps = ((const T*)a.ps)[((long)b * a.A + ai) * a.ld_ps + cc];
+  };
+  auto met_eval = [&](const MetIn& in, const AnchorInfo& an, float& o, float& al) {
     if (ROT) {
-      const float* pb = a.pbox + ((long)b * a.A + ai) * 5;
-      const float p5[5] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride, pb[4]};   // Loss.cs:580-583
+      const float p5[5] = {in.pb[0] * an.stride, in.pb[1] * an.stride, in.pb[2] * an.stride, in.pb[3] * an.stride, in.pb[ROT ? 4 : 0]};   // Loss.cs:580-583
       o = probiou_t<float>(g5, p5);                              // Tal.cs:267-270 (obb1 = gt, obb2 = pred)
     } else {
-      const float* pb = a.pbox + ((long)b * a.A + ai) * 4;
-      const float p4[4] = {pb[0] * an.stride, pb[1] * an.stride, pb[2] * an.stride, pb[3] * an.stride};  // Loss.cs:438
+      const float p4[4] = {in.pb[0] * an.stride, in.pb[1] * an.stride, in.pb[2] * an.stride, in.pb[3] * an.stride};  // Loss.cs:438
       o = ciou_xyxy<float>(g4, p4);                              // Tal.cs:141 (box1 = gt, box2 = pred)
     }
     o = o > 0.f ? o : 0.f;                                        // .clamp(0)
-    const int cc = cls < 0 ? 0 : (cls >= a.nc ? a.nc - 1 : cls);
-    const float sc = ys_sigmoid(Elem<T>::to_f(((const T*)a.ps)[((long)b * a.A + ai) * a.ld_ps + cc]));
+    const float sc = ys_sigmoid(Elem<T>::to_f(in.ps));
     al = sqrtf(sc) * powf(o, 6.0f);                               // Tal.cs:134 (alpha 0.5, beta 6)
   };
+  auto metrics = [&](int ai, const AnchorInfo& an, float& o, float& al) { MetIn in; met_load(ai, in); met_eval(in, an, o, al); };
   __shared__ unsigned short s_list[TAL_LIST_CAP];
   __shared__ int s_wsum[LS_THREADS / 64];
   __shared__ int s_nin;
@@ -358,12 +366,23 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
       }
       __syncthreads();
       // pass 2: dense over the list
-      for (int k = tid; k < nin; k += LS_THREADS) {
-        const int ai = (int)s_list[k];
-        float o, al;
-        metrics(ai, anchor_of(a, ai), o, al);
-        ovr[ai] = o;
-        alr[ai] = al;
+      constexpr int DU = 4;
+      for (int k0 = tid; k0 < nin; k0 += LS_THREADS * DU) {
+        int ai[DU];
+        MetIn in[DU];
+#pragma unroll
+        for (int u = 0; u < DU; u++) { const int k = k0 + u * LS_THREADS; ai[u] = k < nin ? (int)s_list[k] : -1; }
+#pragma unroll
+        for (int u = 0; u < DU; u++) met_load(ai[u] >= 0 ? ai[u] : 0, in[u]);      // unconditional: all requests of the trip in flight together
+#pragma unroll
+        for (int u = 0; u < DU; u++) {
+          if (ai[u] >= 0) {
+            float o, al;
+            met_eval(in[u], anchor_of(a, ai[u]), o, al);
+            ovr[ai[u]] = o;
+            alr[ai[u]] = al;
+          }
+        }
       }
     } else {                                                       // a box that holds more anchors than the list: the one-pass form
       for (int ai = tid; ai < a.A; ai += LS_THREADS) {
@@ -387,6 +406,9 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
     float val[TAL_REG_N];
 #pragma unroll
     for (int j = 0; j < TAL_REG_N; j++) { const int ai = tid + j * LS_THREADS; val[j] = ai < a.A ? alr[ai] : -3.f; }
+    // the selected anchors are marked AFTER the rounds (thread k keeps round k's pick): a global store inside a round sits in front of the
+    // round's barrier, whose s_waitcnt vmcnt(0) then waits out the store's round trip -- ten times (3.7 us per round, round 4 ablation)
+    int mine = -1;
     for (int k = 0; k < a.topk; k++) {
       float bv = -1.f;
       int bi = 0x7fffffff;
@@ -403,7 +425,7 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
       for (int wv = 1; wv < LS_THREADS / 64; wv++)
         if (s_v[wv] > fv || (s_v[wv] == fv && s_i[wv] < fi)) { fv = s_v[wv]; fi = s_i[wv]; }
       if (fi < a.A) {
-        if (tid == 0 && valid && (s_ingt[fi >> 5] & (1u << (fi & 31)))) mp[fi] = 1;     // mask_topk * mask_in_gts * mask_gt (Tal.cs:99)
+        if (tid == k && valid && (s_ingt[fi >> 5] & (1u << (fi & 31)))) mine = fi;     // mask_topk * mask_in_gts * mask_gt (Tal.cs:99)
         const int js = fi / LS_THREADS;
         if (fi - js * LS_THREADS == tid) {
 #pragma unroll
@@ -412,6 +434,7 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
       }
       __syncthreads();                                            // s_v / s_i are rewritten by the next round
     }
+    if (mine >= 0) mp[mine] = 1;
     return;
   }
   for (int k = 0; k < a.topk; k++) {
