@@ -256,15 +256,13 @@ loss_decode_kernel(LossArgs a) {
 
 // ------------------------------------------------------------------ K2: metrics + top-k per (image, gt)
 template <class T, bool ROT>     // ROT: RotatedTaskAlignedAssigner (Tal.cs:260-310) -- compile-time so the plain path keeps its registers
-__global__ void __launch_bounds__(LS_THREADS)
-tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
+__device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict__ gt_valid, const int g, const int b) {
   __shared__ unsigned s_ingt[1056];   // A <= 33792 anchors
   __shared__ unsigned s_taken[1056];
   __shared__ float s_v[LS_THREADS / 64];
   __shared__ int s_i[LS_THREADS / 64];
   __shared__ int s_sel;
-  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  if (g >= a.gt_count[b]) return;
+  const int tid = threadIdx.x;
   const long gi = (long)b * a.gcap + g;
   const bool valid = gt_valid[gi] != 0;
   const float* gb = a.gt_box + gi * (ROT ? 5 : 4);
@@ -468,6 +466,43 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
       }
     }
     __syncthreads();
+  }
+}
+// The (image, box) pairs of a batch are a small, data-dependent subset of the [B][gcap] workspace (labels resident on the device: the host does
+// not know the counts).  A [gcap][B] grid launched 4096 workgroups for ~550 pairs at the headline batch, and the kernel's 96 us were the DISPATCH
+// of the 3.5 thousand that exit at once (SQ_WAVE_CYCLES / SQ_WAVES: the waves that work live ~9 us).  Flat form: every workgroup scans the B
+// counts (one wave, LDS), then walks the pairs p = blockIdx.x, + gridDim.x, ...; (image, slot) of pair p by binary search.
+#define TAL_FLAT_MAXB 1024
+template <class T, bool ROT>
+__global__ void __launch_bounds__(LS_THREADS)
+tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
+  if (gridDim.y > 1) {                                            // [gcap][B] form (B > TAL_FLAT_MAXB)
+    if ((int)blockIdx.x >= a.gt_count[blockIdx.y]) return;
+    tal_metrics_pair<T, ROT>(a, gt_valid, (int)blockIdx.x, (int)blockIdx.y);
+    return;
+  }
+  __shared__ int s_pref[TAL_FLAT_MAXB + 1];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.B; i += LS_THREADS) s_pref[i + 1] = a.gt_count[i];
+  __syncthreads();
+  if (tid < 64) {                                                 // inclusive scan: lane l owns entries [16 l, 16 l + 16)
+    int loc[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int idx = tid * 16 + k; sum += idx < a.B ? s_pref[idx + 1] : 0; loc[k] = sum; }
+    int incl = sum;
+    for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(incl, m); if (tid >= m) incl += v; }
+    const int base = incl - sum;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int idx = tid * 16 + k; if (idx < a.B) s_pref[idx + 1] = base + loc[k]; }
+    if (tid == 0) s_pref[0] = 0;
+  }
+  __syncthreads();
+  const int total = s_pref[a.B];
+  for (int p = blockIdx.x; p < total; p += gridDim.x) {
+    int lo = 0, hi = a.B;                                          // largest b with s_pref[b] <= p
+    while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= p) lo = mid; else hi = mid; }
+    tal_metrics_pair<T, ROT>(a, gt_valid, p - s_pref[lo], lo);
+    __syncthreads();                                              // the next pair re-initialises the bit sets the last top-k round still reads
   }
 }
 
@@ -791,8 +826,15 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
   if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b, LS_THREADS, st, a);
   else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b, LS_THREADS, st, a);
-  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
-  else YS_LAUNCH((tal_metrics_kernel<T, false>), dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B), LS_THREADS, st, a, (const int*)gt_valid);
+  // flat grid: enough workgroups for ~12 boxes per image in one trip, never more than the host-known pair bound
+  const long pair_cap = (long)(a.gmax > 0 ? a.gmax : a.gcap) * a.B;
+  long flat = (long)a.B * 12 > 256 ? (long)a.B * 12 : 256;
+  static const long flat_env = getenv("YS_TAL_GRID") ? atol(getenv("YS_TAL_GRID")) : 0;   // triage: workgroups of the flat grid
+  if (flat_env > 0) flat = flat_env;
+  if (flat > pair_cap) flat = pair_cap;
+  const dim3 tgrid = a.B <= TAL_FLAT_MAXB ? dim3((unsigned)flat) : dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B);
+  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), tgrid, LS_THREADS, st, a, (const int*)gt_valid);
+  else YS_LAUNCH((tal_metrics_kernel<T, false>), tgrid, LS_THREADS, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
   YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);
