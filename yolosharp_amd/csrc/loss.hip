@@ -18,7 +18,10 @@
 
 #define LS_THREADS 256
 #define TAL_LIST_CAP 8192   // in-box anchors of one (image, box) pair walked through an LDS list (16 KB of 16-bit indices; A <= 65535 on that path)
-#define TAL_REG_N 33        // assigner top-k: metrics per thread kept in registers (33 * 256 = 8448 >= the 8400 anchors of 640x640)
+#ifndef TAL_T
+#define TAL_T 256           // threads of a tal_metrics_kernel workgroup.  Measured (round 4, ~550 pairs, flat grid): 128 threads 74 us, 256 64 us, 512 105 us, 1024 119 us
+#endif
+#define TAL_REGS ((8448 + TAL_T - 1) / TAL_T)   // assigner top-k: metrics per thread kept in registers (covers the 8400 anchors of 640x640)
 #define CIOU_EPS 1e-7f
 
 // ------------------------------------------------------------------ dual numbers (value + N partials)
@@ -259,8 +262,8 @@ template <class T, bool ROT>     // ROT: RotatedTaskAlignedAssigner (Tal.cs:260-
 __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict__ gt_valid, const int g, const int b) {
   __shared__ unsigned s_ingt[1056];   // A <= 33792 anchors
   __shared__ unsigned s_taken[1056];
-  __shared__ float s_v[LS_THREADS / 64];
-  __shared__ int s_i[LS_THREADS / 64];
+  __shared__ float s_v[TAL_T / 64];
+  __shared__ int s_i[TAL_T / 64];
   __shared__ int s_sel;
   const int tid = threadIdx.x;
   const long gi = (long)b * a.gcap + g;
@@ -273,7 +276,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
   float* alr = a.align + gi * a.A;
   unsigned char* mp = a.mpos + gi * a.A;
   const int nw = (a.A + 31) / 32;
-  for (int i = tid; i < nw; i += LS_THREADS) { s_ingt[i] = 0u; s_taken[i] = 0u; }
+  for (int i = tid; i < nw; i += TAL_T) { s_ingt[i] = 0u; s_taken[i] = 0u; }
   __syncthreads();
   // select_candidates_in_gts (Tal.cs:202-223): boxes smaller than stride[0]=8 are inflated to stride[1]=16
   float cx = (g4[0] + g4[2]) / 2, cy = (g4[1] + g4[3]) / 2, w = g4[2] - g4[0], h = g4[3] - g4[1];  // Ops.cs:98-101
@@ -329,10 +332,10 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
   };
   auto metrics = [&](int ai, const AnchorInfo& an, float& o, float& al) { MetIn in; met_load(ai, in); met_eval(in, an, o, al); };
   __shared__ unsigned short s_list[TAL_LIST_CAP];
-  __shared__ int s_wsum[LS_THREADS / 64];
+  __shared__ int s_wsum[TAL_T / 64];
   __shared__ int s_nin;
   // pass 1: in-box bits; the anchors outside (and every anchor of an invalid box) get their zeros here
-  for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+  for (int ai = tid; ai < a.A; ai += TAL_T) {
     const bool ingt = in_box(anchor_of(a, ai));
     if (!(ingt && valid)) { ovr[ai] = 0.f; alr[ai] = 0.f; }
     mp[ai] = 0;
@@ -344,7 +347,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
 #endif
   if (valid) {
     // compaction: thread t owns the words [t * wpt, (t + 1) * wpt) -- ascending anchor order in the list, so the result does not depend on timing
-    const int wpt = (nw + LS_THREADS - 1) / LS_THREADS;
+    const int wpt = (nw + TAL_T - 1) / TAL_T;
     int cnt = 0;
     for (int k = 0; k < wpt; k++) { const int wi = tid * wpt + k; if (wi < nw) cnt += __popc(s_ingt[wi]); }
     int incl = cnt;
@@ -353,7 +356,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
     __syncthreads();
     int base = incl - cnt;
     for (int wv = 0; wv < (tid >> 6); wv++) base += s_wsum[wv];
-    if (tid == LS_THREADS - 1) s_nin = base + cnt;
+    if (tid == TAL_T - 1) s_nin = base + cnt;
     __syncthreads();
     const int nin = s_nin;
     if (nin <= TAL_LIST_CAP) {
@@ -365,11 +368,11 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
       __syncthreads();
       // pass 2: dense over the list
       constexpr int DU = 4;
-      for (int k0 = tid; k0 < nin; k0 += LS_THREADS * DU) {
+      for (int k0 = tid; k0 < nin; k0 += TAL_T * DU) {
         int ai[DU];
         MetIn in[DU];
 #pragma unroll
-        for (int u = 0; u < DU; u++) { const int k = k0 + u * LS_THREADS; ai[u] = k < nin ? (int)s_list[k] : -1; }
+        for (int u = 0; u < DU; u++) { const int k = k0 + u * TAL_T; ai[u] = k < nin ? (int)s_list[k] : -1; }
 #pragma unroll
         for (int u = 0; u < DU; u++) met_load(ai[u] >= 0 ? ai[u] : 0, in[u]);      // unconditional: all requests of the trip in flight together
 #pragma unroll
@@ -383,7 +386,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
         }
       }
     } else {                                                       // a box that holds more anchors than the list: the one-pass form
-      for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+      for (int ai = tid; ai < a.A; ai += TAL_T) {
         if (s_ingt[ai >> 5] & (1u << (ai & 31))) {
           float o, al;
           metrics(ai, anchor_of(a, ai), o, al);
@@ -398,12 +401,12 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
   return;
 #endif
   // select_topk_candidates (Tal.cs:144-168): 10 largest align values; ties -> lowest anchor index
-  if (a.A <= TAL_REG_N * LS_THREADS) {
+  if (a.A <= TAL_REGS * TAL_T) {
     // every BASELINE shape (A = 8400 <= 33 * 256): a thread's metrics (anchors tid + j * 256) stay in registers for the ten rounds --
     // one batch of independent loads instead of a reload per round; a taken entry becomes -2
-    float val[TAL_REG_N];
+    float val[TAL_REGS];
 #pragma unroll
-    for (int j = 0; j < TAL_REG_N; j++) { const int ai = tid + j * LS_THREADS; val[j] = ai < a.A ? alr[ai] : -3.f; }
+    for (int j = 0; j < TAL_REGS; j++) { const int ai = tid + j * TAL_T; val[j] = ai < a.A ? alr[ai] : -3.f; }
     // the selected anchors are marked AFTER the rounds (thread k keeps round k's pick): a global store inside a round sits in front of the
     // round's barrier, whose s_waitcnt vmcnt(0) then waits out the store's round trip -- ten times (3.7 us per round, round 4 ablation)
     int mine = -1;
@@ -411,7 +414,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
       float bv = -1.f;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < TAL_REG_N; j++) if (val[j] > bv) { bv = val[j]; bi = tid + j * LS_THREADS; }   // increasing index: strict '>' keeps the lowest among equals
+      for (int j = 0; j < TAL_REGS; j++) if (val[j] > bv) { bv = val[j]; bi = tid + j * TAL_T; }   // increasing index: strict '>' keeps the lowest among equals
       for (int m = 32; m >= 1; m >>= 1) {
         const float ov_ = __shfl_xor(bv, m);
         const int oi = __shfl_xor(bi, m);
@@ -420,14 +423,14 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
       if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
       __syncthreads();
       float fv = s_v[0]; int fi = s_i[0];
-      for (int wv = 1; wv < LS_THREADS / 64; wv++)
+      for (int wv = 1; wv < TAL_T / 64; wv++)
         if (s_v[wv] > fv || (s_v[wv] == fv && s_i[wv] < fi)) { fv = s_v[wv]; fi = s_i[wv]; }
       if (fi < a.A) {
         if (tid == k && valid && (s_ingt[fi >> 5] & (1u << (fi & 31)))) mine = fi;     // mask_topk * mask_in_gts * mask_gt (Tal.cs:99)
-        const int js = fi / LS_THREADS;
-        if (fi - js * LS_THREADS == tid) {
+        const int js = fi / TAL_T;
+        if (fi - js * TAL_T == tid) {
 #pragma unroll
-          for (int j = 0; j < TAL_REG_N; j++) val[j] = (j == js) ? -2.f : val[j];
+          for (int j = 0; j < TAL_REGS; j++) val[j] = (j == js) ? -2.f : val[j];
         }
       }
       __syncthreads();                                            // s_v / s_i are rewritten by the next round
@@ -441,7 +444,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
     // unconditional loads (a `continue` in front of the load made every iteration wait for its own L2 round trip: ~20 us per
     // round); a thread visits its anchors in increasing order, so a strict '>' keeps the lowest index among equals
 #pragma unroll 8
-    for (int ai = tid; ai < a.A; ai += LS_THREADS) {
+    for (int ai = tid; ai < a.A; ai += TAL_T) {
       float v = alr[ai];
       v = (s_taken[ai >> 5] & (1u << (ai & 31))) ? -2.f : v;
       if (v > bv) { bv = v; bi = ai; }
@@ -455,7 +458,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
     __syncthreads();
     if (tid == 0) {
       float fv = s_v[0]; int fi = s_i[0];
-      for (int wv = 1; wv < LS_THREADS / 64; wv++)
+      for (int wv = 1; wv < TAL_T / 64; wv++)
         if (s_v[wv] > fv || (s_v[wv] == fv && s_i[wv] < fi)) { fv = s_v[wv]; fi = s_i[wv]; }
       s_sel = fi;
       if (fi < a.A) {
@@ -474,7 +477,7 @@ __device__ inline void tal_metrics_pair(const LossArgs& a, const int* __restrict
 // counts (one wave, LDS), then walks the pairs p = blockIdx.x, + gridDim.x, ...; (image, slot) of pair p by binary search.
 #define TAL_FLAT_MAXB 1024
 template <class T, bool ROT>
-__global__ void __launch_bounds__(LS_THREADS)
+__global__ void __launch_bounds__(TAL_T)
 tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   if (gridDim.y > 1) {                                            // [gcap][B] form (B > TAL_FLAT_MAXB)
     if ((int)blockIdx.x >= a.gt_count[blockIdx.y]) return;
@@ -483,7 +486,7 @@ tal_metrics_kernel(LossArgs a, const int* __restrict__ gt_valid) {
   }
   __shared__ int s_pref[TAL_FLAT_MAXB + 1];
   const int tid = threadIdx.x;
-  for (int i = tid; i < a.B; i += LS_THREADS) s_pref[i + 1] = a.gt_count[i];
+  for (int i = tid; i < a.B; i += TAL_T) s_pref[i + 1] = a.gt_count[i];
   __syncthreads();
   if (tid < 64) {                                                 // inclusive scan: lane l owns entries [16 l, 16 l + 16)
     int loc[16], sum = 0;
@@ -833,8 +836,8 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   if (flat_env > 0) flat = flat_env;
   if (flat > pair_cap) flat = pair_cap;
   const dim3 tgrid = a.B <= TAL_FLAT_MAXB ? dim3((unsigned)flat) : dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B);
-  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), tgrid, LS_THREADS, st, a, (const int*)gt_valid);
-  else YS_LAUNCH((tal_metrics_kernel<T, false>), tgrid, LS_THREADS, st, a, (const int*)gt_valid);
+  if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), tgrid, TAL_T, st, a, (const int*)gt_valid);
+  else YS_LAUNCH((tal_metrics_kernel<T, false>), tgrid, TAL_T, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
   YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
   YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);
