@@ -328,7 +328,11 @@ struct GemmPlan { int ok, wm, wn, mr, nr, gx, gy; size_t lds; GemmArgs g; };
 static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   GemmPlan p{};
   static const bool off = getenv("YS_NO_GEMM") != nullptr;
-  static const int min_cin = getenv("YS_GEMM_MIN_CIN") ? atoi(getenv("YS_GEMM_MIN_CIN")) : 128;
+  // 160 (was 128 until the end of round 4): with 128 <= Cin < 160 only the wide-output 3x3 layers (below) stay here.  What moved to the patch kernel, per-launch
+  // records of YOLOv8n B = 64: the dgrad of the fused tower input at P3 (cin144 -> cout64, M = 409600: 168 -> 110 us -- a 256 x 64 tile leaves this kernel one
+  // workgroup per CU) and the 2x2 / 1x2 / 2x1 phases of the stride-2 dgrads with 128 gradient channels, which join their 1x1 phase in ONE grouped patch-kernel
+  // launch (141 -> 78 us, 92 -> 49 us); step 8.85 -> 8.76 ms
+  static const int min_cin = getenv("YS_GEMM_MIN_CIN") ? atoi(getenv("YS_GEMM_MIN_CIN")) : 160;
   static const int min_k = getenv("YS_GEMM_MIN_K") ? atoi(getenv("YS_GEMM_MIN_K")) : 256;
   const bool f8 = a.f8 != 0;
   static const bool f8_off = getenv("YS_NO_GEMM_F8") != nullptr;
