@@ -21,6 +21,10 @@ os.environ.setdefault("YS_F8_MIN_TAPS", "1")       # and 1x1 layers too (product
 # tests drop the pixel gate so that oracle-sized shapes reach it.
 os.environ.setdefault("YS_GEMM_MIN_M", "1")
 os.environ.setdefault("YS_WGEMM_MIN_M", "1")      # same for its weight-gradient counterpart (csrc/conv_wgrad_gemm.hip)
+# Inside a pytest-xdist worker the interpreter's OpenMP team (and torch's) is kept small: eight workers with a full team each oversubscribe the
+# cores of the dev container ~8x (the whole `-m "not gpu"` suite: 13 min of wall time for 100 min of CPU time).
+if os.environ.get("PYTEST_XDIST_WORKER"):
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -37,14 +41,35 @@ def pytest_cmdline_main(config):
     opt = config.option
     if not hasattr(opt, "numprocesses") or opt.numprocesses is not None or os.environ.get("YS_TEST_SERIAL") == "1":
         return None
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):
+        return None                                 # inside a worker: never start workers of its own
     if "not gpu" not in (getattr(opt, "markexpr", "") or ""):
         return None
     if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
         return None
-    n = min(8, os.cpu_count() or 1)
-    if n > 1:
+    n = min(4, max(1, (os.cpu_count() or 1) // 2))   # workers x 2 OpenMP threads each
+    if n > 1 and _xdist_workers_start():
         opt.numprocesses = n
     return None
+
+
+def _xdist_workers_start():
+    """pytest-xdist starts its workers through execnet's popen gateway; in some sandboxes that bootstrap dies with a broken pipe and the
+    run hangs for minutes before failing.  Probe it in a throw-away process first: if a gateway cannot echo one value within 40 s the suite
+    runs in this process instead (about eight minutes)."""
+    import subprocess
+    import sys
+    code = ("import execnet\n"
+            "gw = execnet.makegateway('popen')\n"
+            "ch = gw.remote_exec('channel.send(channel.receive() + 1)')\n"
+            "ch.send(41)\n"
+            "assert ch.receive(30) == 42\n"
+            "gw.exit()\n")
+    try:
+        return subprocess.run([sys.executable, "-c", code], stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                              timeout=40).returncode == 0
+    except Exception:
+        return False
 
 
 BACKENDS = ["emu", pytest.param("gpu", marks=pytest.mark.gpu)]
