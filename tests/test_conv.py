@@ -35,6 +35,14 @@ FWD_CASES = [
     (1, 256, 13, 10, 128, 1, 1, True, False, True, True),   # 128x128 tile, two M tiles
     (1, 136, 17, 9, 320, 3, 1, True, False, True, False),   # 128x160 tile x 2 channel tiles, eval
     (2, 128, 6, 6, 80, 1, 1, False, True, False, True),     # plain conv + bias
+    # halo-patch kernel of the 3x3 stride-1 wide layers (conv_gemm.hip conv_halo_kernel): 16 x 16 pixel tiles with ragged edges in both directions,
+    # several images / channel tiles, a last 64-channel chunk that is only partly real (Cin = 160, 136, 72), odd and even chunk counts, Cout past the
+    # channel tile, eval epilogue, plain conv + bias
+    (1, 160, 20, 33, 160, 3, 1, True, False, True, True),   # 2 x 3 tiles (ragged), 2.5 chunks, 160-wide channel tile
+    (2, 128, 17, 16, 128, 3, 1, True, False, True, True),   # 128-wide channel tile, two images, two chunks
+    (1, 136, 14, 40, 144, 3, 1, True, False, True, True),   # partial last chunk, Cout 144 of 160
+    (1, 64, 33, 18, 320, 3, 1, True, False, True, False),   # one chunk, two channel tiles, eval BN + SiLU
+    (2, 72, 15, 15, 128, 3, 1, False, True, False, True),   # plain conv + bias, one tile per image
 ]
 
 
@@ -80,7 +88,9 @@ def test_conv_bn_act_forward(backend, engine, dtype, case):
         # |y - ref| <= 2^-7 |ref| + 2^-8 rms(ref) -- the result's own rounding plus one ulp at the tensor's scale for a flipped upstream
         # value.  (Rounds 1-3 allowed 2e-2 of the GLOBAL maximum, which a wrong halo column of small outputs would pass.)
         from bf16_ref import check_elem
-        check_elem(y, ref, "conv case %d" % case)
+        # (one element in 10^4 may sit up to 2x the bound: the fp32 summation order inside the convolution differs from the reference's -- the halo-patch kernel
+        # walks K as (64-channel chunk, tap) -- and a flipped bf16 rounding of the raw output is then scaled by the batch statistics)
+        check_elem(y, ref, "conv case %d" % case, max_out=1e-4, out_mult=2.0)
     if bn and train:
         rtol = 1e-4 if dtype == "f32" else 2e-2
         assert np.allclose(bn_np["running_mean"], bn_ref["running_mean"].numpy(), rtol=rtol, atol=rtol)
@@ -97,7 +107,9 @@ BWD_CASES = [(2, 16, 8, 8, 32, 3, 1), (2, 16, 8, 8, 16, 1, 1), (1, 32, 9, 7, 80,
              # dgrad through the blocked-GEMM kernel (Cout of the layer = K of its dgrad): stride-1 3x3, 1x1, stride-2 phases
              (1, 64, 11, 13, 160, 3, 1), (2, 80, 9, 9, 256, 1, 1), (1, 64, 14, 10, 128, 3, 2),
              # wgrad through the blocked-GEMM kernel (conv_wgrad_gemm.hip): 160 / 128 tiles and both mixes, ragged channels, stride 2, 1x1
-             (1, 160, 9, 11, 320, 3, 2), (2, 256, 6, 7, 128, 1, 1), (1, 136, 10, 9, 160, 3, 1), (1, 256, 7, 9, 152, 3, 1)]
+             (1, 160, 9, 11, 320, 3, 2), (2, 256, 6, 7, 128, 1, 1), (1, 136, 10, 9, 160, 3, 1), (1, 256, 7, 9, 152, 3, 1),
+             # dgrad through the halo-patch kernel (gradient channels = its K): 160 -> 160 over ragged 16-row tiles, 128 -> 128 two images
+             (1, 160, 19, 21, 160, 3, 1), (2, 128, 9, 17, 128, 3, 1)]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -161,8 +173,8 @@ def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
     engine.kernel_profile_dump(path)
     engine.kernel_profile(False)
     labels = [l.split(",")[1] for l in open(path).read().splitlines()[1:] if l.startswith("conv_igemm")]
-    assert sum(l.startswith("gemm k33 s1 div1 cin128 cout160") for l in labels) == 1          # forward, 128 -> 160
-    assert sum(l.startswith("gemm k33 s1 div1 cin160 cout128") for l in labels) == 1          # its dgrad
+    assert sum(l.startswith("halo k33 s1 div1 cin128 cout160") for l in labels) == 1          # forward, 128 -> 160: the halo-patch form of the 3x3 stride-1 layers
+    assert sum(l.startswith("halo k33 s1 div1 cin160 cout128") for l in labels) == 1          # its dgrad
     assert sum(l.startswith("gemm k33 s1 div1 cin160 cout32") for l in labels) == 0           # Cout < 64: not eligible
     assert sum(l.startswith("p2 k33 s1 div1 cin32 cout160") for l in labels) == 1             # narrow forward: patch kernel
     # stride-2 dgrad of 64 -> 128 (128 gradient channels < the kernel's 160-channel gate): all four phase convolutions on the patch kernel, as ONE grouped
