@@ -20,7 +20,6 @@ os.environ.setdefault("YS_F8_MIN_TAPS", "1")       # and 1x1 layers too (product
 # The blocked-GEMM convolution kernel (csrc/conv_gemm.hip) takes layers with >= 128 input channels and >= 1024 output pixels; the
 # tests drop the pixel gate so that oracle-sized shapes reach it.
 os.environ.setdefault("YS_GEMM_MIN_M", "1")
-os.environ.setdefault("YS_GEMM_HALO", "1")
 os.environ.setdefault("YS_HALO_MIN_FILL", "1")   # its halo-patch form wants feature maps that fill 16 x 16 pixel tiles: the oracle-sized maps of the tests do not
 os.environ.setdefault("YS_WGEMM_MIN_M", "1")      # same for its weight-gradient counterpart (csrc/conv_wgrad_gemm.hip)
 # Inside a pytest-xdist worker the interpreter's OpenMP team (and torch's) is kept small: eight workers with a full team each oversubscribe the

@@ -127,6 +127,9 @@ BF16_CASES = {
     "c2f": (lambda: O.C2f(48, 32, 1, False), "C2f", dict(c1=48, c2=32, n=1, shortcut=False), 48),
     "sppf": (lambda: O.SPPF(32, 32), "SPPF", dict(c1=32, c2=32), 32),
     "c2f_wide": (lambda: O.C2f(256, 256, 1, True), "C2f", dict(c1=256, c2=256, n=1, shortcut=True), 256),   # blocked-GEMM kernels (>= 128 channels)
+    # halo-patch kernel (conv_halo.h) in every epilogue class: 160 -> 160 3x3 Bottleneck convolutions of a YOLOv8x-like C2f -- training forward (statistics),
+    # dgrad with the fused BN-backward reduction, dgrad accumulating into a view that already holds the shortcut's gradient; 2.5 chunks of 64 channels
+    "c2f_halo": (lambda: O.C2f(320, 320, 1, True), "C2f", dict(c1=320, c2=320, n=1, shortcut=True), 320),
 }
 
 
@@ -149,6 +152,8 @@ def _block_bf16_matched(engine, case, B, H, W):
     flips = float((y != rya).mean())
     single_layer = cls == "Conv"                # a flipped value moves what is computed from it: deeper blocks carry more (GPU, 80 x 80, B = 8: C2f(n=2) 1.0 %)
     flip_cap = 5e-3 if single_layer else (1e-1 if c1 >= 128 else 3e-2)   # K = 2304 accumulations flip more often (256-channel C2f on the GPU: 5.8 %)
+    if case == "c2f_halo":
+        flip_cap = 0.2     # the halo-patch kernel walks K as (64-channel chunk, tap, unit-permuted K-step): not the oracle's order even on the interpreter (11 % measured)
     assert flips <= flip_cap, ("forward differs from the rounding-matched oracle in more than isolated flips", flips)
     R.check_elem(y, rya, case + " forward", max_out=flip_cap, out_mult=4.0)      # and a flip is one ulp, not garbage
     dy = R.bf16r(torch.randn(ry.shape, generator=torch.Generator().manual_seed(4)))
@@ -171,10 +176,13 @@ def _block_bf16_matched(engine, case, B, H, W):
     blk.close()
 
 
-@pytest.mark.parametrize("case", ["conv3", "conv3s2", "conv1_noact", "bneck_sc", "c2f_sc", "c2f", "sppf"])
+@pytest.mark.parametrize("case", ["conv3", "conv3s2", "conv1_noact", "bneck_sc", "c2f_sc", "c2f", "sppf", "c2f_halo"])
 @pytest.mark.parametrize("backend", ["emu"])
 def test_block_bf16_rounding_matched_emu(engine, backend, case):
-    _block_bf16_matched(engine, case, 2, 24, 24)
+    if case == "c2f_halo":
+        _block_bf16_matched(engine, case, 1, 20, 18)     # 2 x 2 ragged 16 x 16 tiles
+    else:
+        _block_bf16_matched(engine, case, 2, 24, 24)
 
 
 @pytest.mark.gpu
@@ -185,6 +193,14 @@ def test_block_bf16_rounding_matched_gpu(engine, backend, case):
     256-channel case at 20 x 20 is a P5 C2f of YOLOv8n)."""
     if case == "c2f_wide":
         _block_bf16_matched(engine, case, 8, 20, 20)
+    elif case == "c2f_halo":
+        _block_bf16_matched(engine, case, 8, 80, 80)     # 200 tiles x 1 channel tile: one tile per workgroup ...
+        import os
+        os.environ["YS_HALO_MAX_GRID"] = "48"            # ... and the tile stream (4-5 tiles per workgroup: no per-tile prologue, operands of the next tile land under the epilogue)
+        try:
+            _block_bf16_matched(engine, case, 8, 80, 80)
+        finally:
+            del os.environ["YS_HALO_MAX_GRID"]
     else:
         _block_bf16_matched(engine, case, 8, 80, 80)
 

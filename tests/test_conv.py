@@ -153,6 +153,18 @@ def test_wgrad_gemm_short_k_tile(backend, engine, case, monkeypatch):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("grid", ["1", "2", "4"])
+def test_halo_kernel_tile_stream(backend, engine, grid, monkeypatch):
+    """conv_halo_kernel's workgroups walk their tiles as ONE tap stream: the last chunk of a tile requests the next tile's first patch and taps (no per-tile
+    prologue), patch buffers alternate across the tile boundary for odd chunk counts.  Oracle-sized maps have fewer tiles than the chip has CUs, so the test caps the grid:
+    1, 2 or 4 workgroups for 6 / 2 tiles (odd and even chunk counts, ragged edges), forward (statistics + BN) and dgrad."""
+    monkeypatch.setenv("YS_HALO_MAX_GRID", grid)
+    for case in (len(FWD_CASES) - 5, len(FWD_CASES) - 4, len(FWD_CASES) - 2):
+        test_conv_bn_act_forward(backend, engine, "bf16", case)
+    test_conv_backward(backend, engine, "bf16", len(BWD_CASES) - 2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
     """The per-launch profile names the kernel a layer ran on: wide layers -> conv_gemm_kernel for forward and dgrad; narrower layers and the
     phase convolutions of a stride-2 dgrad with < 160 gradient channels stay on the whole-Cin patch kernel."""

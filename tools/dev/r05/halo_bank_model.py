@@ -18,10 +18,12 @@ def cycles(addr_of_lane):
         tot += max(len(v) for v in per.values())
     return tot
 
-def unit(q, ks): return ((q & 1) << 2) | ((q >> 1) << 1) | ks
-def xmap(li): return li ^ ((li >> 1) & 4)
+def unit(q, ks): return (ks << 2) | ((q & 1) << 1) | (q >> 1)      # K-step = the HIGH unit bit: K-step 0 covers channels 0-31 of the chunk
+def xmap(li):
+    t = (li - 4) & 7 if 4 <= li < 12 else li & 3
+    return ((t & 1) | ((t >> 1) << 2)) + (2 if 4 <= li < 12 else (8 if li >= 12 else 0))
 def swzA(p): return (p >> 1) & 7
-def swzB(n): return ((n >> 1) & 7) ^ ((((n >> 2) ^ (n >> 3)) & 1) << 2)
+def swzB(n): return ((n >> 1) & 7) ^ ((((n >> 2) ^ (n >> 3)) & 1) << 1)
 
 for ks in (0, 1):
     worstA = max(cycles(lambda l: (base + xmap(l & 15)) * 128 + ((unit(l >> 4, ks) ^ swzA(base + xmap(l & 15))) << 4)) for base in range(0, 400))

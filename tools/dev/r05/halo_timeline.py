@@ -11,24 +11,16 @@ os.environ["YS_P2_TL"] = out
 from yolosharp_amd import Engine
 eng = Engine(0, lib_path=os.path.join(ROOT, "build", "libyolosharp_hip_tl.so"))
 rng = np.random.default_rng(0)
-for (B, Cin, H, W, Cout, k, s) in [(16, 320, 80, 80, 320, 3, 1)]:
+for (B, Cin, H, W, Cout, k, s) in [(16, 320, 80, 80, 320, 3, 1), (16, 160, 160, 160, 160, 3, 1)]:
     x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
     w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
     bn = {"weight": np.ones(Cout, np.float32), "bias": np.zeros(Cout, np.float32), "running_mean": np.zeros(Cout, np.float32), "running_var": np.ones(Cout, np.float32)}
     for rep in range(2):
         eng.conv_bn_act(x, w, k, s, bn=bn, act=True, training=True, dtype="bf16")
 txt = open(out).read().splitlines()
-# last launch only
-idx = max(i for i, l in enumerate(txt) if l.startswith("#"))
-print(txt[idx])
-for l in txt[idx + 1: idx + 5]:
-    v = [int(t) for t in l.split(":")[1].split()]
-    print(l.split(":")[0], "stamps (cycles since entry): prologue issued %d, first fragments read %d; chunk 1, per tap: K-step 0 + wait | barrier | K-step 1" % (v[0], v[1]))
-    f = v[2:2 + 27]
-    prev = None
-    for t in range(9):
-        q = f[3 * t: 3 * t + 3]
-        if len(q) < 3: break
-        print("   tap %d: %s+%d | +%d | +%d" % (t, "" if prev is None else "(K-step 0 + wait) ", 0 if prev is None else q[0] - prev, q[1] - q[0], q[2] - q[1]))
-        prev = q[2]
-    print("   rest:", v[29:])
+for hdr in [i for i, l in enumerate(txt) if l.startswith("#")][1::2]:      # second launch of every layer
+    print(txt[hdr])
+    for l in txt[hdr + 1: hdr + 4]:
+        if l.startswith("#"): break
+        v = [int(t) for t in l.split(":")[1].split()]
+        print(l.split(":")[0], "deltas:", [v[0]] + [b - a for a, b in zip(v, v[1:])])

@@ -347,7 +347,10 @@ __device__ inline void ys_row_swap(unsigned& a, unsigned& b) {
 __device__ inline void ys_unpack4_bf16(const uint2& v, float* f) {
   f[0] = ys_u2f(v.x << 16); f[1] = ys_u2f(v.x & 0xffff0000u); f[2] = ys_u2f(v.y << 16); f[3] = ys_u2f(v.y & 0xffff0000u);
 }
-template <int MR, int NR, int RED = 0, class SF = YsNoStamp>
+// FMODE (forward form only): 2 = every run-time option (bias, eval BatchNorm, SiLU, residual, accumulate); 0 = the training forward of a BatchNorm unit -- raw
+// output + statistics, nothing else -- as a compile-time fact: with the options tested per fragment at run time the forward form was ~450 scalar branches and
+// ~1900 v_readlane reloads of spilled kernel-argument SGPRs per call (conv_halo_kernel, 40 fragments: 23 thousand cycles per 256 x 160 tile).
+template <int MR, int NR, int RED = 0, class SF = YsNoStamp, int FMODE = 2, int DEPTH = 2>
 __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR], const int (&orow)[MR], const bool (&pv)[MR],
                                           int n0, float (&s1)[4 * NR], float (&s2)[4 * NR], SF stamp = SF()) {
   const int lane = threadIdx.x & 63, q = lane >> 4;
@@ -372,7 +375,10 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
     // ---- backward form.  Operands of fragment column nf + 1 (old dz, the producer's y, its BN coefficients) are requested before
     // column nf is consumed: two batches of 4*MR + 8 registers in flight instead of every fragment's (which spilled), one exposed
     // memory latency per tile instead of one per column.
-    const bool red_on = a.nred > 0 && !EPI_DBG(512);
+    // FMODE >= 4: (accumulate, fused reduction) = (FMODE & 1, FMODE & 2) are compile-time facts of the launch (conv_halo_kernel)
+    constexpr bool CT = FMODE >= 4;
+    const bool accum_rt = CT ? (FMODE & 1) != 0 : a.accumulate != 0;
+    const bool red_on = CT ? (FMODE & 2) != 0 : (a.nred > 0 && !EPI_DBG(512));
     auto issue = [&](auto nfc, uint2 (&b_old)[MR], uint2 (&b_y)[MR], float (&b_sc)[4], float (&b_sh)[4], bool& b_has, bool& b_act) {
       constexpr int nf = decltype(nfc)::value;
       const int c = n0 + nf * 16 + 4 * q;
@@ -388,7 +394,7 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
 #pragma unroll
       for (int mf = 0; mf < MR; mf++) {
         const bool ok = (bool)((int)pv[mf] & (int)(c < a.Cout));
-        b_old[mf] = a.accumulate ? ys_bufld8(rsY, ok ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB) : make_uint2(0u, 0u);
+        b_old[mf] = accum_rt ? ys_bufld8(rsY, ok ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB) : make_uint2(0u, 0u);
         // unconditional load: a lane without a segment / pixel reads a valid dummy address and is masked when consumed
         const char* yp = (ry && ok) ? ry + ((long)orow[mf] * rC + rcol) * 2L : (const char*)a.y;
         b_y[mf] = red_on ? ys_ld8(yp) : make_uint2(0u, 0u);
@@ -406,7 +412,7 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
         float v[4], o[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = (c + r < a.Cout) ? acc[mf][nf][r] : 0.f;   // channels past Cout inside the last 4-group stay zero
-        if (a.accumulate) {
+        if (accum_rt) {
           ys_unpack4_bf16(b_old[mf], o);
 #pragma unroll
           for (int r = 0; r < 4; r++) v[r] += o[r];
@@ -435,33 +441,41 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
         }
       }
     };
-    uint2 oldA[MR], yA[MR], oldB[MR], yB[MR];
-    float scA[4], shA[4], scB[4], shB[4];
-    bool hasA = false, actA = false, hasB = false, actB = false;
-    issue(std::integral_constant<int, 0>{}, oldA, yA, scA, shA, hasA, actA);
+    // DEPTH operand batches in rotation: column nf's operands are requested DEPTH - 1 columns ahead.  2 (default): the register budget of two waves per SIMD;
+    // NR: everything up front -- one exposed memory latency per tile -- for a kernel with one wave per SIMD and registers to spare (conv_halo_kernel: with two batches
+    // its accumulate launches spent ~35 thousand cycles per 256 x 160 tile in five dependent round trips).
+    uint2 oldv[DEPTH][MR], yv[DEPTH][MR];
+    float scv[DEPTH][4], shv[DEPTH][4];
+    bool hasv[DEPTH], actv[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) { hasv[d] = false; actv[d] = false; }
+    ys_static_for<0, (DEPTH - 1 < NR ? DEPTH - 1 : NR)>([&](auto nfc) {
+      constexpr int nf = decltype(nfc)::value;
+      issue(nfc, oldv[nf % DEPTH], yv[nf % DEPTH], scv[nf % DEPTH], shv[nf % DEPTH], hasv[nf % DEPTH], actv[nf % DEPTH]);
+    });
     stamp();
     ys_static_for<0, NR>([&](auto nfc) {
       constexpr int nf = decltype(nfc)::value;
       // the scheduling fences keep hipcc from hoisting every column's loads to the top (all batches live at once: spills)
-      if constexpr (nf & 1) {
-        if constexpr (nf + 1 < NR) issue(std::integral_constant<int, nf + 1>{}, oldA, yA, scA, shA, hasA, actA);
-        YS_SCHED_FENCE();
-        consume(nfc, oldB, yB, scB, shB, hasB, actB);
-      } else {
-        if constexpr (nf + 1 < NR) issue(std::integral_constant<int, nf + 1>{}, oldB, yB, scB, shB, hasB, actB);
-        YS_SCHED_FENCE();
-        consume(nfc, oldA, yA, scA, shA, hasA, actA);
+      if constexpr (nf + DEPTH - 1 < NR) {
+        constexpr int nx = nf + DEPTH - 1;
+        issue(std::integral_constant<int, nx>{}, oldv[nx % DEPTH], yv[nx % DEPTH], scv[nx % DEPTH], shv[nx % DEPTH], hasv[nx % DEPTH], actv[nx % DEPTH]);
       }
+      YS_SCHED_FENCE();
+      consume(nfc, oldv[nf % DEPTH], yv[nf % DEPTH], scv[nf % DEPTH], shv[nf % DEPTH], hasv[nf % DEPTH], actv[nf % DEPTH]);
       YS_SCHED_FENCE();
     });
     stamp(); stamp(); stamp();
     return;
   }
   // ---- forward / eval form
-  const bool do_stats = a.stats != nullptr && !EPI_DBG(512);
-  const bool bn_eval = a.scale != nullptr;
-  const bool bias = !a.scale && a.shift;
-  const char* rb = (const char*)a.res;
+  const bool do_stats = FMODE == 0 ? true : (a.stats != nullptr && !EPI_DBG(512));
+  const bool bn_eval = FMODE == 0 ? false : a.scale != nullptr;
+  const bool bias = FMODE == 0 ? false : (!a.scale && a.shift);
+  const char* rb = FMODE == 0 ? nullptr : (const char*)a.res;
+  const bool accum = FMODE == 0 ? false : a.accumulate != 0;
+  const bool shift_on = FMODE == 0 ? false : a.shift != nullptr;
+  const bool act_on = FMODE == 0 ? false : a.act != 0;
   stamp();
 #pragma unroll
   for (int nf = 0; nf < NR; nf++) {
@@ -469,7 +483,7 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
     const int cc = c < a.Cout ? c : 0;         // coefficient arrays are padded to a multiple of 4 floats; Cout % 4 == 0 on this path
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (bn_eval) ys_ldcoef<4>(a.scale + cc, sc);
-    if (a.shift) ys_ldcoef<4>(a.shift + cc, sh);
+    if (shift_on) ys_ldcoef<4>(a.shift + cc, sh);
 #pragma unroll
     for (int mf = 0; mf < MR; mf++) {
       const bool ok = (bool)((int)pv[mf] & (int)(c < a.Cout));
@@ -479,7 +493,7 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
       if (bias) {                              // plain conv bias (heads): added to the fp32 accumulators
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] += sh[r];
-        if (a.act) {
+        if (act_on) {
 #pragma unroll
           for (int r = 0; r < 4; r++) v[r] = ys_silu(v[r]);
         }
@@ -488,7 +502,7 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
       for (int r = 0; r < 4; r++) if (c + r >= a.Cout) v[r] = 0.f;   // channels past Cout inside the last 4-group stay zero (Pose: 51 outputs)
       uint2 pk;
       pk.x = ys_pack_bf16x2(v[0], v[1]); pk.y = ys_pack_bf16x2(v[2], v[3]);
-      if (do_stats || bn_eval || rb || a.accumulate) {
+      if (do_stats || bn_eval || rb || accum) {
         float f[4];
         ys_unpack4_bf16(pk, f);                // the rounded conv output: what BN normalises / what the statistics describe
         if (do_stats) {
@@ -498,12 +512,12 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
         if (bn_eval) {
 #pragma unroll
           for (int r = 0; r < 4; r++) f[r] = f[r] * sc[r] + sh[r];
-          if (a.act) {
+          if (act_on) {
 #pragma unroll
             for (int r = 0; r < 4; r++) f[r] = ys_silu(f[r]);
           }
         }
-        if (rb || a.accumulate) {
+        if (rb || accum) {
           float gq[4];
           if (rb) {                            // eval-only path (Bottleneck shortcut)
             const char* rp = ok ? rb + ((long)orow[mf] * a.res_ldc + a.res_coff + c) * 2L : rb;
@@ -511,13 +525,13 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
 #pragma unroll
             for (int r = 0; r < 4; r++) f[r] += gq[r];
           }
-          if (a.accumulate) {
+          if (accum) {
             ys_unpack4_bf16(ys_bufld8(rsY, ok ? roff[mf] + (unsigned)c * 2u : YS_BUF_OOB), gq);
 #pragma unroll
             for (int r = 0; r < 4; r++) f[r] += gq[r];
           }
         }
-        if (bn_eval || rb || a.accumulate) {
+        if (bn_eval || rb || accum) {
 #pragma unroll
           for (int r = 0; r < 4; r++) if (c + r >= a.Cout) f[r] = 0.f;
           pk.x = ys_pack_bf16x2(f[0], f[1]); pk.y = ys_pack_bf16x2(f[2], f[3]);

@@ -22,6 +22,7 @@
 //    batch statistics stay in registers across tiles and leave as one row per workgroup (p2 contract);
 //  * epilogue, statistics, bias / eval-BN / SiLU, residual and gradient accumulation: the shared wide-store stage (conv_epi.h).
 #include "conv_epi.h"
+#include "conv_halo.h"
 #include <atomic>
 #ifndef YS_GEMM_EPI_DIRECT
 #define YS_GEMM_EPI_DIRECT 0   // 1: this kernel's epilogue goes straight from the accumulator registers (16-byte stores after a 16-lane row swap, conv_epi.h
@@ -323,265 +324,6 @@ conv_gemm_kernel(ConvArgs a, GemmArgs g) {
 #endif
 }
 
-// ------------------------------------------------------------------ halo-patch form for the 3x3 stride-1 layers (round 5)
-// conv_gemm_kernel gathers the A operand of a 3x3 layer NINE times (once per tap: 36 KB of LDS DMA per K-tile of its 128 x 160 tile against 640 cycles
-// of MFMA), every wave both requests and multiplies, and the ring is two K-tiles deep.  Here ONE workgroup of 8 waves per CU owns a 2-D tile of 16 x 16
-// output pixels x BN = 160 / 128 output channels (4 x 2 waves, each the blocked kernel's 64 x 80 / 64 x 64 register tile) and stages the INPUT PATCH of
-// the tile -- 18 x 18 pixels, one 64-channel chunk at a time, 128-byte rows -- ONCE per chunk; the nine taps of the chunk read their pixel fragments
-// from that one patch at shifted rows.  Only the weights stream per tap (BN rows x 128 B).  Per tap (= 2 K-steps = 40 MFMAs per wave, 1280 MFMA cycles
-// per SIMD) 5 KB of patch + 20 KB of weights land: ~20 B/clk/CU against the blocked kernel's 56, a wave issues ~3 one-KB requests per 40 MFMAs
-// instead of 18.
-//   * 128-byte rows on purpose: round-5 probe (tools/probe/probe_dma_rate.hip): LDS-DMA pieces that gather 64-byte row segments (16 cache lines per
-//     instruction, half of each used) saturate at 13-21 B/clk/CU with 8 waves per CU requesting, full-line pieces reach 54; a first version of
-//     this kernel with 32-channel chunks (64-byte rows, two 256-thread workgroups per CU) sat exactly on that limit.
-//   * LDS: two patch buffers (chunk c is multiplied while chunk c + 1 lands, 2 x 45 KB) + a three-stage weight ring (stage = tap, slot = tap % 3);
-//     everything by LDS DMA through buffer descriptors (zero padding = out-of-range offsets), counted vmcnt waits with compile-time counts, one
-//     LDS-only barrier per tap.
-//   * the two waves of a SIMD run the same phase (one workgroup), so each wave overlaps its own LDS reads with its own MFMAs: two fragment sets,
-//     the reads of K-step k + 1 are issued before the MFMAs of K-step k, and the barrier of tap t + 1 sits BETWEEN the two K-steps of tap t.
-//   * bank conflicts: a tap shift moves a fragment's 16 pixels to an ARBITRARY patch offset, so the blocked kernel's swizzle (which relies on
-//     16-row-aligned fragments) does not carry over.  Layout (tools/dev/r05/halo_bank_model.py checks every offset against the ds_read_b128 lane
-//     groups of MI355X_MICROARCH.md): patch pixel p (row pitch 20 pixels) stores K-unit u at slot u ^ ((p >> 1) & 7); lane quarter q multiplies
-//     K-unit ((q & 1) << 2) | ((q >> 1) << 1) | ks of the row in K-step ks (both operands agree, so any assignment is a valid dot product); MFMA
-//     column li holds tile column li ^ ((li >> 1) & 4) (the third and fourth groups of four swap).  With these three the 16 lanes the LDS serves
-//     together always hit 16 different 16-byte bank columns.  Weight rows (fragments 16-row aligned): slot u ^ ((n >> 1) & 7) ^ (4 * (((n >> 2) ^ (n >> 3)) & 1)).
-//   * fragment addresses: with a 20-pixel pitch (p >> 1) & 7 of a shifted pixel depends only on (row & 3, column), so a lane keeps 12 offsets
-//     (3 column shifts x 4 row classes); a read is offset + immediate (K-step 1: offset ^ 16).
-//   * epilogue / statistics / fused BN-backward reduction: the shared wide-store stage (conv_epi.h), two fragment rows at a time, staged in the ring.
-struct HaloArgs {
-  int nchunk;                 // 64-channel chunks of the input: ceil(Cin / 64)
-  int tiles_x, tiles_y, mtiles;
-  YsFastDiv dTpi, dTx;        // tile index -> (image, tile row, tile column)
-  unsigned abytes;            // descriptor range of the input view
-};
-#define HALO_PW 18            // patch columns: 16 + halo
-#define HALO_PWP 20           // row pitch of the patch in pixels (see above)
-#define HALO_PH 18            // patch rows
-#define HALO_MR 8             // fragment rows (tile rows) per wave
-#define HALO_EMR 1            // fragment rows per epilogue call (one: 3 store iterations per call, whose accumulate / BN-reduction operands are all requested ahead)
-#define HALO_NPP (HALO_PH * HALO_PWP / 8)       // 1 KB DMA pieces (8 pixels x 128 B) per patch: 45
-#define HALO_PATCH (HALO_NPP * 1024)
-__host__ __device__ constexpr int halo_stage_bytes(int nr) { return 2 * nr * 16 * 128; }
-__host__ __device__ constexpr int halo_wstg(int nr) { return 16 * HALO_EMR * (nr * 16 + 8) * 2 + 16 * HALO_EMR * 16; }
-__host__ __device__ constexpr size_t halo_lds_bytes(int nr) { return (size_t)2 * HALO_PATCH + (size_t)3 * halo_stage_bytes(nr); }
-
-template <int NR, int RED = 0>
-__global__ void __launch_bounds__(256, 1)
-conv_halo_kernel(ConvArgs a, HaloArgs g) {
-  typedef bf16_t T;
-  constexpr int WM = 2, WN = 2, MR = HALO_MR, EMR = HALO_EMR, NWV = 4;
-  constexpr int TH = WM * MR, PH = HALO_PH;
-  constexpr int NPP = HALO_NPP, NPW = (NPP + NWV - 1) / NWV, NPMIN = NPP / NWV;   // patch pieces per chunk: workgroup, wave (most / least): 45, 12, 11
-  constexpr int PATCH = HALO_PATCH;
-  constexpr int BN = WN * NR * 16;
-  constexpr int NBP = BN / 8, NBW = NBP / NWV;                 // weight pieces (8 rows x 128 B) per tap: workgroup, wave
-  constexpr int STAGE = halo_stage_bytes(NR);
-  constexpr int NMF = MR * NR;                                 // MFMAs per K-step and wave
-  static_assert(TH + 2 == PH && NPW == 12 && NPMIN == 11 && NBP % NWV == 0 && MR % EMR == 0 && (HALO_PH * HALO_PWP) % 8 == 0 && NMF >= 2 * (NR + MR) + 8, "halo pipeline");
-  static_assert(NWV * halo_wstg(NR) <= 3 * STAGE && 16 * 256 * 4 <= 3 * STAGE, "epilogue staging / statistics scratch inside the ring");
-#ifdef YS_P2_TIMELINE
-  int tl_n = 0;
-  unsigned long long* tl_p = (a.tl && (blockIdx.x % 37) == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? a.tl + (blockIdx.x / 37) * 64 : nullptr;
-#define HTL_STAMP() do { if (tl_p && tl_n < 63) tl_p[1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define HTL_STAMP() ((void)0)
-#endif
-  HTL_STAMP();
-  YS_DYN_LDS(lds);
-  char* lb = (char*)lds;
-  char* sRing = lb + 2 * PATCH;
-
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, q = lane >> 4;
-#ifdef YS_EMU_BUILD
-  const int wave = tid >> 6;
-#else
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int n0 = blockIdx.y * BN;
-  const int ldu = a.in_ldc >> 3;                      // 16-byte units per input pixel
-  const long Kbytes = (long)9 * a.Cin * 2;            // bytes per weight row
-
-  const ys_rsrc_t rsB = ys_make_rsrc(a.w, (unsigned)((long)a.Cout * Kbytes));
-  const ys_rsrc_t rsA = ys_make_rsrc((const char*)a.x + ((long)(a.in_coff >> 3) << 4), g.abytes);
-
-  // weight requests: piece bp = wave + 4j covers rows 8bp .. 8bp + 7 of the stage, lane l -> row 8bp + (l >> 3), slot l & 7
-  unsigned boff[NBW];
-#pragma unroll
-  for (int j = 0; j < NBW; j++) {
-    const int row = (wave + NWV * j) * 8 + (lane >> 3), n = n0 + row;
-    const int u = (lane & 7) ^ ((row >> 1) & 7) ^ ((((row >> 2) ^ (row >> 3)) & 1) << 2);
-    boff[j] = (n < a.Cout && !GEMM_DBG(2)) ? (unsigned)((long)n * Kbytes) + (unsigned)u * 16u : YS_BUF_OOB;
-  }
-  // fragment read offsets (K-step 0; K-step 1 = the same ^ 16).  Pixels: MFMA column li holds tile column xm; a shifted pixel (row r, column xm + kx) sits at
-  // padded index r * 20 + xm + kx, whose swizzle term (2 (r & 3) + ((xm + kx) >> 1)) & 7 depends on the row only through r & 3 (the wave's first row 8 wm
-  // is a multiple of 4)
-  const int xm = li ^ ((li >> 1) & 4);
-  const int uq0 = ((q & 1) << 2) | ((q >> 1) << 1);
-  int offA[3][4];
-#pragma unroll
-  for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-    for (int rc = 0; rc < 4; rc++) {
-      const int xx = xm + kx;
-      offA[kx][rc] = (wm * MR * HALO_PWP + xx) * 128 + ((uq0 ^ ((2 * rc + (xx >> 1)) & 7)) << 4);
-    }
-  const int offB = (wn * NR * 16 + li) * 128 + ((uq0 ^ ((li >> 1) & 7) ^ ((((li >> 2) ^ (li >> 3)) & 1) << 2)) << 4);
-
-  // tile order: as conv_gemm_kernel -- workgroup i runs on XCD i % 8 and walks that XCD's contiguous share of the tiles
-  const bool xcd_order = (gridDim.x & 7) == 0;
-  const int t_per_xcd = (g.mtiles + 7) >> 3;
-  const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  const int t_first = xcd_order ? (int)(blockIdx.x & 7) * t_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int t_end = xcd_order ? (((int)(blockIdx.x & 7) + 1) * t_per_xcd < g.mtiles ? ((int)(blockIdx.x & 7) + 1) * t_per_xcd : g.mtiles) : g.mtiles;
-
-  float st1[8], st2[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
-
-  for (int tile = t_first; tile < t_end; tile += t_step) {
-    const int b = (int)ys_fastdiv((unsigned)tile, g.dTpi), trem = tile - b * (g.tiles_x * g.tiles_y);
-    const int ty = (int)ys_fastdiv((unsigned)trem, g.dTx), tx = trem - ty * g.tiles_x;
-    const int y0 = ty * TH, x0 = tx * 16;
-    const int iy0 = y0 - 1, ix0 = x0 - 1;     // image coordinates of patch pixel (0, 0); its byte offset from the descriptor base (may be negative at the border)
-    const int tb = (int)((((long)b * a.in_bstride + (long)iy0 * a.Win + ix0) * ldu) << 4);
-    // patch piece j of this wave for chunk c into buffer buf: piece pp = wave + 4j covers padded patch pixels 8pp .. 8pp + 7, lane l -> pixel 8pp + (l >> 3), slot l & 7
-    auto issue_p = [&](const int buf, const int c, const int j) {
-      const int pp = wave + NWV * j;
-      if (pp < NPP) {
-        const int pl = pp * 8 + (lane >> 3);
-        const int py = (pl * 3277) >> 16, px = pl - py * HALO_PWP;    // pl / 20 for pl < 400
-        const int u = (lane & 7) ^ ((pl >> 1) & 7);
-        const bool ok = (bool)((int)(px < HALO_PW) & (int)((unsigned)(iy0 + py) < (unsigned)a.Hin) & (int)((unsigned)(ix0 + px) < (unsigned)a.Win) &
-                               (int)((c * 8 + u) * 8 < a.Cin) & (int)!GEMM_DBG(1));
-        if (GEMM_DBG(64)) return;
-        const int vo = tb + (((py * a.Win + px) * ldu + c * 8 + u) << 4);
-        ys_bufld_lds16(rsA, ok ? (unsigned)vo : YS_BUF_OOB, 0u, lb + buf * PATCH + pp * 1024);
-      }
-    };
-    auto issue_w1 = [&](const int slot, const int c, const int tap, const int j) {   // weight piece j of this wave for tap (c, tap)
-      if (GEMM_DBG(64)) return;
-      ys_bufld_lds16(rsB, boff[j], (unsigned)(tap * a.Cin + c * 64) * 2u, sRing + slot * STAGE + (wave + NWV * j) * 1024);
-    };
-    ys_barrier_lds();                         // every wave is done with the previous tile's staging area (the ring)
-    // prologue: patch of chunk 0, weights of taps 0, 1, 2 (the whole ring)
-#pragma unroll
-    for (int j = 0; j < NPW; j++) issue_p(0, 0, j);
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-      for (int j = 0; j < NBW; j++) issue_w1(t, 0, t, j);
-    HTL_STAMP();
-    f32x4 acc[MR][NR];
-#pragma unroll
-    for (int mf = 0; mf < MR; mf++)
-#pragma unroll
-      for (int nf = 0; nf < NR; nf++) acc[mf][nf] = f32x4_zero();
-
-    // ONE wave per SIMD (up to 512 registers): the wave hides its own LDS reads, operand requests and waits in the issue slots between its MFMAs.  Two fragment
-    // sets: set A holds K-step 0 of a tap, set B K-step 1.  Iteration of tap s:
-    //   K-step 0: 40 (32) MFMAs on A; between them the 13 (12) reads of (s, K-step 1) -> B
-    //   s_waitcnt vmcnt(N) + barrier of tap s + 1 (its requests were issued two iterations ago); frees ring slot s % 3 and, at the last tap of a chunk, the patch buffer
-    //   K-step 1: MFMAs on B; between them this tap's requests (patch pieces of the next chunk, weights of tap s + 3 -> slot s % 3), then the reads of (s + 1, K-step 0) -> A
-    uint4 fwA[NR], fxA[MR], fwB[NR], fxB[MR];
-    // MFMA i of a K-step = (nf, mf) = (i / MR, i % MR); hook(i) runs after it
-    auto kstep = [&](const uint4 (&fw)[NR], const uint4 (&fx)[MR], auto hook) {
-      ys_static_for<0, NMF>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, nf = i / MR, mf = i % MR;
-        if (!GEMM_DBG(4)) acc[mf][nf] = ys_mma<T>(fw[nf], fx[mf], acc[mf][nf]);
-        else acc[mf][nf][0] += ys_u2f(fw[nf].x) + ys_u2f(fx[mf].x);
-        YS_SCHED_FENCE();
-        hook(ic);
-        YS_SCHED_FENCE();
-      });
-    };
-    // read r (0 .. NR + MR - 1) of the fragments of (chunk patch offset table po, tap, K-step ks) into (fw, fx): weights first, then pixels
-    auto frag_read = [&](auto rc_, auto tapc, auto ksc, uint4 (&fw)[NR], uint4 (&fx)[MR], const int pbo) {
-      constexpr int r = decltype(rc_)::value, tap = decltype(tapc)::value, ks = decltype(ksc)::value;
-      constexpr int ky = tap / 3, kx = tap - ky * 3;
-      if (GEMM_DBG(16)) return;
-      if constexpr (r < NR) fw[r] = *(const uint4*)(sRing + (tap % 3) * STAGE + (ks ? (offB ^ 16) : offB) + r * 2048);
-      else {
-        constexpr int mf = r - NR;
-        const int o = offA[kx][(mf + ky) & 3];
-        fx[mf] = *(const uint4*)(lb + pbo + (ks ? (o ^ 16) : o) + (mf + ky) * (HALO_PWP * 128));
-      }
-    };
-    // before the loop: tap 0 landed, its K-step 0 fragments -> A
-    ys_wait_vm<2 * NBW>();
-    ys_barrier_lds();
-    ys_static_for<0, NR + MR>([&](auto rc_) { frag_read(rc_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fwA, fxA, 0); });
-    HTL_STAMP();
-#pragma unroll 1
-    for (int c = 0; c < g.nchunk; c++) {
-      const bool more = c + 1 < g.nchunk;
-      const int pbo = (c & 1) * PATCH;        // patch buffer of this chunk
-      ys_static_for<0, 9>([&](auto tc) {
-        constexpr int tap = decltype(tc)::value;
-        // ---- K-step 0 on A; reads (tap, K-step 1) -> B
-        kstep(fwA, fxA, [&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i < NR + MR) frag_read(ic, tc, std::integral_constant<int, 1>{}, fwB, fxB, pbo);
-        });
-        // ---- tap + 1 has landed (this wave's pieces: everything older than the requests of the previous iteration), everybody's have
-        const bool last = !more && tap == 8;
-        if (!last) {
-          constexpr int np_prev = tap == 0 ? 0 : (tap - 1 < 3 ? 2 : 1);     // patch pieces every wave issued in the previous iteration (chunks with a successor)
-          if (more) ys_wait_vm<np_prev + NBW>();
-          else if constexpr (tap < 7) ys_wait_vm<NBW>(); else YS_WAIT_VM0();
-          if (c == 1 && tile == t_first) HTL_STAMP();   // (triage builds: fine stamps of the second chunk of the first tile)
-          if (!GEMM_DBG(32)) ys_barrier_lds();
-          if (c == 1 && tile == t_first) HTL_STAMP();
-        }
-        // ---- K-step 1 on B; this tap's requests, then reads (tap + 1, K-step 0) -> A
-        constexpr int tap3 = (tap + 3) % 9;
-        const int c3 = c + (tap + 3) / 9;
-        const bool w_on = c3 < g.nchunk;
-        kstep(fwB, fxB, [&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          // requests at MFMAs 0, 2, 4, ...: [patch piece(s) of chunk c + 1: two at taps 0 - 2, one after], weights of tap + 3
-          constexpr int NPT = tap < 3 ? 2 : 1, JP0 = tap < 3 ? 2 * tap : tap + 3;        // patch pieces of this tap: JP0 .. JP0 + NPT - 1 (12 per chunk)
-          if constexpr ((i & 1) == 0 && i / 2 < NPT) { if (more) issue_p((c + 1) & 1, c + 1, JP0 + i / 2); }
-          else if constexpr ((i & 1) == 0 && i / 2 < NPT + NBW) { if (w_on) issue_w1(tap % 3, c3, tap3, i / 2 - NPT); }
-          else if constexpr (i >= 2 * (NPT + NBW) && i < 2 * (NPT + NBW) + NR + MR) {
-            constexpr int r = i - 2 * (NPT + NBW);
-            if constexpr (tap < 8) frag_read(std::integral_constant<int, r>{}, std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{}, fwA, fxA, pbo);
-            else { if (more) frag_read(std::integral_constant<int, r>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fwA, fxA, PATCH - pbo); }
-          }
-        });
-        if (c == 1 && tile == t_first) HTL_STAMP();
-      });
-    }
-    HTL_STAMP();
-    ys_barrier_lds();                         // every wave finished reading the ring: it becomes the epilogue staging area
-
-    char* stg = sRing + wave * halo_wstg(NR);
-#pragma unroll
-    for (int h = 0; h < MR / EMR; h++) {
-      int orow[EMR];
-      bool pv[EMR];
-#pragma unroll
-      for (int e = 0; e < EMR; e++) {
-        const int oy = y0 + wm * MR + h * EMR + e, ox = x0 + xm;
-        pv[e] = (bool)((int)(oy < a.Hout) & (int)(ox < a.Wout));
-        orow[e] = pv[e] ? b * (int)a.out_bstride + oy * a.Wout + ox : 0;
-      }
-      f32x4 sub[EMR][NR];                     // (register moves the allocator coalesces; no address of acc is taken)
-#pragma unroll
-      for (int e = 0; e < EMR; e++)
-#pragma unroll
-        for (int nf = 0; nf < NR; nf++) sub[e][nf] = acc[h * EMR + e][nf];
-      if (!GEMM_DBG(8)) p2_epilogue<EMR, NR, RED, 4>(a, sub, orow, pv, n0 + wn * NR * 16, stg, st1, st2);
-    }
-    HTL_STAMP();
-  }
-  if (RED ? a.nred > 0 : a.stats != nullptr) conv_stats_flush_grid<NR, WM, WN>(a, n0, st1, st2, (float*)sRing, (long)blockIdx.x);
-  HTL_STAMP();
-#ifdef YS_P2_TIMELINE
-  if (tl_p) tl_p[0] = (unsigned long long)tl_n;
-#endif
-}
-
 // ------------------------------------------------------------------ host side
 struct GemmPlan { int ok, wm, wn, mr, nr, gx, gy; size_t lds; GemmArgs g; int halo; HaloArgs h; };
 
@@ -589,8 +331,8 @@ struct GemmPlan { int ok, wm, wn, mr, nr, gx, gy; size_t lds; GemmArgs g; int ha
 // workgroup tile 16 x 16 pixels x (2 * nr * 16) channels, one workgroup of 8 waves per CU
 static GemmPlan conv_halo_plan(const ConvArgs& a) {
   GemmPlan p{};
-  static const bool on = getenv("YS_GEMM_HALO") && atoi(getenv("YS_GEMM_HALO")) != 0;   // (work in progress: opt-in until it beats the blocked kernel)
-  if (!on || a.f8) return p;
+  static const bool off = getenv("YS_GEMM_HALO") && atoi(getenv("YS_GEMM_HALO")) == 0;   // A/B switch against the blocked kernel
+  if (off || a.f8) return p;
   if (!(a.KH == 3 && a.KW == 3 && a.SA == 1 && a.PAD == 1 && a.DIVM == 0 && a.out_rh == 0 && a.pad_w_delta == 0 && a.Hout == a.Hin && a.Wout == a.Win)) return p;
   if (a.Cin < 64 || a.Cout < 64) return p;
   // channel tile 160 (80-multiples: YOLOv8x) or 128, least padding first; more than a quarter padding: the blocked kernel has 64 / 80-wide tiles
@@ -602,6 +344,9 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
   if ((long)p.gy * bn * 4 > (long)a.Cout * 5) return p;
   HaloArgs h{};
   h.nchunk = ys_cdiv(a.Cin, 64);
+  // launches that accumulate / carry the fused BN-backward reduction pay the LDS-staged epilogue once per tile with nothing to hide it behind (one wave per SIMD):
+  // with at most three chunks per tile (YOLOv8x 160 -> 160 at 160 x 160: 293 against 270 us) the blocked kernel keeps them
+  if ((a.nred > 0 || a.accumulate) && h.nchunk <= 3) return p;
   h.tiles_x = ys_cdiv(a.Wout, 16); h.tiles_y = ys_cdiv(a.Hout, 16);
   const long mt = (long)a.B * h.tiles_x * h.tiles_y;
   if (mt >= (1L << 24)) return p;
@@ -622,6 +367,7 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
   if (gx < 8) gx = 8;
   if (gx > mt) gx = mt;
   if (mt * p.gy <= 256) gx = mt;
+  { const char* f = getenv("YS_HALO_MAX_GRID"); if (f && atoi(f) > 0 && gx > atoi(f)) gx = atoi(f); }   // tests: workgroups that walk several tiles on oracle-sized shapes (read per call)
   p.gx = (int)gx;
   p.h = h; p.halo = 1; p.ok = 1;
   return p;
@@ -765,59 +511,9 @@ static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
   return YS_OK;
 }
 
-template <int NR, int RED>
-static int conv_halo_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
-  a.red_koff = (int)offsetof(ConvArgs, red);       // ConvArgs is the kernel's first argument (conv_epi.h ys_red_table)
-#ifdef YS_GEMM_ABLATE
-  a.dbg = getenv("YS_GEMM_DBG") ? atoi(getenv("YS_GEMM_DBG")) : 0;
-#endif
-  static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
-  int dev_id = 0;
-  (void)hipGetDevice(&dev_id);
-  if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
-    hipFuncSetAttribute((const void*)conv_halo_kernel<NR, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
-  }
-  char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "halo k33 s1 div1 cin%d cout%d M%d acc%d tile%dx16x%d grid%dx%d lds%d", a.Cin, a.Cout, a.M, a.accumulate, 16, 2 * NR * 16, p.gx, p.gy, (int)p.lds);
-  YsKprofScope prof(st, "conv_igemm", lab);
-#ifdef YS_P2_TIMELINE
-  static unsigned long long* tl_buf = nullptr;
-  const char* tl_path = getenv("YS_P2_TL");
-  if (tl_path) {
-    if (!tl_buf) hipMalloc(&tl_buf, 64 * 64 * 8);
-    hipMemsetAsync(tl_buf, 0, 64 * 64 * 8, st);
-    a.tl = tl_buf;
-  }
-#endif
-  YS_LAUNCH_LDS((conv_halo_kernel<NR, RED>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.h);
-#ifdef YS_P2_TIMELINE
-  if (tl_path) {
-    static unsigned long long h[64 * 64];
-    hipStreamSynchronize(st);
-    hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
-    FILE* f = fopen(tl_path, "a");
-    if (f) {
-      fprintf(f, "# halo k33 cin%d cout%d M%d acc%d tile%dx16x%d grid%dx%d lds%d mtiles%d nchunk%d (stamps: entry, then per tile: prologue issued, K loop done, epilogue done; exit)\n", a.Cin, a.Cout, a.M, a.accumulate, 16, 2 * NR * 16, p.gx, p.gy, (int)p.lds, p.h.mtiles, p.h.nchunk);
-      for (int w = 0; w < 64 && w * 37 < p.gx; w++) {
-        const int n = (int)h[w * 64];
-        if (n <= 0) continue;
-        fprintf(f, "wg%d:", w * 37);
-        for (int i = 1; i < n; i++) fprintf(f, " %llu", h[w * 64 + 1 + i] - h[w * 64 + 1]);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-  }
-#endif
-  return YS_OK;
-}
-
 static int conv_halo_launch(hipStream_t st, const ConvArgs& a, const GemmPlan& p) {
-#define HL(R_) if (p.nr == R_) return a.nred > 0 ? conv_halo_launch_t<R_, 1>(st, a, p) : conv_halo_launch_t<R_, 0>(st, a, p);
-  HL(5) HL(4)
-#undef HL
-  return YS_ERR_UNSUPPORTED;
+  HaloLaunch l{p.gx, p.gy, p.nr, p.lds, p.h};
+  return p.nr == 5 ? ys_conv_halo_launch_nr5(st, a, l) : ys_conv_halo_launch_nr4(st, a, l);
 }
 
 int ys_conv_gemm_rows(const ConvArgs& a) {
