@@ -164,6 +164,10 @@ def main():
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--no-infer", action="store_true", help="skip the eval-forward secondary metric (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) code path even with WORLD_SIZE=1 (self-test)")
+    ap.add_argument("--dist-backend", default="torch", choices=["torch", "c"],
+                    help="gradient exchange of the N > 1 step: torch = torch.distributed all-reduce (RCCL) driven from yolosharp_amd/dist.py; "
+                         "c = the library's own ys_dist_init / ys_model_backward_allreduce (RCCL dlopen'ed inside libyolosharp_hip.so: the path a C# host under "
+                         "Utils/Amp.cs:260-286 would call); torch.distributed then only carries the rendezvous (unique id broadcast, barriers, timing reductions)")
     ap.add_argument("--lib", default="", help="TRIAGE ONLY: load another build of the library (ablation / timeline variants under build/); the JSON line then carries \"triage_lib\"")
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (class,label,us) of the profiled conv launches (triage)")
     ap.add_argument("--spawn-probe", action="store_true", help="self-test of the --gpus N launch path on CPU (gloo): no GPU work")
@@ -213,6 +217,13 @@ def main():
     eng = Engine(local_rank, stream=stream, lib_path=args.lib or None)   # N>1: run on torch's stream so RCCL orders against our kernels
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
         raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
+    c_dist = distributed and args.dist_backend == "c"
+    if c_dist:
+        # the library's own communicator, BEFORE the model creates its streams (hardware-queue assignment follows creation order): rank 0 creates
+        # the RCCL unique id, torch.distributed ships it (any host channel would do), every rank joins
+        uid = [eng.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.dist_init(rank, world, uid[0])
     seg = args.task == "segment"
     Model = {(8, False): Yolov8, (11, False): Yolov11, (8, True): Yolov8Segment, (11, True): Yolov11Segment}[(args.family, seg)]
     if args.task in ("obb", "pose"):
@@ -238,10 +249,11 @@ def main():
     lr0 = round(0.002 * 5 / (4 + nc), 6)
     lrs = [lr0, lr0, lr0]
     gptr, gn = model.grad_buffer()
+    seg_ranges = [model.segment_grad_range(s) for s in range(model.num_segments())]
     sync = None
-    if distributed:
+    if distributed and not c_dist:
         flat = ysd.device_view(gptr.value, gn, dev)
-        sync = ysd.GradSync(flat, [model.segment_grad_range(s) for s in range(model.num_segments())], model=model,
+        sync = ysd.GradSync(flat, seg_ranges, model=model,
                             force_collective=args.force_dist)   # --force-dist: the one-rank group still issues its (identity) all-reduces
 
     def local_step():
@@ -251,8 +263,17 @@ def main():
         model.adamw_step(lrs)
         model.zero_grad()
 
+    def c_step():       # the C# host's step: forward, criterion, segmented backward with each segment's all-reduce issued by the library, AdamW
+        model.forward_device(d_img, B)
+        crit.forward_device(*d_lab)
+        model.backward_allreduce()
+        model.adamw_step(lrs)
+        model.zero_grad()
+
     def step():
-        if sync is not None:
+        if c_dist:
+            c_step()
+        elif sync is not None:
             ysd.train_step_dp(model, crit, sync, d_img, B, d_lab, lrs)
         else:
             local_step()
@@ -272,13 +293,36 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rccl_ranks = 1
+    dist_info = None
     if distributed:
+        own = elapsed
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         elapsed = float(t.item())
         ones = torch.ones(1, device=dev, dtype=torch.float32)
         dist.all_reduce(ones)                      # SUM over RCCL: how many ranks really took part
         rccl_ranks = int(ones.item())
+        # what the exchange costs this step: the same ranks run the LOCAL step (no all-reduce) for a short timed region right after, between the same
+        # barriers -- exposed all-reduce time = distributed step - local step (max over ranks of each)
+        n_loc = max(5, min(args.steps, 20))
+        for _ in range(3):
+            local_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_loc):
+            local_step()
+        barrier()
+        tl = torch.tensor([(time.perf_counter() - t1) / n_loc], device=dev, dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        ms_local = float(tl.item()) * 1e3
+        dist_info = {"backend": "c (ys_dist_* in libyolosharp_hip.so)" if c_dist else "torch.distributed (nccl = RCCL)",
+                     "rank_ms_per_step_min": round(float(tmin.item()) / args.steps * 1e3, 3), "rank_ms_per_step_max": round(elapsed / args.steps * 1e3, 3),
+                     "local_step_ms": round(ms_local, 3), "allreduce_exposed_ms": round(elapsed / args.steps * 1e3 - ms_local, 3),
+                     "segment_allreduce_bytes": [int(c) * 4 for _, c in seg_ranges], "allreduce_bytes_per_step": int(sum(c for _, c in seg_ranges)) * 4,
+                     "note": "allreduce_exposed_ms = ms_per_step (max over ranks) - the same ranks' local step (forward + criterion + backward + AdamW, no exchange) timed right after; "
+                             "segments in backward order (head, neck, late backbone, stem): each all-reduce is issued when its segment's gradients are complete and overlaps the next segment"}
     items, total = crit.read()[1], None
     ms = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
@@ -350,6 +394,8 @@ def main():
                "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, {'COCO-80' if nc == 80 else str(nc) + '-class'} synthetic labels" + {"segment": " + instance masks", "obb": " (oriented)", "pose": " + 17x3 keypoints"}.get(args.task, ""),
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
+        if dist_info is not None:
+            out["dist"] = dist_info
         if args.lib:
             out["triage_lib"] = args.lib          # not the product library: never a bench line of record
         # ---- secondary metric: inference images/s = eval forward (BN folded into the conv epilogues) + Detect decode
@@ -411,6 +457,8 @@ def main():
             pass
     if distributed:
         dist.barrier()
+        if c_dist:
+            eng.dist_destroy()
         dist.destroy_process_group()
 
 

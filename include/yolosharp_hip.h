@@ -204,6 +204,13 @@ YS_API int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count);
  * ys_dist_wait: the engine stream waits for the outstanding all-reduces.  ys_model_backward_allreduce = the four backward
  * segments with each finished segment's all-reduce overlapped with the next (the loop bench.py runs through torch.distributed).
  * RCCL is dlopen'ed on first use; single-GPU processes never load it. */
+/* Tuning / routing options (process-wide; the kernel plans read them at every launch).  Keys are the historical environment names without the YS_ prefix
+ * (e.g. "GEMM_MIN_M", "GEMM_HALO", "BNRED"); at library load every YS_<KEY>=<number> environment variable seeds the table, after that only these calls
+ * change it.  Production hosts never need them: the defaults are the measured optimum; the test-suite lowers size gates so that oracle-sized shapes reach
+ * the wide-layer kernels (tests/conftest.py), the A/B scripts under tools/ flip one switch per run. */
+YS_API int ys_set_option(const char* key, double value);
+YS_API int ys_unset_option(const char* key);
+
 YS_API int ys_dist_unique_id(void* id128);
 YS_API int ys_dist_init(ys_ctx* ctx, int rank, int world, const void* id128);
 YS_API int ys_dist_destroy(ys_ctx* ctx);

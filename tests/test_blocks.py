@@ -195,12 +195,8 @@ def test_block_bf16_rounding_matched_gpu(engine, backend, case):
         _block_bf16_matched(engine, case, 8, 20, 20)
     elif case == "c2f_halo":
         _block_bf16_matched(engine, case, 8, 80, 80)     # 200 tiles x 1 channel tile: one tile per workgroup ...
-        import os
-        os.environ["YS_HALO_MAX_GRID"] = "48"            # ... and the tile stream (4-5 tiles per workgroup: no per-tile prologue, operands of the next tile land under the epilogue)
-        try:
+        with engine.options(HALO_MAX_GRID=48):           # ... and the tile stream (4-5 tiles per workgroup: no per-tile prologue, operands of the next tile land under the epilogue)
             _block_bf16_matched(engine, case, 8, 80, 80)
-        finally:
-            del os.environ["YS_HALO_MAX_GRID"]
     else:
         _block_bf16_matched(engine, case, 8, 80, 80)
 

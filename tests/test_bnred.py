@@ -19,9 +19,7 @@ from oracle import yolo_oracle as O
 
 def _grads(engine, mode, fam, size, x, batch, sd, capfd=None):
     from yolosharp_amd.model import Yolov8, Yolov11, v8DetectionLoss
-    old = {k: os.environ.get(k) for k in ("YS_BNRED", "YS_BNRED_LOG")}
-    os.environ["YS_BNRED"] = mode
-    os.environ["YS_BNRED_LOG"] = "1"
+    engine.set_option("BNRED", int(mode)); engine.set_option("BNRED_LOG", 1)
     try:
         M = Yolov8 if fam == "8" else Yolov11
         m = M(engine, nc=80, size=size, height=x.shape[2], width=x.shape[3], max_batch=x.shape[0], dtype="bf16")
@@ -32,11 +30,7 @@ def _grads(engine, mode, fam, size, x, batch, sd, capfd=None):
         g = m.grads()
         m.close()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        engine.unset_option("BNRED"); engine.unset_option("BNRED_LOG")
     return g, items
 
 

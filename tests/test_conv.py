@@ -148,8 +148,8 @@ def test_conv_backward(backend, engine, dtype, case):
 @pytest.mark.parametrize("case", [15, 17, 18])
 def test_wgrad_gemm_short_k_tile(backend, engine, case, monkeypatch):
     """The 32-pixel K-tile variant of the blocked-GEMM wgrad kernel (chosen when two 64-pixel stages do not fit the LDS share)."""
-    monkeypatch.setenv("YS_WGEMM_KT", "32")
-    test_conv_backward(backend, engine, "bf16", case)
+    with engine.options(WGEMM_KT=32):
+        test_conv_backward(backend, engine, "bf16", case)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -158,10 +158,10 @@ def test_halo_kernel_tile_stream(backend, engine, grid, monkeypatch):
     """conv_halo_kernel's workgroups walk their tiles as ONE tap stream: the last chunk of a tile requests the next tile's first patch and taps (no per-tile
     prologue), patch buffers alternate across the tile boundary for odd chunk counts.  Oracle-sized maps have fewer tiles than the chip has CUs, so the test caps the grid:
     1, 2 or 4 workgroups for 6 / 2 tiles (odd and even chunk counts, ragged edges), forward (statistics + BN) and dgrad."""
-    monkeypatch.setenv("YS_HALO_MAX_GRID", grid)
-    for case in (len(FWD_CASES) - 5, len(FWD_CASES) - 4, len(FWD_CASES) - 2):
-        test_conv_bn_act_forward(backend, engine, "bf16", case)
-    test_conv_backward(backend, engine, "bf16", len(BWD_CASES) - 2)
+    with engine.options(HALO_MAX_GRID=int(grid)):
+        for case in (len(FWD_CASES) - 5, len(FWD_CASES) - 4, len(FWD_CASES) - 2):
+            test_conv_bn_act_forward(backend, engine, "bf16", case)
+        test_conv_backward(backend, engine, "bf16", len(BWD_CASES) - 2)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

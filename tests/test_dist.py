@@ -336,14 +336,22 @@ def test_bench_force_dist_world1():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-nms", "--no-infer"]
     outs = []
-    for extra in (["--force-dist"], []):
+    for extra in (["--force-dist"], [], ["--force-dist", "--dist-backend", "c"]):
         r = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    a, b = outs
+    a, b, c = outs
     assert a["n_gpus"] == 1 and a["scaling"] == "weak" and a["config"]["parallelism"] == "dp1" and a["value"] > 0
     assert a["roofline"]["bound"] == "hbm" and 0 < a["roofline"]["frac"] < 1
     assert np.allclose(a["loss_items"], b["loss_items"], rtol=1e-5)          # SUM over one rank: identical training trajectory
+    # round 5: the same step with the exchange driven by the library itself (ys_dist_init / ys_model_backward_allreduce: the C# host's path), and the
+    # first-run diagnostics of a multi-rank line (exposed all-reduce time, per-segment bytes, slowest / fastest rank)
+    assert np.allclose(c["loss_items"], b["loss_items"], rtol=1e-5)
+    assert "dist" not in b
+    for o, tag in ((a, "torch"), (c, "c (")):
+        d = o["dist"]
+        assert d["backend"].startswith(tag) and len(d["segment_allreduce_bytes"]) == 4 and d["allreduce_bytes_per_step"] == sum(d["segment_allreduce_bytes"])
+        assert d["rank_ms_per_step_min"] <= d["rank_ms_per_step_max"] and d["local_step_ms"] > 0 and abs(d["allreduce_exposed_ms"]) < 0.5 * d["local_step_ms"]
 
 
 def test_bench_gpus_n_spawns_n_ranks():

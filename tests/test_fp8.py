@@ -143,20 +143,11 @@ def test_model_fp8_mode(backend, engine):
     # Same for the Detect towers: the fp8 mode runs cv2[i][0] / cv3[i][0] as separate launches (c3 = 80 is not a multiple of the fp8
     # K unit) and does not group the levels, so the twin is built with YS_HEAD_FUSE=0 / YS_GROUP=0.  (A fused 144-wide launch and two
     # 64- / 80-wide ones reduce the BatchNorm statistics over different register tiles: equal in exact arithmetic, not bit for bit.)
-    twin_env = {"YS_BNRED": "0", "YS_HEAD_FUSE": "0", "YS_GROUP": "0"}
-    old_env = {k: os.environ.get(k) for k in twin_env}
-    os.environ.update(twin_env)
-    try:
+    with engine.options(BNRED=0, HEAD_FUSE=0, GROUP=0):       # (read when a model is created)
         for dt in ("fp8", "bf16"):
             m = Yolov8(engine, nc=nc, size=SZ, height=H, width=W, max_batch=B, dtype=dt)
             m.init_weights(3); m.train()
             ms[dt] = (m, v8DetectionLoss(m))
-    finally:
-        for k, v in old_env.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
     def step(dt, update=True):
         m, crit = ms[dt]
@@ -177,7 +168,9 @@ def test_model_fp8_mode(backend, engine):
     assert np.all(np.isfinite(i8)) and np.allclose(i8, ib, rtol=1.5e-1), (i8, ib)
     num = sum(float((g8[k].ravel() * gb[k].ravel()).sum()) for k in gb)
     den = np.sqrt(sum(float((g8[k] ** 2).sum()) for k in gb) * sum(float((gb[k] ** 2).sum()) for k in gb))
-    assert num / den > 0.6, num / den                            # 4-pixel deep maps at 64x64 (0.64-0.72 depending on the twin's launch schedule); the GPU test below uses a realistic size
+    # 4-pixel deep maps at 64 x 64: fp8 quantisation noise against the bf16 twin of the SAME routing (built under BNRED=0 / HEAD_FUSE=0 / GROUP=0 above) measures
+    # 0.64 - 0.72 here depending on the kernel routing of the round (0.697 in round 5); the GPU test below holds 0.9 on the classification branch at a realistic size
+    assert num / den > 0.62, num / den
     # eval forward uses the recorded activation scales
     ms["fp8"][0].eval(); ms["bf16"][0].eval()
     p8 = ms["fp8"][0].forward(x)[0]["boxes"]; pb = ms["bf16"][0].forward(x)[0]["boxes"]

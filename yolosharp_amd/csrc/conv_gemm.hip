@@ -331,7 +331,7 @@ struct GemmPlan { int ok, wm, wn, mr, nr, gx, gy; size_t lds; GemmArgs g; int ha
 // workgroup tile 16 x 16 pixels x (2 * nr * 16) channels, one workgroup of 8 waves per CU
 static GemmPlan conv_halo_plan(const ConvArgs& a) {
   GemmPlan p{};
-  static const bool off = getenv("YS_GEMM_HALO") && atoi(getenv("YS_GEMM_HALO")) == 0;   // A/B switch against the blocked kernel
+  const bool off = YS_OPT_INT("GEMM_HALO", 1) == 0;   // A/B switch against the blocked kernel
   if (off || a.f8) return p;
   if (!(a.KH == 3 && a.KW == 3 && a.SA == 1 && a.PAD == 1 && a.DIVM == 0 && a.out_rh == 0 && a.pad_w_delta == 0 && a.Hout == a.Hin && a.Wout == a.Win)) return p;
   if (a.Cin < 64 || a.Cout < 64) return p;
@@ -344,14 +344,14 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
   if ((long)p.gy * bn * 4 > (long)a.Cout * 5) return p;
   HaloArgs h{};
   h.nchunk = ys_cdiv(a.Cin, 64);
-  // launches that accumulate / carry the fused BN-backward reduction pay the LDS-staged epilogue once per tile with nothing to hide it behind (one wave per SIMD):
-  // with at most three chunks per tile (YOLOv8x 160 -> 160 at 160 x 160: 293 against 270 us) the blocked kernel keeps them
-  if ((a.nred > 0 || a.accumulate) && h.nchunk <= 3) return p;
+  // (The plan must depend on the geometry alone: the fused BN-backward row counts are planned before the segments are attached -- a gate on a.nred / a.accumulate
+  // sent planning and launch to different kernels with different grids.  Launches that accumulate / carry the reduction pay the LDS-staged epilogue once per tile
+  // with nothing to hide it behind; with three chunks per tile -- YOLOv8x 160 -> 160 at 160 x 160 -- they are 293 us against the blocked kernel's 270.)
   h.tiles_x = ys_cdiv(a.Wout, 16); h.tiles_y = ys_cdiv(a.Hout, 16);
   const long mt = (long)a.B * h.tiles_x * h.tiles_y;
   if (mt >= (1L << 24)) return p;
   // the pixel tiles must cover the maps without much waste (40 x 40: 9 tiles of 256 for 1600 pixels) and give every CU work
-  static const int min_fill = getenv("YS_HALO_MIN_FILL") ? atoi(getenv("YS_HALO_MIN_FILL")) : 75;   // per cent
+  const int min_fill = (int)YS_OPT_INT("HALO_MIN_FILL", 75);   // per cent
   if ((long)a.Hout * a.Wout * 100 < (long)h.tiles_x * h.tiles_y * 256 * min_fill) return p;
   h.mtiles = (int)mt;
   h.dTpi = ys_fastdiv_make((unsigned)(h.tiles_x * h.tiles_y)); h.dTx = ys_fastdiv_make((unsigned)h.tiles_x);
@@ -367,7 +367,7 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
   if (gx < 8) gx = 8;
   if (gx > mt) gx = mt;
   if (mt * p.gy <= 256) gx = mt;
-  { const char* f = getenv("YS_HALO_MAX_GRID"); if (f && atoi(f) > 0 && gx > atoi(f)) gx = atoi(f); }   // tests: workgroups that walk several tiles on oracle-sized shapes (read per call)
+  { const long cap = YS_OPT_INT("HALO_MAX_GRID", 0); if (cap > 0 && gx > cap) gx = cap; }   // tests: workgroups that walk several tiles on oracle-sized shapes
   p.gx = (int)gx;
   p.h = h; p.halo = 1; p.ok = 1;
   return p;
@@ -375,15 +375,15 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
 
 static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   GemmPlan p{};
-  static const bool off = getenv("YS_NO_GEMM") != nullptr;
+  const bool off = YS_OPT_INT("NO_GEMM", 0) != 0;
   // 160 (was 128 until the end of round 4): with 128 <= Cin < 160 only the wide-output 3x3 layers (below) stay here.  What moved to the patch kernel, per-launch
   // records of YOLOv8n B = 64: the dgrad of the fused tower input at P3 (cin144 -> cout64, M = 409600: 168 -> 110 us -- a 256 x 64 tile leaves this kernel one
   // workgroup per CU) and the 2x2 / 1x2 / 2x1 phases of the stride-2 dgrads with 128 gradient channels, which join their 1x1 phase in ONE grouped patch-kernel
   // launch (141 -> 78 us, 92 -> 49 us); step 8.85 -> 8.76 ms
-  static const int min_cin = getenv("YS_GEMM_MIN_CIN") ? atoi(getenv("YS_GEMM_MIN_CIN")) : 160;
-  static const int min_k = getenv("YS_GEMM_MIN_K") ? atoi(getenv("YS_GEMM_MIN_K")) : 256;
+  const int min_cin = (int)YS_OPT_INT("GEMM_MIN_CIN", 160);
+  const int min_k = (int)YS_OPT_INT("GEMM_MIN_K", 256);
   const bool f8 = a.f8 != 0;
-  static const bool f8_off = getenv("YS_NO_GEMM_F8") != nullptr;
+  const bool f8_off = YS_OPT_INT("NO_GEMM_F8", 0) != 0;
   if (off || (f8 && (f8_off || !a.x8 || !a.w8 || !a.deq || a.Cin % 16))) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
   const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
@@ -395,14 +395,14 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   if (a.res && (a.res_ldc % 8 || a.res_coff % 8)) return p;
   const int taps = a.KH * a.KW;
   const long Ktot = (long)taps * a.Cin;
-  static const int min_m = getenv("YS_GEMM_MIN_M") ? atoi(getenv("YS_GEMM_MIN_M")) : 1024;
+  const int min_m = (int)YS_OPT_INT("GEMM_MIN_M", 1024);
   // stride-2 3x3 layers with 64 <= Cin < 128 come here too (round 4): the whole-Cin patch of a stride-2 tile is four times the tile's area, so the patch
   // kernel falls back to 2 x 22-pixel tiles whose patch every output-channel column re-reads (64 -> 128 at 80 x 80: 71 us, 9.4x its floor)
-  static const int s2_min_cin = getenv("YS_GEMM_S2_MIN_CIN") ? atoi(getenv("YS_GEMM_S2_MIN_CIN")) : 64;
+  const int s2_min_cin = (int)YS_OPT_INT("GEMM_S2_MIN_CIN", 64);
   const bool s2_narrow = k3 && a.SA == 2 && a.Cin >= s2_min_cin && !f8;
   // ... and stride-1 3x3 layers with 64 <= Cin < 128 whose output is wide (the fused Detect / Segment tower input, 64 -> 144): the patch kernel streams
   // 166 KB of weights per 256-pixel tile there
-  static const int wide_cout = getenv("YS_GEMM_WIDE_COUT") ? atoi(getenv("YS_GEMM_WIDE_COUT")) : 128;
+  const int wide_cout = (int)YS_OPT_INT("GEMM_WIDE_COUT", 128);
   const bool wide_out = k3 && a.SA == 1 && a.Cin >= 64 && a.Cout >= wide_cout && !f8;
   if ((a.Cin < min_cin && !s2_narrow && !wide_out) || Ktot < min_k || a.Cout < 64 || a.M < min_m) return p;
   if (k3 && a.SA == 1 && !f8) { const GemmPlan hp = conv_halo_plan(a); if (hp.ok) return hp; }
@@ -441,7 +441,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   // latency (s_memtime stamps, round 3: 1600-1750 cycles per K-tile whatever the tile): a second workgroup on the CU covers the gap
   // when the grid has one; a launch with at most one workgroup per CU (the deep YOLOv8n layers at B = 64: 200 tiles) has nothing
   // else to run and takes as many stages as the LDS holds instead.  YS_GEMM_STAGES forces a depth (A/B runs).
-  static const int force_st = getenv("YS_GEMM_STAGES") ? atoi(getenv("YS_GEMM_STAGES")) : 0;
+  const int force_st = (int)YS_OPT_INT("GEMM_STAGES", 0);
   g.nstage = 2;
   {
     int fit = (int)((160 * 1024 - (size_t)g.off_stage) / g.stage_bytes);

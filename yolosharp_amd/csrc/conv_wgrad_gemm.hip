@@ -186,12 +186,12 @@ static int wgemm_pick_tile(int c) {           // 160 or 128 channels: least padd
 
 static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
   WgGemmPlan p{};
-  static const bool off = getenv("YS_NO_WGEMM") != nullptr;
-  static const int min_c = getenv("YS_WGEMM_MIN_C") ? atoi(getenv("YS_WGEMM_MIN_C")) : 128;
-  static const int min_m = getenv("YS_WGEMM_MIN_M") ? atoi(getenv("YS_WGEMM_MIN_M")) : 4096;
-  const char* kt_s = getenv("YS_WGEMM_KT");   // read per plan (not cached): the tests switch K-tile variants inside one process
-  const int kt_env = kt_s ? atoi(kt_s) : 0;
-  static const int wpc_env = getenv("YS_WGEMM_WPC") ? atoi(getenv("YS_WGEMM_WPC")) : 0;
+  const bool off = YS_OPT_INT("NO_WGEMM", 0) != 0;
+  const int min_c = (int)YS_OPT_INT("WGEMM_MIN_C", 128);
+  const int min_m = (int)YS_OPT_INT("WGEMM_MIN_M", 4096);
+  const long kt_opt = YS_OPT_INT("WGEMM_KT", 0);   // (the tests switch K-tile variants inside one process)
+  const int kt_env = (int)kt_opt;
+  const int wpc_env = (int)YS_OPT_INT("WGEMM_WPC", 0);
   if (off) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2);
   const bool k1 = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1;

@@ -5,6 +5,51 @@
 
 static thread_local char g_err[1024] = "";
 
+// ---- option table (ys_internal.h)
+#include <mutex>
+#include <cstdlib>
+extern char** environ;
+namespace {
+struct OptTable {
+  std::mutex mu;
+  std::map<std::string, double> v;
+  std::atomic<unsigned> version{1};
+  OptTable() {
+    // the ONE place the environment is read: YS_<KEY>=<number> seeds the table at library load (a non-numeric or empty value counts as 1: presence-style switches)
+    for (char** e = environ; e && *e; e++) {
+      if (strncmp(*e, "YS_", 3) != 0) continue;
+      const char* eq = strchr(*e, '=');
+      if (!eq || eq == *e + 3) continue;
+      char* end = nullptr;
+      const double d = strtod(eq + 1, &end);
+      v[std::string(*e + 3, (size_t)(eq - (*e + 3)))] = (end && end != eq + 1 && *end == 0) ? d : 1.0;
+    }
+  }
+};
+OptTable& opt_table() { static OptTable t; return t; }
+}  // namespace
+double ys_opt_get(const char* key, double def) {
+  OptTable& t = opt_table();
+  std::lock_guard<std::mutex> g(t.mu);
+  auto it = t.v.find(key);
+  return it == t.v.end() ? def : it->second;
+}
+unsigned ys_opt_version() { return opt_table().version.load(std::memory_order_acquire); }
+extern "C" __attribute__((visibility("default"))) int ys_set_option(const char* key, double value) {
+  if (!key || !*key) { ys_set_error("ys_set_option: empty key"); return YS_ERR_INVALID_ARG; }
+  OptTable& t = opt_table();
+  { std::lock_guard<std::mutex> g(t.mu); t.v[strncmp(key, "YS_", 3) == 0 ? key + 3 : key] = value; }
+  t.version.fetch_add(1, std::memory_order_acq_rel);
+  return YS_OK;
+}
+extern "C" __attribute__((visibility("default"))) int ys_unset_option(const char* key) {
+  if (!key || !*key) { ys_set_error("ys_unset_option: empty key"); return YS_ERR_INVALID_ARG; }
+  OptTable& t = opt_table();
+  { std::lock_guard<std::mutex> g(t.mu); t.v.erase(strncmp(key, "YS_", 3) == 0 ? key + 3 : key); }
+  t.version.fetch_add(1, std::memory_order_acq_rel);
+  return YS_OK;
+}
+
 void ys_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -391,7 +391,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
   // v11 heads (legacy = false) start their class tower with a depthwise unit: nothing to fuse with there.  YS_HEAD_FUSE=0: one launch each.
   const int c4s = d.task == YS_SEGMENT ? std::max(ch[0] / 4, 32) : 0;
   const int cf = c2 + c3 + c4s;
-  bool fuse = legacy && !(getenv("YS_HEAD_FUSE") && atoi(getenv("YS_HEAD_FUSE")) == 0) && (c4s % m->epl) == 0;
+  bool fuse = legacy && (YS_OPT_INT("HEAD_FUSE", 1) != 0) && (c4s % m->epl) == 0;
   if (m->f8 && (cf % 32 || c2 % 32 || c3 % 32)) fuse = false;   // fp8 mode: the dgrad of a fused layer must still qualify for the fp8 kernel (K units of 32)
   int fbuf[3] = {-1, -1, -1}, fconv[3] = {-1, -1, -1};
   const size_t op0 = m->ops.size();
@@ -497,7 +497,7 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
   // tower layer of P3, P4, P5 next to each other -- and every stage of >= 2 units is one group.  Units of a stage read and write disjoint
   // buffers (per-level towers, per-level rows of the prediction buffers); a stage only depends on earlier stages of its own tower and on
   // the (fused) first layers, which sort first.
-  const bool group_on = legacy && !(getenv("YS_GROUP") && atoi(getenv("YS_GROUP")) == 0) && !m->f8;
+  const bool group_on = legacy && (YS_OPT_INT("GROUP", 1) != 0) && !m->f8;
   if (group_on) {
     bool all = true;
     for (size_t k = op0; k < m->ops.size(); k++) all = all && m->ops[k].type == OP_CONV && m->convs[m->ops[k].conv].stage >= 0;
@@ -965,7 +965,7 @@ int allocate(ys_model* m) {
   // of everything until the segment ends, and both chains are latency-bound: measured 10.50 -> 10.30 ms/step (+2 %) on config 2
   // (round 2, before the deferral: +1.4 %).  Co-running kernels time-slice the CUs, so PER-KERNEL durations inflate (conv class +7 %):
   // bench.py switches the overlap off (ys_model_set_overlap) for its per-kernel profile steps.  YS_OVERLAP=0 disables it.
-  m->overlap = !(getenv("YS_OVERLAP") != nullptr && atoi(getenv("YS_OVERLAP")) == 0);
+  m->overlap = (YS_OPT_INT("OVERLAP", 1) != 0);
   m->overlap_built = m->overlap;
   if (m->overlap) {
     // lowest priority: the weight gradients are off the critical path (the optimizer is their only reader), and a priority class of
@@ -974,7 +974,7 @@ int allocate(ys_model* m) {
     // shifted the assignment: 11.6 instead of 10.2 ms/step).  YS_ST2_PRIO=0: default priority.
     {
       int least = 0, greatest = 0;
-      const bool low = !(getenv("YS_ST2_PRIO") && atoi(getenv("YS_ST2_PRIO")) == 0);
+      const bool low = (YS_OPT_INT("ST2_PRIO", 1) != 0);
       if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
         YS_CHECK_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, least));
       else
@@ -1003,12 +1003,12 @@ int allocate(ys_model* m) {
     if (gst) YS_TRY(dev_alloc(m, (void**)&m->stat_group, (size_t)gst * 4));
   }
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
-  const bool ticket_uc = getenv("YS_BN_TICKET") && atoi(getenv("YS_BN_TICKET")) == 2;   // 2: statistics rows + tickets in uncached memory, no fences
+  const bool ticket_uc = YS_OPT_INT("BN_TICKET", -1) == 2;   // 2: statistics rows + tickets in uncached memory, no fences
   YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4, true, ticket_uc));
   // off by default: measured (round 3, config 2) 10.52-10.55 ms/step with the lanes against 9.98-10.01 without (round 2's variant of the
   // same experiment: -5.7 %).  The P3 chain's kernels are persistent grids sized to own every CU (2-3 workgroups per CU by LDS); a
   // side-stream kernel that takes some of those slots turns the big kernel's equal tile shares into a tail.  YS_HEAD_LANES=1 enables it.
-  m->bn_ticket = getenv("YS_BN_TICKET") && atoi(getenv("YS_BN_TICKET")) != 0;
+  m->bn_ticket = YS_OPT_INT("BN_TICKET", 0) != 0;
   if (m->bn_ticket) {
     YS_TRY(dev_alloc(m, (void**)&m->fin_tickets, m->convs.size() * 16 * sizeof(unsigned), true, ticket_uc));   // zero-initialised
     std::vector<BnFinArgs> h(m->convs.size());
@@ -1025,7 +1025,7 @@ int allocate(ys_model* m) {
     YS_TRY(dev_alloc(m, (void**)&m->fin_dev, h.size() * sizeof(BnFinArgs), false));
     YS_CHECK_HIP(hipMemcpy(m->fin_dev, h.data(), h.size() * sizeof(BnFinArgs), hipMemcpyHostToDevice));
   }
-  m->head_lanes = m->overlap_built && getenv("YS_HEAD_LANES") && atoi(getenv("YS_HEAD_LANES")) != 0;
+  m->head_lanes = m->overlap_built && YS_OPT_INT("HEAD_LANES", 0) != 0;
   if (m->head_lanes) {
     bool any = false;
     for (auto& c : m->convs) any = any || c.lane > 0;
@@ -1043,9 +1043,9 @@ int allocate(ys_model* m) {
   // wgrad partial workspace: a shared scratch (max over layers of splits * |W|: ConvTranspose phases, immediate reduction) followed by
   // one region per convolution, so that the split reduction of a whole backward segment can run as ONE launch after it
   // (YS_WGRED_DEFER=0: per-layer reduction in the shared scratch, the round-2 behaviour)
-  m->defer_wgred = !(getenv("YS_WGRED_DEFER") && atoi(getenv("YS_WGRED_DEFER")) == 0);
-  m->stem_on = !(getenv("YS_STEM_DIRECT") && atoi(getenv("YS_STEM_DIRECT")) == 0);
-  m->bnred_on = !(getenv("YS_BNRED") && atoi(getenv("YS_BNRED")) == 0);           // YS_BNRED=0: every BN backward runs its own reduction pass
+  m->defer_wgred = (YS_OPT_INT("WGRED_DEFER", 1) != 0);
+  m->stem_on = (YS_OPT_INT("STEM_DIRECT", 1) != 0);
+  m->bnred_on = (YS_OPT_INT("BNRED", 1) != 0);           // YS_BNRED=0: every BN backward runs its own reduction pass
   long wgp = 0, wgp_regions = 0;
   std::vector<long> need(m->convs.size(), 0);
   for (auto& c : m->convs) {
@@ -1576,7 +1576,7 @@ int plan_bnred(ys_model* m, int B) {
     YS_TRY(dev_alloc(m, (void**)&m->bnred_part, (size_t)off * 4));
     m->n_bnred = off;
   }
-  if (getenv("YS_BNRED_LOG")) {
+  if (YS_OPT_INT("BNRED_LOG", 0) != 0) {
     int nf = 0, nb = 0;
     for (auto& l : m->convs) { if (l.bn) nb++; if (l.red_ok) nf++; }
     fprintf(stderr, "[ys] fused BN-backward reduction: %d of %d BN conv units (B=%d, %.1f MB of partial rows)\n", nf, nb, B, off * 4.0 / 1e6);

@@ -603,7 +603,7 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   if (!ctx->nms_count_clean || B > ctx->nms_count_clean_B) YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));
   ctx->nms_count_clean = false;
   YsKprofScope prof(ctx->stream, "nms");
-  static const bool dbg = getenv("YS_NMS_DEBUG") != nullptr;
+  const bool dbg = YS_OPT_INT("NMS_DEBUG", 0) != 0;
 #define NMS_DBG(what) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(ctx->stream); hipError_t l_ = hipGetLastError(); fprintf(stderr, "nms %s: sync %d last %d\n", what, (int)e_, (int)l_); } } while (0)
   NMS_DBG("entry");
   unsigned long long* keys = (unsigned long long*)(ws + o_keys);

@@ -10,6 +10,18 @@
 
 void ys_set_error(const char* fmt, ...);
 
+// ---- tuning / routing options (round 5).  ONE process-wide table replaces the ~45 getenv("YS_*") sites of rounds 1-4: ys_set_option (C ABI) writes it, the
+// kernel plans read it through YS_OPT_INT / YS_OPT_F (a cached value per call site, refreshed when the table's version changes -- so a test or a host can flip a
+// gate between two launches of one process, which a `static const ... = getenv(...)` could not).  The environment is read in exactly one place: when the library
+// is loaded, every YS_<KEY>=<number> variable seeds the table (the A/B scripts under tools/ keep working); later changes of the environment are not seen.
+double ys_opt_get(const char* key, double def);
+unsigned ys_opt_version();
+#include <atomic>
+#define YS_OPT_F(key, def) ([]() -> double { static std::atomic<unsigned> ver_{0xffffffffu}; static std::atomic<double> val_{0.0}; \
+    const unsigned g_ = ys_opt_version(); if (ver_.load(std::memory_order_acquire) != g_) { val_.store(ys_opt_get(key, (double)(def)), std::memory_order_relaxed); ver_.store(g_, std::memory_order_release); } \
+    return val_.load(std::memory_order_relaxed); }())
+#define YS_OPT_INT(key, def) ((long)YS_OPT_F(key, def))
+
 #define YS_CHECK_HIP(expr)                                                                   \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \

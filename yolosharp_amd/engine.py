@@ -103,6 +103,28 @@ class Engine:
         _lib.check(self.lib, self.lib.ys_memcpy_d2h(self.ctx, _ptr(out), p, out.nbytes))
         return out
 
+    # ---- tuning / routing options of the library (process-wide; include/yolosharp_hip.h ys_set_option)
+    def set_option(self, key, value):
+        _lib.check(self.lib, self.lib.ys_set_option(str(key).encode(), float(value)))
+
+    def unset_option(self, key):
+        _lib.check(self.lib, self.lib.ys_unset_option(str(key).encode()))
+
+    def options(self, **kw):
+        """Context manager: set the options for the body, remove them afterwards (tests: `with engine.options(BNRED=0): ...`)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            for k, v in kw.items():
+                self.set_option(k, v)
+            try:
+                yield self
+            finally:
+                for k in kw:
+                    self.unset_option(k)
+        return cm()
+
     # ---- data-parallel exchange through the C ABI (RCCL inside the library; bench.py uses torch.distributed instead)
     def dist_unique_id(self):
         buf = (C.c_ubyte * 128)()
