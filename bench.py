@@ -194,9 +194,16 @@ def main():
             pass
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    c_dist = distributed and args.dist_backend == "c"
+    rdev = torch.device("cpu") if c_dist else dev     # where the control-plane tensors (timing reductions) live
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if c_dist:
+            # the library brings its own RCCL communicator (dlopen'ed librccl.so): torch.distributed only carries the rendezvous, over gloo -- a second RCCL
+            # instance (torch's bundled copy) in the same process is exactly what a C# host would not have
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if os.environ.get("YS_BENCH_NO_PG_BARRIER") != "1":   # (triage switch)
             dist.barrier()   # the communicator (its streams and buffers) exists before the engine creates its own streams: without it the
                              # engine's two streams ended up serialised (11.6 instead of 10.3 ms/step at one rank)
@@ -217,7 +224,6 @@ def main():
     eng = Engine(local_rank, stream=stream, lib_path=args.lib or None)   # N>1: run on torch's stream so RCCL orders against our kernels
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
         raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
-    c_dist = distributed and args.dist_backend == "c"
     if c_dist:
         # the library's own communicator, BEFORE the model creates its streams (hardware-queue assignment follows creation order): rank 0 creates
         # the RCCL unique id, torch.distributed ships it (any host channel would do), every rank joins
@@ -294,15 +300,16 @@ def main():
     elapsed = time.perf_counter() - t0
     rccl_ranks = 1
     dist_info = None
+    items = crit.read()[1]                          # loss items of the last TIMED step (before the untimed diagnostic steps below)
     if distributed:
         own = elapsed
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         elapsed = float(t.item())
-        ones = torch.ones(1, device=dev, dtype=torch.float32)
-        dist.all_reduce(ones)                      # SUM over RCCL: how many ranks really took part
+        ones = torch.ones(1, device=rdev, dtype=torch.float32)
+        dist.all_reduce(ones)                      # SUM over the process group (RCCL, or gloo with --dist-backend c): how many ranks really took part
         rccl_ranks = int(ones.item())
         # what the exchange costs this step: the same ranks run the LOCAL step (no all-reduce) for a short timed region right after, between the same
         # barriers -- exposed all-reduce time = distributed step - local step (max over ranks of each)
@@ -314,7 +321,7 @@ def main():
         for _ in range(n_loc):
             local_step()
         barrier()
-        tl = torch.tensor([(time.perf_counter() - t1) / n_loc], device=dev, dtype=torch.float64)
+        tl = torch.tensor([(time.perf_counter() - t1) / n_loc], device=rdev, dtype=torch.float64)
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         ms_local = float(tl.item()) * 1e3
         dist_info = {"backend": "c (ys_dist_* in libyolosharp_hip.so)" if c_dist else "torch.distributed (nccl = RCCL)",
@@ -323,7 +330,6 @@ def main():
                      "segment_allreduce_bytes": [int(c) * 4 for _, c in seg_ranges], "allreduce_bytes_per_step": int(sum(c for _, c in seg_ranges)) * 4,
                      "note": "allreduce_exposed_ms = ms_per_step (max over ranks) - the same ranks' local step (forward + criterion + backward + AdamW, no exchange) timed right after; "
                              "segments in backward order (head, neck, late backbone, stem): each all-reduce is issued when its segment's gradients are complete and overlaps the next segment"}
-    items, total = crit.read()[1], None
     ms = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
 

@@ -229,11 +229,11 @@ def test_c5_v8x_1280_bs16_fp8_train_steps(eng, monkeypatch):
     hist = {}
     for tag, dt in (("fp8", "fp8"), ("fp8_again", "fp8"), ("bf16", "bf16")):
         if dt == "bf16":
-            eng.set_option("HEAD_FUSE", 0); eng.set_option("GROUP", 0)
+            eng.set_option("HEAD_FUSE", 0); eng.set_option("GROUP", 0); eng.set_option("BN_ATOMIC", 0)
         try:
             m = Yolov8(eng, nc=nc, size="x", height=H, width=W, max_batch=B, dtype=dt)
         finally:
-            eng.unset_option("HEAD_FUSE"); eng.unset_option("GROUP")
+            eng.unset_option("HEAD_FUSE"); eng.unset_option("GROUP"); eng.unset_option("BN_ATOMIC")
         m.init_weights(7); m.train()
         crit = v8DetectionLoss(m)
         rec = []

@@ -143,7 +143,8 @@ def test_model_fp8_mode(backend, engine):
     # Same for the Detect towers: the fp8 mode runs cv2[i][0] / cv3[i][0] as separate launches (c3 = 80 is not a multiple of the fp8
     # K unit) and does not group the levels, so the twin is built with YS_HEAD_FUSE=0 / YS_GROUP=0.  (A fused 144-wide launch and two
     # 64- / 80-wide ones reduce the BatchNorm statistics over different register tiles: equal in exact arithmetic, not bit for bit.)
-    with engine.options(BNRED=0, HEAD_FUSE=0, GROUP=0):       # (read when a model is created)
+    # Round 5: ... and with the statistics as rows + bn_finalize (BN_ATOMIC=0), which the fp8 mode keeps (its apply pass also writes the e4m3 image).
+    with engine.options(BNRED=0, HEAD_FUSE=0, GROUP=0, BN_ATOMIC=0):       # (read when a model is created; BN_ATOMIC: the fp8 mode keeps statistics rows + bn_finalize)
         for dt in ("fp8", "bf16"):
             m = Yolov8(engine, nc=nc, size=SZ, height=H, width=W, max_batch=B, dtype=dt)
             m.init_weights(3); m.train()

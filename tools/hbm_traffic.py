@@ -12,7 +12,7 @@ import json
 import re
 import sys
 
-CONV_CLASS = ("conv_p2_kernel", "conv_gemm_kernel", "conv_igemm_kernel", "conv3x3_tile_kernel")
+CONV_CLASS = ("conv_p2_kernel", "conv_p2_group_kernel", "conv_gemm_kernel", "conv_halo_kernel", "conv_igemm_kernel", "conv3x3_tile_kernel")
 
 
 def load(path, counter):

@@ -145,8 +145,11 @@ __device__ inline void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MR][NR], co
     if (tid < BN && n0 + tid < a.Cout) {
       float t1 = 0.f, t2 = 0.f;
       for (int w = 0; w < NW; w++) { t1 += sStat[(w * BN + tid) * 2 + 0]; t2 += sStat[(w * BN + tid) * 2 + 1]; }
-      a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
-      a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
+      if (a.stat_acc) { ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + tid, 0, t1); ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + tid, 1, t2); }
+      else {
+        a.stats[(stat_row * 2 + 0) * a.Cout + n0 + tid] = t1;
+        a.stats[(stat_row * 2 + 1) * a.Cout + n0 + tid] = t2;
+      }
     }
   }
 }

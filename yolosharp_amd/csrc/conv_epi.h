@@ -633,7 +633,7 @@ __device__ inline void p2_stats_flush_direct(const ConvArgs& a, int n0, float (&
 #pragma unroll
     for (int w = 1; w < WM; w++) t += scr[(which * WM + w) * BN + c];
     if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
-    else if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
+    else if (n0 + c < a.Cout) { if (a.stat_acc) ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + c, which, t); else a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t; }
   }
 }
 
@@ -678,7 +678,7 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
 #pragma unroll
     for (int pi = 1; pi < P; pi++) t += part[pi * 2 * BN + o];      // fixed order -> deterministic
     if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
-    else if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
+    else if (n0 + c < a.Cout) { if (a.stat_acc) ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + c, which, t); else a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t; }
   }
 }
 
@@ -705,6 +705,6 @@ __device__ inline void conv_stats_flush_grid(const ConvArgs& a, int n0, float (&
     for (int wm = 0; wm < WM; wm++)
       for (int j = 0; j < PPI; j++) t += col[(wm * WN + wn) * 64 + j * VPP];
     if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
-    else if (n0 + c < a.Cout) a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t;
+    else if (n0 + c < a.Cout) { if (a.stat_acc) ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + c, which, t); else a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t; }
   }
 }

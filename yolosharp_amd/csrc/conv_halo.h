@@ -278,7 +278,12 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
         });
         // ---- tap + 1 has landed (this wave's pieces: everything older than the requests of the previous iteration), everybody's have
         {
-          constexpr int np_prev = tap == 0 ? 0 : (tap - 1 < 3 ? 2 : 1);     // patch pieces every wave issued in the previous iteration (unconditional requests: constants)
+          // patch pieces every wave issued in the previous iteration (unconditional requests: constants).  Schedule of a chunk's 12 pieces: two at taps 0 - 4, one at
+          // taps 5 - 6, NONE at taps 7 - 8: this wait covers what was issued up to TWO iterations ago, and the next chunk's patch is first read right behind the
+          // barrier of tap 8 -- so its last piece must be issued by tap 6.  (The first version issued one piece per tap up to tap 8: the last two were read
+          // without a covering wait -- correct in the interpreter, where a request lands at once, and almost always on the device; it showed as a loss that
+          // differed in the fourth digit between two runs of bench.py.)
+          constexpr int np_prev = tap == 0 ? 0 : (tap - 1 <= 4 ? 2 : (tap - 1 <= 6 ? 1 : 0));
           ys_wait_vm<np_prev + NBW>();
           ys_barrier_lds();
         }
@@ -289,8 +294,8 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
         const unsigned cqs = more ? (unsigned)cq : (YS_BUF_OOB >> 7);     // chunk index of the patch requests; out of range when the stream ends
         auto hook1 = [&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          // requests at MFMAs 0, 2, 4, ...: [patch piece(s) of the next chunk: two at taps 0 - 2, one after], weights of tap + 3
-          constexpr int NPT = tap < 3 ? 2 : 1, JP0 = tap < 3 ? 2 * tap : tap + 3;        // patch pieces of this tap: JP0 .. JP0 + NPT - 1 (12 per chunk)
+          // requests at MFMAs 0, 2, 4, ...: [patch piece(s) of the next chunk: two at taps 0 - 4, one at taps 5 - 6], weights of tap + 3
+          constexpr int NPT = tap <= 4 ? 2 : (tap <= 6 ? 1 : 0), JP0 = tap <= 4 ? 2 * tap : tap + 5;   // patch pieces of this tap: JP0 .. JP0 + NPT - 1 (12 per chunk)
           if constexpr ((i & 1) == 0 && i / 2 < NPT) issue_p(par ^ 1, (int)cqs, std::integral_constant<int, JP0 + i / 2>{});
           else if constexpr ((i & 1) == 0 && i / 2 < NPT + NBW) issue_w1(tap % 3, so3, i / 2 - NPT);
           else if constexpr (i >= 2 * (NPT + NBW) && i < 2 * (NPT + NBW) + NR + MR) {

@@ -30,6 +30,7 @@ struct StemFwdArgs {
   const bf16_t* wf;          // forward weight shadow [Cout][9][8] (channels 3..7 zero)
   bf16_t* y;                 // [B][out_bstride][out_ldc] + out_coff
   float* stats;              // training: one row [2][Cout] per workgroup (sum, sum of squares of the bf16-rounded outputs)
+  unsigned long long* stat_acc;   // ... or, when set, fixed-point integer accumulators (ys_kernels.h ys_stat_acc_add)
   const float* scale;        // eval: BatchNorm folded to scale / shift (+ SiLU when act)
   const float* shift;
   int B, H, W, Hout, Wout, Cout, out_ldc, out_coff, act;
@@ -177,8 +178,11 @@ stem_fwd_kernel(StemFwdArgs a) {
     if (tid < NR * 16 && tid < a.Cout) {
       const float s1 = (sStat[0][tid][0] + sStat[1][tid][0]) + (sStat[2][tid][0] + sStat[3][tid][0]);
       const float s2 = (sStat[0][tid][1] + sStat[1][tid][1]) + (sStat[2][tid][1] + sStat[3][tid][1]);
-      a.stats[((long)blockIdx.x * 2 + 0) * a.Cout + tid] = s1;
-      a.stats[((long)blockIdx.x * 2 + 1) * a.Cout + tid] = s2;
+      if (a.stat_acc) { ys_stat_acc_add(a.stat_acc, (long)blockIdx.x, a.Cout, tid, 0, s1); ys_stat_acc_add(a.stat_acc, (long)blockIdx.x, a.Cout, tid, 1, s2); }
+      else {
+        a.stats[((long)blockIdx.x * 2 + 0) * a.Cout + tid] = s1;
+        a.stats[((long)blockIdx.x * 2 + 1) * a.Cout + tid] = s2;
+      }
     }
   }
 }
@@ -195,9 +199,9 @@ int ys_stem_fwd_rows(int B, int Hout, int Wout) {
 
 // training (stats != nullptr): raw bf16 output + one statistics row per workgroup (*rows); eval: scale / shift (+ SiLU) applied
 int ys_stem_fwd_launch(hipStream_t st, const float* x, int B, int H, int W, const void* wf, int Cout, void* y, int out_ldc, int out_coff,
-                       long out_bstride, float* stats, const float* scale, const float* shift, int act, int* rows) {
+                       long out_bstride, float* stats, const float* scale, const float* shift, int act, int* rows, unsigned long long* stat_acc) {
   StemFwdArgs a{};
-  a.x = x; a.wf = (const bf16_t*)wf; a.y = (bf16_t*)y; a.stats = stats; a.scale = scale; a.shift = shift; a.act = act;
+  a.x = x; a.wf = (const bf16_t*)wf; a.y = (bf16_t*)y; a.stats = stats; a.stat_acc = stat_acc; a.scale = scale; a.shift = shift; a.act = act;
   a.B = B; a.H = H; a.W = W; a.Hout = (H - 1) / 2 + 1; a.Wout = (W - 1) / 2 + 1; a.Cout = Cout;
   a.out_ldc = out_ldc; a.out_coff = out_coff; a.out_bstride = out_bstride;
   a.tiles_x = ys_cdiv(a.Wout, STEM_TW); a.tiles_y = ys_cdiv(a.Hout, STEM_TH); a.ntiles = B * a.tiles_x * a.tiles_y;

@@ -353,6 +353,76 @@ int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, 
   return YS_OK;
 }
 
+// ------------------------------------------------------------------ BN finalize + apply in one pass (round 5)
+// The convolution left the unit's batch statistics as fixed-point integer sums (ys_stat_acc_add: 64-bit atomics, YS_STAT_SHARDS copies).  Every workgroup adds the
+// copies and does bn_finalize_kernel's arithmetic for all C channels itself (same integers in, same double arithmetic: the same coefficients in every workgroup, no
+// hand-off between workgroups) into LDS; workgroup 0 also stores scale / shift / mean / rstd for the backward pass and updates the running statistics.  Grid-stride
+// with a bounded grid so that the C-channel prologue is paid ~2 thousand times per launch, not once per 256 vectors.  The separate bn_finalize launch (4.9 us + a
+// kernel boundary, 45 per YOLOv8n step) goes.
+template <class T, bool ACT>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_fin_apply_kernel(const T* __restrict__ y, long rows, int C, BnAccFin f, const T* __restrict__ res, int res_ldc, int res_coff,
+                    T* __restrict__ z, int z_ldc, int z_coff) {
+  constexpr int EPL = Elem<T>::EPL;
+  YS_DYN_LDS(lds);
+  float* s_sc = (float*)lds;                   // [C] scale, [C] shift
+  float* s_sh = s_sc + C;
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    long long a1 = 0, a2 = 0;
+#pragma unroll
+    for (int s = 0; s < YS_STAT_SHARDS; s++) {
+      a1 += (long long)f.acc[((long)s * C + c) * 2 + 0];
+      a2 += (long long)f.acc[((long)s * C + c) * 2 + 1];
+    }
+    const double s1 = (double)a1 * (1.0 / (double)YS_STAT_FIX), s2 = (double)a2 * (1.0 / (double)YS_STAT_FIX);
+    const double mean = s1 / f.count;
+    double var = s2 / f.count - mean * mean;   // biased (torch BatchNorm2d training normalisation)
+    if (var < 0.0) var = 0.0;
+    const float g = f.gamma[c], bt = f.beta[c];
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float sc = g * rstd, sh = bt - (float)mean * g * rstd;
+    s_sc[c] = sc; s_sh[c] = sh;
+    if (blockIdx.x == 0) {
+      f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = (float)mean; f.rstd[c] = rstd;
+      // running stats: momentum 0.03, unbiased variance (Convs.cs:41-42,48)
+      const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+      f.run_mean[c] = (1.0f - f.momentum) * f.run_mean[c] + f.momentum * (float)mean;
+      f.run_var[c] = (1.0f - f.momentum) * f.run_var[c] + f.momentum * (float)unb;
+      if (c == 0 && f.nbt) f.nbt[0] = f.nbt[0] + 1.0f;
+    }
+  }
+  __syncthreads();
+  const int CG = C / EPL;
+  const long n = rows * CG;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) {
+    const long row = i / CG; const int c = (int)(i - row * CG) * EPL;
+    float v[EPL], r[EPL];
+    ys_unpack<T>(ys_ld16(y + row * C + c), v);
+    if (res) ys_unpack<T>(ys_ld16(res + row * res_ldc + res_coff + c), r);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      float u = v[e] * s_sc[c + e] + s_sh[c + e];
+      if (ACT) u = ys_silu(u);
+      if (res) u += r[e];
+      v[e] = u;
+    }
+    ys_st16(z + row * z_ldc + z_coff + c, ys_pack<T>(v));
+  }
+}
+int ys_bn_fin_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const BnAccFin& f, int act, const void* res, int res_ldc, int res_coff,
+                           void* z, int z_ldc, int z_coff) {
+  const int epl = dtype == YS_BF16 ? 8 : 4;
+  const long n = rows * (C / epl);
+  const long gcap = (long)YS_OPT_INT("FINAPPLY_GRID", 2048);
+  long g = ys_cdiv(n, EW_THREADS * 2L); if (g > gcap) g = gcap; if (g < 1) g = 1;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+#define BFA_LAUNCH(TT, AF) YS_LAUNCH_LDS((bn_fin_apply_kernel<TT, AF>), (int)g, EW_THREADS, lds, st, (const TT*)y, rows, C, f, (const TT*)res, res_ldc, res_coff, (TT*)z, z_ldc, z_coff)
+  if (dtype == YS_BF16) { if (act) BFA_LAUNCH(bf16_t, true); else BFA_LAUNCH(bf16_t, false); }
+  else { if (act) BFA_LAUNCH(float, true); else BFA_LAUNCH(float, false); }
+#undef BFA_LAUNCH
+  return YS_OK;
+}
+
 // ------------------------------------------------------------------ per-channel reductions over rows
 // thread t owns channel vector cv = t % CG and row lane t / CG; workgroup blk owns a contiguous row range.
 // MODE 0: BN backward (sum du, sum du*xhat), optional res_grad += dz.   MODE 1: plain column sum.

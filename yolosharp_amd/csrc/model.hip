@@ -45,6 +45,7 @@ struct ConvL {
   long rm_off = -1, rv_off = -1, nbt_off = -1;  // running stats in `state`
   long wf_off = 0, wd_off = 0;               // element offsets into wf_all / wd_all
   long y_off = 0;                             // element offset into y_all (bn layers)
+  long acc_off = -1;                          // BatchNorm unit: offset (64-bit words) of its statistics accumulators in ys_model::stat_acc_all
   long ch_off = 0;                            // offset into per-channel scratch (scale.. c2), floats
   int seg = 0;
   bool first = false;
@@ -161,6 +162,8 @@ struct ys_model {
   bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
   float* chan = nullptr; long n_chan = 0;       // per conv: scale, shift, mean, rstd, c1, c2 (6*cout)
   float* stat_partial = nullptr; long n_stat = 0;
+  unsigned long long* stat_acc_all = nullptr; long n_stat_acc = 0;   // round 5: [unit][YS_STAT_SHARDS][cout][2] fixed-point statistics sums, cleared by ONE memset per training forward
+  bool bn_atomic = false;                                            // BatchNorm units take their statistics through them and finalize inside the apply pass
   float* stat_group = nullptr;                  // statistics rows of the grouped head stages (one region per unit, ConvL::gstat_off)
   float* wg_partial = nullptr; long n_wgp = 0;   // [shared scratch (ConvTranspose phases) | one region per convolution]
   // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
@@ -1005,6 +1008,16 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
   const bool ticket_uc = YS_OPT_INT("BN_TICKET", -1) == 2;   // 2: statistics rows + tickets in uncached memory, no fences
   YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4, true, ticket_uc));
+  // statistics accumulators of the BatchNorm units (round 5, ys_kernels.h ys_stat_acc_add).  Off in fp8 mode (its apply pass also writes the e4m3 image), with the
+  // in-kernel ticket finalize (a rejected experiment kept for A/B), and by BN_ATOMIC=0 (A/B switch against the row + bn_finalize form)
+  m->bn_atomic = YS_OPT_INT("BN_ATOMIC", 1) != 0 && !m->f8 && !m->bn_ticket;
+  if (m->bn_atomic) {
+    long off = 0;
+    for (auto& c : m->convs) if (c.bn && !c.dw && !c.ct) { c.acc_off = off; off += (long)YS_STAT_SHARDS * c.cout * 2; }
+    m->n_stat_acc = off;
+    if (off > 0) YS_TRY(dev_alloc(m, (void**)&m->stat_acc_all, (size_t)off * 8));
+    else m->bn_atomic = false;
+  }
   // off by default: measured (round 3, config 2) 10.52-10.55 ms/step with the lanes against 9.98-10.01 without (round 2's variant of the
   // same experiment: -5.7 %).  The P3 chain's kernels are persistent grids sized to own every CU (2-3 workgroups per CU by LDS); a
   // side-stream kernel that takes some of those slots turns the big kernel's equal tile shares into a tail.  YS_HEAD_LANES=1 enables it.
@@ -1180,6 +1193,17 @@ static ConvArgs fwd_args(ys_model* m, const ConvL& c, int B) {
   return a;
 }
 
+// finalize-inside-apply operands of BatchNorm unit c (ys_bn_fin_apply_launch): its accumulators + everything bn_finalize_kernel reads and writes
+static BnAccFin bn_acc_fin(ys_model* m, const ConvL& c, long count) {
+  BnAccFin f{};
+  f.acc = m->stat_acc_all + c.acc_off; f.count = (double)count;
+  f.gamma = m->params + c.g_off; f.beta = m->params + c.b_off;
+  f.run_mean = m->state + c.rm_off; f.run_var = m->state + c.rv_off; f.nbt = m->state + c.nbt_off;
+  f.scale = chan_ptr(m, c, 0); f.shift = chan_ptr(m, c, 1); f.mean = chan_ptr(m, c, 2); f.rstd = chan_ptr(m, c, 3);
+  f.eps = 1e-3f; f.momentum = 0.03f;
+  return f;
+}
+
 // `next`: the convolution that runs right after this one, when it reads exactly the view this one writes (else null)
 // `lane_st` / `lane_stat`: side stream and statistics scratch of a head lane (forward_impl), null = the context's stream
 int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr, hipStream_t lane_st = nullptr, float* lane_stat = nullptr) {
@@ -1195,12 +1219,18 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
     if (m->training) {
       void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
       int gm = 0;
-      YS_TRY(ys_stem_fwd_launch(st, m->in_f32, B, c.Hin, c.Win, wf, c.cout, y, c.cout, 0, (long)c.Hout * c.Wout, stat_partial, nullptr, nullptr, 0, &gm));
+      const bool atomic = m->bn_atomic && c.acc_off >= 0;
+      YS_TRY(ys_stem_fwd_launch(st, m->in_f32, B, c.Hin, c.Win, wf, c.cout, y, c.cout, 0, (long)c.Hout * c.Wout, stat_partial, nullptr, nullptr, 0, &gm,
+                                atomic ? m->stat_acc_all + c.acc_off : nullptr));
+      if (atomic) {
+        YS_TRY(ys_bn_fin_apply_launch(st, m->dtype, y, Ms, c.cout, bn_acc_fin(m, c, Ms), c.act ? 1 : 0, nullptr, 0, 0, ob.act, ob.ldc, c.out.coff));
+      } else {
       YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, Ms, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
                                    m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
                                    chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
       YS_TRY(ys_bn_act_apply_launch(st, m->dtype, y, Ms, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, nullptr, 0, 0,
                                     ob.act, ob.ldc, c.out.coff, nullptr));
+      }
     } else {
       YS_TRY(ys_stem_fwd_launch(st, m->in_f32, B, c.Hin, c.Win, wf, c.cout, ob.act, ob.ldc, c.out.coff, ob.rows_per_b, nullptr,
                                 chan_ptr(m, c, 0), chan_ptr(m, c, 1), c.act ? 1 : 0, nullptr));
@@ -1225,16 +1255,22 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
     void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
     a.stats = stat_partial;
+    const bool atomic = m->bn_atomic && c.acc_off >= 0 && !lane_st && !a.f8;
+    if (atomic) a.stat_acc = m->stat_acc_all + c.acc_off;
     const int p2_tiles = (m->bn_ticket && m->dtype == YS_BF16 && !a.f8 && !lane_st) ? ys_conv_is_p2(a) : 0;
     const bool ticket = p2_tiles > 0 && p2_tiles <= 16;     // one arrival counter per channel tile (BnFinArgs::ticket)
     if (ticket) a.fin = m->fin_dev + c.idx;
     YS_TRY(ys_conv_launch(st, m->dtype, a));
+    const void* res = nullptr; int rl = 0, rc = 0;
+    if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
+    if (atomic) {   // the statistics left the convolution already reduced (integer sums): finalize + BN + SiLU in ONE pass, no bn_finalize launch
+      YS_TRY(ys_bn_fin_apply_launch(st, m->dtype, y, M, c.cout, bn_acc_fin(m, c, M), c.act ? 1 : 0, res, rl, rc, ob.act, ob.ldc, c.out.coff));
+      return YS_OK;
+    }
     const int gm = ys_conv_grid_m(a, m->dtype);
     if (!ticket) YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
                                  m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
                                  chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
-    const void* res = nullptr; int rl = 0, rc = 0;
-    if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
     // fp8 mode: the next convolution of the schedule reads exactly this output and will run the fp8 blocked-GEMM kernel -> this pass also writes
     // the e4m3 image it consumes (the consumer's delayed scale) into the scratch and records its maximum
     bool q8_out = false;
@@ -1320,6 +1356,7 @@ int forward_impl(ys_model* m, int B) {
   hipStream_t st = m->ctx->stream;
   YS_TRY(join_wgrad_stream(m));              // asynchronous segment ends: the previous step's weight-gradient kernels still read activations / dy slots
   YS_TRY(prep_weights(m));
+  if (m->training && m->bn_atomic) YS_CHECK_HIP(hipMemsetAsync(m->stat_acc_all, 0, (size_t)m->n_stat_acc * 8, st));   // every unit's statistics accumulators: one clear per forward
   if (m->f8)   // delayed scaling: this pass quantises with the maxima the previous passes recorded (consumed and cleared here)
     YS_TRY(ys_f8_scales_launch(st, m->f8_convs, m->n_f8_convs, m->amax_w, m->amax_act, m->amax_dy, m->f8_scales));
   if (m->f8 && m->f8_bwd_done) m->f8_sg_valid = true;

@@ -39,6 +39,9 @@ struct ConvArgs {
   const float* shift;   // optional per-cout offset (eval BN shift / bias) }
   const void* res;      // optional residual added after the activation (same row mapping as y)
   float* stats;         // optional [gridM][2][Cout] partial (sum, sumsq) of the stored values
+  unsigned long long* stat_acc;   // round 5: when set (with stats != null as the "take statistics" flag), a workgroup ADDS its sums -- as 2^-20 fixed point, 64-bit integer
+                        // atomics, order-independent = deterministic -- into [YS_STAT_SHARDS][Cout][2] accumulators instead of writing a row; the BN + SiLU apply pass
+                        // finalizes from them (ys_bn_fin_apply_launch) and the bn_finalize launch of the unit goes
   int B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW;
   int SA, DIVS, DIVM, PAD;   // ih*DIV = oh*SA + kh - PAD ; DIVS = log2(DIV), DIVM = DIV-1
   int in_ldc, in_coff;
@@ -113,7 +116,7 @@ int ys_conv_gemm_launch(hipStream_t st, const ConvArgs& a);
 bool ys_stem_eligible(int dtype, int cin, int cout, int k, int s);
 int ys_stem_fwd_rows(int B, int Hout, int Wout);
 int ys_stem_fwd_launch(hipStream_t st, const float* x, int B, int H, int W, const void* wf, int Cout, void* y, int out_ldc, int out_coff,
-                       long out_bstride, float* stats, const float* scale, const float* shift, int act, int* rows);
+                       long out_bstride, float* stats, const float* scale, const float* shift, int act, int* rows, unsigned long long* stat_acc = nullptr);
 int ys_stem_wgrad_launch(hipStream_t st, const float* x, int B, int H, int W, const void* dy, int dy_ldc, int dy_coff, long dy_bstride,
                          int Cout, float* partial, int max_splits, int* used);
 int ys_conv_grid_m(const ConvArgs& a, int dtype);
@@ -174,6 +177,31 @@ int ys_bn_finalize_launch(hipStream_t st, const float* partial, int nblk, int C,
 // eval: scale/shift from running stats
 int ys_bn_eval_coeffs_launch(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
                              const float* run_var, float eps, float* scale, float* shift);
+// Statistics as fixed-point integer sums (round 5).  Scale 2^20: a workgroup's partial sum is quantised to 2^-20 ~ 1e-6 absolute (rounded; <= 768 partials per
+// launch), the 64-bit accumulator holds |sum| up to 2^43 = 8.8e12 -- e.g. 6.5 million pixels (the largest map of the BASELINE configs) at a mean square of 1.3e6.
+#define YS_STAT_SHARDS 8          // accumulator copies (workgroup index modulo): ~64 arrivals per cache line and launch instead of ~512
+#define YS_STAT_FIX 1048576.0f
+__device__ inline void ys_stat_acc_add(unsigned long long* acc, long stat_row, int C, int c, int which, float t) {
+#ifdef YS_EMU_BUILD
+  const long long q = (long long)llrintf(t * YS_STAT_FIX);
+#else
+  const long long q = __float2ll_rn(t * YS_STAT_FIX);
+#endif
+  if (q != 0) atomicAdd(acc + (((stat_row & (YS_STAT_SHARDS - 1)) * C + c) * 2 + which), (unsigned long long)q);
+}
+// finalize-inside-apply operands: the accumulators of one BatchNorm unit + what bn_finalize_kernel reads and writes
+struct BnAccFin {
+  const unsigned long long* acc;   // [YS_STAT_SHARDS][C][2]
+  double count;
+  const float* gamma; const float* beta;
+  float* run_mean; float* run_var; float* nbt;
+  float* scale; float* shift; float* mean; float* rstd;   // written by workgroup 0 (the backward pass reads them)
+  float eps, momentum;
+};
+// z[out view] = act(BN(y)) (+ residual view) with the batch statistics finalized from the accumulators by every workgroup (identical arithmetic, identical result);
+// workgroup 0 stores the coefficients and updates the running statistics
+int ys_bn_fin_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const BnAccFin& f, int act, const void* res, int res_ldc, int res_coff,
+                           void* z, int z_ldc, int z_coff);
 // z[out view] = act(y*scale+shift) (+ residual view)
 int ys_bn_act_apply_launch(hipStream_t st, int dtype, const void* y, long rows, int C, const float* scale,
                            const float* shift, int act, const void* res, int res_ldc, int res_coff, void* z,

@@ -21,6 +21,7 @@ KERNELS = {   # label prefix -> (kernel symbol, operand type of its MFMAs)
     "p2": ("conv_p2_kernel", "bf16"), "p2f8": ("conv_p2_kernel<F8>", "fp8"),
     "p2grp": ("conv_p2_group_kernel", "bf16"),     # grouped launch (label "p2grpN ... M<sum of the problems' pixels>"): same channels and taps for every problem
     "gemm": ("conv_gemm_kernel", "bf16"), "gemmf8": ("conv_gemm_kernel<F8>", "fp8"),
+    "halo": ("conv_halo_kernel", "bf16"),          # round 5: halo-patch form of the 3x3 stride-1 wide layers (csrc/conv_halo.h)
     "direct": ("conv_igemm_kernel", "bf16"), "patch": ("conv3x3_tile_kernel", "bf16"),
     "stem": ("stem_fwd_kernel", "bf16"), "wstem": ("stem_wgrad_kernel", "bf16"),   # model.0 straight from the fp32 NCHW image (conv_stem.hip)
     "wgrad_tr": ("conv_wgrad_tr_kernel", "bf16"), "wgemm": ("conv_wgrad_gemm_kernel", "bf16"), "wgrad": ("conv_wgrad_kernel", "bf16"),
