@@ -203,7 +203,10 @@ def test_fp8_tracks_bf16_at_size():
             m.adamw_step([1e-3] * 3)
         hist[dt] = rec
         m.close()
-    assert np.array_equal(hist["fp8"][0][0], hist["bf16"][0][0])                       # step 0: no recorded maxima yet -> bf16 kernels
+    # step 0: no recorded maxima yet -> bf16 kernels.  Bit-equal through round 4; since round 5 the bf16 model sums its BatchNorm statistics as fixed-point integer
+    # atomics (model.hip bn_atomic) while the fp8 model keeps the per-workgroup float rows (its quantising apply pass wants the finalized coefficients earlier): the same
+    # numbers added in a different order and precision, 1e-4 .. 6e-4 relative on the loss items
+    assert np.allclose(hist["fp8"][0][0], hist["bf16"][0][0], rtol=2e-3), (hist["fp8"][0][0], hist["bf16"][0][0])
     for it in range(1, 5):
         assert np.allclose(hist["fp8"][it][0], hist["bf16"][it][0], rtol=5e-2), (it, hist["fp8"][it][0], hist["bf16"][it][0])
     g8, gb = hist["fp8"][1][1], hist["bf16"][1][1]

@@ -284,7 +284,10 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
           // without a covering wait -- correct in the interpreter, where a request lands at once, and almost always on the device; it showed as a loss that
           // differed in the fourth digit between two runs of bench.py.)
           constexpr int np_prev = tap == 0 ? 0 : (tap - 1 <= 4 ? 2 : (tap - 1 <= 6 ? 1 : 0));
-          ys_wait_vm<np_prev + NBW>();
+          // (piece 11, issued at tap 6, exists for wave 0 only -- 45 pieces over 4 waves: the count must be what THIS wave issued, one too many leaves the oldest
+          // weight piece of this tap uncovered)
+          if constexpr (tap == 7) { if (wave + NWV * (NPW - 1) < NPP) ys_wait_vm<np_prev + NBW>(); else ys_wait_vm<np_prev - 1 + NBW>(); }
+          else ys_wait_vm<np_prev + NBW>();
           ys_barrier_lds();
         }
         // ---- K-step 1 on B; this tap's requests, then reads (tap + 1, K-step 0) -> A

@@ -339,6 +339,10 @@ stem_wgrad_kernel(StemWgArgs a) {
     }
   }
   // the four waves' accumulators, summed in a fixed order -> this workgroup's slab.  Lane (li, q) holds D[cout = 4q + r][k = kb*16 + li].
+  // The scratch aliases the dy rows: every wave must be through its last fragment reads first (round 5: without this barrier a wave that finished early wrote
+  // its sums over rows a slower wave was still reading -- fp32 bit patterns read as bf16 pairs, an occasional wrong or NaN stem weight gradient, mostly on the
+  // first launch of a process or model when the waves of a workgroup are furthest apart; found by tools/dev/r05/det_phase.py).
+  __syncthreads();
 #pragma unroll
   for (int nf = 0; nf < NR; nf++)
 #pragma unroll
