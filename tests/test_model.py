@@ -480,3 +480,29 @@ def test_bf16_training_tracks_f32_over_40_steps(backend, engine):
     db = np.concatenate([(final["f32"][k] - init[k]).ravel() for k in keys])
     cos = float(da @ db / np.sqrt((da @ da) * (db @ db)))
     assert cos > 0.55, cos
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_first_step_of_a_new_model_is_deterministic(backend, engine):
+    """Every gradient of the FIRST step of a freshly built model, twelve models in a row on recycled device memory, bit for bit.  Round 5: the stem weight-gradient
+    kernel reused its dy rows as reduction scratch without a barrier; the race showed almost only on a model's first launch (waves of a workgroup furthest apart), as
+    an occasional wrong or NaN model.0 gradient that the repeated-step checks on ONE model never saw (tools/dev/r05/det_phase.py found it: 3 of 40 models)."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    B, H, W, nc = 8, 640, 640, 80
+    x = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
+    batch = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=1).items()}
+    ref = None
+    for trial in range(12):
+        m = Yolov8(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="bf16")
+        m.init_weights(2); m.train()
+        m.forward(x, fetch=False); _, items = v8DetectionLoss(m)(None, batch); m.zero_grad(); m.backward()
+        g = m.grads()
+        m.close()
+        assert all(np.isfinite(v).all() for v in g.values()), trial
+        if ref is None:
+            ref = (items, g)
+            continue
+        assert np.array_equal(items, ref[0]), (trial, items, ref[0])
+        bad = [k for k in g if not np.array_equal(g[k], ref[1][k])]
+        assert not bad, (trial, bad[:4])
