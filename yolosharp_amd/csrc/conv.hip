@@ -1042,7 +1042,6 @@ __device__ __forceinline__ void conv_p2_body(const ConvArgs& a, const P2Args& g,
 #else
   if (RED ? a.nred > 0 : a.stats != nullptr) p2_stats_flush<NR, NWV>(a, n0, st1, st2, (float*)sPb, (long)vbx);
 #endif
-  if (!RED && !F8) conv_bn_finalize_ticket<NT>(a, n0, BN, (double*)sPb);
   if (F8 && a.amax && blockIdx.y == 0) ys_amax_update(a.amax, amx);
   TL_STAMP();
 #ifdef YS_P2_TIMELINE
@@ -1143,19 +1142,16 @@ static double p2_read_cycles(int cin, int kh, int kw, int sa, int th, int tw, in
   return n ? (double)tot / (double)n : 4.0;
 }
 // pixel pitch of the bf16 patch: stride 1 -> smallest slot count >= Cin / 8 that is 2 (mod 4); stride 2 (lanes two pixels apart) -> odd.
-// YS_P2_PITCH=0 restores the odd rule everywhere (A/B runs).
+// (Round 3 measured the odd rule everywhere as the slower alternative.)
 static int p2_pixel_pitch(int cin, int sa) {
-  const int rule = (int)YS_OPT_INT("P2_PITCH", 1);
   const int cu = cin / 8;
-  if (!rule || sa != 1) return cin * 2 + ((cu & 1) ? 32 : 16);
+  if (sa != 1) return cin * 2 + ((cu & 1) ? 32 : 16);
   int p = cu;
   while ((p & 3) != 2) p++;
   return p * 16;
 }
 // row padding (in 16-byte slots, 0..15) of the patch that minimises the modelled read cycles of the chosen tile within `room` bytes
 static int p2_pick_rowpad(int cin, int kh, int kw, int sa, int th, int tw, int mr, int nwv, int ppb, int pw, int ph, size_t room) {
-  const int on = (int)YS_OPT_INT("P2_ROWPAD", 1);
-  if (!on) return 0;
   static std::map<std::vector<int>, int> cache;
   static std::mutex mu;
   const std::vector<int> key = {cin, kh, kw, sa, th, tw, mr, nwv, ppb, pw, ph, (int)(room / (16 * (size_t)(ph > 0 ? ph : 1)) > 15 ? 15 : (int)(room / (16 * (size_t)(ph > 0 ? ph : 1))))};
@@ -1176,8 +1172,6 @@ static int p2_pick_rowpad(int cin, int kh, int kw, int sa, int th, int tw, int m
 struct P2Plan { int ok, mr, nr, wres, npu, nt, gx, gy, per_cu; size_t lds; P2Args g; };
 // fp8 variants whose 32-byte fragments fit the 256-register budget without spilling (hipcc -Rpass-analysis=kernel-resource-usage)
 static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
-  const bool any = YS_OPT_INT("P2_F8_ANYTILE", 0) != 0;      // triage: accept the spilling variants too
-  if (any) return true;
   if (wres) return npu == 6 ? !(mr == 4 && nr == 4) : (mr * nr <= 8 && !(mr == 2 && nr == 5));
   return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
 }
@@ -1214,25 +1208,22 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   const int taps = a.KH * a.KW;
   g.nsteps = f8 ? (taps * a.Cin + 127) / 128 : (taps * a.Cin + 31) / 32;
   // resident up to 40 KB (measured: 20 KB 14.52, 40 KB 14.48, 80 KB 14.96 ms/step -- larger resident sets cost the second
-  // workgroup per CU); YS_P2_WRESMAX overrides for experiments
-  const size_t wresmax_env = (size_t)YS_OPT_INT("P2_WRESMAX", 0);
+  // workgroup per CU)
   // rows padded to 4 K-steps; fp8: 52 KB (the streamed fp8 variants are limited to small register tiles; YOLOv8x 1280 step 165.3 -> 161.7 ms)
-  const size_t wresmax = wresmax_env ? wresmax_env : (f8 ? 52 * 1024 : 44 * 1024);
+  const size_t wresmax = f8 ? 52 * 1024 : 44 * 1024;
   // Streamed weights cost one L2 round trip per K-group on the critical path of every tile.  When half the output channels
   // would make the weight set resident, split the channels over two workgroup columns instead (the patch is then read
   // twice, from L2).
-  const double tileconst = (double)YS_OPT_F("P2_TILECONST", 3000.0);
-  const int nrsplit = (int)YS_OPT_INT("P2_NRSPLIT", 1);   // measured 13.00 -> 12.86 ms/step
+  const double tileconst = 3000.0;
   const int nsteps4 = (g.nsteps + 3) & ~3;           // resident weight rows are zero-padded to whole register groups (<= 4 K-steps)
   // weight rows: 16 consecutive rows per fragment read, same lane-group structure as the patch -> a pitch of 2 (mod 4) slots is
   // conflict-free (the odd pitch was 2-way); fp8 rows (two reads per fragment, quarters two slots apart) keep the odd pitch
-  const int wrule = (int)YS_OPT_INT("P2_WPITCH", 1);
-  auto wp = [&](int units) { if (f8 || !wrule) return units | 1; int p = units; while ((p & 3) != 2) p++; return p; };
+  auto wp = [&](int units) { if (f8) return units | 1; int p = units; while ((p & 3) != 2) p++; return p; };
   g.nsp = nsteps4 + 12;                              // + slack: the pipelined loop reads table entries up to two groups ahead
-  if (nrsplit && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr % 2 == 0 &&
+  if ((size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr % 2 == 0 &&   // (measured 13.00 -> 12.86 ms/step)
       (size_t)(nr / 2) * 16 * wp(nsteps4 * ups) * 16 <= wresmax && nfr % (nr / 2) == 0)
     nr /= 2;
-  if (f8 && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr > 2 && YS_OPT_INT("P2_F8_ANYTILE", 0) == 0) nr = 2;   // streamed fp8 weights: small register tiles only
+  if (f8 && (size_t)nr * 16 * wp(nsteps4 * ups) * 16 > wresmax && nr > 2) nr = 2;   // streamed fp8 weights: small register tiles only
   if (force_nr && force_nr <= nr && nfr % force_nr == 0) nr = force_nr;   // grouped launch: the output-channel split of the group's first member (never wider than this problem's own choice)
   const int bn = nr * 16;
   const size_t wres_bytes = (size_t)bn * wp(nsteps4 * ups) * 16;
@@ -1245,8 +1236,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   const size_t tab = ((size_t)g.nsp * 16 + 15) / 16 * 16;
   const int gy = ys_cdiv(a.Cout, bn);
   // 3x3 layers with >= 256 input channels do not fit a useful whole-Cin patch (<= 64-pixel tiles, the full weight set streamed
-  // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms); override for experiments
-  const int maxcin3 = (int)YS_OPT_INT("P2_MAXCIN3", 255);
+  // per tile): the chunked round-1 kernel handles them better (YOLOv11m-seg step 65.9 -> 63.4 ms)
+  const int maxcin3 = 255;
   if (k3 && a.SA == 1 && a.Cin > (f8 ? 640 : maxcin3)) return p;   // an fp8 patch pixel is half the bytes
   for (size_t budget = (wres && wres_bytes > 52 * 1024 ? 152 : 76) * 1024; budget <= 152 * 1024 && !p.ok; budget *= 2) {   // two workgroups per CU; one if nothing else fits
   // tile = (4 waves x 16*mr pixels, th x tw): minimise the bytes a layer moves through the CU (patch incl. halo, streamed
@@ -1291,8 +1282,8 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   }
   if (!p.ok) return p;
   if ((long)p.g.ntiles > 2L * ys_cdiv(a.M, 64)) { p.ok = 0; return p; }   // stats workspace bound (model.hip stat_max)
-  // three workgroups per CU (TIGHT register variants) when three footprints fit the 160 KB: YS_P2_LDS3 = the per-workgroup limit in bytes
-  const size_t lds3 = (size_t)YS_OPT_INT("P2_LDS3", (size_t)50 * 1024);
+  // three workgroups per CU (TIGHT register variants) when three footprints fit the 160 KB
+  const size_t lds3 = (size_t)50 * 1024;
   p.g.prb = p.g.PW * p.g.ppb;
   if (!f8) {
     // row padding of the patch (bank model, p2_pick_rowpad) inside the occupancy class the tile search settled on
@@ -1437,12 +1428,8 @@ static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
 }
 static int conv_p2_group_dispatch(hipStream_t st, const ConvArgs* a, const P2Plan* p, int n, const int* gxs, size_t lds);
 static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) {
-  // YS_P2_VIA_GROUP=1: single launches through conv_p2_group_kernel with one problem.  That kernel reads its arguments from the
-  // kernel-argument segment where they are used (dynamically indexed problem array) instead of holding the whole ConvArgs in scalar
-  // registers: hipcc's resource report shows 58-100 SGPRs against the 106-register limit every conv_p2_kernel variant sits at, which
-  // takes the scalar spills (VGPR lanes / scratch) out of several variants and lifts a few to the next occupancy step.
-  const bool via_group = YS_OPT_INT("P2_VIA_GROUP", 0) != 0;
-  if (via_group && !a.f8 && !a.fin) { const int gx = p.gx; return conv_p2_group_dispatch(st, &a, &p, 1, &gx, p.lds); }
+  // (Single launches through conv_p2_group_kernel with one problem -- arguments read from the kernel-argument segment instead of held in scalar registers --
+  // were built and measured in round 4 as no faster; the switch is gone.)
   {
 #define P2F(M_, N_, F_, R_) { \
     if (p.wres) return p.npu == 6 ? conv_p2_launch_t<M_, N_, 1, 6, 256, F_, R_>(st, a, p) : conv_p2_launch_t<M_, N_, 1, 12, 256, F_, R_>(st, a, p); \
@@ -1532,7 +1519,7 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
     const ConvArgs& x = a[i];
     // (measured, round 4: the stride-2 dgrad phases of the 128- and 256-channel layers, which the blocked-GEMM kernel takes one by one, run as one
     // patch-kernel grid within noise of the four GEMM launches: 9.01-9.02 -> 8.92-9.00 ms/step; they stay on the GEMM kernel)
-    if (x.f8 || x.fin || ys_conv_gemm_rows(x)) return YS_ERR_UNSUPPORTED;
+    if (x.f8 || ys_conv_gemm_rows(x)) return YS_ERR_UNSUPPORTED;
     if (ys_conv_dgrad_uses_phases(YS_BF16, x.KH, x.DIVM + 1) && x.KW == x.KH) return YS_ERR_UNSUPPORTED;
     if (x.Cin != a[0].Cin || x.Cout != a[0].Cout || x.SA != a[0].SA || x.PAD != a[0].PAD ||   // (kernel sizes may differ: the four phases of a stride-2 dgrad)
         (x.nred > 0) != (a[0].nred > 0) || (x.accumulate != 0) != (a[0].accumulate != 0) || (x.stats != nullptr) != (a[0].stats != nullptr)) return YS_ERR_UNSUPPORTED;
@@ -1651,7 +1638,7 @@ static int conv_pick_nr(int cout, int M = 1 << 30) {
   const int nfr = (cout + 15) / 16;
   if (nfr <= 6) return nfr;
   // small feature maps: narrower column tiles give the chip more workgroups (Cin = 128 -> 256 stride-2 layer at 20x20: 119 -> 83 us)
-  const int smallm = (int)YS_OPT_INT("IG_SMALLM", 30000);
+  const int smallm = 30000;
   if (M <= smallm && nfr % 4 == 0) return 4;
   if (nfr % 8 == 0 || nfr > 10) return 8;
   if (nfr % 5 == 0) return 5;
@@ -1794,8 +1781,7 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_onl
   // The four phases as ONE persistent grid (conv_p2_group_kernel) when every phase is a bf16 patch-kernel launch of one variant: they read the
   // same dy tiles -- side by side on an XCD the second to fourth read hit its L2 -- and three launches' fixed costs go.  The 2x2-tap phase
   // first: the group runs on the variant of its first largest member, and that phase has the largest patch.
-  const bool grp_on = YS_OPT_INT("S2_GROUP", 1) != 0;
-  if (grp_on && !a.f8) {
+  if (!a.f8) {
     ConvArgs qs[4];
     int n = 0;
     for (int ph = 3; ph >= 0; ph--) if (conv_dgrad_s2_phase_args(a, ph, qs[n])) n++; else break;

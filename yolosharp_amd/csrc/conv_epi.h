@@ -550,60 +550,6 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
   stamp(); stamp(); stamp();
 }
 
-// Last-arriver BatchNorm finalize (round-2 verdict item 3, built to be measured: YS_BN_TICKET=1).  Every workgroup has written its
-// statistics row; it publishes it (release fence), takes a ticket of its channel tile, and the workgroup that draws the last one
-// reduces the gridDim.x rows of the tile's channels in double -- RL row lanes x 32 channels per pass, fixed order -> deterministic --
-// and does bn_finalize_kernel's arithmetic (elementwise.hip) in place of that launch.  `scr`: >= (2 * RL * 32) doubles of LDS.
-template <int NT>
-__device__ inline void conv_bn_finalize_ticket(const ConvArgs& a, int n0, int bn_tile, double* scr) {
-  const BnFinArgs* f = a.fin;
-  if (!f) return;
-  volatile int* s_last = (volatile int*)(scr + 2 * (NT / 32) * 32);   // in the dynamic region: a static __shared__ would push static + 160 KB past the limit
-  const bool uc = f->uncached != 0;
-  if (uc) YS_WAIT_VM0(); else __threadfence();   // uncached rows: the wave's stores have reached memory once they are acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) *s_last = atomicAdd(&f->ticket[blockIdx.y], 1u) == gridDim.x - 1 ? 1 : 0;
-  __syncthreads();
-  if (!*s_last) return;
-  if (!uc) __threadfence();
-  constexpr int RL = NT / 32;                  // row lanes per channel
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int rows = (int)gridDim.x;
-  const double count = (double)a.M;
-  for (int c0 = 0; c0 < bn_tile; c0 += 32) {
-    const int c = n0 + c0 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c0 + cl < bn_tile && c < a.Cout) {
-      const float* col = a.stats + c;
-      for (int r = rl; r < rows; r += RL) {
-        s1 += (double)col[((long)r * 2 + 0) * a.Cout];
-        s2 += (double)col[((long)r * 2 + 1) * a.Cout];
-      }
-    }
-    __syncthreads();
-    scr[(0 * RL + rl) * 32 + cl] = s1; scr[(1 * RL + rl) * 32 + cl] = s2;
-    __syncthreads();
-    if (rl == 0 && c0 + cl < bn_tile && c < a.Cout) {
-      double t1 = 0.0, t2 = 0.0;
-      for (int k = 0; k < RL; k++) { t1 += scr[(0 * RL + k) * 32 + cl]; t2 += scr[(1 * RL + k) * 32 + cl]; }
-      const double mean = t1 / count;
-      double var = t2 / count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const float g = f->gamma[c], bt = f->beta[c];
-      const float rstd = (float)(1.0 / sqrt(var + (double)f->eps));
-      f->scale[c] = g * rstd;
-      f->shift[c] = bt - (float)mean * g * rstd;
-      f->mean[c] = (float)mean;
-      f->rstd[c] = rstd;
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      f->run_mean[c] = (1.0f - f->momentum) * f->run_mean[c] + f->momentum * (float)mean;
-      f->run_var[c] = (1.0f - f->momentum) * f->run_var[c] + f->momentum * (float)unb;
-      if (c == 0 && f->nbt) f->nbt[0] = f->nbt[0] + 1.0f;
-    }
-  }
-  if (threadIdx.x == 0) f->ticket[blockIdx.y] = 0u;
-}
-
 // One statistics row per workgroup for the direct layout: lane (li, q) of wave w holds the sums of channels nf*16 + 4q + r over its
 // own pixels.  The 16 pixel lanes of a DPP row are combined in registers (ys_row16_sum: 4 VALU adds per value), lane li == 0 of every
 // row parks its 8*NR totals in LDS ([2][waves][BN] floats), and one thread per (sum, channel) adds the waves' entries in a fixed

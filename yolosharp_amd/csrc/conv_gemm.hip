@@ -381,7 +381,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   // workgroup per CU) and the 2x2 / 1x2 / 2x1 phases of the stride-2 dgrads with 128 gradient channels, which join their 1x1 phase in ONE grouped patch-kernel
   // launch (141 -> 78 us, 92 -> 49 us); step 8.85 -> 8.76 ms
   const int min_cin = (int)YS_OPT_INT("GEMM_MIN_CIN", 160);
-  const int min_k = (int)YS_OPT_INT("GEMM_MIN_K", 256);
+  const int min_k = 256;
   const bool f8 = a.f8 != 0;
   const bool f8_off = YS_OPT_INT("NO_GEMM_F8", 0) != 0;
   if (off || (f8 && (f8_off || !a.x8 || !a.w8 || !a.deq || a.Cin % 16))) return p;
@@ -398,11 +398,11 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   const int min_m = (int)YS_OPT_INT("GEMM_MIN_M", 1024);
   // stride-2 3x3 layers with 64 <= Cin < 128 come here too (round 4): the whole-Cin patch of a stride-2 tile is four times the tile's area, so the patch
   // kernel falls back to 2 x 22-pixel tiles whose patch every output-channel column re-reads (64 -> 128 at 80 x 80: 71 us, 9.4x its floor)
-  const int s2_min_cin = (int)YS_OPT_INT("GEMM_S2_MIN_CIN", 64);
+  const int s2_min_cin = 64;
   const bool s2_narrow = k3 && a.SA == 2 && a.Cin >= s2_min_cin && !f8;
   // ... and stride-1 3x3 layers with 64 <= Cin < 128 whose output is wide (the fused Detect / Segment tower input, 64 -> 144): the patch kernel streams
   // 166 KB of weights per 256-pixel tile there
-  const int wide_cout = (int)YS_OPT_INT("GEMM_WIDE_COUT", 128);
+  const int wide_cout = 128;
   const bool wide_out = k3 && a.SA == 1 && a.Cin >= 64 && a.Cout >= wide_cout && !f8;
   if ((a.Cin < min_cin && !s2_narrow && !wide_out) || Ktot < min_k || a.Cout < 64 || a.M < min_m) return p;
   if (k3 && a.SA == 1 && !f8) { const GemmPlan hp = conv_halo_plan(a); if (hp.ok) return hp; }
@@ -440,14 +440,12 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   // Pipeline depth.  Two stages leave a request one K-tile of MFMA time (~500-1300 cycles) to land against ~1600 cycles of memory
   // latency (s_memtime stamps, round 3: 1600-1750 cycles per K-tile whatever the tile): a second workgroup on the CU covers the gap
   // when the grid has one; a launch with at most one workgroup per CU (the deep YOLOv8n layers at B = 64: 200 tiles) has nothing
-  // else to run and takes as many stages as the LDS holds instead.  YS_GEMM_STAGES forces a depth (A/B runs).
-  const int force_st = (int)YS_OPT_INT("GEMM_STAGES", 0);
+  // else to run and takes as many stages as the LDS holds instead.
   g.nstage = 2;
   {
     int fit = (int)((160 * 1024 - (size_t)g.off_stage) / g.stage_bytes);
     if (fit > 4) fit = 4;
     if ((long)g.mtiles * p.gy <= 256 && g.nkt > 2) g.nstage = fit;
-    if (force_st >= 2 && force_st <= 4) g.nstage = force_st < fit ? force_st : fit;
     if (g.nstage > g.nkt) g.nstage = g.nkt < 2 ? 2 : g.nkt;
   }
   p.lds = g.off_stage + (size_t)g.nstage * g.stage_bytes;

@@ -187,11 +187,10 @@ static int wgemm_pick_tile(int c) {           // 160 or 128 channels: least padd
 static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
   WgGemmPlan p{};
   const bool off = YS_OPT_INT("NO_WGEMM", 0) != 0;
-  const int min_c = (int)YS_OPT_INT("WGEMM_MIN_C", 128);
+  const int min_c = 128;
   const int min_m = (int)YS_OPT_INT("WGEMM_MIN_M", 4096);
   const long kt_opt = YS_OPT_INT("WGEMM_KT", 0);   // (the tests switch K-tile variants inside one process)
   const int kt_env = (int)kt_opt;
-  const int wpc_env = (int)YS_OPT_INT("WGEMM_WPC", 0);
   if (off) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2);
   const bool k1 = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1;
@@ -215,7 +214,7 @@ static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
     if (db <= 0 || xbts <= 0 || db >= (1L << 31) || xbts >= (1L << 31)) return p;      // 32-bit request offsets
     g.dybytes = (unsigned)db; g.xbytes = (unsigned)xbts;
   }
-  const int wpc = wpc_env ? wpc_env : 2;     // 256-register waves: two workgroups per CU
+  const int wpc = 2;     // 256-register waves: two workgroups per CU
   long gx = (256L * wpc) / g.gy;
   if (gx < 1) gx = 1;
   const long wsmax = (48L << 20) / ((long)a.Cout * g.taps * a.Cin * 4);   // bound the partial workspace to 48 MB per layer

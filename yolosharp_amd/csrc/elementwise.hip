@@ -332,7 +332,7 @@ int ys_bn_act_apply_q8_launch(hipStream_t st, const void* y, long rows, int C, c
                               const void* res, int res_ldc, int res_coff, void* z, int z_ldc, int z_coff, void* q8,
                               const float* qscale, unsigned* amax) {
   const long n = rows * (C / 8);
-  const long gcap = (long)YS_OPT_INT("Q8_GRID", 2048);
+  const long gcap = 2048;
   long g = ys_cdiv(n, EW_THREADS * 4L); if (g > gcap) g = gcap; if (g < 1) g = 1;
 #define BAQ_LAUNCH(AF) YS_LAUNCH((bn_act_apply_q8_kernel<AF>), (int)g, EW_THREADS, st, (const bf16_t*)y, rows, C, scale, shift, (const bf16_t*)res, res_ldc, res_coff, (bf16_t*)z, z_ldc, z_coff, (unsigned char*)q8, qscale, amax)
   if (act) BAQ_LAUNCH(true); else BAQ_LAUNCH(false);
@@ -413,7 +413,7 @@ int ys_bn_fin_apply_launch(hipStream_t st, int dtype, const void* y, long rows, 
                            void* z, int z_ldc, int z_coff) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   const long n = rows * (C / epl);
-  const long gcap = (long)YS_OPT_INT("FINAPPLY_GRID", 2048);
+  const long gcap = 2048;
   long g = ys_cdiv(n, EW_THREADS * 2L); if (g > gcap) g = gcap; if (g < 1) g = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
 #define BFA_LAUNCH(TT, AF) YS_LAUNCH_LDS((bn_fin_apply_kernel<TT, AF>), (int)g, EW_THREADS, lds, st, (const TT*)y, rows, C, f, (const TT*)res, res_ldc, res_coff, (TT*)z, z_ldc, z_coff)
@@ -557,8 +557,7 @@ static int reduce_blocks(long rows, int C, int epl) {
   // prefer 16 row passes per workgroup, but keep >= 512 workgroups (2 per CU) while a workgroup still has a few trips of
   // work; at most 768 (3 per CU, one resident round at 4-5 waves per SIMD): more partial rows only lengthen the finalize
   // kernel and add a ragged second round (measured: 2048 -> 12.86, 1024 -> 12.77, 768/512 -> 12.75 ms/step)
-  const long maxnb = (long)YS_OPT_INT("CR_MAXNB", 768);
-  const long minnb = (long)YS_OPT_INT("CR_MINNB", 512);
+  const long maxnb = 768, minnb = 512;
   long passes = 16;
   while (passes > 4 && (rows + (long)rp * passes - 1) / ((long)rp * passes) < minnb) passes >>= 1;
   long nb = (rows + (long)rp * passes - 1) / ((long)rp * passes);
@@ -754,7 +753,7 @@ int ys_bn_bwd_apply_q8_launch(hipStream_t st, const void* dz, int dz_ldc, int dz
                               const float* scale, const float* shift, const float* k2, const float* k3, int act, void* dy,
                               void* q8, const float* qscale, unsigned* amax, void* rg, int rg_ldc, int rg_coff) {
   const long n = rows * (C / 8);
-  const long gcap = (long)YS_OPT_INT("Q8_GRID", 2048);
+  const long gcap = 2048;
   long g = ys_cdiv(n, EW_THREADS * 4L); if (g > gcap) g = gcap; if (g < 1) g = 1;
 #define BQ_LAUNCH(AF) YS_LAUNCH((bn_bwd_apply_q8_kernel<AF>), (int)g, EW_THREADS, st, (const bf16_t*)dz, dz_ldc, dz_coff, (const bf16_t*)y, rows, C, scale, shift, k2, k3, (bf16_t*)dy, (unsigned char*)q8, qscale, amax, (bf16_t*)rg, rg_ldc, rg_coff)
   if (act) BQ_LAUNCH(true); else BQ_LAUNCH(false);

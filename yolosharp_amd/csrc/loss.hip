@@ -832,8 +832,6 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   // flat grid: enough workgroups for ~12 boxes per image in one trip, never more than the host-known pair bound
   const long pair_cap = (long)(a.gmax > 0 ? a.gmax : a.gcap) * a.B;
   long flat = (long)a.B * 12 > 256 ? (long)a.B * 12 : 256;
-  const long flat_env = (long)YS_OPT_INT("TAL_GRID", 0);   // triage: workgroups of the flat grid
-  if (flat_env > 0) flat = flat_env;
   if (flat > pair_cap) flat = pair_cap;
   const dim3 tgrid = a.B <= TAL_FLAT_MAXB ? dim3((unsigned)flat) : dim3(a.gmax > 0 ? a.gmax : a.gcap, a.B);
   if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), tgrid, TAL_T, st, a, (const int*)gt_valid);

@@ -52,7 +52,6 @@ struct ConvL {
   bool dw = false;       // depthwise 3x3 (groups = channels): weights [9][C] fp32, no MFMA path
   bool f8_fwd = false, f8_bwd = false;   // fp8 mode: forward / dgrad of this layer may run the fp8 kernel (f8.hip recipe)
   int idx = -1, prep_idx = -1;           // own index in ys_model::convs; first PrepDesc (weight-amax slot)
-  int lane = 0;          // Detect / Segment / Pose / OBB towers of pyramid level 1 (P4) and 2 (P5): side stream lane (ys_model::lane_st), 0 = main stream
   long wgp_off = -1; int wgp_splits = 0; // own region of the weight-gradient partial workspace (floats) and the splits it holds; -1 = shared scratch + immediate reduce
   int red_slot = -1;                     // index into ys_model::red_host (deferred split reduction)
   bool ct = false;       // ConvTranspose2d(k=2,s=2,bias) = four 1x1 phase GEMMs (Proto.upsample, Block.cs:69); weights [4][Cout][Cin]
@@ -148,11 +147,6 @@ struct ys_model {
   static constexpr int DY_RING = 4;
   // head lanes (round 3): the towers of the three pyramid levels are independent chains (own buffers, own rows of the prediction buffers);
   // the P4 / P5 chains are short, latency-bound launches (100-400 workgroups) that run beside the P3 chain on two side streams
-  static const int NLANE = 2;
-  hipStream_t lane_st[NLANE] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_lane[NLANE] = {nullptr, nullptr};
-  float* stat_lane[NLANE] = {nullptr, nullptr};   // each lane's own BN-statistics partial rows (conv -> finalize scratch)
-  bool head_lanes = false;
-  BnFinArgs* fin_dev = nullptr; unsigned* fin_tickets = nullptr; bool bn_ticket = false;   // in-kernel BatchNorm finalize (YS_BN_TICKET=1), table indexed by conv
   // asynchronous segment ends (data-parallel step): the weight-gradient stream is NOT joined into the main stream when a backward segment
   // ends; the segment's completion is two events (main stream, weight-gradient stream) a communication stream waits on (ys_model_segment_fence)
   hipEvent_t ev_seg_m[NSEG] = {nullptr, nullptr, nullptr, nullptr}, ev_seg_w[NSEG] = {nullptr, nullptr, nullptr, nullptr};
@@ -190,11 +184,9 @@ struct ys_model {
 
 namespace {
 
-int dev_alloc(ys_model* m, void** p, size_t bytes, bool zero = true, bool uncached = false) {
+int dev_alloc(ys_model* m, void** p, size_t bytes, bool zero = true) {
   if (bytes == 0) bytes = 16;
-  // uncached (fine-grained, MTYPE UC): stores go to memory and loads come from it whatever XCD issues them -- data workgroups of one
-  // launch hand to each other (statistics rows of the in-kernel BatchNorm finalize) without a cache write-back / invalidate
-  hipError_t e = uncached ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) : hipMalloc(p, bytes);
+  hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) { ys_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return YS_ERR_OOM; }
   m->allocs.push_back(*p);
   if (zero) { e = hipMemsetAsync(*p, 0, bytes, m->ctx->stream); if (e != hipSuccess) { ys_set_error("hipMemset failed"); return YS_ERR_HIP; } }
@@ -399,7 +391,6 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
   int fbuf[3] = {-1, -1, -1}, fconv[3] = {-1, -1, -1};
   const size_t op0 = m->ops.size();
   auto tag = [&](int idx, int tower, int depth) { m->convs[idx].stage = tower * 4 + depth; };   // towers: 0 cv2, 1 cv3, 2 proto, 3 cv4
-  size_t lane_first = m->convs.size();
   for (int t = 0; t < 2; t++) {   // cv2 towers for all levels, then cv3 towers (registration order cv2.*, cv3.*)
     for (int i = 0; i < 3; i++) {
       const int cm = t == 0 ? c2 : c3;
@@ -434,8 +425,6 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, cm}, View{ob, 0, co}, cm, co, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
       tag(cc, t, 2);
-      if (legacy) for (size_t k = lane_first; k < m->convs.size(); k++) m->convs[k].lane = i;   // level 0 (P3) stays on the main stream; v11 towers hold depthwise units (own launch path): no lanes
-      lane_first = m->convs.size();
     }
   }
   m->dfl_after_conv = m->reg.back();
@@ -468,7 +457,6 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4}, View{m->mc_buf, 0, nm}, c4, nm, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
       tag(cc, 4, 2);
-      if (legacy) for (int k = cc - (fuse ? 1 : 2); k <= cc; k++) m->convs[k].lane = i;
     }
     m->xkind = 1;
   } else if (d.task == YS_OBB || d.task == YS_POSE) {
@@ -493,7 +481,6 @@ int add_detect(ys_model* m, const std::string& hp, const int* pv, const int* ch,
       const int cc = add_conv_reg(m, tp + ".2", View{t1, 0, c4p}, View{m->mc_buf, 0, nx}, c4, nx, 1, 1, false, false, hh[i], ww[i], seg);
       m->convs[cc].out_rowoff = m->lvl_off[i];
       tag(k0, 4, 0); tag(k1, 4, 1); tag(cc, 4, 2);
-      if (legacy) for (int k = k0; k <= cc; k++) m->convs[k].lane = i;
     }
   }
   // Level-parallel schedule (v8 heads; YS_GROUP=0 keeps the level-major order and single launches): the head's ops stage-major -- the same
@@ -974,11 +961,10 @@ int allocate(ys_model* m) {
     // lowest priority: the weight gradients are off the critical path (the optimizer is their only reader), and a priority class of
     // its own is a hardware queue of its own -- streams of one class share a handful of queues in creation order, and with the main
     // stream and this one on the SAME queue nothing overlaps (seen with an eagerly initialised RCCL communicator, whose streams
-    // shifted the assignment: 11.6 instead of 10.2 ms/step).  YS_ST2_PRIO=0: default priority.
+    // shifted the assignment: 11.6 instead of 10.2 ms/step).
     {
       int least = 0, greatest = 0;
-      const bool low = (YS_OPT_INT("ST2_PRIO", 1) != 0);
-      if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
         YS_CHECK_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, least));
       else
         YS_CHECK_HIP(hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking));
@@ -1006,11 +992,10 @@ int allocate(ys_model* m) {
     if (gst) YS_TRY(dev_alloc(m, (void**)&m->stat_group, (size_t)gst * 4));
   }
   YS_TRY(dev_alloc(m, (void**)&m->chan, (size_t)nch * 4));
-  const bool ticket_uc = YS_OPT_INT("BN_TICKET", -1) == 2;   // 2: statistics rows + tickets in uncached memory, no fences
-  YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4, true, ticket_uc));
-  // statistics accumulators of the BatchNorm units (round 5, ys_kernels.h ys_stat_acc_add).  Off in fp8 mode (its apply pass also writes the e4m3 image), with the
-  // in-kernel ticket finalize (a rejected experiment kept for A/B), and by BN_ATOMIC=0 (A/B switch against the row + bn_finalize form)
-  m->bn_atomic = YS_OPT_INT("BN_ATOMIC", 1) != 0 && !m->f8 && !m->bn_ticket;
+  YS_TRY(dev_alloc(m, (void**)&m->stat_partial, (size_t)stat_max * 4));
+  // statistics accumulators of the BatchNorm units (round 5, ys_kernels.h ys_stat_acc_add).  Off in fp8 mode (its apply pass also writes the e4m3 image)
+  // and by BN_ATOMIC=0 (A/B switch against the row + bn_finalize form)
+  m->bn_atomic = YS_OPT_INT("BN_ATOMIC", 1) != 0 && !m->f8;
   if (m->bn_atomic) {
     long off = 0;
     for (auto& c : m->convs) if (c.bn && !c.dw && !c.ct) { c.acc_off = off; off += (long)YS_STAT_SHARDS * c.cout * 2; }
@@ -1018,45 +1003,13 @@ int allocate(ys_model* m) {
     if (off > 0) YS_TRY(dev_alloc(m, (void**)&m->stat_acc_all, (size_t)off * 8));
     else m->bn_atomic = false;
   }
-  // off by default: measured (round 3, config 2) 10.52-10.55 ms/step with the lanes against 9.98-10.01 without (round 2's variant of the
-  // same experiment: -5.7 %).  The P3 chain's kernels are persistent grids sized to own every CU (2-3 workgroups per CU by LDS); a
-  // side-stream kernel that takes some of those slots turns the big kernel's equal tile shares into a tail.  YS_HEAD_LANES=1 enables it.
-  m->bn_ticket = YS_OPT_INT("BN_TICKET", 0) != 0;
-  if (m->bn_ticket) {
-    YS_TRY(dev_alloc(m, (void**)&m->fin_tickets, m->convs.size() * 16 * sizeof(unsigned), true, ticket_uc));   // zero-initialised
-    std::vector<BnFinArgs> h(m->convs.size());
-    for (auto& c : m->convs) {
-      BnFinArgs f{};
-      if (c.bn) {
-        f.gamma = m->params + c.g_off; f.beta = m->params + c.b_off;
-        f.run_mean = m->state + c.rm_off; f.run_var = m->state + c.rv_off; f.nbt = m->state + c.nbt_off;
-        f.scale = chan_ptr(m, c, 0); f.shift = chan_ptr(m, c, 1); f.mean = chan_ptr(m, c, 2); f.rstd = chan_ptr(m, c, 3);
-        f.ticket = m->fin_tickets + (size_t)c.idx * 16; f.eps = 1e-3f; f.momentum = 0.03f; f.uncached = ticket_uc ? 1 : 0;
-      }
-      h[c.idx] = f;
-    }
-    YS_TRY(dev_alloc(m, (void**)&m->fin_dev, h.size() * sizeof(BnFinArgs), false));
-    YS_CHECK_HIP(hipMemcpy(m->fin_dev, h.data(), h.size() * sizeof(BnFinArgs), hipMemcpyHostToDevice));
-  }
-  m->head_lanes = m->overlap_built && YS_OPT_INT("HEAD_LANES", 0) != 0;
-  if (m->head_lanes) {
-    bool any = false;
-    for (auto& c : m->convs) any = any || c.lane > 0;
-    m->head_lanes = any;
-  }
-  if (m->head_lanes) {
-    YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    for (int l = 0; l < ys_model::NLANE; l++) {
-      YS_CHECK_HIP(hipStreamCreateWithFlags(&m->lane_st[l], hipStreamNonBlocking));
-      YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_lane[l], hipEventDisableTiming));
-      YS_TRY(dev_alloc(m, (void**)&m->stat_lane[l], (size_t)stat_max * 4));
-    }
-  }
+  // (Two experiments lived here through round 4 and are gone: side-stream "head lanes" for the P4 / P5 towers -- 10.52-10.55 ms/step against 9.98-10.01 without,
+  // a side-stream kernel that takes CU slots turns the persistent P3 kernels' equal tile shares into a tail -- and the last-arriver "ticket" BatchNorm finalize inside
+  // the producing convolution, +0.9 ms/step: DESIGN.md 6b / 6d.)
   YS_TRY(dev_alloc(m, (void**)&m->argmax, (size_t)amax));
   // wgrad partial workspace: a shared scratch (max over layers of splits * |W|: ConvTranspose phases, immediate reduction) followed by
   // one region per convolution, so that the split reduction of a whole backward segment can run as ONE launch after it
-  // (YS_WGRED_DEFER=0: per-layer reduction in the shared scratch, the round-2 behaviour)
-  m->defer_wgred = (YS_OPT_INT("WGRED_DEFER", 1) != 0);
+  m->defer_wgred = true;
   m->stem_on = (YS_OPT_INT("STEM_DIRECT", 1) != 0);
   m->bnred_on = (YS_OPT_INT("BNRED", 1) != 0);           // YS_BNRED=0: every BN backward runs its own reduction pass
   long wgp = 0, wgp_regions = 0;
@@ -1171,7 +1124,7 @@ int run_convT_fwd(ys_model* m, const ConvL& c, int B) {
 
 // model.0 of a whole-model handle on the bf16 path, with its own weight-gradient partial region (deferred split reduction)
 static const ConvL* stem_conv(const ys_model* m) {
-  if (!m->stem_on || m->is_block || m->is_head || m->dtype != YS_BF16 || m->bn_ticket || m->convs.empty()) return nullptr;
+  if (!m->stem_on || m->is_block || m->is_head || m->dtype != YS_BF16 || m->convs.empty()) return nullptr;
   const ConvL& c = m->convs[0];
   if (!c.first || !c.bn || c.dw || c.ct || c.has_res || c.wgp_off < 0 || c.in.buf != m->in_buf) return nullptr;
   if (!ys_stem_eligible(m->dtype, c.cin, c.cout, c.k, c.s)) return nullptr;
@@ -1205,15 +1158,14 @@ static BnAccFin bn_acc_fin(ys_model* m, const ConvL& c, long count) {
 }
 
 // `next`: the convolution that runs right after this one, when it reads exactly the view this one writes (else null)
-// `lane_st` / `lane_stat`: side stream and statistics scratch of a head lane (forward_impl), null = the context's stream
-int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr, hipStream_t lane_st = nullptr, float* lane_stat = nullptr) {
+int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr) {
   if (c.dw) return run_dwconv_fwd(m, c, B);
   if (c.ct) return run_convT_fwd(m, c, B);
-  hipStream_t st = lane_st ? lane_st : m->ctx->stream;
-  float* stat_partial = lane_stat ? lane_stat : m->stat_partial;
+  hipStream_t st = m->ctx->stream;
+  float* stat_partial = m->stat_partial;
   const Buf& ib = m->bufs[c.in.buf];
   const Buf& ob = m->bufs[c.out.buf];
-  if (c.first && m->in_f32 && !lane_st) {      // model.0 straight from the fp32 image planes (conv_stem.hip)
+  if (c.first && m->in_f32) {      // model.0 straight from the fp32 image planes (conv_stem.hip)
     const long Ms = (long)B * c.Hout * c.Wout;
     const void* wf = (char*)m->wf_all + (size_t)c.wf_off * m->es;
     if (m->training) {
@@ -1255,11 +1207,8 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
     void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
     a.y = y; a.out_ldc = c.cout; a.out_coff = 0; a.out_bstride = (long)c.Hout * c.Wout; a.vec_ok = (c.cout % 4 == 0);
     a.stats = stat_partial;
-    const bool atomic = m->bn_atomic && c.acc_off >= 0 && !lane_st && !a.f8;
+    const bool atomic = m->bn_atomic && c.acc_off >= 0 && !a.f8;
     if (atomic) a.stat_acc = m->stat_acc_all + c.acc_off;
-    const int p2_tiles = (m->bn_ticket && m->dtype == YS_BF16 && !a.f8 && !lane_st) ? ys_conv_is_p2(a) : 0;
-    const bool ticket = p2_tiles > 0 && p2_tiles <= 16;     // one arrival counter per channel tile (BnFinArgs::ticket)
-    if (ticket) a.fin = m->fin_dev + c.idx;
     YS_TRY(ys_conv_launch(st, m->dtype, a));
     const void* res = nullptr; int rl = 0, rc = 0;
     if (c.has_res) { res = m->bufs[c.res.buf].act; rl = m->bufs[c.res.buf].ldc; rc = c.res.coff; }
@@ -1268,7 +1217,7 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
       return YS_OK;
     }
     const int gm = ys_conv_grid_m(a, m->dtype);
-    if (!ticket) YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
+    YS_TRY(ys_bn_finalize_launch(st, stat_partial, gm, c.cout, M, m->params + c.g_off, m->params + c.b_off, 1e-3f, 0.03f,
                                  m->state + c.rm_off, m->state + c.rv_off, m->state + c.nbt_off, chan_ptr(m, c, 0),
                                  chan_ptr(m, c, 1), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
     // fp8 mode: the next convolution of the schedule reads exactly this output and will run the fp8 blocked-GEMM kernel -> this pass also writes
@@ -1306,7 +1255,7 @@ int run_conv_fwd(ys_model* m, const ConvL& c, int B, const ConvL* next = nullptr
 // launch each; then ONE BatchNorm finalize and ONE BN + SiLU apply launch for the whole stage.  Same arithmetic as run_conv_fwd.
 int run_conv_fwd_group(ys_model* m, ConvL* const* cs, int n, int B) {
   hipStream_t st = m->ctx->stream;
-  bool ok = n >= 2 && n <= YS_GROUP_MAX && !m->f8 && !m->bn_ticket;
+  bool ok = n >= 2 && n <= YS_GROUP_MAX && !m->f8;
   for (int i = 0; i < n && ok; i++) {
     const ConvL& c = *cs[i];
     ok = !c.dw && !c.ct && !c.has_res && c.gstat_off >= 0 && c.bn == cs[0]->bn && c.act == cs[0]->act;
@@ -1367,14 +1316,11 @@ int forward_impl(ys_model* m, int B) {
     m->eval_coeffs_dirty = false;
   }
   m->q8_fwd_ready = -1;
-  // head lanes: training forward in bf16 / f32 storage with the overlap switch on (bench.py's per-kernel profile steps switch it off)
-  const bool lanes_on = m->head_lanes && m->overlap && m->training && !m->f8;
-  bool forked = false;
   for (size_t oi = 0; oi < m->ops.size(); oi++) {
     const Op& op = m->ops[oi];
     const Buf& ib = m->bufs[op.in.buf];
     const Buf& ob = m->bufs[op.out.buf];
-    if (op.type == OP_CONV && m->convs[op.conv].group >= 0 && !lanes_on) {
+    if (op.type == OP_CONV && m->convs[op.conv].group >= 0) {
       // a head stage: the consecutive ops of one group run as grouped launches
       ConvL* gc[YS_GROUP_MAX]; int gn = 0;
       const int gid = m->convs[op.conv].group;
@@ -1391,16 +1337,7 @@ int forward_impl(ys_model* m, int B) {
         if (nc.in.buf == cc.out.buf && nc.in.coff == cc.out.coff && nc.in.C == cc.out.C && nc.cin_pad == cc.cout && nc.cin == cc.cout &&
             nc.Hin == cc.Hout && nc.Win == cc.Wout) next = &nc;
       }
-      if (lanes_on && cc.lane > 0 && !cc.dw && !cc.ct) {
-        if (!forked) {                           // everything the towers read (the neck outputs) is complete on the main stream here
-          YS_CHECK_HIP(hipEventRecord(m->ev_fork, st));
-          for (int l = 0; l < ys_model::NLANE; l++) YS_CHECK_HIP(hipStreamWaitEvent(m->lane_st[l], m->ev_fork, 0));
-          forked = true;
-        }
-        YS_TRY(run_conv_fwd(m, cc, B, nullptr, m->lane_st[cc.lane - 1], m->stat_lane[cc.lane - 1]));
-      } else {
-        YS_TRY(run_conv_fwd(m, cc, B, next));
-      }
+      YS_TRY(run_conv_fwd(m, cc, B, next));
     } else if (op.type == OP_MAXPOOL) {
       YS_TRY(ys_maxpool5_fwd_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, B, op.H, op.W, op.in.C, ob.act, ob.ldc,
                                     op.out.coff, m->training ? m->argmax + op.aux_off : nullptr));
@@ -1412,12 +1349,6 @@ int forward_impl(ys_model* m, int B) {
       YS_TRY(ys_attn_v_copy_launch(st, m->dtype, ib.act, ob.act, (long)B * op.H * op.W, ib.ldc, op.heads, op.kd, op.hd, ob.ldc, 0));
     } else if (op.type == OP_COPY) {
       YS_TRY(ys_copy_view_launch(st, m->dtype, ib.act, ib.ldc, op.in.coff, (long)B * op.H * op.W, op.in.C, ob.act, ob.ldc, op.out.coff, 0));
-    }
-  }
-  if (forked) {                            // join: the loss / decode read every level's rows
-    for (int l = 0; l < ys_model::NLANE; l++) {
-      YS_CHECK_HIP(hipEventRecord(m->ev_lane[l], m->lane_st[l]));
-      YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_lane[l], 0));
     }
   }
   if (m->f8) m->f8_sx_valid = true;        // every fp8 candidate has recorded an input maximum (bootstrap pass or its own kernel)
@@ -2043,11 +1974,6 @@ int ys_model_destroy(ys_model* m) {
     if (m->ev_join) hipEventDestroy(m->ev_join);
     hipStreamDestroy(m->st2);
   }
-  for (int l = 0; l < ys_model::NLANE; l++) {
-    if (m->lane_st[l]) { hipStreamSynchronize(m->lane_st[l]); hipStreamDestroy(m->lane_st[l]); }
-    if (m->ev_lane[l]) hipEventDestroy(m->ev_lane[l]);
-  }
-  if (m->ev_fork) hipEventDestroy(m->ev_fork);
   for (int k = 0; k < ys_model::NSEG; k++) { if (m->ev_seg_m[k]) hipEventDestroy(m->ev_seg_m[k]); if (m->ev_seg_w[k]) hipEventDestroy(m->ev_seg_w[k]); }
   for (void* p : m->allocs) hipFree(p);
   delete m;

@@ -603,9 +603,6 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   if (!ctx->nms_count_clean || B > ctx->nms_count_clean_B) YS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * B, ctx->stream));
   ctx->nms_count_clean = false;
   YsKprofScope prof(ctx->stream, "nms");
-  const bool dbg = YS_OPT_INT("NMS_DEBUG", 0) != 0;
-#define NMS_DBG(what) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(ctx->stream); hipError_t l_ = hipGetLastError(); fprintf(stderr, "nms %s: sync %d last %d\n", what, (int)e_, (int)l_); } } while (0)
-  NMS_DBG("entry");
   unsigned long long* keys = (unsigned long long*)(ws + o_keys);
   float* confs = (float*)(ws + o_conf); int* clss = (int*)(ws + o_cls);
   float4* sbox = (float4*)(ws + o_box); float* sarea = (float*)(ws + o_area); int* sidx = (int*)(ws + o_idx);
@@ -621,10 +618,8 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
     if (rotated) YS_LAUNCH((nms_filter_kernel<1, true>), g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
     else YS_LAUNCH((nms_filter_kernel<1, false>), g1, 256, ctx->stream, pred, C, A, nc, conf, count, keys, np2, confs, clss);
   }
-  NMS_DBG("filter");
   YS_LAUNCH(nms_sort_kernel, B, NMS_THREADS, ctx->stream, (const float*)pred, C, A, nc, max_det, max_nms, (float)max_wh, count,
             keys, np2, (const int*)clss, sbox, sarea, sidx, supp, ncap, nsort, out_rows, (long long*)out_keep, (int*)out_count, scov);
-  NMS_DBG("sort");
   ctx->nms_count_clean = true;                // nms_sort_kernel zeroes the B counters it read
   ctx->nms_count_clean_B = B;
   if (rotated) {
@@ -635,7 +630,6 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
     return YS_OK;
   }
   YS_LAUNCH(nms_mask_kernel, dim3(B, NMS_MASK_WGS), 256, ctx->stream, (const int*)nsort, (const float4*)sbox, (const float*)sarea, ncap, iou, mask);
-  NMS_DBG("mask");
   static_assert(NMS_LDS_N_FWD == NMS_LDS_N, "mask / scan kernels disagree on the LDS-resident size");
   static std::atomic<unsigned> attr_done{0};
   int dev_id = 0;
@@ -647,7 +641,6 @@ int ys_nms_launch(ys_ctx* ctx, float* pred, int B, int C, int A, float conf, flo
   YS_LAUNCH_LDS(nms_scan_kernel, B, NMS_THREADS, NMS_SCAN_LDS, ctx->stream, (const float*)pred, C, A, nc, iou, max_det, (const int*)nsort,
                 (const float4*)sbox, (const float*)sarea, (const int*)sidx, ncap, (const float*)confs, (const int*)clss,
                 (const unsigned long long*)mask, supp, out_rows, (long long*)out_keep, (int*)out_count);
-  NMS_DBG("scan");
   (void)big_possible;
   YS_CHECK_HIP(hipGetLastError());
   return YS_OK;

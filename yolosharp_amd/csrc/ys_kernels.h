@@ -21,16 +21,6 @@ struct BnRedSeg {
   int act;              // producer applies SiLU
   int pad_;
 };
-// per-layer operands of the in-kernel BatchNorm finalize (device-resident table, one entry per BN conv unit)
-struct BnFinArgs {
-  const float* gamma; const float* beta;
-  float* run_mean; float* run_var; float* nbt;
-  float* scale; float* shift; float* mean; float* rstd;
-  unsigned* ticket;              // [16] one arrival counter per channel tile (blockIdx.y), zero between launches
-  float eps, momentum;
-  int uncached;                  // statistics rows and tickets live in uncached memory: ordering by s_waitcnt alone, no cache write-back / invalidate
-  int pad_;
-};
 struct ConvArgs {
   const void* x;        // input activations (NHWC view)
   const void* w;        // weights [Cout][KH*KW][Cin], storage type T
@@ -68,8 +58,6 @@ struct ConvArgs {
   // fp8 blocked-GEMM path (conv_gemm_kernel<F8 = 1>): the operand tiles go to LDS by DMA, so the input must already be fp8 in memory
   void* q8;                      // optional scratch of >= B*Hin*Win*Cin bytes: ys_conv_launch quantises the input view into it first
   const void* x8;                // set by ys_conv_launch: the dense [B*Hin*Win][Cin] fp8 image of the input (inside q8)
-  const struct BnFinArgs* fin;   // forward BN launches of conv_p2_kernel with the last-arriver finalize (YS_BN_TICKET=1): the workgroup that flushes the last
-                                 // statistics row of a channel tile reduces the rows and writes scale / shift / mean / rstd / running stats itself
   unsigned long long* tl;        // triage builds (-DYS_P2_TIMELINE): per-workgroup s_memtime stamps of the tile phases; null otherwise
   // fused BN-backward reduction (dgrad launches through conv_epi.h only; see BnRedSeg)
   int nred;                      // segments in use (0 = off)
