@@ -448,7 +448,7 @@ static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   const int per_cu_max = k3 ? (p.mra * p.nrb <= YS_WG_TWO_MAX ? 2 : 1) : 4;   // 9-wave workgroups are register-limited to 1-2 per CU (launch bounds of conv_wgrad_tr_kernel)
   if (per_cu > per_cu_max) per_cu = per_cu_max;
   if (per_cu < 1) per_cu = 1;
-  long gx = (256L * per_cu) / gy;
+  long gx = (256L * per_cu) / gy;                        // (round 5: half / quarter grids -- fewer partial slabs for the split reduction -- measured 8.69 -> 8.73 / 10.01 ms on config 2)
   gx = gx / 8 * 8;                                       // same-x workgroups (same pixels, other channel tiles) share an XCD
   if (gx < 8) gx = 8;
   const long wsmax = (48L << 20) / ((long)a.Cout * a.KH * a.KW * a.Cin * 4);   // bound the partial workspace to 48 MB per layer
@@ -573,7 +573,11 @@ wgrad_reduce_batched_kernel(const WgRedDesc* __restrict__ descs, int nd) {
   // a thread owns FOUR consecutive outputs (16-byte loads of the partial rows: the 4-byte form moved 128 B per half-wave request
   // and ran at ~0.9 TB/s, 0.30 ms per YOLOv8n step); every output keeps the per-layer kernel's summation order, component by
   // component.  n and cin_pad are multiples of 4 (channel padding), so the four share one weight row.
-  __shared__ float4 sred[16][32];
+  // Round 5: a workgroup covers NSUB groups of 128 outputs instead of one, the loads of all of them requested before the first is reduced.  With one group a
+  // workgroup was 8 dependent descriptor loads, ONE 16-byte load per thread, a barrier and 128 stores: 530 thousand such workgroups per YOLOv8x step, 2.4 TB/s
+  // (1.64 ms; 0.37 ms = 3.6 % of the YOLOv8s step).  Same sums in the same order per output.
+  constexpr int NSUB = YS_WGRED_OUT_PER_BLOCK / 128;
+  __shared__ float4 sred[NSUB][16][32];
   int lo = 0, hi = nd - 1;
   const long blk = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].blk0 <= blk) lo = mid; else hi = mid - 1; }
@@ -582,40 +586,57 @@ wgrad_reduce_batched_kernel(const WgRedDesc* __restrict__ descs, int nd) {
   const int splits = d.splits;
   const long n = d.n;
   const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long i = (blk - d.blk0) * YS_WGRED_OUT_PER_BLOCK + o * 4;
-  float gprev[4] = {0.f, 0.f, 0.f, 0.f}; long gidx = -1; int nreal = 0;
-  if (sl == 0 && i < n) {
-    const long row = i / d.cin_pad;
-    const int ci = (int)(i - row * d.cin_pad);
-    nreal = d.cin_real - ci; if (nreal > 4) nreal = 4;
-    if (nreal > 0) {
-      gidx = row * d.cin_real + ci;
-#pragma unroll
-      for (int e = 0; e < 4; e++) if (e < nreal) gprev[e] = d.grad[gidx + e];
-    }
-  }
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  const long i0 = (blk - d.blk0) * YS_WGRED_OUT_PER_BLOCK + o * 4;
   auto add4 = [](float4& acc, const float4& v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; };
-  if (i < n) {
-    int k = sl;
-    for (; k + 48 < splits; k += 64) {
-      const float4 v0 = *(const float4*)(partial + (long)k * n + i);
-      const float4 v1 = *(const float4*)(partial + (long)(k + 16) * n + i);
-      const float4 v2 = *(const float4*)(partial + (long)(k + 32) * n + i);
-      const float4 v3 = *(const float4*)(partial + (long)(k + 48) * n + i);
-      add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
+  float4 tot[NSUB];
+  if (splits <= 16) {          // the common case: one partial row per split lane -> NSUB independent loads in flight per thread
+    float4 v[NSUB];
+#pragma unroll
+    for (int u = 0; u < NSUB; u++) {
+      const long i = i0 + u * 128;
+      v[u] = (i < n && sl < splits) ? *(const float4*)(partial + (long)sl * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (; k < splits; k += 16) add4(s0, *(const float4*)(partial + (long)k * n + i));
+#pragma unroll
+    for (int u = 0; u < NSUB; u++) tot[u] = make_float4((v[u].x + 0.f) + (0.f + 0.f), (v[u].y + 0.f) + (0.f + 0.f), (v[u].z + 0.f) + (0.f + 0.f), (v[u].w + 0.f) + (0.f + 0.f));
+  } else {
+#pragma unroll
+    for (int u = 0; u < NSUB; u++) {
+      const long i = i0 + u * 128;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+      if (i < n) {
+        int k = sl;
+        for (; k + 48 < splits; k += 64) {
+          const float4 v0 = *(const float4*)(partial + (long)k * n + i);
+          const float4 v1 = *(const float4*)(partial + (long)(k + 16) * n + i);
+          const float4 v2 = *(const float4*)(partial + (long)(k + 32) * n + i);
+          const float4 v3 = *(const float4*)(partial + (long)(k + 48) * n + i);
+          add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
+        }
+        for (; k < splits; k += 16) add4(s0, *(const float4*)(partial + (long)k * n + i));
+      }
+      tot[u] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    }
   }
-  sred[sl][o] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+#pragma unroll
+  for (int u = 0; u < NSUB; u++) sred[u][sl][o] = tot[u];
   __syncthreads();
-  if (gidx >= 0) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  // split lane u finishes group u: 32 threads x 4 outputs each
+  if (sl < NSUB) {
+    const long i = i0 + sl * 128;
+    if (i < n) {
+      const long row = i / d.cin_pad;
+      const int ci = (int)(i - row * d.cin_pad);
+      int nreal = d.cin_real - ci; if (nreal > 4) nreal = 4;
+      if (nreal > 0) {
+        const long gidx = row * d.cin_real + ci;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int w = 0; w < 16; w++) add4(t, sred[w][o]);
-    const float tv[4] = {t.x, t.y, t.z, t.w};
+        for (int w = 0; w < 16; w++) add4(t, sred[sl][w][o]);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int e = 0; e < 4; e++) if (e < nreal) d.grad[gidx + e] = gprev[e] + tv[e];
+        for (int e = 0; e < 4; e++) if (e < nreal) d.grad[gidx + e] = d.grad[gidx + e] + tv[e];
+      }
+    }
   }
 }
 int ys_wgrad_reduce_batched_launch(hipStream_t st, const WgRedDesc* descs_dev, int n_desc, long total_blocks) {

@@ -117,7 +117,7 @@ int ys_wgrad_splits(const WgradArgs& a, int dtype);
 // segment); *used_splits = number of partial slabs [Cout][taps][Cin] written to a.partial
 int ys_wgrad_launch(hipStream_t st, int dtype, const WgradArgs& a, int splits, int cin_real, float* grad, int* used_splits = nullptr);
 // one launch reducing the partial slabs of several layers: grad[row * cin_real + ci] += sum_s partial[s][row * cin_pad + ci]
-#define YS_WGRED_OUT_PER_BLOCK 128   // outputs per workgroup of wgrad_reduce_batched_kernel (blk0 prefix of the descriptors)
+#define YS_WGRED_OUT_PER_BLOCK 512   // outputs per workgroup (a multiple of 128) of wgrad_reduce_batched_kernel (blk0 prefix of the descriptors)
 struct WgRedDesc { const float* partial; float* grad; long n; long blk0; int splits, cin_pad, cin_real, pad_; };
 int ys_wgrad_reduce_batched_launch(hipStream_t st, const WgRedDesc* descs_dev, int n_desc, long total_blocks);
 // blocked-GEMM weight-gradient kernel of the wide bf16 layers (conv_wgrad_gemm.hip): pixel splits it wants (0 = not eligible);
