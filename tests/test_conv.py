@@ -226,3 +226,52 @@ def test_wide_bn_layer_reruns_are_bit_identical(backend, engine, case):
     for y, rm, rv in outs[1:]:
         assert np.array_equal(rm, outs[0][1]) and np.array_equal(rv, outs[0][2]), "batch statistics differ between reruns"
         assert np.array_equal(y, outs[0][0]), "outputs differ between reruns"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu"])
+def test_halo_kernel_against_blocked_gemm_on_random_shapes(backend, engine):
+    """conv_halo_kernel (GEMM_HALO=1) and conv_gemm_kernel (GEMM_HALO=0) on the same random 3x3 stride-1 problems -- ragged maps, one to many tiles per workgroup,
+    partial last chunks (Cin mod 64 in 1..32 and above), 128- and 160-wide channel tiles, several batch sizes: forward with training-mode BatchNorm + SiLU (the
+    statistics path), then dx / dw through ys_conv_bwd.  Two different summation orders of the same bf16 products: outputs within bf16 rounding of each other
+    (max |diff| <= 2^-7 of the output scale), and each rerun of the halo launch bit-identical to itself (the races of round 5 showed as run-to-run differences)."""
+    import ctypes as C
+    from yolosharp_amd import _lib
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(11)
+    shapes = []
+    for _ in range(14):
+        cin = int(rng.choice([64, 72, 80, 96, 128, 160, 192, 320]))
+        cout = int(rng.choice([64, 80, 128, 144, 160, 320]))
+        shapes.append((int(rng.integers(1, 5)), cin, int(rng.integers(16, 70)), int(rng.integers(16, 70)), cout))
+    shapes += [(2, 160, 80, 80, 160), (1, 320, 48, 33, 320)]
+    engine.kernel_profile(True)
+    for (B, cin, H, W, cout) in shapes:
+        x = rng.standard_normal((B, cin, H, W), dtype=np.float32)
+        w = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+        dy = rng.standard_normal((B, cout, H, W), dtype=np.float32)
+        res = {}
+        for halo in (1, 0, 1):
+            with engine.options(GEMM_HALO=halo, HALO_MIN_FILL=1, GEMM_MIN_M=1, GEMM_MIN_CIN=64):
+                bn = {"weight": np.ones(cout, np.float32), "bias": np.zeros(cout, np.float32), "running_mean": np.zeros(cout, np.float32), "running_var": np.ones(cout, np.float32)}
+                y = engine.conv_bn_act(x, w, 3, 1, bn=bn, act=True, training=True, dtype="bf16")
+                y = y[0] if isinstance(y, tuple) else y
+                dx = np.zeros(x.shape, np.float32); dw = np.zeros(w.shape, np.float32)
+                _lib.check(engine.lib, engine.lib.ys_conv_bwd(engine.ctx, 1, vp(x), B, cin, H, W, vp(w), cout, 3, 1, vp(dy), vp(dx), vp(dw)))
+            key = "halo" if halo else "gemm"
+            if key in res:                     # second halo run: bit-identical
+                assert np.array_equal(res[key][0], y) and np.array_equal(res[key][1], dx), (B, cin, H, W, cout)
+            res[key] = (np.asarray(y).copy(), dx.copy())
+        for i, nm in ((0, "y"), (1, "dx")):
+            a, b = res["halo"][i], res["gemm"][i]
+            assert np.isfinite(a).all(), (nm, B, cin, H, W, cout)
+            scale = float(np.abs(b).max()) + 1e-6
+            assert float(np.abs(a - b).max()) <= scale * 2.0 ** -7 + 1e-6, (nm, B, cin, H, W, cout, float(np.abs(a - b).max()), scale)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "launches.csv")
+        engine.kernel_profile_dump(path)
+        labels = [l.split(",")[1] for l in open(path).read().splitlines()[1:] if l.startswith("conv_igemm")]
+    engine.kernel_profile(False)
+    n_halo = sum(l.startswith("halo k33") for l in labels)
+    assert n_halo >= 24, (n_halo, len(labels))     # the comparison is not gemm against gemm: most of these shapes (forward and / or dgrad) are halo-eligible
