@@ -210,6 +210,9 @@ YS_API int ys_model_param_buffer(ys_model* m, float** dptr, int64_t* count);
  * the wide-layer kernels (tests/conftest.py), the A/B scripts under tools/ flip one switch per run. */
 YS_API int ys_set_option(const char* key, double value);
 YS_API int ys_unset_option(const char* key);
+/* the table's entry for `key` (set by ys_set_option or seeded from the environment at load): *is_set = 0 and *value = 0 when the built-in default applies.
+ * Lets a caller change an option temporarily and put back exactly what was there (Engine.options in the Python host). */
+YS_API int ys_get_option(const char* key, double* value, int* is_set);
 
 YS_API int ys_dist_unique_id(void* id128);
 YS_API int ys_dist_init(ys_ctx* ctx, int rank, int world, const void* id128);

@@ -88,3 +88,20 @@ def test_csharp_shim_binds_only_exported_symbols():
     assert not unknown, unknown
     for must in ("ys_model_forward", "ys_loss_detect", "ys_model_backward", "ys_optim_adamw_step", "ys_nms_batched", "ys_dist_init"):
         assert must in names, must
+
+
+def test_options_context_restores_what_was_there(emu_lib_path):
+    """Engine.options must put back the PREVIOUS entry of the table, not delete it: tests/conftest.py seeds size gates through the environment at library load
+    (YS_GEMM_MIN_M=1 ...), and a test that changed one of them temporarily used to leave the rest of its process on the production gate (round 5: two chaotic
+    training-curve checks flipped when a new test ran before them)."""
+    import os
+    from yolosharp_amd import Engine
+    eng = Engine(lib_path=emu_lib_path)
+    assert os.environ.get("YS_GEMM_MIN_M") == "1" and eng.get_option("GEMM_MIN_M") == 1.0      # seeded from the environment
+    assert eng.get_option("NO_SUCH_KEY_R05") is None
+    with eng.options(GEMM_MIN_M=4096, NO_SUCH_KEY_R05=3):
+        assert eng.get_option("GEMM_MIN_M") == 4096.0 and eng.get_option("YS_NO_SUCH_KEY_R05") == 3.0
+        with eng.options(GEMM_MIN_M=7):
+            assert eng.get_option("GEMM_MIN_M") == 7.0
+        assert eng.get_option("GEMM_MIN_M") == 4096.0
+    assert eng.get_option("GEMM_MIN_M") == 1.0 and eng.get_option("NO_SUCH_KEY_R05") is None

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "ys_model_param_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p]),
     "ys_set_option": (C.c_int, [C.c_char_p, C.c_double]),
     "ys_unset_option": (C.c_int, [C.c_char_p]),
+    "ys_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ys_dist_unique_id": (C.c_int, [C.c_void_p]),
     "ys_dist_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ys_dist_destroy": (C.c_int, [C.c_void_p]),

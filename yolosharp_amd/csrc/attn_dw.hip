@@ -440,6 +440,252 @@ attn_bwd_q4_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, int he
     ys_wave_sync();                           // the next pass overwrites so / ds
   }
 }
+// ---- round 5, second step: the same two passes on the matrix cores (bf16, kd = 32, hd = 64, N <= 416 tokens = every C2PSA at 640 x 640).  One wave owns 16 query
+// rows: S = Q K^T as one 16x16x32 MFMA per 16 keys (K rows straight from the staged LDS copy), softmax in the accumulator layout (a query row lives in the 16 lanes of
+// a DPP row: four shuffles per reduction), the probabilities go to global memory in fp32 (the backward reads them) and as bf16 into a per-wave LDS tile that feeds the
+// second product O = P V against a TRANSPOSED staged copy of V (the MFMA's K dimension is the key index).  The backward pass mirrors it: dP = dO V^T, dS = P (dP - t),
+// dq = dS K against a transposed K.  The probabilities / dS enter the second product rounded to bf16 (the scalar kernels multiply them in fp32): a 2^-9 relative
+// perturbation per term, below what the bf16 storage of the operands already costs; the parity tests of the block and the model hold their tolerances.
+#define ATT_NM 416
+__host__ __device__ inline int att_np16(int N) { return (N + 15) & ~15; }
+__host__ __device__ inline int att_np32(int N) { return (N + 31) & ~31; }
+__host__ __device__ inline int att_tp(int N) { return att_np32(N) * 2 + 16; }       // pitch (bytes) of a transposed row / a probability row: + 16 keeps 16-row fragment reads off one bank group
+__device__ inline float att_row16_max(float v) { for (int m = 8; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m)); return v; }
+__device__ inline float att_row16_sum(float v) { for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m); return v; }
+// rows [0, np16) of a [N][W bf16] operand -> LDS rows of `pitch` bytes (rows >= N zero); src = first element of row 0, W / 8 16-byte units per row
+__device__ inline void att_stage_rows(const bf16_t* src, int ldq, int N, int np16, int units, int pitch, char* dst) {
+  for (int u = threadIdx.x; u < np16 * units; u += AD_THREADS) {
+    const int m = u / units, c = u - m * units;
+    *(uint4*)(dst + m * pitch + c * 16) = m < N ? *(const uint4*)(src + (long)m * ldq + c * 8) : ys_zero16();
+  }
+}
+// the same operand transposed: LDS row d (0 .. 8 * units - 1) holds element d of keys 0 .. np32 - 1 (keys >= N zero)
+__device__ inline void att_stage_transposed(const bf16_t* src, int ldq, int N, int np32, int units, int tp, char* dst) {
+  for (int u = threadIdx.x; u < np32 * units; u += AD_THREADS) {
+    const int c = u / np32, m = u - c * np32;
+    const uint4 v = m < N ? *(const uint4*)(src + (long)m * ldq + c * 8) : ys_zero16();
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) *(unsigned short*)(dst + (c * 8 + j) * tp + m * 2) = (unsigned short)(w[j >> 1] >> (16 * (j & 1)));
+  }
+}
+#define ATT_TMAX (ATT_NM / 16)
+__global__ void __launch_bounds__(AD_THREADS, 1)
+attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, int heads, float scale, bf16_t* __restrict__ ao, int ldo, float* __restrict__ P) {
+  constexpr int KD = 32, HD = 64, hs = 2 * KD + HD;
+  YS_DYN_LDS(lds);
+  const int np16 = att_np16(N), np32 = att_np32(N), tp = att_tp(N), T = np16 >> 4, KS = np32 >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const bf16_t* base = qkv + (long)b * N * ldq + h * hs;
+  char* sK = (char*)lds;
+  char* sVt = sK + (size_t)np16 * ATT_KP;
+  char* sP = sVt + (size_t)HD * tp + (size_t)wave * 16 * tp;
+  att_stage_rows(base + KD, ldq, N, np16, KD / 8, ATT_KP, sK);
+  att_stage_transposed(base + 2 * KD, ldq, N, np32, HD / 8, tp, sVt);
+  __syncthreads();
+  const int n0 = blockIdx.x * ATT_QB + wave * 16;
+  if (n0 >= N) return;                        // wave-uniform; no workgroup barrier below
+  const int arow = n0 + li < N ? n0 + li : N - 1;
+  const uint4 aq = *(const uint4*)(base + (long)arow * ldq + q4 * 8);
+  f32x4 sacc[ATT_TMAX];
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++) {
+    sacc[t] = f32x4_zero();
+    if (t < T) sacc[t] = mfma_16x16x32_bf16(aq, *(const uint4*)(sK + (16 * t + li) * ATT_KP + q4 * 16), sacc[t]);
+  }
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++) {
+    if (t < T) {
+      const bool colok = 16 * t + li < N;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const float v = colok ? sacc[t][r] * scale : -INFINITY; sacc[t][r] = v; mx[r] = fmaxf(mx[r], v); }
+    }
+  }
+  float sum[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { mx[r] = att_row16_max(mx[r]); sum[r] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++) {
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const float e = __expf(sacc[t][r] - mx[r]); sacc[t][r] = e; sum[r] += e; }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) sum[r] = 1.0f / att_row16_sum(sum[r]);
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++) {
+    if (t < T) {
+      const int col = 16 * t + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float pv = sacc[t][r] * sum[r];
+        const int row = n0 + 4 * q4 + r;
+        if (row < N && col < N) P[((long)bh * N + row) * N + col] = pv;
+        *(unsigned short*)(sP + (4 * q4 + r) * tp + col * 2) = Elem<bf16_t>::from_f(pv).v;
+      }
+    }
+  }
+  if (np32 > np16) *(uint2*)(sP + li * tp + (np16 + 4 * q4) * 2) = make_uint2(0u, 0u);     // columns np16 .. np32 - 1 of the last K-step
+  ys_wave_sync();
+  f32x4 oacc[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; dt++) oacc[dt] = f32x4_zero();
+  for (int ks = 0; ks < KS; ks++) {
+    const uint4 ap = *(const uint4*)(sP + li * tp + (32 * ks + 8 * q4) * 2);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; dt++)
+      oacc[dt] = mfma_16x16x32_bf16(ap, *(const uint4*)(sVt + (16 * dt + li) * tp + (32 * ks + 8 * q4) * 2), oacc[dt]);
+  }
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; dt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = n0 + 4 * q4 + r;
+      if (row < N) ao[((long)b * N + row) * ldo + h * HD + 16 * dt + li] = Elem<bf16_t>::from_f(oacc[dt][r]);
+    }
+}
+
+__global__ void __launch_bounds__(AD_THREADS, 1)
+attn_bwd_q_mfma_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, int heads, float scale, const bf16_t* __restrict__ dao, int ldo,
+                       const float* __restrict__ P, float* __restrict__ dS, bf16_t* __restrict__ dqkv) {
+  constexpr int KD = 32, HD = 64, hs = 2 * KD + HD;
+  YS_DYN_LDS(lds);
+  const int np16 = att_np16(N), np32 = att_np32(N), tp = att_tp(N), T = np16 >> 4, KS = np32 >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const bf16_t* base = qkv + (long)b * N * ldq + h * hs;
+  char* sV = (char*)lds;
+  char* sKt = sV + (size_t)np16 * ATT_VP;
+  char* sS = sKt + (size_t)KD * tp + (size_t)wave * 16 * tp;
+  att_stage_rows(base + 2 * KD, ldq, N, np16, HD / 8, ATT_VP, sV);
+  att_stage_transposed(base + KD, ldq, N, np32, KD / 8, tp, sKt);
+  __syncthreads();
+  const int n0 = blockIdx.x * ATT_QB + wave * 16;
+  if (n0 >= N) return;
+  const int arow = n0 + li < N ? n0 + li : N - 1;
+  const bf16_t* dorow = dao + ((long)b * N + arow) * ldo + h * HD;
+  const uint4 ao0 = *(const uint4*)(dorow + q4 * 8), ao1 = *(const uint4*)(dorow + 32 + q4 * 8);
+  f32x4 dp[ATT_TMAX];
+  float pv[ATT_TMAX][4];
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++) {
+    dp[t] = f32x4_zero();
+    if (t < T) {
+      const char* vr = sV + (16 * t + li) * ATT_VP;
+      dp[t] = mfma_16x16x32_bf16(ao0, *(const uint4*)(vr + q4 * 16), dp[t]);
+      dp[t] = mfma_16x16x32_bf16(ao1, *(const uint4*)(vr + 64 + q4 * 16), dp[t]);
+      const int col = 16 * t + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = n0 + 4 * q4 + r;
+        pv[t][r] = (row < N && col < N) ? P[((long)bh * N + row) * N + col] : 0.f;
+      }
+    }
+  }
+  float tr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++)
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) tr[r] += dp[t][r] * pv[t][r];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; r++) tr[r] = att_row16_sum(tr[r]);
+#pragma unroll
+  for (int t = 0; t < ATT_TMAX; t++) {
+    if (t < T) {
+      const int col = 16 * t + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float v = pv[t][r] * (dp[t][r] - tr[r]);
+        const int row = n0 + 4 * q4 + r;
+        if (row < N && col < N) dS[((long)bh * N + row) * N + col] = v;
+        *(unsigned short*)(sS + (4 * q4 + r) * tp + col * 2) = Elem<bf16_t>::from_f(v).v;
+      }
+    }
+  }
+  if (np32 > np16) *(uint2*)(sS + li * tp + (np16 + 4 * q4) * 2) = make_uint2(0u, 0u);
+  ys_wave_sync();
+  f32x4 qacc[KD / 16];
+#pragma unroll
+  for (int dt = 0; dt < KD / 16; dt++) qacc[dt] = f32x4_zero();
+  for (int ks = 0; ks < KS; ks++) {
+    const uint4 as = *(const uint4*)(sS + li * tp + (32 * ks + 8 * q4) * 2);
+#pragma unroll
+    for (int dt = 0; dt < KD / 16; dt++)
+      qacc[dt] = mfma_16x16x32_bf16(as, *(const uint4*)(sKt + (16 * dt + li) * tp + (32 * ks + 8 * q4) * 2), qacc[dt]);
+  }
+#pragma unroll
+  for (int dt = 0; dt < KD / 16; dt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = n0 + 4 * q4 + r;
+      if (row < N) dqkv[((long)b * N + row) * ldq + h * hs + 16 * dt + li] = Elem<bf16_t>::from_f(qacc[dt][r] * scale);
+    }
+}
+// pass 2 on the matrix cores: a wave owns 16 key columns; dk = scale dS^T q and dv += P^T dO walk the query rows 32 at a time.  The A operand (rows = keys, K = query
+// index) is gathered from the fp32 dS / P matrices in global memory -- eight 4-byte loads per lane and K-step, 64-byte segments per row -- and rounded to bf16; the B
+// operands are q and dO staged TRANSPOSED in LDS.
+__global__ void __launch_bounds__(AD_THREADS, 1)
+attn_bwd_kv_mfma_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, int heads, float scale, const bf16_t* __restrict__ dao, int ldo,
+                        const float* __restrict__ P, const float* __restrict__ dS, bf16_t* __restrict__ dqkv) {
+  constexpr int KD = 32, HD = 64, hs = 2 * KD + HD;
+  YS_DYN_LDS(lds);
+  const int np32 = att_np32(N), tp = att_tp(N), KS = np32 >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const bf16_t* base = qkv + (long)b * N * ldq + h * hs;
+  char* sQt = (char*)lds;
+  char* sOt = sQt + (size_t)KD * tp;
+  att_stage_transposed(base, ldq, N, np32, KD / 8, tp, sQt);
+  att_stage_transposed(dao + (long)b * N * ldo + h * HD, ldo, N, np32, HD / 8, tp, sOt);
+  __syncthreads();
+  const int m0 = blockIdx.x * ATT_QB + wave * 16;
+  if (m0 >= N) return;
+  const int mcol = m0 + li;                    // this lane's key column of the A operands
+  const float* Sb = dS + (long)bh * N * N + mcol;
+  const float* Pb = P + (long)bh * N * N + mcol;
+  f32x4 kacc[KD / 16], vacc[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < KD / 16; dt++) kacc[dt] = f32x4_zero();
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; dt++) vacc[dt] = f32x4_zero();
+  for (int ks = 0; ks < KS; ks++) {
+    float fs[8], fp[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int n = 32 * ks + 8 * q4 + j;
+      const bool ok = (bool)((int)(n < N) & (int)(mcol < N));
+      const long o = ok ? (long)n * N : 0;
+      const float a = Sb[ok ? o : -(long)mcol], c = Pb[ok ? o : -(long)mcol];      // (clamped to element 0 of the matrix: an unconditional load)
+      fs[j] = ok ? a : 0.f; fp[j] = ok ? c : 0.f;
+    }
+    const uint4 as = ys_pack<bf16_t>(fs), ap = ys_pack<bf16_t>(fp);
+#pragma unroll
+    for (int dt = 0; dt < KD / 16; dt++)
+      kacc[dt] = mfma_16x16x32_bf16(as, *(const uint4*)(sQt + (16 * dt + li) * tp + (32 * ks + 8 * q4) * 2), kacc[dt]);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; dt++)
+      vacc[dt] = mfma_16x16x32_bf16(ap, *(const uint4*)(sOt + (16 * dt + li) * tp + (32 * ks + 8 * q4) * 2), vacc[dt]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = m0 + 4 * q4 + r;
+    if (m < N) {
+      bf16_t* row = dqkv + ((long)b * N + m) * ldq + h * hs;
+#pragma unroll
+      for (int dt = 0; dt < KD / 16; dt++) row[KD + 16 * dt + li] = Elem<bf16_t>::from_f(kacc[dt][r] * scale);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; dt++) { bf16_t* dst = row + 2 * KD + 16 * dt + li; *dst = Elem<bf16_t>::from_f(vacc[dt][r] + Elem<bf16_t>::to_f(*dst)); }
+    }
+  }
+}
+static bool attn_mfma_ok(int dtype, int ldq, int ldo, int N, int heads, int kd, int hd) {
+  return dtype == YS_BF16 && kd == 32 && hd == 64 && (ldq & 7) == 0 && (ldo & 7) == 0 && N >= 1 && N <= ATT_NM && YS_OPT_INT("ATTN_MFMA", 1) != 0;
+}
 static bool attn_fast_ok(int dtype, int ldq, int ldo, int N, int heads, int kd, int hd) {
   return dtype == YS_BF16 && kd == 32 && hd == 64 && (ldq & 7) == 0 && N >= 1 && N <= ATT_NFAST && YS_OPT_INT("ATTN_R4", 1) != 0;
 }
@@ -532,6 +778,12 @@ int ys_attn_fwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int 
                        void* ao, int ldo, float* P) {
   if (N > ATT_NMAX || kd > 128 || hd > 256) { ys_set_error("attention: N=%d kd=%d hd=%d outside the supported range", N, kd, hd); return YS_ERR_UNSUPPORTED; }
   const float scale = 1.0f / sqrtf((float)kd);   // Math.Pow(key_dim, -0.5) (Block.cs:733)
+  if (attn_mfma_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
+    const size_t lb = (size_t)att_np16(N) * ATT_KP + (size_t)(64 + 64) * att_tp(N);
+    attn_lds_attr(attn_fwd_mfma_kernel, lb);
+    YS_LAUNCH_LDS(attn_fwd_mfma_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lb, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (bf16_t*)ao, ldo, P);
+    return YS_OK;
+  }
   if (attn_fast_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
     const size_t lb = att_lds_bytes(N, 0);
     attn_lds_attr(attn_fwd4_kernel, lb);
@@ -547,6 +799,15 @@ int ys_attn_fwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int 
 int ys_attn_bwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int B, int N, int heads, int kd, int hd,
                        const void* dao, int ldo, const float* P, float* dS, void* dqkv) {
   const float scale = 1.0f / sqrtf((float)kd);
+  if (attn_mfma_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
+    const size_t lb = (size_t)att_np16(N) * ATT_VP + (size_t)(32 + 64) * att_tp(N);
+    attn_lds_attr(attn_bwd_q_mfma_kernel, lb);
+    YS_LAUNCH_LDS(attn_bwd_q_mfma_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lb, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (const bf16_t*)dao, ldo, P, dS, (bf16_t*)dqkv);
+    const size_t lk = (size_t)(32 + 64) * att_tp(N);
+    attn_lds_attr(attn_bwd_kv_mfma_kernel, lk);
+    YS_LAUNCH_LDS(attn_bwd_kv_mfma_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lk, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (const bf16_t*)dao, ldo, P, (const float*)dS, (bf16_t*)dqkv);
+    return YS_OK;
+  }
   if (attn_fast_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
     const size_t lb = att_lds_bytes(N, ATT_R * 64);
     attn_lds_attr(attn_bwd_q4_kernel, lb);

@@ -42,6 +42,15 @@ extern "C" __attribute__((visibility("default"))) int ys_set_option(const char* 
   t.version.fetch_add(1, std::memory_order_acq_rel);
   return YS_OK;
 }
+extern "C" __attribute__((visibility("default"))) int ys_get_option(const char* key, double* value, int* is_set) {
+  if (!key || !*key) { ys_set_error("ys_get_option: empty key"); return YS_ERR_INVALID_ARG; }
+  OptTable& t = opt_table();
+  std::lock_guard<std::mutex> g(t.mu);
+  auto it = t.v.find(strncmp(key, "YS_", 3) == 0 ? key + 3 : key);
+  if (is_set) *is_set = it != t.v.end() ? 1 : 0;
+  if (value) *value = it != t.v.end() ? it->second : 0.0;
+  return YS_OK;
+}
 extern "C" __attribute__((visibility("default"))) int ys_unset_option(const char* key) {
   if (!key || !*key) { ys_set_error("ys_unset_option: empty key"); return YS_ERR_INVALID_ARG; }
   OptTable& t = opt_table();

@@ -110,19 +110,30 @@ class Engine:
     def unset_option(self, key):
         _lib.check(self.lib, self.lib.ys_unset_option(str(key).encode()))
 
+    def get_option(self, key):
+        """The table's entry for `key` (None = not set: the built-in default applies)."""
+        v, s = C.c_double(), C.c_int()
+        _lib.check(self.lib, self.lib.ys_get_option(str(key).encode(), C.byref(v), C.byref(s)))
+        return float(v.value) if s.value else None
+
     def options(self, **kw):
-        """Context manager: set the options for the body, remove them afterwards (tests: `with engine.options(BNRED=0): ...`)."""
+        """Context manager: set the options for the body, then put back what was there before -- a value set earlier or seeded from the environment at load
+        (tests/conftest.py lowers size gates that way), or nothing (tests: `with engine.options(BNRED=0): ...`)."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
+            old = {k: self.get_option(k) for k in kw}
             for k, v in kw.items():
                 self.set_option(k, v)
             try:
                 yield self
             finally:
-                for k in kw:
-                    self.unset_option(k)
+                for k, v in old.items():
+                    if v is None:
+                        self.unset_option(k)
+                    else:
+                        self.set_option(k, v)
         return cm()
 
     # ---- data-parallel exchange through the C ABI (RCCL inside the library; bench.py uses torch.distributed instead)
