@@ -165,6 +165,19 @@ def test_halo_kernel_tile_stream(backend, engine, grid, monkeypatch):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("grid", ["0", "1", "3"])
+def test_halo_kernel_16x8_tiles(backend, engine, grid):
+    """conv_halo_kernel with 16 x 8-pixel tiles (MR = 4: patch 18 x 10, 25 request pieces per chunk, one patch request per tap, requests in every MFMA slot) -- what the
+    plan picks for maps that 16 x 16 tiles cover badly (40 x 40).  HALO_MR4=2 forces it on the halo test shapes: forward (statistics + BN + SiLU), dgrad with and
+    without accumulation / fused reduction, default grid and workgroups that walk several tiles (1 and 3 workgroups)."""
+    with engine.options(HALO_MR4=2, HALO_MAX_GRID=int(grid)):
+        for case in range(len(FWD_CASES) - 5, len(FWD_CASES)):
+            test_conv_bn_act_forward(backend, engine, "bf16", case)
+        for case in (len(BWD_CASES) - 2, len(BWD_CASES) - 1):
+            test_conv_backward(backend, engine, "bf16", case)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_wide_layers_run_the_blocked_gemm_kernel(backend, engine, tmp_path):
     """The per-launch profile names the kernel a layer ran on: wide layers -> conv_gemm_kernel for forward and dgrad; narrower layers and the
     phase convolutions of a stride-2 dgrad with < 160 gradient channels stay on the whole-Cin patch kernel."""
@@ -251,19 +264,19 @@ def test_halo_kernel_against_blocked_gemm_on_random_shapes(backend, engine):
         w = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
         dy = rng.standard_normal((B, cout, H, W), dtype=np.float32)
         res = {}
-        for halo in (1, 0, 1):
-            with engine.options(GEMM_HALO=halo, HALO_MIN_FILL=1, GEMM_MIN_M=1, GEMM_MIN_CIN=64):
+        for halo in (1, 0, 1, 2, 2):           # 2: the halo kernel with 16 x 8-pixel tiles forced (twice: bit-identical reruns)
+            with engine.options(GEMM_HALO=1 if halo else 0, HALO_MR4=2 if halo == 2 else 1, HALO_MIN_FILL=1, GEMM_MIN_M=1, GEMM_MIN_CIN=64):
                 bn = {"weight": np.ones(cout, np.float32), "bias": np.zeros(cout, np.float32), "running_mean": np.zeros(cout, np.float32), "running_var": np.ones(cout, np.float32)}
                 y = engine.conv_bn_act(x, w, 3, 1, bn=bn, act=True, training=True, dtype="bf16")
                 y = y[0] if isinstance(y, tuple) else y
                 dx = np.zeros(x.shape, np.float32); dw = np.zeros(w.shape, np.float32)
                 _lib.check(engine.lib, engine.lib.ys_conv_bwd(engine.ctx, 1, vp(x), B, cin, H, W, vp(w), cout, 3, 1, vp(dy), vp(dx), vp(dw)))
-            key = "halo" if halo else "gemm"
+            key = {0: "gemm", 1: "halo", 2: "halo8"}[halo]
             if key in res:                     # second halo run: bit-identical
                 assert np.array_equal(res[key][0], y) and np.array_equal(res[key][1], dx), (B, cin, H, W, cout)
             res[key] = (np.asarray(y).copy(), dx.copy())
-        for i, nm in ((0, "y"), (1, "dx")):
-            a, b = res["halo"][i], res["gemm"][i]
+        for key, i, nm in (("halo", 0, "y"), ("halo", 1, "dx"), ("halo8", 0, "y8"), ("halo8", 1, "dx8")):
+            a, b = res[key][i], res["gemm"][i]
             assert np.isfinite(a).all(), (nm, B, cin, H, W, cout)
             scale = float(np.abs(b).max()) + 1e-6
             assert float(np.abs(a - b).max()) <= scale * 2.0 ** -7 + 1e-6, (nm, B, cin, H, W, cout, float(np.abs(a - b).max()), scale)
@@ -274,4 +287,4 @@ def test_halo_kernel_against_blocked_gemm_on_random_shapes(backend, engine):
         labels = [l.split(",")[1] for l in open(path).read().splitlines()[1:] if l.startswith("conv_igemm")]
     engine.kernel_profile(False)
     n_halo = sum(l.startswith("halo k33") for l in labels)
-    assert n_halo >= 24, (n_halo, len(labels))     # the comparison is not gemm against gemm: most of these shapes (forward and / or dgrad) are halo-eligible
+    assert n_halo >= 48 and sum("tile8x16" in l for l in labels) >= 20, (n_halo, len(labels))     # the comparison is not gemm against gemm: most of these shapes (forward and / or dgrad) are halo-eligible

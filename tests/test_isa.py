@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-CONV_TUS = ["conv.hip", "conv_gemm.hip", "conv_halo4.hip", "conv_halo5.hip", "conv_stem.hip"]
+CONV_TUS = ["conv.hip", "conv_gemm.hip", "conv_halo4.hip", "conv_halo5.hip", "conv_halo4m.hip", "conv_halo5m.hip", "conv_stem.hip"]
 PACKED = re.compile(r"\bv_pk_(add|fma|mul)_f32\b|\bv_pk_mov_b32\b")
 
 

@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, "yolosharp_amd", "csrc")
 EMU = os.path.join(ROOT, "tools", "hipemu")
 BUILD = os.path.join(ROOT, "build")
 
-SOURCES = ["core.hip", "nms.hip", "conv.hip", "conv_gemm.hip", "conv_halo5.hip", "conv_halo4.hip", "conv_stem.hip", "conv_wgrad.hip", "conv_wgrad_gemm.hip", "elementwise.hip", "ops_api.hip", "loss.hip", "attn_dw.hip", "segloss.hip", "poseloss.hip", "valmetrics.hip", "dist.hip", "f8.hip", "model.hip"]
+SOURCES = ["core.hip", "nms.hip", "conv.hip", "conv_gemm.hip", "conv_halo5.hip", "conv_halo4.hip", "conv_halo5m.hip", "conv_halo4m.hip", "conv_stem.hip", "conv_wgrad.hip", "conv_wgrad_gemm.hip", "elementwise.hip", "ops_api.hip", "loss.hip", "attn_dw.hip", "segloss.hip", "poseloss.hip", "valmetrics.hip", "dist.hip", "f8.hip", "model.hip"]
 # bit-exact fp32 sections (NMS IoU arithmetic) must not be contracted into FMAs
 NO_CONTRACT = {"nms.hip", "valmetrics.hip"}
 

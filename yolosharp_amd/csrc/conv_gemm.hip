@@ -338,7 +338,7 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
   // channel tile 160 (80-multiples: YOLOv8x) or 128, least padding first; more than a quarter padding: the blocked kernel has 64 / 80-wide tiles
   const long pad5 = (long)ys_cdiv(a.Cout, 160) * 160, pad4 = (long)ys_cdiv(a.Cout, 128) * 128;
   p.nr = pad5 <= pad4 ? 5 : 4;
-  p.wm = 2; p.wn = 2; p.mr = HALO_MR;
+  p.wm = 2; p.wn = 2; p.mr = 8;
   const int bn = p.wn * p.nr * 16;
   p.gy = ys_cdiv(a.Cout, bn);
   if ((long)p.gy * bn * 4 > (long)a.Cout * 5) return p;
@@ -347,12 +347,18 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
   // (The plan must depend on the geometry alone: the fused BN-backward row counts are planned before the segments are attached -- a gate on a.nred / a.accumulate
   // sent planning and launch to different kernels with different grids.  Launches that accumulate / carry the reduction pay the LDS-staged epilogue once per tile
   // with nothing to hide it behind; with three chunks per tile -- YOLOv8x 160 -> 160 at 160 x 160 -- they are 293 us against the blocked kernel's 270.)
+  // the pixel tiles must cover the maps without much waste and give every CU work: 16 x 16 tiles (MR = 8) when they fill; else 16 x 8 tiles (MR = 4: half the MFMAs per
+  // weight byte landed, but 40 x 40 maps fill 15 of them to 83 % -- 480 tile-jobs per 32 images -- where nine 16 x 16 tiles fill 69 % and make 288)
+  const int min_fill = (int)YS_OPT_INT("HALO_MIN_FILL", 75);   // per cent
+  const int mr4_opt = (int)YS_OPT_INT("HALO_MR4", 1);          // 0: never, 1: when 16 x 16 tiles do not fill, 2: whenever 16 x 8 tiles fill (tests)
+  const bool mr4_on = mr4_opt != 0;
   h.tiles_x = ys_cdiv(a.Wout, 16); h.tiles_y = ys_cdiv(a.Hout, 16);
+  if (mr4_opt == 2 || (long)a.Hout * a.Wout * 100 < (long)h.tiles_x * h.tiles_y * 256 * min_fill) {
+    h.tiles_y = ys_cdiv(a.Hout, 8); p.mr = 4;
+    if (!mr4_on || (long)a.Hout * a.Wout * 100 < (long)h.tiles_x * h.tiles_y * 128 * min_fill) return p;
+  }
   const long mt = (long)a.B * h.tiles_x * h.tiles_y;
   if (mt >= (1L << 24)) return p;
-  // the pixel tiles must cover the maps without much waste (40 x 40: 9 tiles of 256 for 1600 pixels) and give every CU work
-  const int min_fill = (int)YS_OPT_INT("HALO_MIN_FILL", 75);   // per cent
-  if ((long)a.Hout * a.Wout * 100 < (long)h.tiles_x * h.tiles_y * 256 * min_fill) return p;
   h.mtiles = (int)mt;
   h.dTpi = ys_fastdiv_make((unsigned)(h.tiles_x * h.tiles_y)); h.dTx = ys_fastdiv_make((unsigned)h.tiles_x);
   {
@@ -362,7 +368,7 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
     if ((long)a.B * a.out_bstride * a.out_ldc * 2L >= (1L << 31)) return p;                      // the epilogue's store offsets
     h.abytes = (unsigned)ab;
   }
-  p.lds = halo_lds_bytes(p.nr);
+  p.lds = halo_lds_bytes(p.nr, p.mr);
   long gx = (256 / p.gy) & ~7L;               // one workgroup per CU; the XCD-ordered tile walk needs a multiple of 8
   if (gx < 8) gx = 8;
   if (gx > mt) gx = mt;
@@ -510,7 +516,8 @@ static int conv_gemm_launch_t(hipStream_t st, ConvArgs a, const GemmPlan& p) {
 }
 
 static int conv_halo_launch(hipStream_t st, const ConvArgs& a, const GemmPlan& p) {
-  HaloLaunch l{p.gx, p.gy, p.nr, p.lds, p.h};
+  HaloLaunch l{p.gx, p.gy, p.nr, p.mr, p.lds, p.h};
+  if (p.mr == 4) return p.nr == 5 ? ys_conv_halo_launch_nr5m(st, a, l) : ys_conv_halo_launch_nr4m(st, a, l);
   return p.nr == 5 ? ys_conv_halo_launch_nr5(st, a, l) : ys_conv_halo_launch_nr4(st, a, l);
 }
 

@@ -48,37 +48,49 @@ struct HaloArgs {
 };
 #define HALO_PW 18            // patch columns: 16 + halo
 #define HALO_PWP 20           // row pitch of the patch in pixels (see above)
-#define HALO_PH 18            // patch rows
-#define HALO_MR 8             // fragment rows (tile rows) per wave
 #define HALO_EMR 2            // fragment rows per staged epilogue call (accumulate / reduction launches)
-#define HALO_NPP (HALO_PH * HALO_PWP / 8)       // 1 KB DMA pieces (8 pixels x 128 B) per patch: 45
-#define HALO_PATCH (HALO_NPP * 1024)
+// MR = fragment rows (tile rows) per wave: 8 (tile 16 x 16 pixels, patch 18 x 18) or -- round 5, for maps that 16-row tiles cover badly (40 x 40: 69 %, 288 tile-jobs
+// on 256 CUs) -- 4 (tile 16 columns x 8 rows, patch 18 x 10)
+__host__ __device__ constexpr int halo_ph(int mr) { return 2 * mr + 2; }                        // patch rows
+__host__ __device__ constexpr int halo_npp(int mr) { return halo_ph(mr) * HALO_PWP / 8; }       // 1 KB DMA pieces (8 pixels x 128 B) per patch: 45 / 25
+__host__ __device__ constexpr int halo_patch(int mr) { return halo_npp(mr) * 1024; }
 __host__ __device__ constexpr int halo_stage_bytes(int nr) { return 2 * nr * 16 * 128; }
 __host__ __device__ constexpr int halo_wstg(int nr) { return 16 * HALO_EMR * (nr * 16 + 8) * 2 + 16 * HALO_EMR * 16; }
-__host__ __device__ constexpr size_t halo_lds_bytes(int nr) { return (size_t)2 * HALO_PATCH + (size_t)3 * halo_stage_bytes(nr); }
+__host__ __device__ constexpr size_t halo_lds_bytes(int nr, int mr) { return (size_t)2 * halo_patch(mr) + (size_t)3 * halo_stage_bytes(nr); }
 
 
 // launch description handed from the plan (conv_gemm.hip) to the instantiating translation units
-struct HaloLaunch { int gx, gy, nr; size_t lds; HaloArgs h; };
+struct HaloLaunch { int gx, gy, nr, mr; size_t lds; HaloArgs h; };
 int ys_conv_halo_launch_nr4(hipStream_t st, const ConvArgs& a, const HaloLaunch& p);
 int ys_conv_halo_launch_nr5(hipStream_t st, const ConvArgs& a, const HaloLaunch& p);
+int ys_conv_halo_launch_nr4m(hipStream_t st, const ConvArgs& a, const HaloLaunch& p);     // MR = 4 (conv_halo4m.hip / conv_halo5m.hip)
+int ys_conv_halo_launch_nr5m(hipStream_t st, const ConvArgs& a, const HaloLaunch& p);
 
 #ifdef HALO_INSTANTIATE_NR
+template <int MR> struct HaloSched {
+  static constexpr int npt(int tap) { return MR == 8 ? (tap <= 4 ? 2 : (tap <= 6 ? 1 : 0)) : (tap <= 6 ? 1 : 0); }   // patch pieces a wave requests at this tap
+  static constexpr int jp0(int tap) { return MR == 8 ? (tap <= 4 ? 2 * tap : tap + 5) : tap; }                      // ... the first of them
+};
 // HALF: Cin mod 64 in 1 .. 32 (the last chunk's K-step 1 is all padding).  RED = epilogue class, a compile-time fact of the launch: 0 = forward with every run-time
 // option; 2 = the training forward of a BatchNorm unit (raw output + statistics only); 4 .. 7 = dgrad: 4 + (accumulate) + 2 (fused BN-backward reduction)
-template <int NR, int RED = 0, int HALF = 0>
+template <int NR, int RED = 0, int HALF = 0, int MR = 8>
 __global__ void __launch_bounds__(256, 1)
 conv_halo_kernel(ConvArgs a, HaloArgs g) {
   typedef bf16_t T;
-  constexpr int WM = 2, WN = 2, MR = HALO_MR, EMR = HALO_EMR, NWV = 4;
-  constexpr int TH = WM * MR, PH = HALO_PH;
-  constexpr int NPP = HALO_NPP, NPW = (NPP + NWV - 1) / NWV, NPMIN = NPP / NWV;   // patch pieces per chunk: workgroup, wave (most / least): 45, 12, 11
-  constexpr int PATCH = HALO_PATCH;
+  constexpr int WM = 2, WN = 2, EMR = HALO_EMR, NWV = 4;
+  constexpr int TH = WM * MR, PH = halo_ph(MR);
+  constexpr int NPP = halo_npp(MR), NPW = (NPP + NWV - 1) / NWV, NPMIN = NPP / NWV;   // patch pieces per chunk: workgroup, wave (most / least): 45, 12, 11 (MR = 4: 25, 7, 6)
+  constexpr int PATCH = halo_patch(MR);
+  // request schedule of a chunk's NPW patch pieces over the taps (all of them by tap 6, see the wait below): MR = 8: two at taps 0 - 4, one at taps 5 - 6; MR = 4: one at taps 0 - 6.
+  // Requests sit in every second MFMA slot of K-step 1 (MR = 8: 40 / 32 slots) or in every slot (MR = 4: 20 / 16 slots), the fragment reads of the next tap behind them.
+  constexpr int RSTRIDE = MR == 8 ? 2 : 1;
+  typedef HaloSched<MR> Sched;
   constexpr int BN = WN * NR * 16;
   constexpr int NBP = BN / 8, NBW = NBP / NWV;                 // weight pieces (8 rows x 128 B) per tap: workgroup, wave
   constexpr int STAGE = halo_stage_bytes(NR);
   constexpr int NMF = MR * NR;                                 // MFMAs per K-step and wave
-  static_assert(TH + 2 == PH && NPW == 12 && NPMIN == 11 && NBP % NWV == 0 && MR % EMR == 0 && (HALO_PH * HALO_PWP) % 8 == 0 && NMF >= 2 * (NR + MR) + 8, "halo pipeline");
+  static_assert((MR == 8 || MR == 4) && TH + 2 == PH && NPW == (MR == 8 ? 12 : 7) && NPMIN == NPW - 1 && NBP % NWV == 0 && MR % EMR == 0 && (PH * HALO_PWP) % 8 == 0 &&
+                NMF >= RSTRIDE * ((MR == 8 ? 2 : 1) + NBW) + NR + MR && PH * HALO_PWP <= 400, "halo pipeline");
   static_assert(2 * WM * BN * 4 <= 3 * STAGE && 16 * 256 * 4 <= 3 * STAGE && NWV * halo_wstg(NR) <= PATCH, "statistics scratch inside the ring, epilogue staging inside one patch buffer");
 #ifdef YS_P2_TIMELINE
   int tl_n = 0;
@@ -191,7 +203,7 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
         const int pl = (wave + NWV * j) * 8 + (ln >> 3);
         const int py = (pl * 3277) >> 16, px = pl - py * HALO_PWP;    // pl / 20 for pl < 400
         const int u = (ln & 7) ^ ((pl >> 1) & 7);
-        const bool ok = (bool)((int)(wave + NWV * j < NPP) & (int)(px < HALO_PW) & (int)((unsigned)(t.y0 - 1 + py) < (unsigned)a.Hin) & (int)((unsigned)(t.x0 - 1 + px) < (unsigned)a.Win));
+        const bool ok = (bool)((int)(wave + NWV * j < NPP) & (int)(px < HALO_PW) & (int)(py < PH) & (int)((unsigned)(t.y0 - 1 + py) < (unsigned)a.Hin) & (int)((unsigned)(t.x0 - 1 + px) < (unsigned)a.Win));
         const unsigned v = (unsigned)(t.tb + (((py * a.Win + px) * ldu + u) << 4));
         prq[j] = ok ? v : YS_BUF_OOB;
         if (j == 0) prl_bad = 0u;
@@ -283,7 +295,7 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
           // barrier of tap 8 -- so its last piece must be issued by tap 6.  (The first version issued one piece per tap up to tap 8: the last two were read
           // without a covering wait -- correct in the interpreter, where a request lands at once, and almost always on the device; it showed as a loss that
           // differed in the fourth digit between two runs of bench.py.)
-          constexpr int np_prev = tap == 0 ? 0 : (tap - 1 <= 4 ? 2 : (tap - 1 <= 6 ? 1 : 0));
+          constexpr int np_prev = tap == 0 ? 0 : Sched::npt(tap - 1);
           // (piece 11, issued at tap 6, exists for wave 0 only -- 45 pieces over 4 waves: the count must be what THIS wave issued, one too many leaves the oldest
           // weight piece of this tap uncovered)
           if constexpr (tap == 7) { if (wave + NWV * (NPW - 1) < NPP) ys_wait_vm<np_prev + NBW>(); else ys_wait_vm<np_prev - 1 + NBW>(); }
@@ -298,11 +310,11 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
         auto hook1 = [&](auto ic) {
           constexpr int i = decltype(ic)::value;
           // requests at MFMAs 0, 2, 4, ...: [patch piece(s) of the next chunk: two at taps 0 - 4, one at taps 5 - 6], weights of tap + 3
-          constexpr int NPT = tap <= 4 ? 2 : (tap <= 6 ? 1 : 0), JP0 = tap <= 4 ? 2 * tap : tap + 5;   // patch pieces of this tap: JP0 .. JP0 + NPT - 1 (12 per chunk)
-          if constexpr ((i & 1) == 0 && i / 2 < NPT) issue_p(par ^ 1, (int)cqs, std::integral_constant<int, JP0 + i / 2>{});
-          else if constexpr ((i & 1) == 0 && i / 2 < NPT + NBW) issue_w1(tap % 3, so3, i / 2 - NPT);
-          else if constexpr (i >= 2 * (NPT + NBW) && i < 2 * (NPT + NBW) + NR + MR) {
-            constexpr int r = i - 2 * (NPT + NBW);
+          constexpr int NPT = Sched::npt(tap), JP0 = Sched::jp0(tap);   // patch pieces of this tap: JP0 .. JP0 + NPT - 1 (NPW per chunk)
+          if constexpr ((i % RSTRIDE) == 0 && i / RSTRIDE < NPT) issue_p(par ^ 1, (int)cqs, std::integral_constant<int, JP0 + i / RSTRIDE>{});
+          else if constexpr ((i % RSTRIDE) == 0 && i / RSTRIDE < NPT + NBW) issue_w1(tap % 3, so3, i / RSTRIDE - NPT);
+          else if constexpr (i >= RSTRIDE * (NPT + NBW) && i < RSTRIDE * (NPT + NBW) + NR + MR) {
+            constexpr int r = i - RSTRIDE * (NPT + NBW);
             if constexpr (tap < 8) frag_read(std::integral_constant<int, r>{}, std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{}, fwA, fxA, pbo);
             else { if (in_tile) frag_read(std::integral_constant<int, r>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fwA, fxA, PATCH - pbo); }
           }
@@ -365,18 +377,18 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
 }
 
 
-template <int NR, int RED, int HALF>
+template <int NR, int RED, int HALF, int MR = 8>
 static int conv_halo_launch_t(hipStream_t st, ConvArgs a, const HaloLaunch& p) {
   a.red_koff = (int)offsetof(ConvArgs, red);       // ConvArgs is the kernel's first argument (conv_epi.h ys_red_table)
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   if (!(attr_done.load(std::memory_order_relaxed) & (1u << (dev_id & 31)))) {
-    hipFuncSetAttribute((const void*)conv_halo_kernel<NR, RED, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_halo_kernel<NR, RED, HALF, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.fetch_or(1u << (dev_id & 31), std::memory_order_relaxed);
   }
   char lab[192] = "";
-  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "halo k33 s1 div1 cin%d cout%d M%d acc%d tile%dx16x%d grid%dx%d lds%d", a.Cin, a.Cout, a.M, a.accumulate, 16, 2 * NR * 16, p.gx, p.gy, (int)p.lds);
+  if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "halo k33 s1 div1 cin%d cout%d M%d acc%d tile%dx16x%d grid%dx%d lds%d", a.Cin, a.Cout, a.M, a.accumulate, 2 * MR, 2 * NR * 16, p.gx, p.gy, (int)p.lds);
   YsKprofScope prof(st, "conv_igemm", lab);
 #ifdef YS_P2_TIMELINE
   static unsigned long long* tl_buf = nullptr;
@@ -387,7 +399,7 @@ static int conv_halo_launch_t(hipStream_t st, ConvArgs a, const HaloLaunch& p) {
     a.tl = tl_buf;
   }
 #endif
-  YS_LAUNCH_LDS((conv_halo_kernel<NR, RED, HALF>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.h);
+  YS_LAUNCH_LDS((conv_halo_kernel<NR, RED, HALF, MR>), dim3(p.gx, p.gy), 256, p.lds, st, a, p.h);
 #ifdef YS_P2_TIMELINE
   if (tl_path) {
     static unsigned long long h[64 * 64];
@@ -395,7 +407,7 @@ static int conv_halo_launch_t(hipStream_t st, ConvArgs a, const HaloLaunch& p) {
     hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
     FILE* f = fopen(tl_path, "a");
     if (f) {
-      fprintf(f, "# halo k33 cin%d cout%d M%d acc%d tile%dx16x%d grid%dx%d lds%d mtiles%d nchunk%d (stamps: entry, then per tile: prologue issued, K loop done, epilogue done; exit)\n", a.Cin, a.Cout, a.M, a.accumulate, 16, 2 * NR * 16, p.gx, p.gy, (int)p.lds, p.h.mtiles, p.h.nchunk);
+      fprintf(f, "# halo k33 cin%d cout%d M%d acc%d tile%dx16x%d grid%dx%d lds%d mtiles%d nchunk%d (stamps: entry, then per tile: prologue issued, K loop done, epilogue done; exit)\n", a.Cin, a.Cout, a.M, a.accumulate, 2 * MR, 2 * NR * 16, p.gx, p.gy, (int)p.lds, p.h.mtiles, p.h.nchunk);
       for (int w = 0; w < 64 && w * 37 < p.gx; w++) {
         const int n = (int)h[w * 64];
         if (n <= 0) continue;
@@ -416,14 +428,17 @@ static int conv_halo_launch_nr(hipStream_t st, const ConvArgs& a, const HaloLaun
   // epilogue class (conv_halo_kernel's RED parameter)
   const bool plain = !a.stats && !a.scale && !a.shift && !a.res && !a.act;
   const int ec = (a.nred > 0 || (plain && a.accumulate)) ? 4 + (a.accumulate ? 1 : 0) + (a.nred > 0 ? 2 : 0) : ((a.stats && !a.scale && !a.shift && !a.res && !a.accumulate && !a.act) ? 2 : (plain ? 4 : 0));
-#define HL(R_) if (p.nr == R_) { \
-    if (ec == 4) return half ? conv_halo_launch_t<R_, 4, 1>(st, a, p) : conv_halo_launch_t<R_, 4, 0>(st, a, p); \
-    if (ec == 5) return half ? conv_halo_launch_t<R_, 5, 1>(st, a, p) : conv_halo_launch_t<R_, 5, 0>(st, a, p); \
-    if (ec == 6) return half ? conv_halo_launch_t<R_, 6, 1>(st, a, p) : conv_halo_launch_t<R_, 6, 0>(st, a, p); \
-    if (ec == 7) return half ? conv_halo_launch_t<R_, 7, 1>(st, a, p) : conv_halo_launch_t<R_, 7, 0>(st, a, p); \
-    if (ec == 2) return half ? conv_halo_launch_t<R_, 2, 1>(st, a, p) : conv_halo_launch_t<R_, 2, 0>(st, a, p); \
-    return half ? conv_halo_launch_t<R_, 0, 1>(st, a, p) : conv_halo_launch_t<R_, 0, 0>(st, a, p); }
-  HL(HALO_INSTANTIATE_NR)
+#ifndef HALO_INSTANTIATE_MR
+#define HALO_INSTANTIATE_MR 8
+#endif
+#define HL(R_, M_) if (p.nr == R_ && p.mr == M_) { \
+    if (ec == 4) return half ? conv_halo_launch_t<R_, 4, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 4, 0, M_>(st, a, p); \
+    if (ec == 5) return half ? conv_halo_launch_t<R_, 5, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 5, 0, M_>(st, a, p); \
+    if (ec == 6) return half ? conv_halo_launch_t<R_, 6, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 6, 0, M_>(st, a, p); \
+    if (ec == 7) return half ? conv_halo_launch_t<R_, 7, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 7, 0, M_>(st, a, p); \
+    if (ec == 2) return half ? conv_halo_launch_t<R_, 2, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 2, 0, M_>(st, a, p); \
+    return half ? conv_halo_launch_t<R_, 0, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 0, 0, M_>(st, a, p); }
+  HL(HALO_INSTANTIATE_NR, HALO_INSTANTIATE_MR)
 #undef HL
   return YS_ERR_UNSUPPORTED;
 }
