@@ -13,50 +13,72 @@
 // ------------------------------------------------------------------ depthwise 3x3, stride 1, pad 1
 // FLIP = 0: y[p,c] = sum_t w[t][c] * x[p + off(t), c]            (forward)
 // FLIP = 1: dx[p,c] = sum_t w[t][c] * dy[p - off(t), c]          (input gradient)
+// Round 5: a thread owns DW_PX consecutive pixels of a row for its channel vector: the 3 x (DW_PX + 2) input window is loaded once (4.5 vector loads per output
+// instead of 9) and the 9 x EPL weights once per thread instead of once per pixel (the one-pixel form issued 81 load instructions per 16-byte output: 59 us per
+// launch at 3.8 TB/s on YOLOv11m-seg's 80 x 80 towers).  Same products in the same order per output (taps outside the image contribute 0 * w instead of being skipped).
+#define DW_PX 4
 template <class T, int FLIP>
 __global__ void __launch_bounds__(AD_THREADS)
 dwconv3x3_kernel(const T* __restrict__ x, int x_ldc, int x_coff, int B, int H, int W, int C, const float* __restrict__ w,
                  T* __restrict__ y, int y_ldc, int y_coff, int accumulate) {
-  constexpr int EPL = Elem<T>::EPL;
-  const int CG = C / EPL;
+  constexpr int EPL = Elem<T>::EPL, PX = DW_PX;
+  const int CG = C / EPL, WS = (W + PX - 1) / PX;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * H * W * CG) return;
+  if (i >= (long)B * H * WS * CG) return;
   const int c = (int)(i % CG) * EPL;
-  const long pix = i / CG;
-  const int ww = (int)(pix % W), hh = (int)((pix / W) % H);
-  const long b = pix / ((long)W * H);
-  float acc[EPL];
+  const long seg = i / CG;
+  const int w0 = (int)(seg % WS) * PX, hh = (int)((seg / WS) % H);
+  const long b = seg / ((long)WS * H);
+  float wt[9][EPL];
 #pragma unroll
-  for (int e = 0; e < EPL; e++) acc[e] = 0.f;
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int e = 0; e < EPL; e++) wt[t][e] = w[t * C + c + e];   // flat-buffer offsets are not 16-byte aligned in general
+  float acc[PX][EPL];
+#pragma unroll
+  for (int p = 0; p < PX; p++)
+#pragma unroll
+    for (int e = 0; e < EPL; e++) acc[p][e] = 0.f;
+#pragma unroll
   for (int kh = 0; kh < 3; kh++) {
     const int ih = FLIP ? hh - kh + 1 : hh + kh - 1;
-    if (ih < 0 || ih >= H) continue;
-    for (int kw = 0; kw < 3; kw++) {
-      const int iw = FLIP ? ww - kw + 1 : ww + kw - 1;
-      if (iw < 0 || iw >= W) continue;
-      float f[EPL], wt[EPL];
-      ys_unpack<T>(ys_ld16(x + ((b * H + ih) * W + iw) * x_ldc + x_coff + c), f);
+    const bool rok = ih >= 0 && ih < H;
+    float f[PX + 2][EPL];
 #pragma unroll
-      for (int e = 0; e < EPL; e++) wt[e] = w[(kh * 3 + kw) * C + c + e];   // flat-buffer offsets are not 16-byte aligned in general
-#pragma unroll
-      for (int e = 0; e < EPL; e++) acc[e] += f[e] * wt[e];
+    for (int q = 0; q < PX + 2; q++) {
+      const int iw = w0 - 1 + q;
+      const bool ok = (bool)((int)rok & (int)(iw >= 0) & (int)(iw < W));
+      const uint4 v = ys_ld16(x + ((b * H + (rok ? ih : 0)) * W + (ok ? iw : 0)) * x_ldc + x_coff + c);    // clamped address, masked value: no exec-masked loads
+      ys_unpack<T>(ok ? v : ys_zero16(), f[q]);
     }
-  }
-  T* yp = y + pix * y_ldc + y_coff + c;
-  if (accumulate) {
-    float o[EPL];
-    ys_unpack<T>(ys_ld16(yp), o);
 #pragma unroll
-    for (int e = 0; e < EPL; e++) acc[e] += o[e];
+    for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+      for (int p = 0; p < PX; p++) {
+        const int q = FLIP ? p + 2 - kw : p + kw;            // input column w0 + p -+ (kw - 1)
+#pragma unroll
+        for (int e = 0; e < EPL; e++) acc[p][e] += f[q][e] * wt[kh * 3 + kw][e];
+      }
   }
-  ys_st16(yp, ys_pack<T>(acc));
+#pragma unroll
+  for (int p = 0; p < PX; p++) {
+    if (w0 + p >= W) continue;
+    T* yp = y + ((b * H + hh) * (long)W + w0 + p) * y_ldc + y_coff + c;
+    if (accumulate) {
+      float o[EPL];
+      ys_unpack<T>(ys_ld16(yp), o);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) acc[p][e] += o[e];
+    }
+    ys_st16(yp, ys_pack<T>(acc[p]));
+  }
 }
 
 int ys_dwconv_launch(hipStream_t st, int dtype, int flip, const void* x, int x_ldc, int x_coff, int B, int H, int W, int C,
                      const float* w, void* y, int y_ldc, int y_coff, int accumulate) {
   const int epl = dtype == YS_BF16 ? 8 : 4;
   if (C % epl) { ys_set_error("dwconv: C=%d must be a multiple of %d", C, epl); return YS_ERR_UNSUPPORTED; }
-  const long n = (long)B * H * W * (C / epl);
+  const long n = (long)B * H * ((W + DW_PX - 1) / DW_PX) * (C / epl);
   const int g = ys_cdiv(n, AD_THREADS);
 #define DW(TT, FL) YS_LAUNCH((dwconv3x3_kernel<TT, FL>), g, AD_THREADS, st, (const TT*)x, x_ldc, x_coff, B, H, W, C, w, (TT*)y, y_ldc, y_coff, accumulate)
   if (dtype == YS_BF16) { if (flip) DW(bf16_t, 1); else DW(bf16_t, 0); }
