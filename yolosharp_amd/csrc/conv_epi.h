@@ -44,15 +44,18 @@ __device__ inline ys_redp_t ys_red_table(const ConvArgs& a) {
 }
 #endif
 
-// destination of one fused BN-backward partial sum: output-view channel c of the launch, `which` = 0 (sum du) / 1 (sum du * y)
-__device__ inline float* ys_bnred_dst(const ConvArgs& a, int c, int which, long row) {
-  float* d = nullptr;
+// destination of one fused BN-backward partial sum (output-view channel c of the launch, `which` = 0: sum du / 1: sum du * y): a row entry of the covering
+// producer's partial buffer, or (round 5) an exact integer add into that producer's accumulators
+__device__ inline void ys_bnred_put(const ConvArgs& a, int c, int which, long row, float t) {
   const ys_redp_t rt = ys_red_table(a);
 #pragma unroll
   for (int k = 0; k < YS_BNRED_MAXSEG; k++)
-    if (k < a.nred && c >= rt[k].c0 && c < rt[k].c1)
-      d = rt[k].part + (((long)a.red_row0 + row) * 2 + which) * rt[k].C + (c - rt[k].c0 + rt[k].yc0);
-  return d;
+    if (k < a.nred && c >= rt[k].c0 && c < rt[k].c1) {
+      const int pc = c - rt[k].c0 + rt[k].yc0;
+      unsigned long long* acc = rt[k].acc;
+      if (acc) ys_gacc_add(acc, (long)a.red_row0 + row, rt[k].C, pc, which, t);
+      else rt[k].part[(((long)a.red_row0 + row) * 2 + which) * rt[k].C + pc] = t;
+    }
 }
 
 // RED = 1: the dgrad form -- gradient accumulation and the fused BN-backward reduction only (no bias / eval-BN / SiLU / residual:
@@ -578,7 +581,7 @@ __device__ inline void p2_stats_flush_direct(const ConvArgs& a, int n0, float (&
     float t = scr[(which * WM) * BN + c];
 #pragma unroll
     for (int w = 1; w < WM; w++) t += scr[(which * WM + w) * BN + c];
-    if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
+    if (a.nred) ys_bnred_put(a, n0 + c, which, stat_row, t);
     else if (n0 + c < a.Cout) { if (a.stat_acc) ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + c, which, t); else a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t; }
   }
 }
@@ -623,7 +626,7 @@ __device__ inline void p2_stats_flush(const ConvArgs& a, int n0, float (&s1)[8],
     float t = part[o];
 #pragma unroll
     for (int pi = 1; pi < P; pi++) t += part[pi * 2 * BN + o];      // fixed order -> deterministic
-    if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
+    if (a.nred) ys_bnred_put(a, n0 + c, which, stat_row, t);
     else if (n0 + c < a.Cout) { if (a.stat_acc) ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + c, which, t); else a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t; }
   }
 }
@@ -650,7 +653,7 @@ __device__ inline void conv_stats_flush_grid(const ConvArgs& a, int n0, float (&
     float t = 0.f;
     for (int wm = 0; wm < WM; wm++)
       for (int j = 0; j < PPI; j++) t += col[(wm * WN + wn) * 64 + j * VPP];
-    if (a.nred) { float* d = ys_bnred_dst(a, n0 + c, which, stat_row); if (d) *d = t; }
+    if (a.nred) ys_bnred_put(a, n0 + c, which, stat_row, t);
     else if (n0 + c < a.Cout) { if (a.stat_acc) ys_stat_acc_add(a.stat_acc, stat_row, a.Cout, n0 + c, which, t); else a.stats[(stat_row * 2 + which) * a.Cout + n0 + c] = t; }
   }
 }

@@ -46,6 +46,7 @@ struct ConvL {
   long wf_off = 0, wd_off = 0;               // element offsets into wf_all / wd_all
   long y_off = 0;                             // element offset into y_all (bn layers)
   long acc_off = -1;                          // BatchNorm unit: offset (64-bit words) of its statistics accumulators in ys_model::stat_acc_all
+  long bacc_off = -1;                         // ... of its BN-BACKWARD sum accumulators in ys_model::bnb_acc_all (units that finalize inside the apply pass)
   long ch_off = 0;                            // offset into per-channel scratch (scale.. c2), floats
   int seg = 0;
   bool first = false;
@@ -162,6 +163,8 @@ struct ys_model {
   float* stat_partial = nullptr; long n_stat = 0;
   unsigned long long* stat_acc_all = nullptr; long n_stat_acc = 0;   // round 5: [unit][YS_STAT_SHARDS][cout][2] fixed-point statistics sums, cleared by ONE memset per training forward
   bool bn_atomic = false;                                            // BatchNorm units take their statistics through them and finalize inside the apply pass
+  unsigned long long* bnb_acc_all = nullptr; long n_bnb_acc = 0;     // round 5: [unit][YS_GACC_SHARDS][cout][2][YS_GACC_WORDS] exact BN-backward sums, cleared by ONE memset per backward
+  bool bnb_atomic = false;
   float* stat_group = nullptr;                  // statistics rows of the grouped head stages (one region per unit, ConvL::gstat_off)
   float* wg_partial = nullptr; long n_wgp = 0;   // [shared scratch (ConvTranspose phases) | one region per convolution]
   // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
@@ -1160,6 +1163,21 @@ int allocate(ys_model* m) {
     if (off > 0) YS_TRY(dev_alloc(m, (void**)&m->stat_acc_all, (size_t)off * 8));
     else m->bn_atomic = false;
   }
+  // BN-backward sums through exact integer accumulators (ys_kernels.h ys_gacc_add): units outside the grouped head stages (those finalize as one grouped launch
+  // from rows) and up to BNB_MAXC channels (every workgroup of the apply pass reads 2 x C x 2 x 5 words: 40 KB at 256 channels).  Off in fp8 mode (its apply pass
+  // is the quantising one).  OFF BY DEFAULT (BNB_ATOMIC=1 enables): built and measured at the end of round 5 -- results identical to the row form to the last digit of the
+  // loss, bit-reproducible, 51 chan_finalize launches fewer per YOLOv8n step (292 launches) -- and NOT faster: config 2 8.94-8.97 ms against 8.83-8.94, config 3 9.78
+  // against 9.69-9.75, config 4 equal (tools/dev/r05/s40.sh - s42.sh): the per-workgroup finalize prologue and the grid-stride form of the apply pass cost what the
+  // 5 us finalizers did (a smaller apply grid is far worse: 512 workgroups 9.2 ms, 256 9.7; larger grids equal).
+  m->bnb_atomic = YS_OPT_INT("BNB_ATOMIC", 0) != 0 && !m->f8 && m->bnred_on;
+  if (m->bnb_atomic) {
+    const int maxc = (int)YS_OPT_INT("BNB_MAXC", 256);
+    long off = 0;
+    for (auto& c : m->convs) if (c.bn && !c.dw && !c.ct && c.group < 0 && c.cout <= maxc) { c.bacc_off = off; off += (long)YS_GACC_SHARDS * c.cout * 2 * YS_GACC_WORDS; }
+    m->n_bnb_acc = off;
+    if (off > 0) YS_TRY(dev_alloc(m, (void**)&m->bnb_acc_all, (size_t)off * 8));
+    else m->bnb_atomic = false;
+  }
   // (Two experiments lived here through round 4 and are gone: side-stream "head lanes" for the P4 / P5 towers -- 10.52-10.55 ms/step against 9.98-10.01 without,
   // a side-stream kernel that takes CU slots turns the persistent P3 kernels' equal tile shares into a tail -- and the last-arriver "ticket" BatchNorm finalize inside
   // the producing convolution, +0.9 ms/step: DESIGN.md 6b / 6d.)
@@ -1752,6 +1770,7 @@ static void attach_bnred_feeds(ys_model* m, ConvL& c, ConvArgs& a, int rows) {
     BnRedSeg& sg = a.red[k];
     sg.y = (char*)m->y_all + (size_t)l.y_off * m->es; sg.scale = chan_ptr(m, l, 0); sg.shift = chan_ptr(m, l, 1);
     sg.part = m->bnred_part + f.part_off; sg.c0 = f.c0; sg.c1 = f.c1; sg.yc0 = f.yc0; sg.C = l.cout; sg.act = l.act ? 1 : 0;
+    sg.acc = (m->bnb_atomic && l.bacc_off >= 0) ? m->bnb_acc_all + l.bacc_off : nullptr;
     f.rows = rows;
     l.red_seen++;
   }
@@ -1784,7 +1803,10 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
     const bool fused = c.red_ok && c.red_seen == (int)c.red_src.size() && !c.red_src.empty();
     c.red_seen = 0;
     void* rg_apply = nullptr;                    // the shortcut's residual-gradient accumulation rides on the reduction pass; without one, on the apply pass
-    if (fused) {
+    const bool fin_in_apply = fused && m->bnb_atomic && c.bacc_off >= 0;   // the sums sit in the unit's integer accumulators: no chan_finalize launch
+    if (fin_in_apply) {
+      rg_apply = rg;
+    } else if (fused) {
       FinSrc src{};
       src.n = (int)c.red_src.size();
       for (int k = 0; k < src.n; k++) {
@@ -1814,7 +1836,12 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
       q.f8 = 2; q.w8 = m->wd8_all + c.wd_off; q.qscale = m->f8_scales + 4L * c.idx + 2; q.deq = m->f8_scales + 4L * c.idx + 3;
       dy_q8 = ys_conv_wants_x8(q);
     }
-    if (dy_q8) {
+    if (fin_in_apply) {
+      BnBwdFin bf{};
+      bf.acc = m->bnb_acc_all + c.bacc_off; bf.count = (double)M; bf.dgamma = m->grads + c.g_off; bf.dbeta = m->grads + c.b_off;
+      bf.scale = chan_ptr(m, c, 0); bf.shift = chan_ptr(m, c, 1); bf.mean = chan_ptr(m, c, 2); bf.rstd = chan_ptr(m, c, 3);
+      YS_TRY(ys_bn_bwd_fin_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, bf, c.act ? 1 : 0, dyb, rg_apply, rgl, rgc));
+    } else if (dy_q8) {
       YS_TRY(ys_bn_bwd_apply_q8_launch(st, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), chan_ptr(m, c, 4),
                                        chan_ptr(m, c, 5), c.act ? 1 : 0, dyb, m->q8, m->f8_scales + 4L * c.idx + 2,
                                        m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS, rg_apply, rgl, rgc));
@@ -2061,6 +2088,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) 
 }
 
 void reset_grad_state(ys_model* m) {
+  if (m->bnb_atomic) (void)hipMemsetAsync(m->bnb_acc_all, 0, (size_t)m->n_bnb_acc * 8, m->ctx->stream);   // every unit's BN-backward accumulators: one clear per backward
   for (auto& b : m->bufs) std::fill(b.gw.begin(), b.gw.end(), 0);
   for (auto& c : m->convs) c.red_seen = 0;
   if (m->is_block) { std::fill(m->bufs[m->blk_out].gw.begin(), m->bufs[m->blk_out].gw.end(), 1); return; }   // the caller's dy

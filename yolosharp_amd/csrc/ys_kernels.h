@@ -20,6 +20,8 @@ struct BnRedSeg {
   int C;                // producer channel count
   int act;              // producer applies SiLU
   int pad_;
+  unsigned long long* acc;   // round 5: when set, the two sums are ADDED to the producer's exact integer accumulators (ys_gacc_add) instead of written to `part` rows:
+                             // the BN-backward apply pass finalizes from them (ys_bn_bwd_fin_apply_launch) and the unit's chan_finalize launch goes
 };
 struct ConvArgs {
   const void* x;        // input activations (NHWC view)
@@ -177,6 +179,38 @@ __device__ inline void ys_stat_acc_add(unsigned long long* acc, long stat_row, i
 #endif
   if (q != 0) atomicAdd(acc + (((stat_row & (YS_STAT_SHARDS - 1)) * C + c) * 2 + which), (unsigned long long)q);
 }
+// ---- BN-BACKWARD sums as exact integer accumulators (round 5).  Gradient sums span far more decades than the forward statistics (a loss-scale x batch x depth
+// product), so one fixed point cannot hold them.  A float partial t = m 2^e (24-bit m) is added -- EXACTLY, as the integer t / 2^(lo - 24) -- to the one of FOUR
+// 64-bit accumulators whose 26-binade window [lo, lo + 26), lo = -64 + 26 level, holds e: below 2^50 per partial, i.e. 2^12 partials of headroom per shard.
+// Integer addition commutes: the total is the exact sum of the partials, whatever the order the workgroups arrive in = run-to-run deterministic, and more
+// accurate than the double-precision row sum it replaces.  |t| < 2^-64 contributes nothing; |t| >= 2^40 keeps adding into level 3 (exact up to 2^62 / count);
+// a non-finite partial raises the fifth word, which the finalize turns into NaN.  Layout [YS_GACC_SHARDS][C][2][YS_GACC_WORDS].
+#define YS_GACC_SHARDS 2
+#define YS_GACC_WORDS 5
+__device__ inline void ys_gacc_add(unsigned long long* acc, long row, int C, int c, int which, float t) {
+  const unsigned bits = ys_f2u(t);
+  const int e = (int)((bits >> 23) & 255u) - 127;
+  unsigned long long* a = acc + ((((row & (YS_GACC_SHARDS - 1)) * C + c) * 2 + which) * (long)YS_GACC_WORDS);
+  if (e > 60) { atomicAdd(a + 4, 1ull); return; }              // inf / NaN (e = 128) or beyond any gradient: poison
+  if (e < -64) return;
+  const int lv = e < -38 ? 0 : (e < -12 ? 1 : (e < 14 ? 2 : 3));
+  const double sc = lv == 0 ? 0x1p88 : (lv == 1 ? 0x1p62 : (lv == 2 ? 0x1p36 : 0x1p10));   // 2^(24 - lo)
+  const long long q = (long long)((double)t * sc);             // exact: an integer below 2^50 (level 3 beyond its window: below 2^61)
+  atomicAdd(a + lv, (unsigned long long)q);
+}
+__host__ __device__ inline double ys_gacc_value(const unsigned long long* a) {      // one shard's five words -> double
+  if (a[4]) return __builtin_nan("");
+  return (double)(long long)a[0] * 0x1p-88 + (double)(long long)a[1] * 0x1p-62 + (double)(long long)a[2] * 0x1p-36 + (double)(long long)a[3] * 0x1p-10;
+}
+// BN backward of one unit with the finalize inside: dgamma / dbeta (+=), then dy = scale du - k2 - y k3 with k2 / k3 computed per workgroup from the accumulators
+struct BnBwdFin {
+  const unsigned long long* acc;   // [YS_GACC_SHARDS][C][2][YS_GACC_WORDS]
+  double count;
+  float* dgamma; float* dbeta;     // += (workgroup 0)
+  const float* scale; const float* shift; const float* mean; const float* rstd;
+};
+int ys_bn_bwd_fin_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C, const BnBwdFin& f, int act,
+                               void* dy, void* rg = nullptr, int rg_ldc = 0, int rg_coff = 0);
 // finalize-inside-apply operands: the accumulators of one BatchNorm unit + what bn_finalize_kernel reads and writes
 struct BnAccFin {
   const unsigned long long* acc;   // [YS_STAT_SHARDS][C][2]
