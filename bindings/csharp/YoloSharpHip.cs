@@ -115,6 +115,10 @@ namespace YoloSharp.Native
         // communicator's streams must exist before the engine creates its weight-gradient stream (otherwise both engine streams can land
         // on one hardware queue and nothing overlaps: 11.6 instead of 10.3 ms/step measured at one rank; ys_dist_init also runs one
         // all-reduce so that RCCL's lazily created resources exist when it returns).
+        // routing / tuning options (include/yolosharp_hip.h: process-wide table, seeded from YS_<KEY>=<number> environment variables at load)
+        [DllImport(Lib)] internal static extern int ys_set_option([MarshalAs(UnmanagedType.LPStr)] string key, double value);
+        [DllImport(Lib)] internal static extern int ys_unset_option([MarshalAs(UnmanagedType.LPStr)] string key);
+        [DllImport(Lib)] internal static extern int ys_get_option([MarshalAs(UnmanagedType.LPStr)] string key, out double value, out int isSet);
         [DllImport(Lib)] internal static extern int ys_dist_unique_id([Out] byte[] id128);
         [DllImport(Lib)] internal static extern int ys_dist_init(IntPtr ctx, int rank, int world, byte[] id128);
         [DllImport(Lib)] internal static extern int ys_dist_destroy(IntPtr ctx);
