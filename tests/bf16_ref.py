@@ -64,16 +64,46 @@ def _plain_conv_forward(self, x):
     return rste(F.conv2d(x, bf16r(self.weight), self.bias, self.stride, self.padding))
 
 
+def _attention_forward(self, x):
+    """C2PSA attention (Block.cs:719-810) with the engine's storage points (csrc/model.hip add_c2psa, csrc/attn_dw.hip): q / k / v are the
+    stored (bf16) qkv output; softmax probabilities are rounded to bf16 for the second product (the MFMA kernels' P operand); the attention
+    output is stored bf16; `attention + pe(v)` is one rounding inside pe's BatchNorm + SiLU pass.  Returns the INPUT of proj: proj carries
+    the PSABlock shortcut in its own apply pass (see _psablock_forward)."""
+    B, C, H, W = x.shape
+    N = H * W
+    qkv = self.qkv(x)
+    q, k, v = qkv.view(B, self.num_heads, self.key_dim * 2 + self.head_dim, N).split([self.key_dim, self.key_dim, self.head_dim], dim=2)
+    attn = rste(((q.transpose(-2, -1) @ k) * self.scale).softmax(dim=-1))
+    a = rste((v @ attn.transpose(-2, -1)).view(B, C, H, W))
+    return _conv_forward(self.pe, v.reshape(B, C, H, W), fuse_residual=a)
+
+
+def _psablock_forward(self, x):
+    h = _attention_forward(self.attn, x)
+    x = _conv_forward(self.attn.proj, h, fuse_residual=x if self.add else None)
+    f = self.ffn[0](x)
+    return _conv_forward(self.ffn[1], f, fuse_residual=x if self.add else None)
+
+
+def _proto_forward(self, x):
+    """Proto (Block.cs:51-84): the ConvTranspose2d adds its bias to the fp32 accumulators and stores bf16."""
+    u = self.upsample
+    up = rste(F.conv_transpose2d(self.cv1(x), bf16r(u.weight), u.bias, u.stride, u.padding))
+    return self.cv3(self.cv2(up))
+
+
 @contextlib.contextmanager
 def bf16_storage(model):
-    """Inside the context, `model(x)` (an oracle Yolov8 / Yolov8 detect graph) follows the engine's bf16 storage points."""
-    saved = (O.Conv.forward, O.Bottleneck.forward)
+    """Inside the context, `model(x)` (an oracle Yolov8 / Yolov11 detect or segment graph) follows the engine's bf16 storage points."""
+    saved = (O.Conv.forward, O.Bottleneck.forward, O.PSABlock.forward, O.Proto.forward)
     O.Conv.forward = _conv_forward
     O.Bottleneck.forward = _bottleneck_forward
+    O.PSABlock.forward = _psablock_forward
+    O.Proto.forward = _proto_forward
     patched = []
     for mod in model.modules():
         if isinstance(mod, O.Detect):
-            for seq in list(mod.cv2) + list(mod.cv3):
+            for seq in list(mod.cv2) + list(mod.cv3) + list(getattr(mod, "cv4", [])):
                 last = seq[-1]
                 if isinstance(last, torch.nn.Conv2d):
                     last.forward = _plain_conv_forward.__get__(last, type(last))
@@ -81,7 +111,7 @@ def bf16_storage(model):
     try:
         yield
     finally:
-        O.Conv.forward, O.Bottleneck.forward = saved
+        O.Conv.forward, O.Bottleneck.forward, O.PSABlock.forward, O.Proto.forward = saved
         for last in patched:
             del last.forward
 

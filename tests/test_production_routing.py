@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "workers", "prod_routing_worker.py")
 
 
-def run_worker(tmp_path, B, H, W, emu=False, f32=False):
+def run_worker(tmp_path, B, H, W, emu=False, f32=False, **kw):
     out = str(tmp_path / "prod.npz")
     env = {k: v for k, v in os.environ.items() if not k.startswith("YS_")}
-    cmd = [sys.executable, WORKER, out, str(B), str(H), str(W)] + (["emu"] if emu else []) + (["f32"] if f32 else [])
+    cmd = [sys.executable, WORKER, out, str(B), str(H), str(W)] + (["emu"] if emu else []) + (["f32"] if f32 else []) + ["%s=%s" % kv for kv in kw.items()]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:]
     return np.load(out, allow_pickle=False)
@@ -28,7 +28,7 @@ def summarize(d):
     tests/bf16_ref.py), parameter gradients (cosine per tensor and overall, norm ratio)."""
     from bf16_ref import elem_bound
     out = {"items": d["items"], "r_items": d["r_items"], "f_items": d["f_items"]}
-    for k in ("boxes", "scores"):
+    for k in [k for k in ("boxes", "scores", "mask_coefficient", "proto") if k in d.files]:
         for tag in ("r", "f"):
             ref = d[tag + "_" + k].astype(np.float64)
             r = np.abs(d[k] - ref) / elem_bound(ref)
@@ -98,26 +98,46 @@ def test_v8n_640_b8_bf16_production_routing(tmp_path):
     compare(d, big=True)
 
 
+def _relerr(a, b):
+    """Per-element distance of tests/test_model.py: max |a - b| / (|b| + rms(b))."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (np.abs(b) + max(float(np.sqrt((b * b).mean())), 1e-6))).max())
+
+
+def _dump(name, s, extra=()):
+    dump = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(dump):
+        with open(os.path.join(dump, name), "w") as f:
+            for k, v in s.items():
+                f.write("%s: %s\n" % (k, v))
+            for line in extra:
+                f.write(line + "\n")
+
+
+def _conv_labels(d):
+    """(class, plan label) of every profiled convolution launch of the step the worker ran."""
+    return [tuple(str(l).split(",")[:2]) for l in d["labels"]]
+
+
 @pytest.mark.gpu
 def test_v8n_640_b64_production_routing(tmp_path):
     """The HEADLINE point (BASELINE config 2: YOLOv8n, B = 64, 640 x 640 -- the exact plan set bench.py times: tile plans, grouped-grid residency and persistent tile
-    walks depend on M = B * H * W) against the oracle, in its own process = production routing: the bf16 engine against the rounding-matched oracle (items,
-    gradient direction and size), and the fp32 engine against the plain fp32 oracle at the north-star tolerance (items rtol 1e-3, every parameter gradient per
-    element).  Reference step: Utils/Amp.cs:260-286, loss Utils/Loss.cs:411-477.  The two oracle passes cost ~25 s each on the GPU box's host cores."""
+    walks depend on M = B * H * W) against the oracle, in its own process = production routing: the bf16 engine against the rounding-matched oracle (items, head
+    outputs, gradient direction and size), and the fp32 engine against the plain oracle IN DOUBLE at the north-star tolerance (items and head logits 1e-3, every
+    parameter gradient per element 2e-3).  Reference step: Utils/Amp.cs:260-286, loss Utils/Loss.cs:411-477.  The two oracle passes cost ~25 s each on the GPU box's host cores."""
     d = run_worker(tmp_path, 64, 640, 640, f32=True)
     s = summarize(d)
-    dump = os.path.join(ROOT, "gpurun_out")
-    if os.path.isdir(dump):
-        with open(os.path.join(dump, "prod_routing_b64_summary.txt"), "w") as f:
-            for k, v in s.items():
-                f.write("%s: %s\n" % (k, v))
-    # bf16, production routing, against the rounding-matched oracle
+    # bf16, production routing, against the rounding-matched oracle: items, head outputs (the B = 8 test's bounds), gradients
     assert np.allclose(s["items"], s["r_items"], rtol=ITEMS_R), (s["items"], s["r_items"])
+    for k in ("boxes", "scores"):
+        frac1, frac8, worst, rms = s[k + "_r"]
+        assert rms < HEAD_RMS and frac8 < HEAD_FRAC8, (k, s[k + "_r"])
     cos, ratio, per = s["grad_r"]
     assert cos > GRAD_COS and abs(ratio - 1.0) < GRAD_NORM, s["grad_r"]
     assert per[0][0] > GRAD_COS_MIN, per
-    # fp32 engine against the plain fp32 oracle: north-star tolerance
+    # fp32 engine against the plain oracle in double: north-star tolerance on the items AND on the head logits, per element
     assert np.allclose(d["items32"], d["f_items"], rtol=1e-3, atol=1e-5), (d["items32"], d["f_items"])
+    head32 = {k: _relerr(d["e32_" + k], d["f_" + k]) for k in ("boxes", "scores")}
     names = [k[6:] for k in d.files if k.startswith("e32_g_") and "f_g_" + k[6:] in d.files]
     assert len(names) > 150
     gscale = max(float(np.abs(d["f_g_" + n]).max()) for n in names)
@@ -126,14 +146,83 @@ def test_v8n_640_b64_production_routing(tmp_path):
         a, b = d["e32_g_" + n].astype(np.float64), d["f_g_" + n].astype(np.float64)
         ratios.append((float(np.abs(a - b).max() / (np.abs(b).max() + 1e-3 * gscale)), n))
     ratios.sort(reverse=True)
-    over = [r for r in ratios if r[0] >= 2e-3]
-    with open(os.path.join(dump, "prod_routing_b64_summary.txt"), "a") as f:
-        f.write("f32 gradient tensors by max |a - b| / (max |b| + 1e-3 gscale), worst first: %s\n" % (ratios[:8],))
-    # At the headline batch every reduction runs over 16x the terms of the B = 4 statement (test_model.py::test_full_resolution_parity_f32, 2e-3 against the float
-    # oracle): against the oracle in DOUBLE the fp32 engine's gradients are within 1.2e-2 of each tensor's maximum (worst: model.0.bn.bias, a sum of 6.5 million signed
-    # terms per channel; model.9.cv1.conv.weight, model.2.*: 0.8-1.0e-2) -- fp32 accumulation with cancellation, measured, stated with a 2x margin.
-    assert ratios[0][0] < 2.5e-2, ratios[:4]
-    assert sum(1 for r in ratios if r[0] >= 1e-2) <= 4, ratios[:8]
+    _dump("prod_routing_b64_summary.txt", s, ["f32 head logits, per-element relerr: %s" % (head32,),
+                                               "f32 gradient tensors by max |a - b| / (max |b| + 1e-3 gscale), worst first: %s" % (ratios[:8],)])
+    assert max(head32.values()) < 1e-3, head32
+    # Round 6: 2e-3 of each tensor's maximum for EVERY tensor (the round-5 run measured 4.9e-4 on the worst one, model.9.cv1.conv.weight, against the oracle in double;
+    # the 2.5e-2 / "at most 4 tensors >= 1e-2" of round 5 described the FLOAT oracle's own summation error and would have passed a wrong tile column)
+    assert ratios[0][0] < 2e-3, ratios[:4]
+
+
+# ---- the other BASELINE configurations under production routing (round-5 verdict 1b / 5b: tests/conftest.py lowers the routing gates for the whole suite, so
+# test_configs.py pushes 20 x 20 / 40 x 40 maps through the 16 x 16 halo tiles and 1x1 / 32-channel layers through fp8; these runs have no YS_* in their environment).
+# Graph family / size / task / dtype go to the worker; the bf16 engine is compared with the rounding-matched oracle (tests/bf16_ref.py: Conv, Bottleneck, Detect / Segment
+# towers, C2PSA attention, Proto), the loss items also with the plain fp32 oracle.  Thresholds: CFG[...] = (items vs matched, items vs fp32, head rms, overall gradient
+# cosine, |norm ratio - 1|, worst-tensor cosine); measured values next to each (gpurun_out/prod_routing_<tag>_summary.txt of the calibration run, round 6).
+CFG = {
+    # config 3 per-GPU shape: YOLOv8s B = 32
+    "v8s_b32": (dict(B=32, H=640, W=640, family=8, size="s"), (1e-2, 1.5e-2, 0.15, 0.99, 2e-2, 0.85)),
+    # config 4 graph: YOLOv11m-seg, B = 4 (the oracle's per-image mask loop and the C2PSA attention in fp32 on host cores bound the batch)
+    "v11m_seg_b4": (dict(B=4, H=640, W=640, family=11, size="m", task="segment"), (3e-2, 5e-2, 0.25, 0.97, 5e-2, 0.5)),
+    # config 5 graph and resolution: YOLOv8x 1280 x 1280, B = 2, bf16 and fp8
+    "v8x_1280_b2": (dict(B=2, H=1280, W=1280, family=8, size="x"), (8e-2, 8e-2, 0.40, 0.93, 8e-2, 0.3)),
+    "v8x_1280_b2_fp8": (dict(B=2, H=1280, W=1280, family=8, size="x", dtype="fp8"), (1e-1, 1e-1, 0.50, 0.85, 1.5e-1, 0.2)),
+}
+# launch labels that must occur (class, prefix): the kernels bench.py times on that configuration
+WANT = {
+    "v8s_b32": [("conv_igemm", "gemm "), ("conv_igemm", "p2"), ("conv_igemm", "halo "), ("conv_wgrad", "wgemm "), ("conv_wgrad", "wgrad_tr ")],
+    "v11m_seg_b4": [("conv_igemm", "gemm "), ("conv_igemm", "p2"), ("conv_wgrad", "wgemm ")],
+    "v8x_1280_b2": [("conv_igemm", "gemm "), ("conv_igemm", "halo "), ("conv_igemm", "p2"), ("conv_wgrad", "wgemm ")],
+    "v8x_1280_b2_fp8": [("conv_igemm", "gemmf8 "), ("conv_igemm", "p2"), ("conv_wgrad", "wgemm ")],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(CFG))
+def test_other_configs_production_routing(tmp_path, tag):
+    a, (it_r, it_f, head_rms, gcos, gnorm, gmin) = CFG[tag]
+    a = dict(a)
+    B, H, W = a.pop("B"), a.pop("H"), a.pop("W")
+    d = run_worker(tmp_path, B, H, W, **a)
+    labels = _conv_labels(d)
+    s = summarize(d)
+    kinds = sorted(set((c, l.split(" ")[0]) for c, l in labels))
+    _dump("prod_routing_%s_summary.txt" % tag, s, ["launch kinds: %s" % (kinds,)] + ["%s,%s" % cl for cl in sorted(set(labels))])
+    for c, pre in WANT[tag]:
+        assert any(cl == c and l.startswith(pre) for cl, l in labels), (c, pre, kinds)
+    if tag == "v8x_1280_b2":
+        assert any(l.startswith("halo ") and "tile16x16" in l for _, l in labels) and any(l.startswith("halo ") and "tile8x16" in l for _, l in labels), kinds
+    assert np.all(np.isfinite(s["items"]))
+    assert np.allclose(s["items"], s["r_items"], rtol=it_r), (s["items"], s["r_items"])
+    assert np.allclose(s["items"], s["f_items"], rtol=it_f), (s["items"], s["f_items"])
+    for k in [k for k in ("boxes", "scores", "mask_coefficient", "proto") if k + "_r" in s]:
+        assert s[k + "_r"][3] < head_rms, (k, s[k + "_r"])
+    cos, ratio, per = s["grad_r"]
+    assert cos > gcos and abs(ratio - 1.0) < gnorm, s["grad_r"]
+    assert per[0][0] > gmin, per
+
+
+DET = {
+    "v8s_b32": dict(B=32, H=640, W=640, family=8, size="s"),
+    "v11m_seg_b4": dict(B=4, H=640, W=640, family=11, size="m", task="segment"),
+    "v8x_1280_b2_fp8": dict(B=2, H=1280, W=1280, family=8, size="x", dtype="fp8"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(DET))
+def test_fresh_model_first_step_is_deterministic_production_routing(tmp_path, tag):
+    """Three freshly created models, same seed: the first training step of each (fp8: the second as well -- the first runs the bf16 kernels) must agree bit for bit in the
+    loss items, the head outputs and EVERY gradient tensor, under production routing (round-5 verdict 5c: the round-3 race in stem_wgrad_kernel only ever showed on a
+    model's first step; test_model.py covers YOLOv8n)."""
+    a = dict(DET[tag])
+    B, H, W = a.pop("B"), a.pop("H"), a.pop("W")
+    d = run_worker(tmp_path, B, H, W, mode="det", **a)
+    names = [str(n) for n in d["names"]]
+    assert len(names) > 150
+    diff = [n for n, p0, p1, p2 in zip(names, d["per0"], d["per1"], d["per2"]) if not (p0 == p1 == p2)]
+    assert not diff, diff[:8]
+    assert str(d["hash0"]) == str(d["hash1"]) == str(d["hash2"]), (d["items0"], d["items1"], d["items2"])
 
 
 def test_worker_runs_on_the_interpreter(tmp_path):

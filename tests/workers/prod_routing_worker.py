@@ -1,18 +1,25 @@
 """Worker of tests/test_production_routing.py: runs in its OWN process so that the conv-routing gates are the production ones (the
-library reads YS_GEMM_MIN_M / YS_WGEMM_MIN_M / YS_F8_MIN_CIN / YS_F8_MIN_TAPS once, at the first convolution plan of a process, and
-tests/conftest.py lowers them for the rest of the suite).  YOLOv8n, bf16, one training step's forward + loss + backward on the engine
-and on the rounding-matched oracle (tests/bf16_ref.py); writes everything the test compares into an .npz.
+library seeds its options table from YS_* once, at load, and tests/conftest.py lowers the gates for the rest of the suite).  One
+training step's forward + loss + backward on the engine and on the oracle -- the rounding-matched one (tests/bf16_ref.py) and the
+plain one -- and everything the test compares goes into an .npz.
 
-usage: prod_routing_worker.py <out.npz> <B> <H> <W> [emu] [f32]
+usage: prod_routing_worker.py <out.npz> <B> <H> <W> [emu] [f32] [family=8|11] [size=n|s|m|l|x] [task=detect|segment] [dtype=bf16|fp8] [mode=parity|det]
+
+  f32        also run the fp32 engine on the same step and take the plain oracle in DOUBLE (headline batch, YOLOv8n)
+  dtype=fp8  the step is run TWICE (pass 0 records the delayed-scaling maxima on the bf16 kernels, pass 1 runs the fp8 kernels on the same weights)
+  mode=det   no oracle: THREE fresh models, same seed, first training step of each; sha256 over every gradient tensor, the loss items and the
+             head outputs per model (round-5 verdict 5c: fresh-model first-step determinism under production routing)
+Reference step: Utils/Amp.cs:260-286; losses Utils/Loss.cs:411-477, 688-865; graphs Models/Yolo.cs:43-51, 200-258, 337-370.
 """
+import hashlib
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-for k in ("YS_GEMM_MIN_M", "YS_WGEMM_MIN_M", "YS_F8_MIN_CIN", "YS_F8_MIN_TAPS"):
-    assert k not in os.environ, "%s is set: this process would not test production routing" % k
+_ys = [k for k in os.environ if k.startswith("YS_")]
+assert not _ys, "%s set: this process would not test production routing" % _ys
 
 import numpy as np
 import torch
@@ -21,12 +28,42 @@ from oracle import yolo_oracle as O
 import bf16_ref as R
 
 
+def parse(argv):
+    out, B, H, W = argv[1], int(argv[2]), int(argv[3]), int(argv[4])
+    kw = {"family": "8", "size": "n", "task": "detect", "dtype": "bf16", "mode": "parity"}
+    flags = set()
+    for a in argv[5:]:
+        if "=" in a:
+            k, v = a.split("=", 1)
+            assert k in kw, a
+            kw[k] = v
+        else:
+            assert a in ("emu", "f32"), a
+            flags.add(a)
+    return out, B, H, W, kw, flags
+
+
+def make_models(eng, kw, nc, B, H, W, dtype):
+    import yolosharp_amd.model as M
+    seg = kw["task"] == "segment"
+    name = "Yolov%s%s" % (kw["family"], "Segment" if seg else "")
+    ref = getattr(O, name)(nc=nc, size=kw["size"])
+    m = getattr(M, name)(eng, nc=nc, size=kw["size"], height=H, width=W, max_batch=B, dtype=dtype)
+    crit = (M.v8SegmentationLoss if seg else M.v8DetectionLoss)(m)
+    rcrit = (O.v8SegmentationLoss if seg else O.v8DetectionLoss)(nc)
+    return ref, m, crit, rcrit
+
+
+def head_outputs(preds, seg):
+    keys = ["boxes", "scores"] + (["mask_coefficient", "proto"] if seg else [])
+    return {k: np.asarray(preds[k]) for k in keys if k in preds}
+
+
 def main():
-    out, B, H, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    emu = "emu" in sys.argv[5:]
-    with_f32 = "f32" in sys.argv[5:]          # also run the fp32 engine on the same step (tests/test_production_routing.py, headline batch)
+    out, B, H, W, kw, flags = parse(sys.argv)
+    emu, with_f32 = "emu" in flags, "f32" in flags
+    seg = kw["task"] == "segment"
     from yolosharp_amd import Engine
-    from yolosharp_amd.model import Yolov8, v8DetectionLoss
     if emu:
         from yolosharp_amd import build
         eng = Engine(lib_path=build.build_emu())
@@ -34,20 +71,55 @@ def main():
         eng = Engine(0)
         assert eng.is_device_build
     nc = 80
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(12))
+    batch = O.synthetic_batch(B, H, W, nc, seed=13, **({"kmax": 6} if seg else {}))
+    if seg:
+        batch["masks"] = O.synthetic_masks(batch, B, H // 4, W // 4)
+    nb = {k: v.numpy() for k, v in batch.items()}
+
+    if kw["mode"] == "det":
+        # fresh-model first-step determinism: three models, each created, initialised and stepped once (fp8: twice, the second pass runs the fp8 kernels)
+        res = {}
+        for i in range(3):
+            _, m, crit, _ = make_models(eng, kw, nc, B, H, W, kw["dtype"])
+            m.init_weights(5)
+            m.train()
+            for _ in range(2 if kw["dtype"] == "fp8" else 1):
+                _, preds = m.forward(x.numpy())
+                _, items = crit(None, nb)
+                m.zero_grad(); m.backward()
+            h = hashlib.sha256()
+            h.update(np.asarray(items, np.float32).tobytes())
+            for k, v in sorted(head_outputs(preds, seg).items()):
+                h.update(np.ascontiguousarray(v).tobytes())
+            per = {}
+            for name, g in sorted(m.grads().items()):
+                b = np.ascontiguousarray(g).tobytes()
+                h.update(b)
+                per[name] = hashlib.sha256(b).hexdigest()[:16]
+            res["hash%d" % i] = np.array(h.hexdigest())
+            res["names"] = np.array(sorted(per))
+            res["per%d" % i] = np.array([per[n] for n in sorted(per)])
+            res["items%d" % i] = np.asarray(items, np.float32)
+            m.close()
+        np.savez(out, **res)
+        return
+
     torch.manual_seed(11)
-    ref = O.Yolov8(nc=nc, size="n")
+    ref, m, crit, rcrit = make_models(eng, kw, nc, B, H, W, kw["dtype"])
     for mod in ref.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.1)
             mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
-    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(12))
-    batch = O.synthetic_batch(B, H, W, nc, seed=13)
-    m = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="bf16")
-    m.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
-    eng.kernel_profile(True)
+    sd = {k: v.detach().numpy().copy() for k, v in ref.state_dict().items()}
+    m.load_state_dict(sd)
     m.train()
+    if kw["dtype"] == "fp8":           # pass 0: bf16 kernels, records the maxima; no optimizer step, the weights stay the oracle's.  BatchNorm running statistics move,
+        m.forward(x.numpy(), fetch=False)   # which a train-mode forward does not read
+        crit(None, nb); m.zero_grad(); m.backward()
+    eng.kernel_profile(True)
     _, preds = m.forward(x.numpy())
-    loss, items = v8DetectionLoss(m)(None, {k: v.numpy() for k, v in batch.items()})
+    loss, items = crit(None, nb)
     m.zero_grad(); m.backward()
     grads = m.grads()
     lp = out + ".launches.csv"
@@ -55,7 +127,8 @@ def main():
     eng.kernel_profile(False)
     labels = [l for l in open(lp).read().splitlines()[1:]]
     os.remove(lp)
-    res = {"items": np.asarray(items, np.float32), "boxes": preds["boxes"], "scores": preds["scores"], "labels": np.array(labels)}
+    res = {"items": np.asarray(items, np.float32), "labels": np.array(labels)}
+    res.update(head_outputs(preds, seg))
     # ---- oracle, twice: rounding-matched (bf16 storage points) and plain fp32
     ref.train()
     def plain():
@@ -66,12 +139,14 @@ def main():
             return ref(x.double())
         return ref(x)
     for tag, fwd in (("r", lambda: R.forward_bf16(ref, x)), ("f", plain)):
+        ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})     # the same running statistics for both passes (they are outputs, not inputs, of a train-mode step)
         ref.zero_grad()
         _, rp = fwd()
-        rloss, ritems = O.v8DetectionLoss(nc)(rp, batch)
+        rloss, ritems = rcrit(rp, batch)
         rloss.sum().backward()                # the recorded graph already carries the gradient roundings (bf16_ref._RoundSTE)
         res[tag + "_items"] = ritems.detach().numpy()
-        res[tag + "_boxes"] = rp["boxes"].detach().numpy(); res[tag + "_scores"] = rp["scores"].detach().numpy()
+        for k, v in head_outputs({k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in rp.items() if k != "feats"}, seg).items():
+            res[tag + "_" + k] = v
         for name, p in ref.named_parameters():
             if p.grad is not None:
                 res[tag + "_g_" + name] = p.grad.numpy().copy()
@@ -80,13 +155,15 @@ def main():
         res["e_g_" + name] = g
     m.close()
     if with_f32:
-        m32 = Yolov8(eng, nc=nc, size="n", height=H, width=W, max_batch=B, dtype="f32")
-        m32.load_state_dict({k: v.detach().numpy() for k, v in ref.state_dict().items()})
+        _, m32, crit32, _ = make_models(eng, kw, nc, B, H, W, "f32")
+        m32.load_state_dict(sd)
         m32.train()
-        m32.forward(x.numpy(), fetch=False)
-        _, items32 = v8DetectionLoss(m32)(None, {k: v.numpy() for k, v in batch.items()})
+        _, p32 = m32.forward(x.numpy())
+        _, items32 = crit32(None, nb)
         m32.zero_grad(); m32.backward()
         res["items32"] = np.asarray(items32, np.float32)
+        for k, v in head_outputs(p32, seg).items():
+            res["e32_" + k] = v
         for name, g in m32.grads().items():
             res["e32_g_" + name] = g
         m32.close()
