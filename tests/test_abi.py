@@ -98,10 +98,15 @@ def test_options_context_restores_what_was_there(emu_lib_path):
     from yolosharp_amd import Engine
     eng = Engine(lib_path=emu_lib_path)
     assert os.environ.get("YS_GEMM_MIN_M") == "1" and eng.get_option("GEMM_MIN_M") == 1.0      # seeded from the environment
-    assert eng.get_option("NO_SUCH_KEY_R05") is None
-    with eng.options(GEMM_MIN_M=4096, NO_SUCH_KEY_R05=3):
-        assert eng.get_option("GEMM_MIN_M") == 4096.0 and eng.get_option("YS_NO_SUCH_KEY_R05") == 3.0
+    assert eng.get_option("WGEMM_KT") is None
+    with eng.options(GEMM_MIN_M=4096, WGEMM_KT=32):
+        assert eng.get_option("GEMM_MIN_M") == 4096.0 and eng.get_option("YS_WGEMM_KT") == 32.0
         with eng.options(GEMM_MIN_M=7):
             assert eng.get_option("GEMM_MIN_M") == 7.0
         assert eng.get_option("GEMM_MIN_M") == 4096.0
-    assert eng.get_option("GEMM_MIN_M") == 1.0 and eng.get_option("NO_SUCH_KEY_R05") is None
+    assert eng.get_option("GEMM_MIN_M") == 1.0 and eng.get_option("WGEMM_KT") is None
+    # round 6: the keys are a registered list -- a typo is an error, not a silent no-op, and leaves the table untouched
+    with pytest.raises(Exception) as ei:
+        eng.set_option("NO_SUCH_KEY_R06", 3)
+    assert "unknown key" in str(ei.value)
+    assert eng.get_option("NO_SUCH_KEY_R06") is None

@@ -90,38 +90,3 @@ def test_fused_reduction_with_shortcut_blocks_and_two_sources(backend, engine):
         if scale < 0.05:
             continue
         assert np.abs(a - b).max() <= 0.08 * scale, (k, np.abs(a - b).max(), scale)
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("fam", ["8", "11"])
-def test_bn_backward_sums_through_integer_accumulators(backend, engine, fam):
-    """Round 5: the fused BN-backward sums leave the dgrad epilogues as exact integer adds (ys_gacc_add: four 26-binade windows of 64-bit fixed point per value) and
-    bn_bwd_fin_apply_kernel finalizes for itself -- no chan_finalize launch (BNB_ATOMIC=1; off by default: measured no faster).  Against BNB_ATOMIC=0 (rows + chan_finalize in double) the SAME partials are summed
-    exactly instead of in double: dgamma / dbeta agree to fp32 rounding (<= 2 ulp of the value, or of the largest value of the tensor for cancelling sums),
-    everything downstream within the bf16 re-rounding of dy that such a difference can flip; two runs of the accumulator path are bit-identical (integer addition
-    commutes); and the launch record shows the finalizers gone for the units that took the path."""
-    from yolosharp_amd.model import Yolov8, Yolov11, v8DetectionLoss
-    B, H, W = 2, 64, 64
-    x = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
-    batch = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, 80, seed=1).items()}
-    def run(mode):
-        with engine.options(BNB_ATOMIC=mode):
-            m = (Yolov8 if fam == "8" else Yolov11)(engine, nc=80, size="n", height=H, width=W, max_batch=B, dtype="bf16")
-        m.init_weights(3); m.train(); m.forward(x, fetch=False)
-        _, items = v8DetectionLoss(m)(None, batch)
-        m.zero_grad(); m.backward()
-        g = m.grads(); m.close()
-        return g
-    ga, gb, ga2 = run(1), run(0), run(1)
-    assert all(np.array_equal(ga[k], ga2[k]) for k in ga), "accumulator path not bit-reproducible"
-    n_bn = 0
-    for k in ga:
-        a, b = ga[k], gb[k]
-        assert np.isfinite(a).all(), k
-        if k.endswith("bn.weight") or k.endswith("bn.bias"):
-            n_bn += 1
-        sc = float(np.abs(b).max()) + 1e-30
-        rel = float(np.abs(a - b).max()) / sc
-        assert rel < 2e-2, (k, rel)              # bf16 re-rounding noise downstream of a last-bit coefficient difference (most tensors: exactly equal)
-    same = sum(np.array_equal(ga[k], gb[k]) for k in ga)
-    assert n_bn > 20 and same >= len(ga) // 2, (n_bn, same, len(ga))

@@ -506,32 +506,3 @@ def test_first_step_of_a_new_model_is_deterministic(backend, engine):
         assert np.array_equal(items, ref[0]), (trial, items, ref[0])
         bad = [k for k in g if not np.array_equal(g[k], ref[1][k])]
         assert not bad, (trial, bad[:4])
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("family,dtype", [(8, "bf16"), (11, "bf16"), (8, "fp8")])
-def test_weight_prep_fast_matches_element_kernel(backend, engine, family, dtype):
-    """Round 5: the per-step weight shadows (bf16 forward layout, transposed + flipped dgrad layout, phase-major stride-2 dgrad layout, e4m3 copies) come from
-    weight_prep_fast_kernel (8 elements per thread / LDS transpose tiles); the element-per-thread kernel it replaces stays behind PREP_FAST=0.  Same bits: loss items,
-    head outputs and every gradient of two steps (the second after an AdamW update, fp8: with recorded scales) must be identical."""
-    from yolosharp_amd.model import Yolov8, Yolov11, v8DetectionLoss
-    B, H, W, nc = 2, 64, 64, 80
-    x = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
-    batch = {k: v.numpy() for k, v in O.synthetic_batch(B, H, W, nc, seed=1).items()}
-    outs = []
-    for fast in (1, 0):
-        with engine.options(PREP_FAST=fast):
-            m = (Yolov8 if family == 8 else Yolov11)(engine, nc=nc, size="n", height=H, width=W, max_batch=B, dtype=dtype)
-        m.init_weights(4); m.train()
-        rec = []
-        for it in range(2):
-            m.forward(x, fetch=False); _, items = v8DetectionLoss(m)(None, batch); m.zero_grad(); m.backward()
-            rec.append((items.copy(), m.get_output("boxes"), m.grads()))
-            m.adamw_step([1e-3] * 3)
-        outs.append(rec)
-        m.close()
-    for (ia, ba, ga), (ib, bb, gb) in zip(*outs):
-        assert np.array_equal(ia, ib), (ia, ib)
-        assert np.array_equal(ba, bb)
-        bad = [k for k in ga if not np.array_equal(ga[k], gb[k])]
-        assert not bad, bad[:4]

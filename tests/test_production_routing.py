@@ -163,10 +163,10 @@ CFG = {
     # config 3 per-GPU shape: YOLOv8s B = 32
     "v8s_b32": (dict(B=32, H=640, W=640, family=8, size="s"), (1e-2, 1.5e-2, 0.15, 0.99, 2e-2, 0.85)),
     # config 4 graph: YOLOv11m-seg, B = 4 (the oracle's per-image mask loop and the C2PSA attention in fp32 on host cores bound the batch)
-    "v11m_seg_b4": (dict(B=4, H=640, W=640, family=11, size="m", task="segment"), (3e-2, 5e-2, 0.25, 0.97, 5e-2, 0.5)),
+    "v11m_seg_b4": (dict(B=4, H=640, W=640, family=11, size="m", task="segment", damp=0.25), (3e-2, 5e-2, 0.25, 0.97, 5e-2, 0.5)),
     # config 5 graph and resolution: YOLOv8x 1280 x 1280, B = 2, bf16 and fp8
-    "v8x_1280_b2": (dict(B=2, H=1280, W=1280, family=8, size="x"), (8e-2, 8e-2, 0.40, 0.93, 8e-2, 0.3)),
-    "v8x_1280_b2_fp8": (dict(B=2, H=1280, W=1280, family=8, size="x", dtype="fp8"), (1e-1, 1e-1, 0.50, 0.85, 1.5e-1, 0.2)),
+    "v8x_1280_b2": (dict(B=2, H=1280, W=1280, family=8, size="x", damp=0.25), (8e-2, 8e-2, 0.40, 0.93, 8e-2, 0.3)),
+    "v8x_1280_b2_fp8": (dict(B=2, H=1280, W=1280, family=8, size="x", dtype="fp8", damp=0.25), (1e-1, 1e-1, 0.50, 0.85, 1.5e-1, 0.2)),
 }
 # launch labels that must occur (class, prefix): the kernels bench.py times on that configuration
 WANT = {

@@ -285,183 +285,12 @@ attn_bwd_q_kernel(const T* __restrict__ qkv, int ldq, int B, int N, int heads, i
   }
 }
 
-// ---- round 5: the two row-wise kernels above for bf16, kd = 32, hd = 64, N <= 512 (every C2PSA of the YOLOv11 graphs at 640 x 640) with the head's K and V rows
-// staged ONCE per workgroup in LDS (77 KB at 400 tokens) and four query rows per wave pass.  The one-row form fetched a key / value row as kd / hd separate 2-byte
-// global loads per lane and used each once (0.41 + 0.76 ms per YOLOv11m-seg step for 4 + 6 GFLOP); a first rewrite that kept the operands in global memory and
-// only blocked four rows per wave was SLOWER (0.79 ms forward: 100 dependent global round trips per wave in the P.V pass at two waves per SIMD).  Here a workgroup
-// owns 64 query rows of one (image, head); every inner loop reads LDS.  Every output keeps the one-row kernel's summation order (d ascending inside a dot product,
-// m ascending in the second pass): bit-identical results (tests/test_blocks.py).
-#define ATT_R 4
-#define ATT_QB 64            // query rows per workgroup (16 per wave, four passes of ATT_R)
+// ---- round 5: bf16, kd = 32, hd = 64 (every C2PSA of the YOLOv11 graphs at 640 x 640).  (A four-query-rows-per-wave scalar generation -- attn_fwd4_kernel /
+// attn_bwd_q4_kernel: K / V of a head staged once per workgroup in LDS, bit-identical to the one-row kernels above, 412 -> 290 us forward -- was deleted in round 6
+// once the MFMA kernels below had replaced it everywhere it ran; the one-row kernels remain for fp32, other head sizes and > ATT_NM tokens.)
+#define ATT_QB 64            // query rows per workgroup (16 per wave)
 #define ATT_KP 80            // LDS pitch of a K row: 64 B + 16 (consecutive rows shift by four banks: the 16-byte row reads of a wave do not collide)
 #define ATT_VP 144           // ... of a V row: 128 B + 16
-#define ATT_NFAST 512
-__host__ __device__ inline size_t att_lds_bytes(int N, int extra_floats_per_wave) {
-  const int Np = (N + 3) & ~3;
-  return (size_t)Np * (ATT_KP + ATT_VP) + (size_t)(AD_THREADS / 64) * (ATT_R * Np + extra_floats_per_wave) * 4;     // K / V rows N .. Np - 1: zeros (the 4-wide second passes read them unconditionally)
-}
-__device__ inline void att_stage_kv(const bf16_t* base, int ldq, int N, int Np, char* sK, char* sV) {
-  for (int u = threadIdx.x; u < Np * 4; u += AD_THREADS) { const int m = u >> 2, c = u & 3; *(uint4*)(sK + m * ATT_KP + c * 16) = m < N ? *(const uint4*)(base + (long)m * ldq + 32 + c * 8) : ys_zero16(); }
-  for (int u = threadIdx.x; u < Np * 8; u += AD_THREADS) { const int m = u >> 3, c = u & 7; *(uint4*)(sV + m * ATT_VP + c * 16) = m < N ? *(const uint4*)(base + (long)m * ldq + 64 + c * 8) : ys_zero16(); }
-}
-__device__ inline void att_row32(const uint4* p, float* f) {     // 32 bf16 -> 32 floats (four 16-byte reads)
-#pragma unroll
-  for (int u = 0; u < 4; u++) { const uint4 v = p[u]; ys_unpack<bf16_t>(v, f + 8 * u); }
-}
-__device__ inline float att_bf16(const char* p) { return ys_u2f((unsigned)(*(const unsigned short*)p) << 16); }
-
-__global__ void __launch_bounds__(AD_THREADS)
-attn_fwd4_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, int heads, float scale, bf16_t* __restrict__ ao, int ldo, float* __restrict__ P) {
-  constexpr int KD = 32, HD = 64, R = ATT_R, hs = 2 * KD + HD;
-  YS_DYN_LDS(lds);
-  const int Np = (N + 3) & ~3;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
-  const bf16_t* base = qkv + (long)b * N * ldq + h * hs;
-  char* sK = (char*)lds;
-  char* sV = sK + (size_t)Np * ATT_KP;
-  float* pr = (float*)(sV + (size_t)Np * ATT_VP) + (size_t)wave * R * Np;
-  att_stage_kv(base, ldq, N, Np, sK, sV);
-  __syncthreads();
-  for (int pass = 0; pass < ATT_QB / (AD_THREADS / 64) / R; pass++) {
-    const int n0 = blockIdx.x * ATT_QB + (wave * (ATT_QB / (AD_THREADS / 64) / R) + pass) * R;
-    if (n0 >= N) break;                       // wave-uniform; no workgroup barrier below
-    float q[R][KD];
-#pragma unroll
-    for (int r = 0; r < R; r++) att_row32((const uint4*)(base + (long)(n0 + r < N ? n0 + r : N - 1) * ldq), q[r]);
-    float mx[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) mx[r] = -INFINITY;
-    for (int m = lane; m < Np; m += 64) {
-      if (m < N) {
-        float k[KD];
-        att_row32((const uint4*)(sK + m * ATT_KP), k);
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          float sv = 0.f;
-#pragma unroll
-          for (int d = 0; d < KD; d++) sv += q[r][d] * k[d];
-          sv *= scale;
-          pr[r * Np + m] = sv;
-          mx[r] = fmaxf(mx[r], sv);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; r++) pr[r * Np + m] = 0.f;      // the padding of the 4-wide second pass
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const float mxr = ys_wave_max(mx[r]);
-      float sum = 0.f;
-      for (int m = lane; m < N; m += 64) { const float e = __expf(pr[r * Np + m] - mxr); pr[r * Np + m] = e; sum += e; }
-      sum = ys_wave_sum(sum);
-      const float inv = 1.0f / sum;
-      if (n0 + r < N) {
-        float* Prow = P + ((long)bh * N + n0 + r) * N;
-        for (int m = lane; m < N; m += 64) { const float pv = pr[r * Np + m] * inv; pr[r * Np + m] = pv; Prow[m] = pv; }
-      }
-    }
-    ys_wave_sync();
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.f;
-    const char* vb = sV + 2 * lane;
-#pragma unroll 2
-    for (int m = 0; m < Np; m += 4) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = att_bf16(vb + (m + j) * ATT_VP);
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const float4 p4 = *(const float4*)(pr + r * Np + m);
-        acc[r] += p4.x * v[0]; acc[r] += p4.y * v[1]; acc[r] += p4.z * v[2]; acc[r] += p4.w * v[3];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) if (n0 + r < N) ao[((long)b * N + n0 + r) * ldo + h * HD + lane] = Elem<bf16_t>::from_f(acc[r]);
-    ys_wave_sync();                           // the next pass overwrites this wave's probability rows
-  }
-}
-
-__global__ void __launch_bounds__(AD_THREADS)
-attn_bwd_q4_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, int heads, float scale, const bf16_t* __restrict__ dao, int ldo,
-                   const float* __restrict__ P, float* __restrict__ dS, bf16_t* __restrict__ dqkv) {
-  constexpr int KD = 32, HD = 64, R = ATT_R, hs = 2 * KD + HD;
-  YS_DYN_LDS(lds);
-  const int Np = (N + 3) & ~3;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
-  const bf16_t* base = qkv + (long)b * N * ldq + h * hs;
-  char* sK = (char*)lds;
-  char* sV = sK + (size_t)Np * ATT_KP;
-  float* ds = (float*)(sV + (size_t)Np * ATT_VP) + (size_t)wave * (R * Np + R * HD);
-  float* so = ds + R * Np;
-  att_stage_kv(base, ldq, N, Np, sK, sV);
-  __syncthreads();
-  for (int pass = 0; pass < ATT_QB / (AD_THREADS / 64) / R; pass++) {
-    const int n0 = blockIdx.x * ATT_QB + (wave * (ATT_QB / (AD_THREADS / 64) / R) + pass) * R;
-    if (n0 >= N) break;
-#pragma unroll
-    for (int r = 0; r < R; r++) so[r * HD + lane] = n0 + r < N ? Elem<bf16_t>::to_f(dao[((long)b * N + n0 + r) * ldo + h * HD + lane]) : 0.f;
-    ys_wave_sync();
-    const float* Prow0 = P + ((long)bh * N + n0) * N;
-    float t[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) t[r] = 0.f;
-    for (int m = lane; m < Np; m += 64) {
-      if (m < N) {
-        float v[HD];
-        att_row32((const uint4*)(sV + m * ATT_VP), v);
-        att_row32((const uint4*)(sV + m * ATT_VP + 64), v + 32);
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          float dp = 0.f;
-#pragma unroll
-          for (int d4 = 0; d4 < HD; d4 += 4) {
-            const float4 o4 = *(const float4*)(so + r * HD + d4);
-            dp += o4.x * v[d4]; dp += o4.y * v[d4 + 1]; dp += o4.z * v[d4 + 2]; dp += o4.w * v[d4 + 3];
-          }
-          ds[r * Np + m] = dp;
-          if (n0 + r < N) t[r] += dp * Prow0[(long)r * N + m];
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; r++) ds[r * Np + m] = 0.f;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const float tr = ys_wave_sum(t[r]);
-      if (n0 + r < N) {
-        float* dSrow = dS + ((long)bh * N + n0 + r) * N;
-        for (int m = lane; m < N; m += 64) { const float v = Prow0[(long)r * N + m] * (ds[r * Np + m] - tr); ds[r * Np + m] = v; dSrow[m] = v; }
-      } else {
-        for (int m = lane; m < N; m += 64) ds[r * Np + m] = 0.f;
-      }
-    }
-    ys_wave_sync();
-    // dq: lane half hf owns rows 2 hf, 2 hf + 1; d = lane & 31
-    const int hf = lane >> 5, d = lane & 31;
-    float a0 = 0.f, a1 = 0.f;
-    const char* kb = sK + 2 * d;
-    const float* d0 = ds + (2 * hf) * Np;
-    const float* d1 = d0 + Np;
-#pragma unroll 2
-    for (int m = 0; m < Np; m += 4) {
-      float k[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) k[j] = att_bf16(kb + (m + j) * ATT_KP);
-      const float4 x0 = *(const float4*)(d0 + m), x1 = *(const float4*)(d1 + m);
-      a0 += x0.x * k[0]; a0 += x0.y * k[1]; a0 += x0.z * k[2]; a0 += x0.w * k[3];
-      a1 += x1.x * k[0]; a1 += x1.y * k[1]; a1 += x1.z * k[2]; a1 += x1.w * k[3];
-    }
-    const int r0 = n0 + 2 * hf;
-    if (r0 < N) dqkv[((long)b * N + r0) * ldq + h * hs + d] = Elem<bf16_t>::from_f(a0 * scale);
-    if (r0 + 1 < N) dqkv[((long)b * N + r0 + 1) * ldq + h * hs + d] = Elem<bf16_t>::from_f(a1 * scale);
-    ys_wave_sync();                           // the next pass overwrites so / ds
-  }
-}
 // ---- round 5, second step: the same two passes on the matrix cores (bf16, kd = 32, hd = 64, N <= 416 tokens = every C2PSA at 640 x 640).  One wave owns 16 query
 // rows: S = Q K^T as one 16x16x32 MFMA per 16 keys (K rows straight from the staged LDS copy), softmax in the accumulator layout (a query row lives in the 16 lanes of
 // a DPP row: four shuffles per reduction), the probabilities go to global memory in fp32 (the backward reads them) and as bf16 into a per-wave LDS tile that feeds the
@@ -708,12 +537,17 @@ attn_bwd_kv_mfma_kernel(const bf16_t* __restrict__ qkv, int ldq, int B, int N, i
 static bool attn_mfma_ok(int dtype, int ldq, int ldo, int N, int heads, int kd, int hd) {
   return dtype == YS_BF16 && kd == 32 && hd == 64 && (ldq & 7) == 0 && (ldo & 7) == 0 && N >= 1 && N <= ATT_NM && YS_OPT_INT("ATTN_MFMA", 1) != 0;
 }
-static bool attn_fast_ok(int dtype, int ldq, int ldo, int N, int heads, int kd, int hd) {
-  return dtype == YS_BF16 && kd == 32 && hd == 64 && (ldq & 7) == 0 && N >= 1 && N <= ATT_NFAST && YS_OPT_INT("ATTN_R4", 1) != 0;
-}
+// dynamic LDS above 64 KB needs the attribute once per (kernel, device): cached like the convolution launchers' (it was set on every launch and its result dropped)
 template <class K>
-static void attn_lds_attr(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+static int attn_lds_attr(K kernel, size_t bytes, std::atomic<unsigned>& done) {
+  if (bytes <= 64 * 1024) return YS_OK;
+  int dev = 0;
+  YS_CHECK_HIP(hipGetDevice(&dev));
+  const unsigned bit = 1u << (dev & 31);
+  if (done.load(std::memory_order_acquire) & bit) return YS_OK;
+  YS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done.fetch_or(bit, std::memory_order_acq_rel);
+  return YS_OK;
 }
 
 // pass 2 (per key column m): dk = scale * dS^T q ; dv = dO P  (added to the gradient that arrived through pe(v)).
@@ -802,14 +636,9 @@ int ys_attn_fwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int 
   const float scale = 1.0f / sqrtf((float)kd);   // Math.Pow(key_dim, -0.5) (Block.cs:733)
   if (attn_mfma_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
     const size_t lb = (size_t)att_np16(N) * ATT_KP + (size_t)(64 + 64) * att_tp(N);
-    attn_lds_attr(attn_fwd_mfma_kernel, lb);
+    static std::atomic<unsigned> attr_f{0};
+    YS_TRY(attn_lds_attr(attn_fwd_mfma_kernel, lb, attr_f));
     YS_LAUNCH_LDS(attn_fwd_mfma_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lb, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (bf16_t*)ao, ldo, P);
-    return YS_OK;
-  }
-  if (attn_fast_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
-    const size_t lb = att_lds_bytes(N, 0);
-    attn_lds_attr(attn_fwd4_kernel, lb);
-    YS_LAUNCH_LDS(attn_fwd4_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lb, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (bf16_t*)ao, ldo, P);
     return YS_OK;
   }
   dim3 grid(ys_cdiv(N, AD_THREADS / 64), B * heads);
@@ -823,18 +652,13 @@ int ys_attn_bwd_launch(hipStream_t st, int dtype, const void* qkv, int ldq, int 
   const float scale = 1.0f / sqrtf((float)kd);
   if (attn_mfma_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
     const size_t lb = (size_t)att_np16(N) * ATT_VP + (size_t)(32 + 64) * att_tp(N);
-    attn_lds_attr(attn_bwd_q_mfma_kernel, lb);
+    static std::atomic<unsigned> attr_q{0}, attr_kv{0};
+    YS_TRY(attn_lds_attr(attn_bwd_q_mfma_kernel, lb, attr_q));
     YS_LAUNCH_LDS(attn_bwd_q_mfma_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lb, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (const bf16_t*)dao, ldo, P, dS, (bf16_t*)dqkv);
     const size_t lk = (size_t)(32 + 64) * att_tp(N);
-    attn_lds_attr(attn_bwd_kv_mfma_kernel, lk);
+    YS_TRY(attn_lds_attr(attn_bwd_kv_mfma_kernel, lk, attr_kv));
     YS_LAUNCH_LDS(attn_bwd_kv_mfma_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lk, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (const bf16_t*)dao, ldo, P, (const float*)dS, (bf16_t*)dqkv);
     return YS_OK;
-  }
-  if (attn_fast_ok(dtype, ldq, ldo, N, heads, kd, hd)) {
-    const size_t lb = att_lds_bytes(N, ATT_R * 64);
-    attn_lds_attr(attn_bwd_q4_kernel, lb);
-    YS_LAUNCH_LDS(attn_bwd_q4_kernel, dim3(ys_cdiv(N, ATT_QB), B * heads), AD_THREADS, lb, st, (const bf16_t*)qkv, ldq, B, N, heads, scale, (const bf16_t*)dao, ldo, P, dS, (bf16_t*)dqkv);
-    return attn_bwd_kv_dispatch<bf16_t>(st, (const bf16_t*)qkv, ldq, B, N, heads, kd, hd, scale, (const bf16_t*)dao, ldo, P, (const float*)dS, (bf16_t*)dqkv);
   }
   dim3 grid(ys_cdiv(N, AD_THREADS / 64), B * heads);
   if (dtype == YS_BF16) {

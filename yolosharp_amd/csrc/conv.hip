@@ -1310,7 +1310,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
   // (measured, round 4: a 168-register variant that LDS limits to two workgroups per CU anyway is NOT better off on the 12-unit variant of the
   // same tile with 2-4 K-steps per LDS wait: config 2 patch-kernel time 2.58 -> 2.65 ms, config 5 6.8 -> 6.9 -- the K loop of these tiles is
   // bound by LDS read bandwidth / issue, not by the exposed wait)
-  long gx = (256L * per_cu) / p.gy;                           // persistent grid: the next tile's patch is prefetched
+  long gx = ((long)ys_cu_count() * per_cu) / p.gy;            // persistent grid: the next tile's patch is prefetched
   if (gx > p.g.ntiles) gx = p.g.ntiles;
   if (gx < 1) gx = 1;
   p.gx = (int)gx;
@@ -1380,8 +1380,9 @@ static const int* p2_tables(const ConvArgs& a, const P2Plan& p) {
 
 template <int MR, int NR, int WRES, int NPU, int NT, int F8, int RED = 0>
 static int conv_p2_launch_t(hipStream_t st, ConvArgs a, const P2Plan& p) {
-  const int dbg = (int)YS_OPT_INT("DBG", 0);   // ablation switches (performance triage only)
-  a.dbg = dbg;
+#ifdef YS_P2_ABLATE
+  a.dbg = (int)YS_OPT_INT("DBG", 0);   // ablation switches (triage build only: build.py p2ablate)
+#endif
   a.red_koff = (int)offsetof(ConvArgs, red);       // ConvArgs is the kernel's first argument (conv_epi.h ys_red_table)
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
   int dev_id = 0;
@@ -1458,7 +1459,11 @@ static int conv_p2_dispatch(hipStream_t st, const ConvArgs& a, const P2Plan& p) 
 // (the caller then launches them one by one).  row_cap[i] > 0 bounds problem i's workgroups (partial-row regions sized elsewhere).
 template <int MR, int NR, int WRES, int NPU, int NT, int RED>
 static int conv_p2_group_launch_t(hipStream_t st, const ConvArgs* a, const P2Plan* p, int n, const int* gxs, size_t lds) {
+#ifdef YS_P2_ABLATE
   const int dbg = (int)YS_OPT_INT("DBG", 0);
+#else
+  const int dbg = 0;
+#endif
   static std::atomic<unsigned> attr_done{0};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
@@ -1511,7 +1516,7 @@ static int conv_p2_group_dispatch(hipStream_t st, const ConvArgs* a, const P2Pla
 }
 
 int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int* row_cap, int* rows, bool plan_only) {
-  const bool off = YS_OPT_INT("NO_P2", 0) != 0 || YS_OPT_INT("GROUP", 1) == 0;
+  const bool off = YS_OPT_INT("GROUP", 1) == 0;
   if (off || n < 2 || n > YS_GROUP_MAX) return YS_ERR_UNSUPPORTED;
   P2Plan p[YS_GROUP_MAX];
   int big = 0;
@@ -1536,7 +1541,7 @@ int ys_conv_p2_group_launch(hipStream_t st, const ConvArgs* a, int n, const int*
   size_t lds = 0; int per_cu = 3;
   long tiles = 0;
   for (int i = 0; i < n; i++) { lds = lds > p[i].lds ? lds : p[i].lds; per_cu = per_cu < p[i].per_cu ? per_cu : p[i].per_cu; tiles += p[i].g.ntiles; }
-  const long slots = (256L * per_cu) / p[0].gy > 0 ? (256L * per_cu) / p[0].gy : 1;
+  const long slots = ((long)ys_cu_count() * per_cu) / p[0].gy > 0 ? ((long)ys_cu_count() * per_cu) / p[0].gy : 1;
   int gxs[YS_GROUP_MAX];
   long used = 0;
   for (int i = 0; i < n; i++) {
@@ -1703,12 +1708,13 @@ int ys_conv_is_p2(const ConvArgs& a) {
 template <class T, int MR, int NR>
 static int conv3x3_launch_t(hipStream_t st, ConvArgs a, const TileChoice& t, const C3Plan& p) {
   a.TH = t.th; a.TW = t.tw; a.tiles_x = t.tx; a.tiles_y = t.ty;
-  const int dbg = (int)YS_OPT_INT("DBG", 0);
-  a.dbg = dbg;
+#ifdef YS_P2_ABLATE
+  a.dbg = (int)YS_OPT_INT("DBG", 0);
+#endif
   const int ntiles = t.tx * t.ty * a.B;
   const int gy = ys_cdiv(a.Cout, NR * 16);
   const int per_cu = p.lds_bytes <= 76 * 1024 ? 2 : 1;
-  int gx = (256 * per_cu + gy - 1) / gy;
+  int gx = (ys_cu_count() * per_cu + gy - 1) / gy;
   if (gx > ntiles) gx = ntiles;
   static std::atomic<unsigned> attr_done{0};      // per device: the attribute belongs to the device's code object
   int dev_id = 0;
@@ -1819,8 +1825,7 @@ static int conv_dgrad_s2_phases(hipStream_t st, const ConvArgs& a, bool rows_onl
 
 // mirrors ys_conv_launch's routing (bf16 storage): the fused reduction lives in conv_epi.h, i.e. in conv_p2_kernel and conv_gemm_kernel
 int ys_conv_bnred_rows(const ConvArgs& a, int dtype) {
-  const bool p2_off = YS_OPT_INT("NO_P2", 0) != 0;
-  if (dtype != YS_BF16 || p2_off) return 0;
+  if (dtype != YS_BF16) return 0;
   if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_bnred_rows(b, dtype); }
   const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
   if (a.f8 && !a.x8 && a.q8 && ys_conv_wants_x8(a)) { ConvArgs b = a; b.x8 = a.q8; return ys_conv_bnred_rows(b, dtype); }
@@ -1854,7 +1859,6 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
     return YS_ERR_INVALID_ARG;
   }
   if (dtype == YS_BF16) {
-    const bool p2_off = YS_OPT_INT("NO_P2", 0) != 0;
     if (conv_f8_declined(a)) { ConvArgs b = a; b.f8 = 0; return ys_conv_launch(st, dtype, b); }
     const bool phases = ys_conv_dgrad_uses_phases(dtype, a.KH, a.DIVM + 1) && a.KW == a.KH;
     if (a.f8 && !a.x8 && a.q8) {
@@ -1873,13 +1877,13 @@ int ys_conv_launch(hipStream_t st, int dtype, const ConvArgs& a) {
     if (a.f8) {                                                       // fp8 request: the blocked-GEMM kernel on the fp8 image, else the P2 kernel's fp8 mode
       if (a.x8 && ys_conv_gemm_rows(a)) return ys_conv_gemm_launch(st, a);
       const P2Plan pf = conv_p2_plan(a);
-      if (pf.ok && !p2_off) return conv_p2_dispatch(st, a, pf);
+      if (pf.ok) return conv_p2_dispatch(st, a, pf);
       ConvArgs b = a; b.f8 = 0;
       return ys_conv_launch(st, dtype, b);
     }
     if (ys_conv_gemm_rows(a)) return ys_conv_gemm_launch(st, a);
     const P2Plan p2 = conv_p2_plan(a);
-    if (p2.ok && !p2_off) return conv_p2_dispatch(st, a, p2);
+    if (p2.ok) return conv_p2_dispatch(st, a, p2);
     return conv_launch_dtype<bf16_t>(st, a);
   }
   return conv_launch_dtype<float>(st, a);

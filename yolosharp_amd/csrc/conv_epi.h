@@ -45,16 +45,14 @@ __device__ inline ys_redp_t ys_red_table(const ConvArgs& a) {
 #endif
 
 // destination of one fused BN-backward partial sum (output-view channel c of the launch, `which` = 0: sum du / 1: sum du * y): a row entry of the covering
-// producer's partial buffer, or (round 5) an exact integer add into that producer's accumulators
+// producer's partial buffer
 __device__ inline void ys_bnred_put(const ConvArgs& a, int c, int which, long row, float t) {
   const ys_redp_t rt = ys_red_table(a);
 #pragma unroll
   for (int k = 0; k < YS_BNRED_MAXSEG; k++)
     if (k < a.nred && c >= rt[k].c0 && c < rt[k].c1) {
       const int pc = c - rt[k].c0 + rt[k].yc0;
-      unsigned long long* acc = rt[k].acc;
-      if (acc) ys_gacc_add(acc, (long)a.red_row0 + row, rt[k].C, pc, which, t);
-      else rt[k].part[(((long)a.red_row0 + row) * 2 + which) * rt[k].C + pc] = t;
+      rt[k].part[(((long)a.red_row0 + row) * 2 + which) * rt[k].C + pc] = t;
     }
 }
 

@@ -369,10 +369,11 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
     h.abytes = (unsigned)ab;
   }
   p.lds = halo_lds_bytes(p.nr, p.mr);
-  long gx = (256 / p.gy) & ~7L;               // one workgroup per CU; the XCD-ordered tile walk needs a multiple of 8
+  const int ncu = ys_cu_count();
+  long gx = (ncu / p.gy) & ~7L;               // one workgroup per CU; the XCD-ordered tile walk needs a multiple of 8
   if (gx < 8) gx = 8;
   if (gx > mt) gx = mt;
-  if (mt * p.gy <= 256) gx = mt;
+  if (mt * p.gy <= ncu) gx = mt;
   { const long cap = YS_OPT_INT("HALO_MAX_GRID", 0); if (cap > 0 && gx > cap) gx = cap; }   // tests: workgroups that walk several tiles on oracle-sized shapes
   p.gx = (int)gx;
   p.h = h; p.halo = 1; p.ok = 1;
@@ -381,7 +382,6 @@ static GemmPlan conv_halo_plan(const ConvArgs& a) {
 
 static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   GemmPlan p{};
-  const bool off = YS_OPT_INT("NO_GEMM", 0) != 0;
   // 160 (was 128 until the end of round 4): with 128 <= Cin < 160 only the wide-output 3x3 layers (below) stay here.  What moved to the patch kernel, per-launch
   // records of YOLOv8n B = 64: the dgrad of the fused tower input at P3 (cin144 -> cout64, M = 409600: 168 -> 110 us -- a 256 x 64 tile leaves this kernel one
   // workgroup per CU) and the 2x2 / 1x2 / 2x1 phases of the stride-2 dgrads with 128 gradient channels, which join their 1x1 phase in ONE grouped patch-kernel
@@ -389,8 +389,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   const int min_cin = (int)YS_OPT_INT("GEMM_MIN_CIN", 160);
   const int min_k = 256;
   const bool f8 = a.f8 != 0;
-  const bool f8_off = YS_OPT_INT("NO_GEMM_F8", 0) != 0;
-  if (off || (f8 && (f8_off || !a.x8 || !a.w8 || !a.deq || a.Cin % 16))) return p;
+  if (f8 && (!a.x8 || !a.w8 || !a.deq || a.Cin % 16)) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
   const bool phase = a.KH >= 1 && a.KH <= 2 && a.KW >= 1 && a.KW <= 2 && a.SA == 1 && a.out_rh != 0 && a.PAD == 0;
   const bool k1 = a.KH == 1 && a.KW == 1 && a.PAD == 0 && a.SA == 1 && a.out_rh == 0;
@@ -451,16 +450,16 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   {
     int fit = (int)((160 * 1024 - (size_t)g.off_stage) / g.stage_bytes);
     if (fit > 4) fit = 4;
-    if ((long)g.mtiles * p.gy <= 256 && g.nkt > 2) g.nstage = fit;
+    if ((long)g.mtiles * p.gy <= ys_cu_count() && g.nkt > 2) g.nstage = fit;
     if (g.nstage > g.nkt) g.nstage = g.nkt < 2 ? 2 : g.nkt;
   }
   p.lds = g.off_stage + (size_t)g.nstage * g.stage_bytes;
   const int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
-  long gx = (256L * per_cu) / p.gy;
+  long gx = ((long)ys_cu_count() * per_cu) / p.gy;
   gx &= ~7L;                                  // XCD-ordered tile walk needs a multiple of 8
   if (gx < 8) gx = 8;
   if (gx > g.mtiles) gx = g.mtiles;
-  if ((long)g.mtiles * p.gy <= 256) gx = g.mtiles;   // the whole launch fits the chip at one workgroup per CU: one tile each
+  if ((long)g.mtiles * p.gy <= ys_cu_count()) gx = g.mtiles;   // the whole launch fits the chip at one workgroup per CU: one tile each
   p.gx = (int)gx;
   p.g = g;
   p.ok = 1;

@@ -186,12 +186,10 @@ static int wgemm_pick_tile(int c) {           // 160 or 128 channels: least padd
 
 static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
   WgGemmPlan p{};
-  const bool off = YS_OPT_INT("NO_WGEMM", 0) != 0;
   const int min_c = 128;
   const int min_m = (int)YS_OPT_INT("WGEMM_MIN_M", 4096);
   const long kt_opt = YS_OPT_INT("WGEMM_KT", 0);   // (the tests switch K-tile variants inside one process)
   const int kt_env = (int)kt_opt;
-  if (off) return p;
   const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2);
   const bool k1 = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1;
   if (!(k3 || k1) || (a.dy_rh && !k1)) return p;
@@ -215,7 +213,7 @@ static WgGemmPlan wgrad_gemm_plan(const WgradArgs& a) {
     g.dybytes = (unsigned)db; g.xbytes = (unsigned)xbts;
   }
   const int wpc = 2;     // 256-register waves: two workgroups per CU
-  long gx = (256L * wpc) / g.gy;
+  long gx = ((long)ys_cu_count() * wpc) / g.gy;
   if (gx < 1) gx = 1;
   const long wsmax = (48L << 20) / ((long)a.Cout * g.taps * a.Cin * 4);   // bound the partial workspace to 48 MB per layer
   if (gx > wsmax) gx = wsmax > 0 ? wsmax : 1;

@@ -10,19 +10,34 @@ static thread_local char g_err[1024] = "";
 #include <cstdlib>
 extern char** environ;
 namespace {
+// THE registered keys (round 6: an unknown key is an error in ys_set_option and ignored -- with the rest of the unrelated YS_* environment -- when the table is seeded).
+// Read at MODEL CREATION (a later change does not re-plan an existing model): BN_ATOMIC, BNRED, HEAD_FUSE, GROUP (head grouping), OVERLAP, STEM_DIRECT.
+// Read at every convolution PLAN (i.e. per launch, through the cached YS_OPT_INT sites): the routing gates GEMM_MIN_M, GEMM_MIN_CIN, GEMM_HALO, HALO_MIN_FILL, HALO_MR4,
+// HALO_MAX_GRID, WGEMM_MIN_M, WGEMM_KT, F8_MIN_CIN, F8_MIN_TAPS, GROUP (grouped launches), ATTN_MFMA; at every backward: WG_BATCH, WG_BATCH_MB (hand-over batches).  DBG / GEMM_DBG exist in the ablation builds only.
+// The table is process-wide: a host that flips a gate from one thread while another thread's model is between its plan-only dry run and the launch re-routes that launch;
+// set options before creating models, or from the thread that drives them.
+const char* const kOptKeys[] = {"ATTN_MFMA", "BNRED", "BNRED_LOG", "BN_ATOMIC", "F8_MIN_CIN", "F8_MIN_TAPS", "GEMM_HALO", "GEMM_MIN_CIN", "GEMM_MIN_M", "GROUP", "HALO_MAX_GRID",
+                                "HALO_MIN_FILL", "HALO_MR4", "HEAD_FUSE", "OVERLAP", "STEM_DIRECT", "WGEMM_KT", "WGEMM_MIN_M", "WG_BATCH", "WG_BATCH_MB", "DBG", "GEMM_DBG"};
+bool opt_known(const std::string& k) {
+  for (const char* n : kOptKeys) if (k == n) return true;
+  return false;
+}
 struct OptTable {
   std::mutex mu;
   std::map<std::string, double> v;
   std::atomic<unsigned> version{1};
   OptTable() {
-    // the ONE place the environment is read: YS_<KEY>=<number> seeds the table at library load (a non-numeric or empty value counts as 1: presence-style switches)
+    // the ONE place the environment is read: YS_<KEY>=<number> of a REGISTERED key seeds the table, at the first option access of the process (= the first plan or
+    // model creation).  Values are numbers: YS_GROUP=0 turns grouping OFF (rounds 1-4 treated some switches as presence flags); a non-numeric value is ignored.
     for (char** e = environ; e && *e; e++) {
       if (strncmp(*e, "YS_", 3) != 0) continue;
       const char* eq = strchr(*e, '=');
       if (!eq || eq == *e + 3) continue;
+      const std::string key(*e + 3, (size_t)(eq - (*e + 3)));
+      if (!opt_known(key)) continue;
       char* end = nullptr;
       const double d = strtod(eq + 1, &end);
-      v[std::string(*e + 3, (size_t)(eq - (*e + 3)))] = (end && end != eq + 1 && *end == 0) ? d : 1.0;
+      if (end && end != eq + 1 && *end == 0) v[key] = d;
     }
   }
 };
@@ -37,8 +52,10 @@ double ys_opt_get(const char* key, double def) {
 unsigned ys_opt_version() { return opt_table().version.load(std::memory_order_acquire); }
 extern "C" __attribute__((visibility("default"))) int ys_set_option(const char* key, double value) {
   if (!key || !*key) { ys_set_error("ys_set_option: empty key"); return YS_ERR_INVALID_ARG; }
+  const char* k = strncmp(key, "YS_", 3) == 0 ? key + 3 : key;
+  if (!opt_known(k)) { ys_set_error("ys_set_option: unknown key '%s'", k); return YS_ERR_INVALID_ARG; }
   OptTable& t = opt_table();
-  { std::lock_guard<std::mutex> g(t.mu); t.v[strncmp(key, "YS_", 3) == 0 ? key + 3 : key] = value; }
+  { std::lock_guard<std::mutex> g(t.mu); t.v[k] = value; }
   t.version.fetch_add(1, std::memory_order_acq_rel);
   return YS_OK;
 }
@@ -57,6 +74,23 @@ extern "C" __attribute__((visibility("default"))) int ys_unset_option(const char
   { std::lock_guard<std::mutex> g(t.mu); t.v.erase(strncmp(key, "YS_", 3) == 0 ? key + 3 : key); }
   t.version.fetch_add(1, std::memory_order_acq_rel);
   return YS_OK;
+}
+
+// compute units of the current device (MI355X: 256), cached per device; the persistent-grid plans size themselves with it
+int ys_cu_count() {
+  static std::atomic<int> cache[32];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cache[dev & 31].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+#ifdef YS_EMU_BUILD
+  int n = 256;             // the test interpreter plans like the MI355X it stands in for
+#else
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+#endif
+  cache[dev & 31].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 void ys_set_error(const char* fmt, ...) {

@@ -369,15 +369,19 @@ bn_fin_apply_kernel(const T* __restrict__ y, long rows, int C, BnAccFin f, const
   float* s_sh = s_sc + C;
   for (int c = threadIdx.x; c < C; c += EW_THREADS) {
     long long a1 = 0, a2 = 0;
+    bool poisoned = false;
 #pragma unroll
     for (int s = 0; s < YS_STAT_SHARDS; s++) {
+      const unsigned long long w2 = f.acc[((long)s * C + c) * 2 + 1];
+      poisoned |= (w2 >> 62) != 0;               // a producer workgroup saw a non-finite / out-of-range partial (ys_stat_acc_add)
       a1 += (long long)f.acc[((long)s * C + c) * 2 + 0];
-      a2 += (long long)f.acc[((long)s * C + c) * 2 + 1];
+      a2 += (long long)w2;
     }
     const double s1 = (double)a1 * (1.0 / (double)YS_STAT_FIX), s2 = (double)a2 * (1.0 / (double)YS_STAT_FIX);
-    const double mean = s1 / f.count;
+    double mean = s1 / f.count;
     double var = s2 / f.count - mean * mean;   // biased (torch BatchNorm2d training normalisation)
     if (var < 0.0) var = 0.0;
+    if (poisoned) { mean = __builtin_nan(""); var = mean; }
     const float g = f.gamma[c], bt = f.beta[c];
     const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
     const float sc = g * rstd, sh = bt - (float)mean * g * rstd;
@@ -771,74 +775,6 @@ int ys_bn_bwd_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc
   if (dtype == YS_BF16) { if (act) BB_LAUNCH(bf16_t, true); else BB_LAUNCH(bf16_t, false); }
   else { if (act) BB_LAUNCH(float, true); else BB_LAUNCH(float, false); }
 #undef BB_LAUNCH
-  return YS_OK;
-}
-
-// BN backward with the finalize inside (round 5): the sums arrive as exact integer accumulators (ys_kernels.h ys_gacc_add) from the epilogues of the dgrad
-// launches that completed dz; every workgroup turns them into k2 / k3 for itself (2 shards x C x 2 x 5 words, L2-resident), workgroup 0 also adds dgamma / dbeta.
-// Same arithmetic as chan_finalize_kernel<0> + bn_bwd_apply_kernel; the chan_finalize launch (5 us + a kernel boundary on the backward chain, 51 per YOLOv8n step) goes.
-template <class T, bool ACT>
-__global__ void __launch_bounds__(EW_THREADS)
-bn_bwd_fin_apply_kernel(const T* __restrict__ dz, int dz_ldc, int dz_coff, const T* __restrict__ y, long rows, int C, BnBwdFin f,
-                        T* __restrict__ dy, T* __restrict__ rg, int rg_ldc, int rg_coff) {
-  constexpr int EPL = Elem<T>::EPL;
-  YS_DYN_LDS(lds);
-  float* s_k2 = (float*)lds;                   // [C] k2, [C] k3
-  float* s_k3 = s_k2 + C;
-  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int s = 0; s < YS_GACC_SHARDS; s++) {
-      const unsigned long long* a = f.acc + (((long)s * C + c) * 2) * YS_GACC_WORDS;
-      unsigned long long w0[YS_GACC_WORDS], w1[YS_GACC_WORDS];
-#pragma unroll
-      for (int k = 0; k < YS_GACC_WORDS; k++) { w0[k] = a[k]; w1[k] = a[YS_GACC_WORDS + k]; }
-      s1 += ys_gacc_value(w0); s2 += ys_gacc_value(w1);
-    }
-    const float sc = f.scale[c], mu = f.mean[c], rs = f.rstd[c];
-    s2 = (double)rs * (s2 - (double)mu * s1);   // sum(du * xhat) from sum(du * y)
-    const float m1 = (float)(s1 / f.count), m2 = (float)(s2 / f.count);
-    s_k2[c] = sc * (m1 - mu * rs * m2);
-    s_k3[c] = sc * rs * m2;
-    if (blockIdx.x == 0) { f.dgamma[c] = f.dgamma[c] + (float)s2; f.dbeta[c] = f.dbeta[c] + (float)s1; }
-  }
-  __syncthreads();
-  const int CG = C / EPL;
-  const long n = rows * CG;
-  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) {
-    const long row = i / CG; const int c = (int)(i - row * CG) * EPL;
-    float g[EPL], v[EPL], sc[EPL], sh[EPL];
-    ys_unpack<T>(ys_ld16(dz + row * dz_ldc + dz_coff + c), g);
-    ys_unpack<T>(ys_ld16(y + row * C + c), v);
-    if (rg) {     // d(residual input) += dz (the Bottleneck shortcut's share)
-      float o[EPL];
-      T* rp = rg + row * rg_ldc + rg_coff + c;
-      ys_unpack<T>(ys_ld16(rp), o);
-#pragma unroll
-      for (int e = 0; e < EPL; e++) o[e] += g[e];
-      ys_st16(rp, ys_pack<T>(o));
-    }
-    ys_ldcoef<EPL>(f.scale + c, sc); ys_ldcoef<EPL>(f.shift + c, sh);
-#pragma unroll
-    for (int e = 0; e < EPL; e++) {
-      const float u = v[e] * sc[e] + sh[e];
-      const float du = ACT ? g[e] * ys_silu_grad(u) : g[e];
-      v[e] = sc[e] * du - s_k2[c + e] - v[e] * s_k3[c + e];
-    }
-    ys_st16(dy + row * C + c, ys_pack<T>(v));
-  }
-}
-int ys_bn_bwd_fin_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C, const BnBwdFin& f, int act,
-                               void* dy, void* rg, int rg_ldc, int rg_coff) {
-  const int epl = dtype == YS_BF16 ? 8 : 4;
-  const long n = rows * (C / epl);
-  const long gcap = 2048;     // (measured: 512 / 256 workgroups 9.21 / 9.72 ms per YOLOv8n step against 8.94; 4096 / 8192 equal)
-  long g = ys_cdiv(n, EW_THREADS * 2L); if (g > gcap) g = gcap; if (g < 1) g = 1;
-  const size_t lds = (size_t)2 * C * sizeof(float);
-#define BBF_LAUNCH(TT, AF) YS_LAUNCH_LDS((bn_bwd_fin_apply_kernel<TT, AF>), (int)g, EW_THREADS, lds, st, (const TT*)dz, dz_ldc, dz_coff, (const TT*)y, rows, C, f, (TT*)dy, (TT*)rg, rg_ldc, rg_coff)
-  if (dtype == YS_BF16) { if (act) BBF_LAUNCH(bf16_t, true); else BBF_LAUNCH(bf16_t, false); }
-  else { if (act) BBF_LAUNCH(float, true); else BBF_LAUNCH(float, false); }
-#undef BBF_LAUNCH
   return YS_OK;
 }
 

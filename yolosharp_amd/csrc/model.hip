@@ -46,7 +46,6 @@ struct ConvL {
   long wf_off = 0, wd_off = 0;               // element offsets into wf_all / wd_all
   long y_off = 0;                             // element offset into y_all (bn layers)
   long acc_off = -1;                          // BatchNorm unit: offset (64-bit words) of its statistics accumulators in ys_model::stat_acc_all
-  long bacc_off = -1;                         // ... of its BN-BACKWARD sum accumulators in ys_model::bnb_acc_all (units that finalize inside the apply pass)
   long ch_off = 0;                            // offset into per-channel scratch (scale.. c2), floats
   int seg = 0;
   bool first = false;
@@ -150,6 +149,13 @@ struct ys_model {
   // weight gradients run on a second stream, concurrently with the BN-backward / dgrad chain of the following layers
   // (both mostly latency-bound); dy lives in a ring of DY_RING buffers guarded by events
   static constexpr int DY_RING = 4;
+  // round 6: weight gradients are handed to the second stream in BATCHES.  Every BatchNorm unit keeps its own dy buffer (ConvL::dy_own: no ring slot to wait for),
+  // a unit's weight-gradient launch is queued instead of issued, and ONE event record / wait pair hands a whole batch over (flush_wgrads).  A rocprofv3 trace of
+  // config 2 showed what the per-layer hand-off cost: every hipEventRecord between two kernels of the main stream is a ~6.6 us bubble (29 + 10 + 5 of them per step
+  // between bn_bwd_apply and the dgrad that follows) and every ring-slot wait another ~6 us (21 per step): 0.6 ms of an 8.7 ms step with no kernel running on
+  // the main stream, all of it in the backward pass (the forward has none).
+  struct PendWg { int conv; const void* dy; int ldc, coff; long bstride; };
+  std::vector<PendWg> pend_wg; double pend_mb = 0.0; int ev_hand = 0;
   // head lanes (round 3): the towers of the three pyramid levels are independent chains (own buffers, own rows of the prediction buffers);
   // the P4 / P5 chains are short, latency-bound launches (100-400 workgroups) that run beside the P3 chain on two side streams
   // asynchronous segment ends (data-parallel step): the weight-gradient stream is NOT joined into the main stream when a backward segment
@@ -157,14 +163,12 @@ struct ys_model {
   hipEvent_t ev_seg_m[NSEG] = {nullptr, nullptr, nullptr, nullptr}, ev_seg_w[NSEG] = {nullptr, nullptr, nullptr, nullptr};
   bool seg_on_st2[NSEG] = {false, false, false, false};
   bool overlap = false, overlap_built = false; hipStream_t st2 = nullptr;   // overlap_built: second stream / dy ring exist; overlap: in use (ys_model_set_overlap)
-  void* dy_ring[DY_RING] = {nullptr}; hipEvent_t ev_dy[DY_RING + 1] = {nullptr}, ev_free[DY_RING] = {nullptr}, ev_join = nullptr;
-  bool slot_busy[DY_RING] = {false}; int dy_next = 0; bool st2_dirty = false;
+  hipEvent_t ev_dy[DY_RING + 1] = {nullptr}, ev_join = nullptr;     // hand-over events (rotated; a wait binds to the record that preceded it)
+  bool st2_dirty = false;
   float* chan = nullptr; long n_chan = 0;       // per conv: scale, shift, mean, rstd, c1, c2 (6*cout)
   float* stat_partial = nullptr; long n_stat = 0;
   unsigned long long* stat_acc_all = nullptr; long n_stat_acc = 0;   // round 5: [unit][YS_STAT_SHARDS][cout][2] fixed-point statistics sums, cleared by ONE memset per training forward
   bool bn_atomic = false;                                            // BatchNorm units take their statistics through them and finalize inside the apply pass
-  unsigned long long* bnb_acc_all = nullptr; long n_bnb_acc = 0;     // round 5: [unit][YS_GACC_SHARDS][cout][2][YS_GACC_WORDS] exact BN-backward sums, cleared by ONE memset per backward
-  bool bnb_atomic = false;
   float* stat_group = nullptr;                  // statistics rows of the grouped head stages (one region per unit, ConvL::gstat_off)
   float* wg_partial = nullptr; long n_wgp = 0;   // [shared scratch (ConvTranspose phases) | one region per convolution]
   // deferred split reduction of the weight gradients: one batched launch per backward_range call instead of one per layer
@@ -1092,7 +1096,7 @@ int allocate(ys_model* m) {
       }
     }
     if ((nf & 7) || tiles + ys_cdiv(nf / 8, 256) + ys_cdiv(pe, 256) >= (1L << 31)) ok = false;
-    m->prep_fast = ok && YS_OPT_INT("PREP_FAST", 1) != 0;
+    m->prep_fast = ok;      // (the element-per-thread kernel stays for fp32 and for tables that miss the 8-element alignment; bit-identity of the two was a round-5 test, profiles/README.md)
     if (m->prep_fast) {
       m->n_prep_tile = (int)pt.size(); m->prep_tiles = tiles; m->n_prep_phase = (int)pp.size(); m->prep_nd_phase = pe;
       if (pt.empty()) pt.push_back(PrepDesc{});
@@ -1129,9 +1133,11 @@ int allocate(ys_model* m) {
       else
         YS_CHECK_HIP(hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking));
     }
-    for (int k = 0; k < ys_model::DY_RING; k++) {
-      YS_TRY(dev_alloc(m, &m->dy_ring[k], (size_t)dy_max * m->es));
-      YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_free[k], hipEventDisableTiming));
+    // (rounds 3-5: a ring of DY_RING dy_max-sized buffers guarded by events; round 6: one buffer per unit, sized for that unit -- sum of the BN outputs, 1.9 GB for
+    // YOLOv8n at B = 64, ~10 GB for YOLOv8x at 1280 x 1280 x 16)
+    for (auto& c : m->convs) {
+      if (!c.bn || c.dw || c.ct || c.dy_own) continue;
+      YS_TRY(dev_alloc(m, &c.dy_own, (size_t)B * c.Hout * c.Wout * c.cout_ld * m->es));
     }
     for (int k = 0; k <= ys_model::DY_RING; k++) YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dy[k], hipEventDisableTiming));
     YS_CHECK_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
@@ -1147,7 +1153,7 @@ int allocate(ys_model* m) {
       if (c.group < 0) continue;
       const long M = (long)B * c.Hout * c.Wout;
       c.gstat_off = gst; gst += (2L * ys_cdiv(M, 64) * 2 * c.cout_ld + 63) / 64 * 64;
-      if (c.bn) YS_TRY(dev_alloc(m, &c.dy_own, (size_t)M * c.cout_ld * m->es));
+      if (c.bn && !c.dy_own) YS_TRY(dev_alloc(m, &c.dy_own, (size_t)M * c.cout_ld * m->es));
     }
     if (gst) YS_TRY(dev_alloc(m, (void**)&m->stat_group, (size_t)gst * 4));
   }
@@ -1163,21 +1169,8 @@ int allocate(ys_model* m) {
     if (off > 0) YS_TRY(dev_alloc(m, (void**)&m->stat_acc_all, (size_t)off * 8));
     else m->bn_atomic = false;
   }
-  // BN-backward sums through exact integer accumulators (ys_kernels.h ys_gacc_add): units outside the grouped head stages (those finalize as one grouped launch
-  // from rows) and up to BNB_MAXC channels (every workgroup of the apply pass reads 2 x C x 2 x 5 words: 40 KB at 256 channels).  Off in fp8 mode (its apply pass
-  // is the quantising one).  OFF BY DEFAULT (BNB_ATOMIC=1 enables): built and measured at the end of round 5 -- results identical to the row form to the last digit of the
-  // loss, bit-reproducible, 51 chan_finalize launches fewer per YOLOv8n step (292 launches) -- and NOT faster: config 2 8.94-8.97 ms against 8.83-8.94, config 3 9.78
-  // against 9.69-9.75, config 4 equal (tools/dev/r05/s40.sh - s42.sh): the per-workgroup finalize prologue and the grid-stride form of the apply pass cost what the
-  // 5 us finalizers did (a smaller apply grid is far worse: 512 workgroups 9.2 ms, 256 9.7; larger grids equal).
-  m->bnb_atomic = YS_OPT_INT("BNB_ATOMIC", 0) != 0 && !m->f8 && m->bnred_on;
-  if (m->bnb_atomic) {
-    const int maxc = (int)YS_OPT_INT("BNB_MAXC", 256);
-    long off = 0;
-    for (auto& c : m->convs) if (c.bn && !c.dw && !c.ct && c.group < 0 && c.cout <= maxc) { c.bacc_off = off; off += (long)YS_GACC_SHARDS * c.cout * 2 * YS_GACC_WORDS; }
-    m->n_bnb_acc = off;
-    if (off > 0) YS_TRY(dev_alloc(m, (void**)&m->bnb_acc_all, (size_t)off * 8));
-    else m->bnb_atomic = false;
-  }
+  // (BN-backward sums through exact integer accumulators + a finalize inside the apply pass -- BNB_ATOMIC, round 5: identical results, 51 launches fewer, NOT faster
+  // (8.94-8.97 against 8.83-8.94 ms) -- was deleted in round 6; the record is in profiles/README.md round 5.)
   // (Two experiments lived here through round 4 and are gone: side-stream "head lanes" for the P4 / P5 towers -- 10.52-10.55 ms/step against 9.98-10.01 without,
   // a side-stream kernel that takes CU slots turns the persistent P3 kernels' equal tile shares into a tail -- and the last-arriver "ticket" BatchNorm finalize inside
   // the producing convolution, +0.9 ms/step: DESIGN.md 6b / 6d.)
@@ -1550,8 +1543,10 @@ int grad_mode(ys_model* m, const View& v) {
   return nw ? 1 : 0;
 }
 
+static int flush_wgrads(ys_model* m, int B);
 int run_convT_bwd(ys_model* m, const ConvL& c, int B) {
   hipStream_t st = m->ctx->stream;
+  YS_TRY(flush_wgrads(m, B));            // queued weight gradients go first: this path drains the second stream and then uses the shared workspace
   if (m->overlap && m->st2_dirty) {      // this path uses the shared wgrad workspace on `st`: drain the weight-gradient stream first
     YS_CHECK_HIP(hipEventRecord(m->ev_join, m->st2));
     YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
@@ -1719,7 +1714,7 @@ int plan_bnred(ys_model* m, int B) {
     YS_TRY(dev_alloc(m, (void**)&m->bnred_part, (size_t)off * 4));
     m->n_bnred = off;
   }
-  if (YS_OPT_INT("BNRED_LOG", 0) != 0) {
+  if (YS_OPT_INT("BNRED_LOG", 0) != 0) {        // plan report (tests/test_bnred.py reads the count)
     int nf = 0, nb = 0;
     for (auto& l : m->convs) { if (l.bn) nb++; if (l.red_ok) nf++; }
     fprintf(stderr, "[ys] fused BN-backward reduction: %d of %d BN conv units (B=%d, %.1f MB of partial rows)\n", nf, nb, B, off * 4.0 / 1e6);
@@ -1761,6 +1756,34 @@ static int launch_wgrad(ys_model* m, ConvL& c, int B, const void* dy, int dy_ldc
   return YS_OK;
 }
 
+// Hand the queued weight-gradient launches to the second stream behind ONE event (everything they read -- their units' dy, written by bn_bwd_apply launches
+// already issued on the main stream -- is complete there once the event fires).  Without the second stream nothing is ever queued.
+static int flush_wgrads(ys_model* m, int B) {
+  if (m->pend_wg.empty()) return YS_OK;
+  hipStream_t sw = m->ctx->stream;
+  if (m->overlap) {
+    hipEvent_t ev = m->ev_dy[m->ev_hand];
+    m->ev_hand = (m->ev_hand + 1) % (ys_model::DY_RING + 1);
+    YS_CHECK_HIP(hipEventRecord(ev, m->ctx->stream));
+    YS_CHECK_HIP(hipStreamWaitEvent(m->st2, ev, 0));
+    sw = m->st2;
+    m->st2_dirty = true;
+  }
+  for (const auto& p : m->pend_wg) YS_TRY(launch_wgrad(m, m->convs[p.conv], B, p.dy, p.ldc, p.coff, p.bstride, sw));
+  m->pend_wg.clear(); m->pend_mb = 0.0;
+  return YS_OK;
+}
+// queue layer c's weight gradient; flush when the batch is full: WG_BATCH launches (default 6) or WG_BATCH_MB megabytes of (input + dy) tensors (default 40:
+// the P1 / P2 / P3 layers, whose kernels run 50-150 us, go over one or two at a time -- the bubble is small next to them and the second stream should not start
+// them late; the P4 / P5 layers, 15-30 us each, go over in fours to sixes)
+static int queue_wgrad(ys_model* m, ConvL& c, int B, const void* dy, int ldc, int coff, long bstride) {
+  if (!m->overlap) return launch_wgrad(m, c, B, dy, ldc, coff, bstride, m->ctx->stream);
+  m->pend_wg.push_back(ys_model::PendWg{c.idx, dy, ldc, coff, bstride});
+  m->pend_mb += ((double)B * c.Hout * c.Wout * c.cout + (double)B * c.Hin * c.Win * c.cin_pad) * m->es * 1e-6;
+  if ((long)m->pend_wg.size() >= YS_OPT_INT("WG_BATCH", 6) || m->pend_mb >= (double)YS_OPT_INT("WG_BATCH_MB", 40)) return flush_wgrads(m, B);
+  return YS_OK;
+}
+
 // the BN-backward segments of the producers whose dz this dgrad launch completes (c.feeds) -> a.red[]; `rows` = partial rows it will write
 static void attach_bnred_feeds(ys_model* m, ConvL& c, ConvArgs& a, int rows) {
   a.nred = (int)c.feeds.size(); a.red_row0 = 0;
@@ -1770,7 +1793,6 @@ static void attach_bnred_feeds(ys_model* m, ConvL& c, ConvArgs& a, int rows) {
     BnRedSeg& sg = a.red[k];
     sg.y = (char*)m->y_all + (size_t)l.y_off * m->es; sg.scale = chan_ptr(m, l, 0); sg.shift = chan_ptr(m, l, 1);
     sg.part = m->bnred_part + f.part_off; sg.c0 = f.c0; sg.c1 = f.c1; sg.yc0 = f.yc0; sg.C = l.cout; sg.act = l.act ? 1 : 0;
-    sg.acc = (m->bnb_atomic && l.bacc_off >= 0) ? m->bnb_acc_all + l.bacc_off : nullptr;
     f.rows = rows;
     l.red_seen++;
   }
@@ -1783,7 +1805,6 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
   const Buf& ob = m->bufs[c.out.buf];
   const long M = (long)B * c.Hout * c.Wout;
   const void* dy = nullptr; int dy_ldc = 0, dy_coff = 0; long dy_bstride = (long)c.Hout * c.Wout;
-  int slot = -1;
   bool dy_q8 = false;                       // m->q8 already holds the e5m2 image of dy (written by the BN backward pass)
   if (c.bn) {
     const void* y = (char*)m->y_all + (size_t)c.y_off * m->es;
@@ -1803,10 +1824,7 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
     const bool fused = c.red_ok && c.red_seen == (int)c.red_src.size() && !c.red_src.empty();
     c.red_seen = 0;
     void* rg_apply = nullptr;                    // the shortcut's residual-gradient accumulation rides on the reduction pass; without one, on the apply pass
-    const bool fin_in_apply = fused && m->bnb_atomic && c.bacc_off >= 0;   // the sums sit in the unit's integer accumulators: no chan_finalize launch
-    if (fin_in_apply) {
-      rg_apply = rg;
-    } else if (fused) {
+    if (fused) {
       FinSrc src{};
       src.n = (int)c.red_src.size();
       for (int k = 0; k < src.n; k++) {
@@ -1824,11 +1842,7 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
                                        chan_ptr(m, c, 4), chan_ptr(m, c, 5), chan_ptr(m, c, 0), chan_ptr(m, c, 2), chan_ptr(m, c, 3)));
     }
     void* dyb = m->dy_scratch;
-    if (m->overlap && !c.dw) {           // ring slot: wait until the weight-gradient kernel that last read it has finished
-      slot = m->dy_next; m->dy_next = (slot + 1) % ys_model::DY_RING;
-      dyb = m->dy_ring[slot];
-      if (m->slot_busy[slot]) YS_CHECK_HIP(hipStreamWaitEvent(st, m->ev_free[slot], 0));
-    }
+    if (m->overlap && !c.dw && c.dy_own) dyb = c.dy_own;   // the unit's own buffer: its weight gradient reads it later, from the second stream (queue_wgrad)
     // fp8 mode: when this layer's dgrad will run the fp8 blocked-GEMM kernel, the same pass writes the e5m2 image of dy it consumes
     // (and records amax(|dy|)) -- no separate quantisation pass over dy
     if (m->f8 && c.f8_bwd && m->f8_sg_valid && !c.first && !c.dw && m->q8 && m->dtype == YS_BF16 && c.cout_ld == c.cout) {
@@ -1836,12 +1850,7 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
       q.f8 = 2; q.w8 = m->wd8_all + c.wd_off; q.qscale = m->f8_scales + 4L * c.idx + 2; q.deq = m->f8_scales + 4L * c.idx + 3;
       dy_q8 = ys_conv_wants_x8(q);
     }
-    if (fin_in_apply) {
-      BnBwdFin bf{};
-      bf.acc = m->bnb_acc_all + c.bacc_off; bf.count = (double)M; bf.dgamma = m->grads + c.g_off; bf.dbeta = m->grads + c.b_off;
-      bf.scale = chan_ptr(m, c, 0); bf.shift = chan_ptr(m, c, 1); bf.mean = chan_ptr(m, c, 2); bf.rstd = chan_ptr(m, c, 3);
-      YS_TRY(ys_bn_bwd_fin_apply_launch(st, m->dtype, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, bf, c.act ? 1 : 0, dyb, rg_apply, rgl, rgc));
-    } else if (dy_q8) {
+    if (dy_q8) {
       YS_TRY(ys_bn_bwd_apply_q8_launch(st, ob.grad, ob.ldc, c.out.coff, y, M, c.cout, chan_ptr(m, c, 0), chan_ptr(m, c, 1), chan_ptr(m, c, 4),
                                        chan_ptr(m, c, 5), c.act ? 1 : 0, dyb, m->q8, m->f8_scales + 4L * c.idx + 2,
                                        m->amax_dy + (size_t)c.idx * YS_AMAX_WAYS, rg_apply, rgl, rgc));
@@ -1863,21 +1872,9 @@ int run_conv_bwd(ys_model* m, ConvL& c, int B) {
     YS_TRY(ys_dwconv_launch(st, m->dtype, 1, dy, c.cout, 0, B, c.Hin, c.Win, c.cout, m->params + c.w_off, ib.grad, ib.ldc, c.in.coff, mode));
     return YS_OK;
   }
-  // ---- wgrad
-  {
-    hipStream_t sw = st;
-    if (m->overlap) {                    // dy is complete on `st`: hand it to the weight-gradient stream
-      hipEvent_t ev = m->ev_dy[slot >= 0 ? slot : ys_model::DY_RING];
-      YS_CHECK_HIP(hipEventRecord(ev, st));
-      YS_CHECK_HIP(hipStreamWaitEvent(m->st2, ev, 0));
-      sw = m->st2;
-    }
-    YS_TRY(launch_wgrad(m, c, B, dy, dy_ldc, dy_coff, dy_bstride, sw));
-    if (m->overlap) {
-      m->st2_dirty = true;
-      if (slot >= 0) { YS_CHECK_HIP(hipEventRecord(m->ev_free[slot], m->st2)); m->slot_busy[slot] = true; }
-    }
-  }
+  // ---- wgrad: queued for the second stream (issued at once without it)
+  if (c.bn && m->overlap && dy != c.dy_own) { ys_set_error("backward: %s has no dy buffer of its own", c.name.c_str()); return YS_ERR_STATE; }
+  YS_TRY(queue_wgrad(m, c, B, dy, dy_ldc, dy_coff, dy_bstride));
   // ---- dgrad (gather form with flipped/transposed weights)
   if (!c.first) {
     const int mode = grad_mode(m, c.in);
@@ -1949,18 +1946,9 @@ int run_conv_bwd_group(ys_model* m, ConvL* const* cs, int n, int B) {
       YS_TRY(ys_colsum_launch(st, m->dtype, dy[i], dy_ldc[i], dy_coff[i], M, (long)c.Hout * c.Wout, dy_bs[i], c.cout, m->stat_partial, m->grads + c.g_off));
     }
   }
-  // ---- weight gradients: every dy of the stage is complete on `st` here
-  {
-    hipStream_t sw = st;
-    if (m->overlap) {
-      hipEvent_t ev = m->ev_dy[ys_model::DY_RING];
-      YS_CHECK_HIP(hipEventRecord(ev, st));
-      YS_CHECK_HIP(hipStreamWaitEvent(m->st2, ev, 0));
-      sw = m->st2;
-      m->st2_dirty = true;
-    }
-    for (int i = 0; i < n; i++) YS_TRY(launch_wgrad(m, *cs[i], B, dy[i], dy_ldc[i], dy_coff[i], dy_bs[i], sw));
-  }
+  // ---- weight gradients: every dy of the stage is complete on `st` here -- queued, and handed over together
+  for (int i = 0; i < n; i++) YS_TRY(queue_wgrad(m, *cs[i], B, dy[i], dy_ldc[i], dy_coff[i], dy_bs[i]));
+  YS_TRY(flush_wgrads(m, B));
   // ---- input gradients
   ConvArgs a[YS_GROUP_MAX];
   int cap[YS_GROUP_MAX] = {0, 0, 0}, rows[YS_GROUP_MAX] = {0, 0, 0};
@@ -2005,7 +1993,7 @@ static int join_wgrad_stream(ys_model* m) {
 }
 
 // async_end: leave the weight-gradient stream unjoined (its split reduction runs there too) and record the segment's completion events
-int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) {
+int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false, bool seg_events = true) {
   hipStream_t st = m->ctx->stream;
   const int B = m->B;
   YS_TRY(plan_bnred(m, B));
@@ -2057,6 +2045,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) 
   // the segment's gradients are complete only when the weight-gradient stream has drained: the main stream waits for it here, unless the
   // caller asked for an asynchronous end -- then the split reduction below goes to that stream as well, nothing on the main stream waits,
   // and whoever consumes the segment's gradients (the all-reduce) waits on the two events recorded at the end
+  YS_TRY(flush_wgrads(m, B));
   const bool on_st2 = async_end && m->overlap && m->st2_dirty;
   hipStream_t sr = on_st2 ? m->st2 : st;
   if (!on_st2) YS_TRY(join_wgrad_stream(m));
@@ -2076,7 +2065,7 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) 
       YS_TRY(ys_wgrad_reduce_batched_launch(sr, m->red_dev + lo, hi - lo, blk));
     }
   }
-  if (async_end) {
+  if (async_end && seg_events) {
     for (int sgi = seg_lo; sgi <= seg_hi; sgi++) {
       m->seg_on_st2[sgi] = on_st2;
       YS_CHECK_HIP(hipEventRecord(m->ev_seg_m[sgi], st));
@@ -2088,7 +2077,6 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false) 
 }
 
 void reset_grad_state(ys_model* m) {
-  if (m->bnb_atomic) (void)hipMemsetAsync(m->bnb_acc_all, 0, (size_t)m->n_bnb_acc * 8, m->ctx->stream);   // every unit's BN-backward accumulators: one clear per backward
   for (auto& b : m->bufs) std::fill(b.gw.begin(), b.gw.end(), 0);
   for (auto& c : m->convs) c.red_seen = 0;
   if (m->is_block) { std::fill(m->bufs[m->blk_out].gw.begin(), m->bufs[m->blk_out].gw.end(), 1); return; }   // the caller's dy
@@ -2154,7 +2142,6 @@ int ys_model_destroy(ys_model* m) {
   hipStreamSynchronize(m->ctx->stream);
   if (m->st2) {
     hipStreamSynchronize(m->st2);
-    for (int k = 0; k < ys_model::DY_RING; k++) if (m->ev_free[k]) hipEventDestroy(m->ev_free[k]);
     for (int k = 0; k <= ys_model::DY_RING; k++) if (m->ev_dy[k]) hipEventDestroy(m->ev_dy[k]);
     if (m->ev_join) hipEventDestroy(m->ev_join);
     hipStreamDestroy(m->st2);
@@ -2659,6 +2646,15 @@ int ys_model_backward(ys_model* m) {
   YS_CHECK_HIP(hipSetDevice(m->ctx->device));
   YsTimer timer(m->ctx, "backward");
   reset_grad_state(m);
+  // Round 6: the one-call backward ends every segment asynchronously as well -- a segment's split reduction (wgrad_reduce_batched_kernel: 1.08 GB of partial slabs per
+  // YOLOv8n step, 0.21 ms when it runs alone at the end) goes to the weight-gradient stream behind that segment's weight gradients and runs beside the next segment's
+  // BN-backward / dgrad chain; only the last (stem) segment's share is left for the end.  Nothing on the main stream waits: AdamW, zero_grad, gradient reads and the
+  // next forward order themselves behind the second stream (join_wgrad_stream), as they do after ys_model_backward_segment_async.  Same kernels, same operands, same
+  // order per stream: bit-identical gradients (tests/test_dist.py::test_async_segment_ends_give_the_same_gradients compares the two forms).
+  if (m->overlap) {
+    for (int sg = 0; sg < ys_model::NSEG; sg++) YS_TRY(backward_range(m, sg, sg, true, false));
+    return YS_OK;
+  }
   return backward_range(m, 0, ys_model::NSEG - 1);
 }
 

@@ -16,6 +16,7 @@ void ys_set_error(const char* fmt, ...);
 // is loaded, every YS_<KEY>=<number> variable seeds the table (the A/B scripts under tools/ keep working); later changes of the environment are not seen.
 double ys_opt_get(const char* key, double def);
 unsigned ys_opt_version();
+int ys_cu_count();       // compute units of the current device (core.hip)
 #include <atomic>
 #define YS_OPT_F(key, def) ([]() -> double { static std::atomic<unsigned> ver_{0xffffffffu}; static std::atomic<double> val_{0.0}; \
     const unsigned g_ = ys_opt_version(); if (ver_.load(std::memory_order_acquire) != g_) { val_.store(ys_opt_get(key, (double)(def)), std::memory_order_relaxed); ver_.store(g_, std::memory_order_release); } \

@@ -20,8 +20,6 @@ struct BnRedSeg {
   int C;                // producer channel count
   int act;              // producer applies SiLU
   int pad_;
-  unsigned long long* acc;   // round 5: when set, the two sums are ADDED to the producer's exact integer accumulators (ys_gacc_add) instead of written to `part` rows:
-                             // the BN-backward apply pass finalizes from them (ys_bn_bwd_fin_apply_launch) and the unit's chan_finalize launch goes
 };
 struct ConvArgs {
   const void* x;        // input activations (NHWC view)
@@ -168,49 +166,25 @@ int ys_bn_finalize_launch(hipStream_t st, const float* partial, int nblk, int C,
 int ys_bn_eval_coeffs_launch(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
                              const float* run_var, float eps, float* scale, float* shift);
 // Statistics as fixed-point integer sums (round 5).  Scale 2^20: a workgroup's partial sum is quantised to 2^-20 ~ 1e-6 absolute (rounded; <= 768 partials per
-// launch), the 64-bit accumulator holds |sum| up to 2^43 = 8.8e12 -- e.g. 6.5 million pixels (the largest map of the BASELINE configs) at a mean square of 1.3e6.
+// launch), the 64-bit accumulator holds |sum| up to 2^42 = 4.4e12 -- e.g. 6.5 million pixels (the largest map of the BASELINE configs) at a mean square of 6.7e5 (a single
+// workgroup partial is bounded at 2^32, see the poison rule below).
 #define YS_STAT_SHARDS 8          // accumulator copies (workgroup index modulo): ~64 arrivals per cache line and launch instead of ~512
 #define YS_STAT_FIX 1048576.0f
+// A partial that is not finite, or too large for the fixed point (|t| >= 2^32: 768 such partials would pass 2^62), POISONS the channel: bit 62 of its sum-of-squares
+// word is raised (legitimate sums of squares are non-negative and below 2^62, so later adds cannot clear it) and bn_fin_apply_kernel turns the flag into NaN mean /
+// variance -- what the row path and the reference do on divergence (an unguarded fptosi of NaN / Inf is a garbage FINITE integer that would be folded into
+// run_mean / run_var: ADVICE r5).
+#define YS_STAT_POISON (1ull << 62)
 __device__ inline void ys_stat_acc_add(unsigned long long* acc, long stat_row, int C, int c, int which, float t) {
+  unsigned long long* a = acc + (((stat_row & (YS_STAT_SHARDS - 1)) * C + c) * 2);
+  if (!(fabsf(t) < 4294967296.0f)) { atomicOr(a + 1, YS_STAT_POISON); return; }     // NaN fails the comparison too
 #ifdef YS_EMU_BUILD
   const long long q = (long long)llrintf(t * YS_STAT_FIX);
 #else
   const long long q = __float2ll_rn(t * YS_STAT_FIX);
 #endif
-  if (q != 0) atomicAdd(acc + (((stat_row & (YS_STAT_SHARDS - 1)) * C + c) * 2 + which), (unsigned long long)q);
+  if (q != 0) atomicAdd(a + which, (unsigned long long)q);
 }
-// ---- BN-BACKWARD sums as exact integer accumulators (round 5).  Gradient sums span far more decades than the forward statistics (a loss-scale x batch x depth
-// product), so one fixed point cannot hold them.  A float partial t = m 2^e (24-bit m) is added -- EXACTLY, as the integer t / 2^(lo - 24) -- to the one of FOUR
-// 64-bit accumulators whose 26-binade window [lo, lo + 26), lo = -64 + 26 level, holds e: below 2^50 per partial, i.e. 2^12 partials of headroom per shard.
-// Integer addition commutes: the total is the exact sum of the partials, whatever the order the workgroups arrive in = run-to-run deterministic, and more
-// accurate than the double-precision row sum it replaces.  |t| < 2^-64 contributes nothing; |t| >= 2^40 keeps adding into level 3 (exact up to 2^62 / count);
-// a non-finite partial raises the fifth word, which the finalize turns into NaN.  Layout [YS_GACC_SHARDS][C][2][YS_GACC_WORDS].
-#define YS_GACC_SHARDS 2
-#define YS_GACC_WORDS 5
-__device__ inline void ys_gacc_add(unsigned long long* acc, long row, int C, int c, int which, float t) {
-  const unsigned bits = ys_f2u(t);
-  const int e = (int)((bits >> 23) & 255u) - 127;
-  unsigned long long* a = acc + ((((row & (YS_GACC_SHARDS - 1)) * C + c) * 2 + which) * (long)YS_GACC_WORDS);
-  if (e > 60) { atomicAdd(a + 4, 1ull); return; }              // inf / NaN (e = 128) or beyond any gradient: poison
-  if (e < -64) return;
-  const int lv = e < -38 ? 0 : (e < -12 ? 1 : (e < 14 ? 2 : 3));
-  const double sc = lv == 0 ? 0x1p88 : (lv == 1 ? 0x1p62 : (lv == 2 ? 0x1p36 : 0x1p10));   // 2^(24 - lo)
-  const long long q = (long long)((double)t * sc);             // exact: an integer below 2^50 (level 3 beyond its window: below 2^61)
-  atomicAdd(a + lv, (unsigned long long)q);
-}
-__host__ __device__ inline double ys_gacc_value(const unsigned long long* a) {      // one shard's five words -> double
-  if (a[4]) return __builtin_nan("");
-  return (double)(long long)a[0] * 0x1p-88 + (double)(long long)a[1] * 0x1p-62 + (double)(long long)a[2] * 0x1p-36 + (double)(long long)a[3] * 0x1p-10;
-}
-// BN backward of one unit with the finalize inside: dgamma / dbeta (+=), then dy = scale du - k2 - y k3 with k2 / k3 computed per workgroup from the accumulators
-struct BnBwdFin {
-  const unsigned long long* acc;   // [YS_GACC_SHARDS][C][2][YS_GACC_WORDS]
-  double count;
-  float* dgamma; float* dbeta;     // += (workgroup 0)
-  const float* scale; const float* shift; const float* mean; const float* rstd;
-};
-int ys_bn_bwd_fin_apply_launch(hipStream_t st, int dtype, const void* dz, int dz_ldc, int dz_coff, const void* y, long rows, int C, const BnBwdFin& f, int act,
-                               void* dy, void* rg = nullptr, int rg_ldc = 0, int rg_coff = 0);
 // finalize-inside-apply operands: the accumulators of one BatchNorm unit + what bn_finalize_kernel reads and writes
 struct BnAccFin {
   const unsigned long long* acc;   // [YS_STAT_SHARDS][C][2]
