@@ -296,6 +296,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0     # the host has ENQUEUED every step (diagnostic: a value close to `elapsed` means the GPU waits for the host)
     barrier()
     elapsed = time.perf_counter() - t0
     rccl_ranks = 1
@@ -399,7 +400,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{gname} {args.task} train step (fwd+loss+bwd+AdamW), {B}x3x{H}x{W} per GPU, {'COCO-80' if nc == 80 else str(nc) + '-class'} synthetic labels" + {"segment": " + instance masks", "obb": " (oriented)", "pose": " + 17x3 keypoints"}.get(args.task, ""),
                           "global_batch": B * world, "parallelism": f"dp{world}"},
-               "loss_items": [round(float(v), 5) for v in items], "roofline": roofline}
+               "loss_items": [round(float(v), 5) for v in items], "roofline": roofline,
+               "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3)}
         if dist_info is not None:
             out["dist"] = dist_info
         if args.lib:

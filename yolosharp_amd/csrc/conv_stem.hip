@@ -54,9 +54,40 @@ __device__ inline void stem_patch_fetch(const float* __restrict__ x, int b, int 
   }
 }
 
+// Round 6: the same patch as 16-byte vectors.  A patch row is input columns ix0 .. ix0 + 64 with ix0 = 2 ox0 - 1: the left halo column, then 64 columns that start
+// at a multiple of 64 -- sixteen aligned float4 when W % 4 == 0.  816 vectors + 51 halo scalars per tile instead of 3315 scalars: the element form spent ~35 integer
+// instructions per 4-byte load (two divisions by constants, bounds, 64-bit address) and ~15 per 2-byte LDS store, 13 of each per thread and tile -- both kernels
+// were instruction-bound at 2.2-2.5 TB/s (8 workgroups per CU already cover the latency).  Vector u = tid + 256 k: row u / 16 = (c, r), columns 1 + 4 (u % 16) .. + 3.
+#define STEM_NVEC (3 * STEM_PH * 16)            // 816
+#define STEM_NVL ((STEM_NVEC + STEM_THREADS - 1) / STEM_THREADS)   // 4 per thread (the last round partial)
+struct StemPatchV { float4 v[STEM_NVL]; float h; };
+__device__ inline void stem_patch_fetch_v(const float* __restrict__ x, int b, int iy0, int ix0, int H, int W, StemPatchV& p) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < STEM_NVL; k++) {
+    const int u = tid + STEM_THREADS * k;
+    const int row = u >> 4, j = u & 15;
+    const int c = row / STEM_PH, r = row - c * STEM_PH;
+    const int iy = iy0 + r, ix = ix0 + 1 + 4 * j;
+    const bool ok = (bool)((int)(u < STEM_NVEC) & (int)((unsigned)iy < (unsigned)H) & (int)(ix + 3 < W));
+    const long off = ok ? (((long)b * 3 + c) * H + iy) * (long)W + ix : 0;
+    const float4 f = *(const float4*)(x + off);
+    p.v[k] = ok ? f : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    const int row = tid < 3 * STEM_PH ? tid : 0;
+    const int c = row / STEM_PH, r = row - c * STEM_PH;
+    const int iy = iy0 + r;
+    const bool ok = (bool)((int)(tid < 3 * STEM_PH) & (int)((unsigned)iy < (unsigned)H) & (int)(ix0 >= 0));
+    const long off = ok ? (((long)b * 3 + c) * H + iy) * (long)W + ix0 : 0;
+    const float f = x[off];
+    p.h = ok ? f : 0.f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ forward
 // LDS patch: planar bf16 [3][17][66].  Lane (li, q) of a pixel fragment supplies K values k = 8q .. 8q+7 of pixel li, k = tap * 3 + c.
-template <int NR, int EVAL>
+template <int NR, int EVAL, int VEC>
 __global__ void __launch_bounds__(STEM_THREADS)
 stem_fwd_kernel(StemFwdArgs a) {
   constexpr int PWP = STEM_PW + 1;
@@ -113,16 +144,34 @@ stem_fwd_kernel(StemFwdArgs a) {
     const int tx = tile % a.tiles_x, trem = tile / a.tiles_x;
     const int ty = trem % a.tiles_y, b = trem / a.tiles_y;
     const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
-    float v[STEM_NLD];
-    stem_patch_fetch(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, v);
-    __syncthreads();                          // the previous tile's fragments are read
+    if (VEC) {
+      StemPatchV pv;
+      stem_patch_fetch_v(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, pv);
+      __syncthreads();                        // the previous tile's fragments are read
 #pragma unroll
-    for (int k = 0; k < STEM_NLD; k++) {
-      const int e = tid + STEM_THREADS * k;
-      if (e < STEM_NPATCH) {
-        const int c = e / (STEM_PH * STEM_PW), rem = e - c * (STEM_PH * STEM_PW);
-        const int r = rem / STEM_PW, col = rem - r * STEM_PW;
-        sP[(c * STEM_PH + r) * PWP + col] = Elem<bf16_t>::from_f(v[k]).v;
+      for (int k = 0; k < STEM_NVL; k++) {
+        const int u = tid + STEM_THREADS * k;
+        if (u < STEM_NVEC) {
+          unsigned short* d = sP + (u >> 4) * PWP + 1 + 4 * (u & 15);      // odd element: 2-byte, 4-byte (PWP is even), 2-byte stores
+          const unsigned lo = ys_pack_bf16x2(pv.v[k].x, pv.v[k].y), hi = ys_pack_bf16x2(pv.v[k].z, pv.v[k].w);
+          d[0] = (unsigned short)(lo & 0xffffu);
+          *(unsigned*)(d + 1) = (lo >> 16) | (hi << 16);
+          d[3] = (unsigned short)(hi >> 16);
+        }
+      }
+      if (tid < 3 * STEM_PH) sP[tid * PWP] = Elem<bf16_t>::from_f(pv.h).v;
+    } else {
+      float v[STEM_NLD];
+      stem_patch_fetch(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, v);
+      __syncthreads();                        // the previous tile's fragments are read
+#pragma unroll
+      for (int k = 0; k < STEM_NLD; k++) {
+        const int e = tid + STEM_THREADS * k;
+        if (e < STEM_NPATCH) {
+          const int c = e / (STEM_PH * STEM_PW), rem = e - c * (STEM_PH * STEM_PW);
+          const int r = rem / STEM_PW, col = rem - r * STEM_PW;
+          sP[(c * STEM_PH + r) * PWP + col] = Elem<bf16_t>::from_f(v[k]).v;
+        }
       }
     }
     __syncthreads();
@@ -214,7 +263,11 @@ int ys_stem_fwd_launch(hipStream_t st, const float* x, int B, int H, int W, cons
   char lab[160] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "stem k33 s2 div1 cin3 cout%d M%ld acc0 tile%dx%d grid%dx1", Cout, (long)B * a.Hout * a.Wout, STEM_TH, STEM_TW, grid);
   YsKprofScope prof(st, "conv_igemm", lab);
-#define STEM_F(N_) if (nr == N_) { if (eval) YS_LAUNCH((stem_fwd_kernel<N_, 1>), grid, STEM_THREADS, st, a); else YS_LAUNCH((stem_fwd_kernel<N_, 0>), grid, STEM_THREADS, st, a); return YS_OK; }
+  const bool vec = (W & 3) == 0 && ((size_t)x & 15) == 0;       // aligned float4 rows (every BASELINE shape: W is a multiple of 32)
+#define STEM_F(N_) if (nr == N_) { \
+    if (eval) { if (vec) YS_LAUNCH((stem_fwd_kernel<N_, 1, 1>), grid, STEM_THREADS, st, a); else YS_LAUNCH((stem_fwd_kernel<N_, 1, 0>), grid, STEM_THREADS, st, a); } \
+    else { if (vec) YS_LAUNCH((stem_fwd_kernel<N_, 0, 1>), grid, STEM_THREADS, st, a); else YS_LAUNCH((stem_fwd_kernel<N_, 0, 0>), grid, STEM_THREADS, st, a); } \
+    return YS_OK; }
   STEM_F(1) STEM_F(2) STEM_F(3) STEM_F(4) STEM_F(5)
 #undef STEM_F
   ys_set_error("stem conv: %d output channels", Cout);
@@ -239,7 +292,7 @@ struct StemWgArgs {
   int tiles_x, tiles_y, ntiles;
 };
 
-template <int NR>
+template <int NR, int VEC>
 __global__ void __launch_bounds__(STEM_THREADS)
 stem_wgrad_kernel(StemWgArgs a) {
   constexpr int PL = 40;                                // plane row pitch (entries): a multiple of 8 -> aligned 16-byte reads
@@ -274,8 +327,10 @@ stem_wgrad_kernel(StemWgArgs a) {
     const int tx = tile % a.tiles_x, trem = tile / a.tiles_x;
     const int ty = trem % a.tiles_y, b = trem / a.tiles_y;
     const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
-    float v[STEM_NLD];
-    stem_patch_fetch(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, v);
+    float v[STEM_NLD];                        // (the form not taken is dead code: VEC is a template parameter)
+    StemPatchV pv;
+    if (VEC) stem_patch_fetch_v(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, pv);
+    else stem_patch_fetch(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, v);
     // dy rows of the tile: 256 pixels x NR*16 channels, 16-byte units (8 channels), zero outside the image
     constexpr int DU = STEM_TH * STEM_TW * NR * 2;      // 16-byte units of the tile
     constexpr int NDU = (DU + STEM_THREADS - 1) / STEM_THREADS;
@@ -292,16 +347,34 @@ stem_wgrad_kernel(StemWgArgs a) {
       dv[k] = ok ? t : ys_zero16();
     }
     __syncthreads();                          // the previous tile's fragments are read
+    if (VEC) {
+      // vector u holds patch columns 1 + 4j .. 4 + 4j of row u / 16: the odd ones (1 + 4j, 3 + 4j) are entries 2j, 2j + 1 of the odd plane, the even ones
+      // (2 + 4j, 4 + 4j) entries 2j + 1, 2j + 2 of the even plane and 2j, 2j + 1 of its shifted copy
 #pragma unroll
-    for (int k = 0; k < STEM_NLD; k++) {
-      const int e = tid + STEM_THREADS * k;
-      if (e < STEM_NPATCH) {
-        const int c = e / (STEM_PH * STEM_PW), rem = e - c * (STEM_PH * STEM_PW);
-        const int r = rem / STEM_PW, col = rem - r * STEM_PW;
-        const unsigned short h = Elem<bf16_t>::from_f(v[k]).v;
-        const int row = (c * STEM_PH + r) * PL;
-        if (col & 1) sO[row + (col >> 1)] = h;
-        else { sE[row + (col >> 1)] = h; if (col >= 2) sE1[row + (col >> 1) - 1] = h; }
+      for (int k = 0; k < STEM_NVL; k++) {
+        const int u = tid + STEM_THREADS * k;
+        if (u < STEM_NVEC) {
+          const int row = (u >> 4) * PL, j2 = 2 * (u & 15);
+          const unsigned od = ys_pack_bf16x2(pv.v[k].x, pv.v[k].z), ev = ys_pack_bf16x2(pv.v[k].y, pv.v[k].w);
+          *(unsigned*)(sO + row + j2) = od;
+          *(unsigned*)(sE1 + row + j2) = ev;
+          sE[row + j2 + 1] = (unsigned short)(ev & 0xffffu);
+          sE[row + j2 + 2] = (unsigned short)(ev >> 16);
+        }
+      }
+      if (tid < 3 * STEM_PH) sE[tid * PL] = Elem<bf16_t>::from_f(pv.h).v;      // patch column 0 (the left halo): entry 0 of the even plane
+    } else {
+#pragma unroll
+      for (int k = 0; k < STEM_NLD; k++) {
+        const int e = tid + STEM_THREADS * k;
+        if (e < STEM_NPATCH) {
+          const int c = e / (STEM_PH * STEM_PW), rem = e - c * (STEM_PH * STEM_PW);
+          const int r = rem / STEM_PW, col = rem - r * STEM_PW;
+          const unsigned short h = Elem<bf16_t>::from_f(v[k]).v;
+          const int row = (c * STEM_PH + r) * PL;
+          if (col & 1) sO[row + (col >> 1)] = h;
+          else { sE[row + (col >> 1)] = h; if (col >= 2) sE1[row + (col >> 1) - 1] = h; }
+        }
       }
     }
 #pragma unroll
@@ -380,7 +453,8 @@ int ys_stem_wgrad_launch(hipStream_t st, const float* x, int B, int H, int W, co
   char lab[160] = "";
   if (ys_kprof_enabled()) snprintf(lab, sizeof(lab), "wstem k3 s2 cin3 cout%d M%ld tile%dx%d grid%dx1", Cout, (long)B * a.Hout * a.Wout, STEM_TH, STEM_TW, grid);
   YsKprofScope prof(st, "conv_wgrad", lab);
-#define STEM_W(N_) if (nr == N_) { YS_LAUNCH((stem_wgrad_kernel<N_>), grid, STEM_THREADS, st, a); return YS_OK; }
+  const bool vec = (W & 3) == 0 && ((size_t)x & 15) == 0;
+#define STEM_W(N_) if (nr == N_) { if (vec) YS_LAUNCH((stem_wgrad_kernel<N_, 1>), grid, STEM_THREADS, st, a); else YS_LAUNCH((stem_wgrad_kernel<N_, 0>), grid, STEM_THREADS, st, a); return YS_OK; }
   STEM_W(1) STEM_W(2) STEM_W(3) STEM_W(4) STEM_W(5)
 #undef STEM_W
   ys_set_error("stem wgrad: %d output channels", Cout);
