@@ -140,13 +140,18 @@ stem_fwd_kernel(StemFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { st1[nf][r] = 0.f; st2[nf][r] = 0.f; }
 
+  // VEC: the NEXT tile's patch is requested as soon as the current one sits in LDS, so every workgroup has 13 KB in flight all the time (round 6: without it a
+  // workgroup's loads were only outstanding during ~40 % of its tile period -- 8 workgroups x 13 KB x 0.4 per CU is half of what 5 TB/s needs at ~3 us latency)
+  StemPatchV pv;
+  if (VEC && (int)blockIdx.x < a.ntiles) {
+    const int t0 = blockIdx.x, tx = t0 % a.tiles_x, trem = t0 / a.tiles_x;
+    stem_patch_fetch_v(a.x, trem / a.tiles_y, 2 * (trem % a.tiles_y) * STEM_TH - 1, 2 * tx * STEM_TW - 1, a.H, a.W, pv);
+  }
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int tx = tile % a.tiles_x, trem = tile / a.tiles_x;
     const int ty = trem % a.tiles_y, b = trem / a.tiles_y;
     const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
     if (VEC) {
-      StemPatchV pv;
-      stem_patch_fetch_v(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, pv);
       __syncthreads();                        // the previous tile's fragments are read
 #pragma unroll
       for (int k = 0; k < STEM_NVL; k++) {
@@ -160,6 +165,11 @@ stem_fwd_kernel(StemFwdArgs a) {
         }
       }
       if (tid < 3 * STEM_PH) sP[tid * PWP] = Elem<bf16_t>::from_f(pv.h).v;
+      const int nt = tile + gridDim.x;
+      if (nt < a.ntiles) {
+        const int ntx = nt % a.tiles_x, ntrem = nt / a.tiles_x;
+        stem_patch_fetch_v(a.x, ntrem / a.tiles_y, 2 * (ntrem % a.tiles_y) * STEM_TH - 1, 2 * ntx * STEM_TW - 1, a.H, a.W, pv);
+      }
     } else {
       float v[STEM_NLD];
       stem_patch_fetch(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, v);
@@ -323,18 +333,18 @@ stem_wgrad_kernel(StemWgArgs a) {
 #pragma unroll
   for (int nf = 0; nf < NR; nf++) { acc[nf][0] = f32x4_zero(); acc[nf][1] = f32x4_zero(); }
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int tx = tile % a.tiles_x, trem = tile / a.tiles_x;
+  // dy rows of a tile: 256 pixels x NR*16 channels, 16-byte units (8 channels), zero outside the image
+  constexpr int DU = STEM_TH * STEM_TW * NR * 2;      // 16-byte units of the tile
+  constexpr int NDU = (DU + STEM_THREADS - 1) / STEM_THREADS;
+  float v[STEM_NLD];                          // (the form not taken is dead code: VEC is a template parameter)
+  StemPatchV pv;
+  uint4 dv[NDU];
+  auto fetch_tile = [&](int t) {              // everything tile t needs from memory, all loads back to back
+    const int tx = t % a.tiles_x, trem = t / a.tiles_x;
     const int ty = trem % a.tiles_y, b = trem / a.tiles_y;
     const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
-    float v[STEM_NLD];                        // (the form not taken is dead code: VEC is a template parameter)
-    StemPatchV pv;
     if (VEC) stem_patch_fetch_v(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, pv);
     else stem_patch_fetch(a.x, b, 2 * oy0 - 1, 2 * ox0 - 1, a.H, a.W, v);
-    // dy rows of the tile: 256 pixels x NR*16 channels, 16-byte units (8 channels), zero outside the image
-    constexpr int DU = STEM_TH * STEM_TW * NR * 2;      // 16-byte units of the tile
-    constexpr int NDU = (DU + STEM_THREADS - 1) / STEM_THREADS;
-    uint4 dv[NDU];
 #pragma unroll
     for (int k = 0; k < NDU; k++) {
       const int u = tid + STEM_THREADS * k;
@@ -343,9 +353,13 @@ stem_wgrad_kernel(StemWgArgs a) {
       const int oy = oy0 + oyl, ox = ox0 + oxl;
       const bool ok = (bool)((int)(u < DU) & (int)(oy < a.Hout) & (int)(ox < a.Wout) & (int)(cu * 8 < a.Cout));
       const long off = ok ? (((long)b * a.dy_bstride + (long)oy * a.Wout + ox) * a.dy_ldc + a.dy_coff + cu * 8) : 0;
-      const uint4 t = *(const uint4*)(a.dy + off);
-      dv[k] = ok ? t : ys_zero16();
+      const uint4 t4 = *(const uint4*)(a.dy + off);
+      dv[k] = ok ? t4 : ys_zero16();
     }
+  };
+  // the NEXT tile's operands are requested as soon as the current ones sit in LDS (round 6, as in stem_fwd_kernel)
+  if ((int)blockIdx.x < a.ntiles) fetch_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();                          // the previous tile's fragments are read
     if (VEC) {
       // vector u holds patch columns 1 + 4j .. 4 + 4j of row u / 16: the odd ones (1 + 4j, 3 + 4j) are entries 2j, 2j + 1 of the odd plane, the even ones
@@ -386,6 +400,7 @@ stem_wgrad_kernel(StemWgArgs a) {
         d[0] = dv[k].x; d[1] = dv[k].y; d[2] = dv[k].z; d[3] = dv[k].w;
       }
     }
+    if (tile + (int)gridDim.x < a.ntiles) fetch_tile(tile + gridDim.x);
     __syncthreads();
     // wave w: output rows 2w, 2w + 1 of the tile; one K = 32 step per row
 #pragma unroll

@@ -448,7 +448,7 @@ static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   const int per_cu_max = k3 ? (p.mra * p.nrb <= YS_WG_TWO_MAX ? 2 : 1) : 4;   // 9-wave workgroups are register-limited to 1-2 per CU (launch bounds of conv_wgrad_tr_kernel)
   if (per_cu > per_cu_max) per_cu = per_cu_max;
   if (per_cu < 1) per_cu = 1;
-  long gx = ((long)ys_cu_count() * per_cu * YS_OPT_INT("WG_GRID_X10", 10) / 10) / gy;   // (round 6 experiment: > 10 = more, shorter-lived workgroups than resident slots)   (round 5: half / quarter grids -- fewer partial slabs for the split reduction -- measured 8.69 -> 8.73 / 10.01 ms on config 2)
+  long gx = ((long)ys_cu_count() * per_cu) / gy;          // (round 6: 1.5x / 2x / 3x the resident slots -- shorter-lived workgroups, so that the main stream's kernels find free slots sooner -- measured 8.78 -> 8.89 / 8.99 / 9.27 ms on config 2)   (round 5: half / quarter grids -- fewer partial slabs for the split reduction -- measured 8.69 -> 8.73 / 10.01 ms on config 2)
   gx = gx / 8 * 8;                                       // same-x workgroups (same pixels, other channel tiles) share an XCD
   if (gx < 8) gx = 8;
   const long wsmax = (48L << 20) / ((long)a.Cout * a.KH * a.KW * a.Cin * 4);   // bound the partial workspace to 48 MB per layer
