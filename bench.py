@@ -135,18 +135,41 @@ def spawn_ranks(n, argv, probe=False):
     return subprocess.call(cmd, env=env)
 
 
-def spawn_probe():
+def spawn_probe(backend="torch", expect=0):
     """CPU self-test of the --gpus N launch path (tests/test_dist.py): every rank joins a gloo group, a SUM all-reduce of ones counts
-    the ranks, rank 0 prints one JSON line.  No GPU, no engine."""
+    the ranks, rank 0 prints one JSON line.  No GPU, no engine.  --dist-backend c takes the control-plane steps of the C-ABI path as well:
+    rank 0 makes the (here: stand-in) RCCL unique id, broadcast_object_list ships it, every rank checks it received the 128 bytes
+    ys_dist_init expects.  The line is checked like the real one: a rank count that differs from --gpus is a non-zero exit."""
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo")
     t = torch.ones(1)
     dist.all_reduce(t)
+    uid_ok = None
+    if backend == "c":
+        uid = [bytes(range(128)) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ok = torch.tensor([1.0 if (isinstance(uid[0], bytes) and len(uid[0]) == 128 and uid[0] == bytes(range(128))) else 0.0])
+        dist.all_reduce(ok)
+        uid_ok = int(ok.item()) == dist.get_world_size()
+    ranks = int(t.item())
     if dist.get_rank() == 0:
-        print(json.dumps({"probe": True, "n_gpus": dist.get_world_size(), "rccl_ranks": int(t.item()), "spawned": os.environ.get("YS_BENCH_SPAWNED") == "1"}), flush=True)
+        line = {"probe": True, "n_gpus": dist.get_world_size(), "rccl_ranks": ranks, "spawned": os.environ.get("YS_BENCH_SPAWNED") == "1"}
+        if backend == "c":
+            line["dist_backend"] = "c"; line["uid_broadcast_ok"] = uid_ok
+        print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    check_rank_count(ranks, expect or ranks)
+    if uid_ok is False:
+        raise SystemExit("bench.py: the unique-id broadcast of the C-ABI path did not reach every rank")
+
+
+def check_rank_count(ranks, n_gpus):
+    """A multi-rank line is only a line of record when as many ranks took part in the collective as --gpus promised (round-5 verdict item 9)."""
+    if ranks != n_gpus:
+        sys.stderr.write(f"bench.py: {ranks} rank(s) took part in the all-reduce but --gpus says {n_gpus}: not a {n_gpus}-GPU measurement\n")
+        raise SystemExit(3)
 
 
 def main():
@@ -178,7 +201,7 @@ def main():
         # no launcher around us: the bench contract is `bench.py --gpus N`, so start the N ranks here (one process per GPU)
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], probe=args.spawn_probe))
     if args.spawn_probe:
-        return spawn_probe()
+        return spawn_probe(args.dist_backend, args.gpus)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -468,6 +491,7 @@ def main():
         if c_dist:
             eng.dist_destroy()
         dist.destroy_process_group()
+        check_rank_count(rccl_ranks, args.gpus)     # every rank: the line above stays readable, the exit status says it is not an N-GPU measurement
 
 
 if __name__ == "__main__":

@@ -367,6 +367,25 @@ def test_bench_gpus_n_spawns_n_ranks():
     assert out == {"probe": True, "n_gpus": 2, "rccl_ranks": 2, "spawned": True}
 
 
+def test_bench_gpus_n_c_backend_probe_and_rank_count_check():
+    """Round-5 verdict item 9: the C-ABI transport's launch path (`--dist-backend c`: gloo rendezvous, rank 0's unique id shipped with broadcast_object_list) through
+    the same re-exec as the torch backend, and the rank-count check of the multi-rank line -- a launcher that started fewer ranks than --gpus promises is a
+    non-zero exit with a message, not a line of record."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "c", "--spawn-probe"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == {"probe": True, "n_gpus": 2, "rccl_ranks": 2, "spawned": True, "dist_backend": "c", "uid_broadcast_ok": True}
+    # two ranks started by a launcher, --gpus 4 on the command line: the probe (like the real line) must exit non-zero
+    from bench import _free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dist-backend", "c", "--spawn-probe"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not a 4-GPU measurement" in (r.stderr + r.stdout), (r.returncode, r.stderr[-1500:])
+
+
 def test_bench_gpus_n_refuses_without_devices():
     """Without N visible GPUs the N-rank launch must refuse loudly instead of printing a one-rank number (no GPU in the dev container)."""
     import subprocess

@@ -13,11 +13,11 @@ namespace {
 // THE registered keys (round 6: an unknown key is an error in ys_set_option and ignored -- with the rest of the unrelated YS_* environment -- when the table is seeded).
 // Read at MODEL CREATION (a later change does not re-plan an existing model): BN_ATOMIC, BNRED, HEAD_FUSE, GROUP (head grouping), OVERLAP, STEM_DIRECT.
 // Read at every convolution PLAN (i.e. per launch, through the cached YS_OPT_INT sites): the routing gates GEMM_MIN_M, GEMM_MIN_CIN, GEMM_HALO, HALO_MIN_FILL, HALO_MR4,
-// HALO_MAX_GRID, WGEMM_MIN_M, WGEMM_KT, F8_MIN_CIN, F8_MIN_TAPS, GROUP (grouped launches), ATTN_MFMA; at every backward: WG_BATCH, WG_BATCH_MB (hand-over batches).  DBG / GEMM_DBG exist in the ablation builds only.
+// HALO_MAX_GRID, WGEMM_MIN_M, WGEMM_KT, F8_MIN_CIN, F8_MIN_TAPS, GROUP (grouped launches), ATTN_MFMA.  DBG / GEMM_DBG exist in the ablation builds only.
 // The table is process-wide: a host that flips a gate from one thread while another thread's model is between its plan-only dry run and the launch re-routes that launch;
 // set options before creating models, or from the thread that drives them.
 const char* const kOptKeys[] = {"ATTN_MFMA", "BNRED", "BNRED_LOG", "BN_ATOMIC", "F8_MIN_CIN", "F8_MIN_TAPS", "GEMM_HALO", "GEMM_MIN_CIN", "GEMM_MIN_M", "GROUP", "HALO_MAX_GRID",
-                                "HALO_MIN_FILL", "HALO_MR4", "HEAD_FUSE", "OVERLAP", "STEM_DIRECT", "WGEMM_KT", "WGEMM_MIN_M", "WG_BATCH", "WG_BATCH_MB", "DBG", "GEMM_DBG"};
+                                "HALO_MIN_FILL", "HALO_MR4", "HEAD_FUSE", "OVERLAP", "STEM_DIRECT", "WGEMM_KT", "WGEMM_MIN_M", "DBG", "GEMM_DBG"};
 bool opt_known(const std::string& k) {
   for (const char* n : kOptKeys) if (k == n) return true;
   return false;

@@ -146,10 +146,51 @@ __device__ inline AnchorInfo anchor_of(const LossArgs& a, int idx) {
   return r;
 }
 
-// ------------------------------------------------------------------ K0: GT padding (Loss.cs:363-390,431)
-__global__ void __launch_bounds__(LS_THREADS)
-loss_prep_kernel(LossArgs a, int* gt_valid) {
+// ---- round 6: the criterion's four global sums as fixed-point integer accumulators (the scheme of the BatchNorm statistics, ys_kernels.h ys_stat_acc_add).
+// Rounds 1-5: every producer wrote one partial row per workgroup and a one-workgroup loss_sum_kernel launch added them -- three 7 us launches (+ boundaries) on the
+// step's critical path between forward and backward.  Now a workgroup adds its partial -- rounded to 2^-30 (target-score sum: |partial| <= 256) or 2^-20 (loss sums:
+// |partial| < 2^42) -- with ONE 64-bit integer atomic; integer addition commutes, so the totals are bit-reproducible whatever the arrival order, and the
+// consumers (loss_cls / loss_box: tss; loss_items: all of them) read the words directly.  Words live behind the float scalars: (u64*)(scalars + 16) [0] tss, [1] cls,
+// [2] iou, [3] dfl, [4] angle, [5] poison (a non-finite or out-of-range partial: the items become NaN, as the reference's do on divergence).
+#define LOSS_ACC(a) ((unsigned long long*)((a).scalars + 16))
+#define LOSS_FIX_T 1073741824.0f      // 2^30
+#define LOSS_FIX_L 1048576.0f         // 2^20
+__device__ inline void loss_acc_add(unsigned long long* acc, int word, float t, float fix) {
+  if (!(fabsf(t) * fix < 9.0e18f)) { atomicOr(acc + 5, 1ull); return; }       // NaN fails the comparison too
+#ifdef YS_EMU_BUILD
+  const long long q = (long long)llrintf(t * fix);
+#else
+  const long long q = __float2ll_rn(t * fix);
+#endif
+  if (q != 0) atomicAdd(acc + word, (unsigned long long)q);
+}
+__device__ inline float loss_acc_get(const unsigned long long* acc, int word, float fix) {
+  if (acc[5]) return __builtin_nanf("");
+  return (float)((double)(long long)acc[word] * (1.0 / (double)fix));
+}
+__device__ inline float loss_tss(const LossArgs& a) {        // target_scores_sum = max(sum, 1) (Loss.cs:444)
+  const float t = loss_acc_get(LOSS_ACC(a), 0, LOSS_FIX_T);
+  return t > 1.0f ? t : (t != t ? t : 1.0f);
+}
+// workgroup sum of up to four values -> lane 0 of wave 0 (fixed order: wave butterflies, then the waves in index order)
+__device__ inline void block_sum4(float& v0, float& v1, float& v2, float& v3) {
+  __shared__ float s[LS_THREADS / 64][4];
+  v0 = ys_wave_sum(v0); v1 = ys_wave_sum(v1); v2 = ys_wave_sum(v2); v3 = ys_wave_sum(v3);
   const int tid = threadIdx.x;
+  if ((tid & 63) == 0) { s[tid >> 6][0] = v0; s[tid >> 6][1] = v1; s[tid >> 6][2] = v2; s[tid >> 6][3] = v3; }
+  __syncthreads();
+  if (tid == 0) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < LS_THREADS / 64; w++) for (int k = 0; k < 4; k++) t[k] += s[w][k];
+    v0 = t[0]; v1 = t[1]; v2 = t[2]; v3 = t[3];
+  }
+}
+
+// ------------------------------------------------------------------ K0: GT padding (Loss.cs:363-390,431)
+// (round 6: runs as the FIRST workgroup of the bbox_decode launch -- the two are independent -- instead of a one-workgroup launch of its own)
+__device__ inline void loss_prep_body(const LossArgs& a, int* gt_valid) {
+  const int tid = threadIdx.x;
+  if (tid < 6) LOSS_ACC(a)[tid] = 0ull;
   for (int i = tid; i < a.B; i += LS_THREADS) a.gt_count[i] = 0;
   for (int i = tid; i < a.B * a.gcap; i += LS_THREADS) { a.pos_align[i] = 0u; a.pos_ov[i] = 0u; }
   if (tid < 8) a.scalars[tid] = 0.f;
@@ -213,9 +254,10 @@ loss_prep_kernel(LossArgs a, int* gt_valid) {
 // four consecutive lanes own one anchor (one side each): 32-byte contiguous logit reads instead of a 128-byte stride per lane
 template <class T, int RR>     // RR = reg_max when it is 16 (row of 16 bins as 16-byte vector loads, unrolled), 0 = run-time
 __global__ void __launch_bounds__(LS_THREADS)
-loss_decode_kernel(LossArgs a) {
+loss_decode_kernel(LossArgs a, int* gt_valid) {
+  if (blockIdx.x == 0) { loss_prep_body(a, gt_valid); return; }     // workgroup-uniform; dispatched first: its O(labels^2) rank loop is the longest workgroup of the launch
   constexpr int EPL = Elem<T>::EPL;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.A * 4;
   const bool inb = i < total;
   const long row = inb ? i >> 2 : 0;
@@ -542,21 +584,8 @@ tal_resolve_kernel(LossArgs a) {
 }
 
 // ------------------------------------------------------------------ K4: normalised target scores (Tal.cs:86-87)
-__device__ inline void block_partial4(float v0, float v1, float v2, float v3, float* out) {
-  __shared__ float s[LS_THREADS / 64][4];
-  v0 = ys_wave_sum(v0); v1 = ys_wave_sum(v1); v2 = ys_wave_sum(v2); v3 = ys_wave_sum(v3);
-  const int tid = threadIdx.x;
-  if ((tid & 63) == 0) { s[tid >> 6][0] = v0; s[tid >> 6][1] = v1; s[tid >> 6][2] = v2; s[tid >> 6][3] = v3; }
-  __syncthreads();
-  if (tid == 0) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int w = 0; w < LS_THREADS / 64; w++) for (int k = 0; k < 4; k++) t[k] += s[w][k];
-    for (int k = 0; k < 4; k++) out[k] = t[k];
-  }
-}
-
 __global__ void __launch_bounds__(LS_THREADS)
-tal_targets_kernel(LossArgs a, float* partial) {
+tal_targets_kernel(LossArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float nrm = 0.f;
   if (i < (long)a.B * a.A) {
@@ -569,48 +598,15 @@ tal_targets_kernel(LossArgs a, float* partial) {
     }
     a.tnorm[i] = nrm;
   }
-  block_partial4(nrm, 0.f, 0.f, 0.f, partial + (long)blockIdx.x * 4);
-}
-
-// sums partial[nblk][4] column-wise (fixed order); mode 0: tss = max(sum0, 1) -> scalars[0]
-//                                                   mode 1: adds columns 1..3 into scalars[5..7]
-__global__ void __launch_bounds__(LS_THREADS)
-loss_sum_kernel(const float* __restrict__ partial, int nblk, float* scalars, int mode) {
-  // one pass over the [nblk][4] partial rows (16-byte loads, four independent rows in flight per thread), double accumulators,
-  // wave shuffles and a fixed-order combine of the wave totals -- deterministic
-  __shared__ double sbuf[LS_THREADS / 64][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-  const float4* rows = (const float4*)partial;
-  int k = tid;
-  for (; k + 3 * LS_THREADS < nblk; k += 4 * LS_THREADS) {
-    const float4 r0 = rows[k], r1 = rows[k + LS_THREADS], r2 = rows[k + 2 * LS_THREADS], r3 = rows[k + 3 * LS_THREADS];
-    s[0] += ((double)r0.x + (double)r1.x) + ((double)r2.x + (double)r3.x);
-    s[1] += ((double)r0.y + (double)r1.y) + ((double)r2.y + (double)r3.y);
-    s[2] += ((double)r0.z + (double)r1.z) + ((double)r2.z + (double)r3.z);
-    s[3] += ((double)r0.w + (double)r1.w) + ((double)r2.w + (double)r3.w);
-  }
-  for (; k < nblk; k += LS_THREADS) { const float4 r = rows[k]; s[0] += r.x; s[1] += r.y; s[2] += r.z; s[3] += r.w; }
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s[c] += __shfl_down(s[c], off);
-  }
-  if (lane == 0) { sbuf[wave][0] = s[0]; sbuf[wave][1] = s[1]; sbuf[wave][2] = s[2]; sbuf[wave][3] = s[3]; }
-  __syncthreads();
-  if (tid == 0) {
-    double t[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int w = 0; w < LS_THREADS / 64; w++) for (int c = 0; c < 4; c++) t[c] += sbuf[w][c];
-    if (mode == 0) scalars[0] = (float)(t[0] > 1.0 ? t[0] : 1.0);  // Loss.cs:444
-    if (mode >= 1) for (int c = 1; c < 4; c++) scalars[4 + c] += (float)t[c];
-    if (mode == 2) scalars[12] += (float)t[0];                       // angle term of v8OBBLoss (column 0 of the box partials)
-  }
+  float z1 = 0.f, z2 = 0.f, z3 = 0.f;
+  block_sum4(nrm, z1, z2, z3);
+  if (threadIdx.x == 0) loss_acc_add(LOSS_ACC(a), 0, nrm, LOSS_FIX_T);
 }
 
 // ------------------------------------------------------------------ K5: BCE cls loss + gradient (Loss.cs:447)
 template <class T>
 __global__ void __launch_bounds__(LS_THREADS)
-loss_cls_kernel(LossArgs a, float* partial) {
+loss_cls_kernel(LossArgs a) {
   constexpr int EPL = Elem<T>::EPL;
   const int vpr = a.ld_ps / EPL;  // 16-byte vectors per anchor row (row padded to EPL)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -631,7 +627,7 @@ loss_cls_kernel(LossArgs a, float* partial) {
       tc = tc < 0 ? 0 : tc;  // target_labels.clamp_(0) (Tal.cs:183)
       tv = a.tnorm[row];
     }
-    const float gs = a.hyp_cls * (float)a.B / a.scalars[0];
+    const float gs = a.hyp_cls * (float)a.B / loss_tss(a);
     float x[EPL], gr[EPL];
     ys_unpack<T>(ys_ld16((const T*)a.ps + row * a.ld_ps + c0), x);
 #pragma unroll
@@ -653,7 +649,9 @@ loss_cls_kernel(LossArgs a, float* partial) {
     }
     ys_st16((T*)a.dps + row * a.ld_ps + c0, ys_pack<T>(gr));
   }
-  block_partial4(0.f, lsum, 0.f, 0.f, partial + (long)blockIdx.x * 4);
+  float z0 = 0.f, z2 = 0.f, z3 = 0.f;
+  block_sum4(z0, lsum, z2, z3);
+  if (threadIdx.x == 0) loss_acc_add(LOSS_ACC(a), 1, lsum, LOSS_FIX_L);
 }
 
 // ------------------------------------------------------------------ K6: CIoU + DFL loss + gradient (Loss.cs:134-166)
@@ -662,7 +660,7 @@ loss_cls_kernel(LossArgs a, float* partial) {
 // Only foreground anchors (a few per cent) need the softmax at all; every other row just receives a zero gradient.
 template <class T, int RR, bool ROT>
 __global__ void __launch_bounds__(LS_THREADS)
-loss_box_kernel(LossArgs a, float* partial) {
+loss_box_kernel(LossArgs a) {
   constexpr int EPL = Elem<T>::EPL;
   constexpr int RM = RR ? RR : 32;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -704,7 +702,7 @@ loss_box_kernel(LossArgs a, float* partial) {
     const int b = (int)(row / a.A), ai = (int)(row - (long)b * a.A);
     const AnchorInfo an = anchor_of(a, ai);
     const float w = a.tnorm[row];                      // weight = target_scores.sum(-1) (Loss.cs:138)
-    const float tss = a.scalars[0];
+    const float tss = loss_tss(a);
     const float gbox = a.hyp_box * (float)a.B / tss * w;
     float gd, t;                                       // d(total)/d(dist_s) through the box term; DFL target of this side
     if (ROT) {
@@ -783,14 +781,23 @@ loss_box_kernel(LossArgs a, float* partial) {
       for (int j = 0; j < R; j++) drow[j] = Elem<T>::from_f(gl[j]);
     }
   }
-  block_partial4(l_ang, 0.f, l_iou, l_dfl, partial + (long)blockIdx.x * 4);
+  float z1 = 0.f;
+  block_sum4(l_ang, z1, l_iou, l_dfl);
+  if (threadIdx.x == 0) {
+    unsigned long long* acc = LOSS_ACC(a);
+    loss_acc_add(acc, 2, l_iou, LOSS_FIX_L); loss_acc_add(acc, 3, l_dfl, LOSS_FIX_L);
+    if (ROT) loss_acc_add(acc, 4, l_ang, LOSS_FIX_L);
+  }
 }
 
 // ------------------------------------------------------------------ K7: items (Loss.cs:463-476)
 __global__ void loss_items_kernel(LossArgs a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float* sc = a.scalars;
-    const float tss = sc[0];
+    const unsigned long long* acc = LOSS_ACC(a);
+    const float tss = loss_tss(a);
+    sc[0] = tss; sc[5] = loss_acc_get(acc, 1, LOSS_FIX_L); sc[6] = loss_acc_get(acc, 2, LOSS_FIX_L); sc[7] = loss_acc_get(acc, 3, LOSS_FIX_L);
+    if (a.rot) sc[12] = loss_acc_get(acc, 4, LOSS_FIX_L);
     const float l_cls = sc[5] / tss, l_iou = sc[6] / tss, l_dfl = sc[7] / tss;
     sc[1] = l_iou * a.hyp_box;
     sc[2] = l_cls * a.hyp_cls;
@@ -819,16 +826,13 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   // gt_valid lives behind gt_cls ([B][gcap] ints each)
   int* gt_valid = a.gt_cls + (long)a.B * a.gcap;
   const int nb_a = anc_blocks(a), nb_c = cls_blocks(a, EPL), nb_b = box_blocks(a);
-  float* part_t = a.partial;
-  float* part_c = part_t + (size_t)nb_a * 4;
-  float* part_b = part_c + (size_t)nb_c * 4;
   if (a.rot) {
     if (!a.pa || !a.dpa) { ys_set_error("loss: the OBB criterion needs the angle logits"); return YS_ERR_INVALID_ARG; }
     YS_CHECK_HIP(hipMemsetAsync(a.dpa, 0, (size_t)a.B * a.A * a.ld_pa * sizeof(T), st));   // background anchors: no angle gradient
   }
-  YS_LAUNCH(loss_prep_kernel, 1, LS_THREADS, st, a, gt_valid);
-  if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b, LS_THREADS, st, a);
-  else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b, LS_THREADS, st, a);
+  // seven launches (rounds 1-5: eleven): [bbox_decode + GT padding] -> metrics / top-k -> resolve -> targets -> cls -> box -> items
+  if (a.reg_max == 16) YS_LAUNCH((loss_decode_kernel<T, 16>), nb_b + 1, LS_THREADS, st, a, gt_valid);
+  else YS_LAUNCH((loss_decode_kernel<T, 0>), nb_b + 1, LS_THREADS, st, a, gt_valid);
   // flat grid: enough workgroups for ~12 boxes per image in one trip, never more than the host-known pair bound
   const long pair_cap = (long)(a.gmax > 0 ? a.gmax : a.gcap) * a.B;
   long flat = (long)a.B * 12 > 256 ? (long)a.B * 12 : 256;
@@ -837,18 +841,15 @@ static int loss_launch_t(hipStream_t st, const LossArgs& a) {
   if (a.rot) YS_LAUNCH((tal_metrics_kernel<T, true>), tgrid, TAL_T, st, a, (const int*)gt_valid);
   else YS_LAUNCH((tal_metrics_kernel<T, false>), tgrid, TAL_T, st, a, (const int*)gt_valid);
   YS_LAUNCH(tal_resolve_kernel, nb_a, LS_THREADS, st, a);
-  YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a, part_t);
-  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_t, nb_a, a.scalars, 0);
-  YS_LAUNCH((loss_cls_kernel<T>), nb_c, LS_THREADS, st, a, part_c);
-  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_c, nb_c, a.scalars, 1);
+  YS_LAUNCH(tal_targets_kernel, nb_a, LS_THREADS, st, a);
+  YS_LAUNCH((loss_cls_kernel<T>), nb_c, LS_THREADS, st, a);
   if (a.rot) {
-    if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16, true>), nb_b, LS_THREADS, st, a, part_b);
-    else YS_LAUNCH((loss_box_kernel<T, 0, true>), nb_b, LS_THREADS, st, a, part_b);
+    if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16, true>), nb_b, LS_THREADS, st, a);
+    else YS_LAUNCH((loss_box_kernel<T, 0, true>), nb_b, LS_THREADS, st, a);
   } else {
-    if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16, false>), nb_b, LS_THREADS, st, a, part_b);
-    else YS_LAUNCH((loss_box_kernel<T, 0, false>), nb_b, LS_THREADS, st, a, part_b);
+    if (a.reg_max == 16) YS_LAUNCH((loss_box_kernel<T, 16, false>), nb_b, LS_THREADS, st, a);
+    else YS_LAUNCH((loss_box_kernel<T, 0, false>), nb_b, LS_THREADS, st, a);
   }
-  YS_LAUNCH(loss_sum_kernel, 1, LS_THREADS, st, (const float*)part_b, nb_b, a.scalars, a.rot ? 2 : 1);
   YS_LAUNCH(loss_items_kernel, 1, 64, st, a);
   return YS_OK;
 }

@@ -1773,14 +1773,16 @@ static int flush_wgrads(ys_model* m, int B) {
   m->pend_wg.clear(); m->pend_mb = 0.0;
   return YS_OK;
 }
-// queue layer c's weight gradient; flush when the batch is full: WG_BATCH launches (default 6) or WG_BATCH_MB megabytes of (input + dy) tensors (default 40:
+// queue layer c's weight gradient; flush when the batch is full: 6 launches or 40 megabytes of (input + dy) tensors (
 // the P1 / P2 / P3 layers, whose kernels run 50-150 us, go over one or two at a time -- the bubble is small next to them and the second stream should not start
 // them late; the P4 / P5 layers, 15-30 us each, go over in fours to sixes)
 static int queue_wgrad(ys_model* m, ConvL& c, int B, const void* dy, int ldc, int coff, long bstride) {
   if (!m->overlap) return launch_wgrad(m, c, B, dy, ldc, coff, bstride, m->ctx->stream);
   m->pend_wg.push_back(ys_model::PendWg{c.idx, dy, ldc, coff, bstride});
   m->pend_mb += ((double)B * c.Hout * c.Wout * c.cout + (double)B * c.Hin * c.Win * c.cin_pad) * m->es * 1e-6;
-  if ((long)m->pend_wg.size() >= YS_OPT_INT("WG_BATCH", 6) || m->pend_mb >= (double)YS_OPT_INT("WG_BATCH_MB", 40)) return flush_wgrads(m, B);
+  // (measured on config 2, same box, two rounds each: one per launch 8.71 / 8.71 ms, 4 / 24 MB 8.74 / 8.72, 6 / 40 MB 8.65 / 8.66, 12 / 80 MB 8.81 / 8.75, 8 / 200 MB 8.84 / 8.81,
+  // everything in one batch per segment 8.93 / 8.87; round 5's ring + per-launch events 8.79 / 8.73)
+  if (m->pend_wg.size() >= 6 || m->pend_mb >= 40.0) return flush_wgrads(m, B);
   return YS_OK;
 }
 
