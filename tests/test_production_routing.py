@@ -160,13 +160,20 @@ def test_v8n_640_b64_production_routing(tmp_path):
 # towers, C2PSA attention, Proto), the loss items also with the plain fp32 oracle.  Thresholds: CFG[...] = (items vs matched, items vs fp32, head rms, overall gradient
 # cosine, |norm ratio - 1|, worst-tensor cosine); measured values next to each (gpurun_out/prod_routing_<tag>_summary.txt of the calibration run, round 6).
 CFG = {
-    # config 3 per-GPU shape: YOLOv8s B = 32
-    "v8s_b32": (dict(B=32, H=640, W=640, family=8, size="s"), (1e-2, 1.5e-2, 0.15, 0.99, 2e-2, 0.85)),
-    # config 4 graph: YOLOv11m-seg, B = 4 (the oracle's per-image mask loop and the C2PSA attention in fp32 on host cores bound the batch)
-    "v11m_seg_b4": (dict(B=4, H=640, W=640, family=11, size="m", task="segment", damp=0.25), (3e-2, 5e-2, 0.25, 0.97, 5e-2, 0.5)),
-    # config 5 graph and resolution: YOLOv8x 1280 x 1280, B = 2, bf16 and fp8
-    "v8x_1280_b2": (dict(B=2, H=1280, W=1280, family=8, size="x", damp=0.25), (8e-2, 8e-2, 0.40, 0.93, 8e-2, 0.3)),
-    "v8x_1280_b2_fp8": (dict(B=2, H=1280, W=1280, family=8, size="x", dtype="fp8", damp=0.25), (1e-1, 1e-1, 0.50, 0.85, 1.5e-1, 0.2)),
+    # config 3 per-GPU shape: YOLOv8s B = 32.  Measured (round 6, MI355X): items 6e-4 / 8e-4 / 7e-4 from the matched oracle, head rms 0.073-0.074, gradient cosine 0.99921,
+    # norm ratio 1.0007, worst tensor 0.954 (model.22.cv2.2.0.conv.weight)
+    "v8s_b32": (dict(B=32, H=640, W=640, family=8, size="s"), (5e-3, 1.5e-2, 0.15, 0.998, 5e-3, 0.90)),
+    # config 4 graph: YOLOv11m-seg, B = 4 (the oracle's per-image mask loop and the C2PSA attention in fp32 on host cores bound the batch).  damp = 0.25: see the worker.
+    # Measured: items 1.7e-3 / 4.7e-3 / 1.6e-3 / 5e-5, head rms 0.070-0.090, cosine 0.99218, norm ratio 0.9995, worst tensor 0.923 (model.22.m.0.m.1.cv2.bn.weight)
+    # (undamped: cosine 0.955, worst 0.778 -- and the two ORACLES then differ by more than that)
+    "v11m_seg_b4": (dict(B=4, H=640, W=640, family=11, size="m", task="segment", damp=0.25), (1.5e-2, 3e-2, 0.15, 0.985, 1e-2, 0.85)),
+    # config 5 graph and resolution: YOLOv8x 1280 x 1280, B = 2, bf16 and fp8; damp = 0.25.  bf16 measured: items 4e-4 / 8e-4 / 1.2e-3, head rms 0.052, cosine 0.99964,
+    # norm ratio 1.0008, worst tensor 0.926 (model.22.cv2.0.1.conv.weight) (undamped: cosine 0.776, worst 0.43)
+    "v8x_1280_b2": (dict(B=2, H=1280, W=1280, family=8, size="x", damp=0.25), (5e-3, 1e-2, 0.10, 0.999, 5e-3, 0.85)),
+    # fp8 against the BF16-matched oracle (no e4m3 / e5m2 operand rounding in it): the distance is the fp8 mode's own -- items 9e-4 / 7.7e-2 / 3.4e-3, head rms 0.39
+    # (e4m3 operands carry ~2^-4 relative rounding per element, i.e. percents per layer output, through 60 convolutions), cosine 0.9940, norm ratio 1.077, worst tensor 0.459
+    # (model.21.m.1.cv1.bn.weight).  Per-layer statements against quantised-operand fp32 are in tests/test_fp8.py.
+    "v8x_1280_b2_fp8": (dict(B=2, H=1280, W=1280, family=8, size="x", dtype="fp8", damp=0.25), (1.2e-1, 1.2e-1, 0.60, 0.98, 0.12, 0.30)),
 }
 # launch labels that must occur (class, prefix): the kernels bench.py times on that configuration
 WANT = {

@@ -156,6 +156,7 @@ struct ys_model {
   // the main stream, all of it in the backward pass (the forward has none).
   struct PendWg { int conv; const void* dy; int ldc, coff; long bstride; };
   std::vector<PendWg> pend_wg; double pend_mb = 0.0; int ev_hand = 0;
+  bool hold_stem = false;                      // one-call backward: model.0's weight gradient stays queued until the segment end (backward_range: stem_split)
   // head lanes (round 3): the towers of the three pyramid levels are independent chains (own buffers, own rows of the prediction buffers);
   // the P4 / P5 chains are short, latency-bound launches (100-400 workgroups) that run beside the P3 chain on two side streams
   // asynchronous segment ends (data-parallel step): the weight-gradient stream is NOT joined into the main stream when a backward segment
@@ -1778,6 +1779,11 @@ static int flush_wgrads(ys_model* m, int B) {
 // them late; the P4 / P5 layers, 15-30 us each, go over in fours to sixes)
 static int queue_wgrad(ys_model* m, ConvL& c, int B, const void* dy, int ldc, int coff, long bstride) {
   if (!m->overlap) return launch_wgrad(m, c, B, dy, ldc, coff, bstride, m->ctx->stream);
+  if (c.first && m->hold_stem) {               // everything queued so far goes now; the stem's own launch waits for the segment end
+    YS_TRY(flush_wgrads(m, B));
+    m->pend_wg.push_back(ys_model::PendWg{c.idx, dy, ldc, coff, bstride});
+    return YS_OK;
+  }
   m->pend_wg.push_back(ys_model::PendWg{c.idx, dy, ldc, coff, bstride});
   m->pend_mb += ((double)B * c.Hout * c.Wout * c.cout + (double)B * c.Hin * c.Win * c.cin_pad) * m->es * 1e-6;
   // (measured on config 2, same box, two rounds each: one per launch 8.71 / 8.71 ms, 4 / 24 MB 8.74 / 8.72, 6 / 40 MB 8.65 / 8.66, 12 / 80 MB 8.81 / 8.75, 8 / 200 MB 8.84 / 8.81,
@@ -2047,25 +2053,42 @@ int backward_range(ys_model* m, int seg_lo, int seg_hi, bool async_end = false, 
   // the segment's gradients are complete only when the weight-gradient stream has drained: the main stream waits for it here, unless the
   // caller asked for an asynchronous end -- then the split reduction below goes to that stream as well, nothing on the main stream waits,
   // and whoever consumes the segment's gradients (the all-reduce) waits on the two events recorded at the end
+  // split reduction of weight gradients [lo, hi) of the descriptor table in one launch on stream sr (the partial slabs sit in per-layer regions)
+  auto reduce_range = [&](int lo, int hi, hipStream_t sr) -> int {
+    if (hi <= lo) return YS_OK;
+    long blk = 0;
+    for (int i = lo; i < hi; i++) { m->red_host[i].blk0 = blk; blk += (m->red_host[i].n + YS_WGRED_OUT_PER_BLOCK - 1) / YS_WGRED_OUT_PER_BLOCK; }
+    if (m->red_uploaded.size() != m->red_host.size()) m->red_uploaded.assign(m->red_host.size(), WgRedDesc{});
+    if (memcmp(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc)) != 0) {   // first step / batch size / launch partition changed
+      YS_CHECK_HIP(hipMemcpyAsync(m->red_dev + lo, &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc), hipMemcpyHostToDevice, st));
+      YS_CHECK_HIP(hipStreamSynchronize(st));
+      memcpy(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc));
+    }
+    return ys_wgrad_reduce_batched_launch(sr, m->red_dev + lo, hi - lo, blk);
+  };
+  const int rlo = m->red_first[seg_lo], rhi = m->red_first[seg_hi + 1];
+  // The step's LAST dependency chain is dgrad(model.1) -> BN backward of model.0 -> stem weight gradient -> split reduction -> AdamW (round-6 trace: 200 us with the
+  // main stream idle).  In the one-call backward the stem's weight gradient is therefore handed over on its own, AFTER the reduction of everything else in its
+  // segment has been queued on the second stream: that reduction (48 us) then runs while the main stream is still in the BatchNorm backward of model.0, and only
+  // the stem's own slabs are reduced behind its weight gradient.
+  bool stem_split = false;
+  ys_model::PendWg stem_job{};
+  if (async_end && !seg_events && m->overlap && seg_hi == ys_model::NSEG - 1 && !m->pend_wg.empty() && m->convs[m->pend_wg.back().conv].first &&
+      m->convs[m->pend_wg.back().conv].red_slot == rlo && m->defer_wgred && rhi - rlo > 1) {
+    stem_split = true; stem_job = m->pend_wg.back(); m->pend_wg.pop_back();
+  }
   YS_TRY(flush_wgrads(m, B));
-  const bool on_st2 = async_end && m->overlap && m->st2_dirty;
+  const bool on_st2 = async_end && m->overlap && (m->st2_dirty || stem_split);
   hipStream_t sr = on_st2 ? m->st2 : st;
   if (!on_st2) YS_TRY(join_wgrad_stream(m));
   if (m->f8 && seg_hi == ys_model::NSEG - 1) m->f8_bwd_done = true;     // every gradient maximum of the step is recorded (last segment = stem)
-  {
-    // split reduction of every weight gradient of these segments in one launch (the partial slabs sit in per-layer regions)
-    const int lo = m->red_first[seg_lo], hi = m->red_first[seg_hi + 1];
-    if (hi > lo) {
-      long blk = 0;
-      for (int i = lo; i < hi; i++) { m->red_host[i].blk0 = blk; blk += (m->red_host[i].n + YS_WGRED_OUT_PER_BLOCK - 1) / YS_WGRED_OUT_PER_BLOCK; }
-      if (m->red_uploaded.size() != m->red_host.size()) m->red_uploaded.assign(m->red_host.size(), WgRedDesc{});
-      if (memcmp(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc)) != 0) {   // first step / batch size changed
-        YS_CHECK_HIP(hipMemcpyAsync(m->red_dev + lo, &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc), hipMemcpyHostToDevice, st));
-        YS_CHECK_HIP(hipStreamSynchronize(st));
-        memcpy(&m->red_uploaded[lo], &m->red_host[lo], (size_t)(hi - lo) * sizeof(WgRedDesc));
-      }
-      YS_TRY(ys_wgrad_reduce_batched_launch(sr, m->red_dev + lo, hi - lo, blk));
-    }
+  if (stem_split) {
+    YS_TRY(reduce_range(rlo + 1, rhi, sr));
+    m->pend_wg.push_back(stem_job);
+    YS_TRY(flush_wgrads(m, B));
+    YS_TRY(reduce_range(rlo, rlo + 1, sr));
+  } else {
+    YS_TRY(reduce_range(rlo, rhi, sr));
   }
   if (async_end && seg_events) {
     for (int sgi = seg_lo; sgi <= seg_hi; sgi++) {
@@ -2654,8 +2677,11 @@ int ys_model_backward(ys_model* m) {
   // next forward order themselves behind the second stream (join_wgrad_stream), as they do after ys_model_backward_segment_async.  Same kernels, same operands, same
   // order per stream: bit-identical gradients (tests/test_dist.py::test_async_segment_ends_give_the_same_gradients compares the two forms).
   if (m->overlap) {
-    for (int sg = 0; sg < ys_model::NSEG; sg++) YS_TRY(backward_range(m, sg, sg, true, false));
-    return YS_OK;
+    m->hold_stem = true;
+    int rc = YS_OK;
+    for (int sg = 0; sg < ys_model::NSEG && rc == YS_OK; sg++) rc = backward_range(m, sg, sg, true, false);
+    m->hold_stem = false;
+    return rc;
   }
   return backward_range(m, 0, ys_model::NSEG - 1);
 }
