@@ -1176,8 +1176,14 @@ static bool p2_f8_tile_ok(int mr, int nr, int wres, int npu) {
   return npu == 6 ? (mr * nr <= 6 || (mr == 4 && nr == 2)) && !(mr == 1 && nr == 5) : (mr * nr <= 4 && mr + nr <= 5);
 }
 // force_mr / force_npu (0 = free): grouped launches need every problem on the kernel variant of the group's largest problem
+// plan sweep (tools/dev/r06/p2_sweep.py through ys_debug_p2_force): a register-tile height, a tile width and an output-channel split imposed on every plan of the
+// process; 0 = the cost model's own choice.  Triage only -- nothing in the package sets them.
+static int g_p2_force_mr = 0, g_p2_force_tw = 0, g_p2_force_nr = 0;
+extern "C" __attribute__((visibility("default"))) int ys_debug_p2_force(int mr, int tw, int nr) { g_p2_force_mr = mr; g_p2_force_tw = tw; g_p2_force_nr = nr; return 0; }
 static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 0, bool want_full = true, int force_nr = 0) {
   P2Plan p{};
+  if (g_p2_force_mr && !force_mr) force_mr = g_p2_force_mr;
+  if (g_p2_force_nr && !force_nr) force_nr = g_p2_force_nr;
   // 3x3 forward / stride-1 dgrad, 1x1 forward / dgrad, and the 1x1 .. 2x2 phase convolutions of a stride-2 dgrad (strided
   // output-row map)
   const bool k3 = a.KH == 3 && a.KW == 3 && a.out_rh == 0;
@@ -1254,6 +1260,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
       const int npx = 16 * nwv * mr;
       const size_t stage = (size_t)nwv * (16 * mr * (bn + 8) * 2 + 16 * mr * 16);
       for (int tw = 1; tw <= npx && tw <= a.Wout; tw++) {
+        if (g_p2_force_tw && tw != g_p2_force_tw) continue;
         int th = npx / tw; if (th > a.Hout) th = a.Hout;
         const int ph = (th - 1) * a.SA + a.KH, pw = (tw - 1) * a.SA + a.KW;
         size_t pbytes = (size_t)ph * pw * g.ppb; if (pbytes < stage) pbytes = stage;

@@ -149,28 +149,45 @@ __device__ inline AnchorInfo anchor_of(const LossArgs& a, int idx) {
 // ---- round 6: the criterion's four global sums as fixed-point integer accumulators (the scheme of the BatchNorm statistics, ys_kernels.h ys_stat_acc_add).
 // Rounds 1-5: every producer wrote one partial row per workgroup and a one-workgroup loss_sum_kernel launch added them -- three 7 us launches (+ boundaries) on the
 // step's critical path between forward and backward.  Now a workgroup adds its partial -- rounded to 2^-30 (target-score sum: |partial| <= 256) or 2^-20 (loss sums:
-// |partial| < 2^42) -- with ONE 64-bit integer atomic; integer addition commutes, so the totals are bit-reproducible whatever the arrival order, and the
-// consumers (loss_cls / loss_box: tss; loss_items: all of them) read the words directly.  Words live behind the float scalars: (u64*)(scalars + 16) [0] tss, [1] cls,
-// [2] iou, [3] dfl, [4] angle, [5] poison (a non-finite or out-of-range partial: the items become NaN, as the reference's do on divergence).
-#define LOSS_ACC(a) ((unsigned long long*)((a).scalars + 16))
+// |partial| < 2^42) -- with ONE 64-bit integer atomic into shard (workgroup index mod LOSS_SHARDS): integer addition commutes, so the totals are bit-reproducible
+// whatever the arrival order.  (Unsharded -- 21 thousand workgroups of loss_cls_kernel adding to ONE address -- the atomics serialised in the L2: 51 -> 261 us.)
+// Consumers sum the shards: loss_cls / loss_box once per workgroup (loss_tss_block), loss_items all of them.  The words live behind the 64 float scalars:
+// (u64*)(scalars + 64) [shard][8]: [0] tss, [1] cls, [2] iou, [3] dfl, [4] angle, [5] poison (a non-finite or out-of-range partial: the items become NaN, as the
+// reference's do on divergence).
+#define LOSS_SHARDS 64
+#define LOSS_ACC(a) ((unsigned long long*)((a).scalars + 64))
 #define LOSS_FIX_T 1073741824.0f      // 2^30
 #define LOSS_FIX_L 1048576.0f         // 2^20
 __device__ inline void loss_acc_add(unsigned long long* acc, int word, float t, float fix) {
-  if (!(fabsf(t) * fix < 9.0e18f)) { atomicOr(acc + 5, 1ull); return; }       // NaN fails the comparison too
+  unsigned long long* a = acc + (size_t)(blockIdx.x & (LOSS_SHARDS - 1)) * 8;
+  if (!(fabsf(t) * fix < 9.0e18f)) { atomicOr(a + 5, 1ull); return; }       // NaN fails the comparison too
 #ifdef YS_EMU_BUILD
   const long long q = (long long)llrintf(t * fix);
 #else
   const long long q = __float2ll_rn(t * fix);
 #endif
-  if (q != 0) atomicAdd(acc + word, (unsigned long long)q);
+  if (q != 0) atomicAdd(a + word, (unsigned long long)q);
 }
+// one thread: every shard of a word (loss_items_kernel)
 __device__ inline float loss_acc_get(const unsigned long long* acc, int word, float fix) {
-  if (acc[5]) return __builtin_nanf("");
-  return (float)((double)(long long)acc[word] * (1.0 / (double)fix));
+  long long t = 0; unsigned long long bad = 0;
+  for (int s = 0; s < LOSS_SHARDS; s++) { t += (long long)acc[s * 8 + word]; bad |= acc[s * 8 + 5]; }
+  if (bad) return __builtin_nanf("");
+  return (float)((double)t * (1.0 / (double)fix));
 }
-__device__ inline float loss_tss(const LossArgs& a) {        // target_scores_sum = max(sum, 1) (Loss.cs:444)
-  const float t = loss_acc_get(LOSS_ACC(a), 0, LOSS_FIX_T);
-  return t > 1.0f ? t : (t != t ? t : 1.0f);
+__device__ inline float loss_tss_of(float t) { return t > 1.0f ? t : (t != t ? t : 1.0f); }        // target_scores_sum = max(sum, 1) (Loss.cs:444); NaN stays NaN
+// a whole workgroup (>= 64 threads): lane l of wave 0 reads shard l, the wave adds them up, LDS hands the value to everybody.  Contains a barrier.
+__device__ inline float loss_tss_block(const LossArgs& a) {
+  __shared__ float s_tss;
+  if (threadIdx.x < 64) {
+    const unsigned long long* acc = LOSS_ACC(a) + (size_t)threadIdx.x * 8;
+    long long t = threadIdx.x < LOSS_SHARDS ? (long long)acc[0] : 0;
+    int bad = threadIdx.x < LOSS_SHARDS ? (acc[5] != 0ull) : 0;
+    for (int m = 32; m >= 1; m >>= 1) { t += __shfl_xor(t, m); bad |= __shfl_xor(bad, m); }
+    if (threadIdx.x == 0) s_tss = bad ? __builtin_nanf("") : loss_tss_of((float)((double)t * (1.0 / (double)LOSS_FIX_T)));
+  }
+  __syncthreads();
+  return s_tss;
 }
 // workgroup sum of up to four values -> lane 0 of wave 0 (fixed order: wave butterflies, then the waves in index order)
 __device__ inline void block_sum4(float& v0, float& v1, float& v2, float& v3) {
@@ -190,7 +207,7 @@ __device__ inline void block_sum4(float& v0, float& v1, float& v2, float& v3) {
 // (round 6: runs as the FIRST workgroup of the bbox_decode launch -- the two are independent -- instead of a one-workgroup launch of its own)
 __device__ inline void loss_prep_body(const LossArgs& a, int* gt_valid) {
   const int tid = threadIdx.x;
-  if (tid < 6) LOSS_ACC(a)[tid] = 0ull;
+  for (int i = tid; i < LOSS_SHARDS * 8; i += LS_THREADS) LOSS_ACC(a)[i] = 0ull;
   for (int i = tid; i < a.B; i += LS_THREADS) a.gt_count[i] = 0;
   for (int i = tid; i < a.B * a.gcap; i += LS_THREADS) { a.pos_align[i] = 0u; a.pos_ov[i] = 0u; }
   if (tid < 8) a.scalars[tid] = 0.f;
@@ -608,6 +625,7 @@ template <class T>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_cls_kernel(LossArgs a) {
   constexpr int EPL = Elem<T>::EPL;
+  const float tss_blk = loss_tss_block(a);
   const int vpr = a.ld_ps / EPL;  // 16-byte vectors per anchor row (row padded to EPL)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float lsum = 0.f;
@@ -627,7 +645,7 @@ loss_cls_kernel(LossArgs a) {
       tc = tc < 0 ? 0 : tc;  // target_labels.clamp_(0) (Tal.cs:183)
       tv = a.tnorm[row];
     }
-    const float gs = a.hyp_cls * (float)a.B / loss_tss(a);
+    const float gs = a.hyp_cls * (float)a.B / tss_blk;
     float x[EPL], gr[EPL];
     ys_unpack<T>(ys_ld16((const T*)a.ps + row * a.ld_ps + c0), x);
 #pragma unroll
@@ -662,6 +680,7 @@ template <class T, int RR, bool ROT>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_box_kernel(LossArgs a) {
   constexpr int EPL = Elem<T>::EPL;
+  const float tss_blk = loss_tss_block(a);
   constexpr int RM = RR ? RR : 32;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.A * 4;
@@ -702,7 +721,7 @@ loss_box_kernel(LossArgs a) {
     const int b = (int)(row / a.A), ai = (int)(row - (long)b * a.A);
     const AnchorInfo an = anchor_of(a, ai);
     const float w = a.tnorm[row];                      // weight = target_scores.sum(-1) (Loss.cs:138)
-    const float tss = loss_tss(a);
+    const float tss = tss_blk;
     const float gbox = a.hyp_box * (float)a.B / tss * w;
     float gd, t;                                       // d(total)/d(dist_s) through the box term; DFL target of this side
     if (ROT) {
@@ -795,7 +814,7 @@ __global__ void loss_items_kernel(LossArgs a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float* sc = a.scalars;
     const unsigned long long* acc = LOSS_ACC(a);
-    const float tss = loss_tss(a);
+    const float tss = loss_tss_of(loss_acc_get(acc, 0, LOSS_FIX_T));
     sc[0] = tss; sc[5] = loss_acc_get(acc, 1, LOSS_FIX_L); sc[6] = loss_acc_get(acc, 2, LOSS_FIX_L); sc[7] = loss_acc_get(acc, 3, LOSS_FIX_L);
     if (a.rot) sc[12] = loss_acc_get(acc, 4, LOSS_FIX_L);
     const float l_cls = sc[5] / tss, l_iou = sc[6] / tss, l_dfl = sc[7] / tss;

@@ -1242,7 +1242,7 @@ int allocate(ys_model* m) {
   YS_TRY(dev_alloc(m, (void**)&m->fg_gt, (size_t)B * m->A * 4));
   YS_TRY(dev_alloc(m, (void**)&m->tnorm, (size_t)B * m->A * 4));
   YS_TRY(dev_alloc(m, (void**)&m->loss_partial, ys_loss_partial_floats(B, m->A) * 4));
-  YS_TRY(dev_alloc(m, (void**)&m->scalars, 64));
+  YS_TRY(dev_alloc(m, (void**)&m->scalars, 64 * 4 + 64 * 8 * 8));     // 64 float scalars + the criterion's sharded integer accumulators (loss.hip LOSS_ACC: [64][8] u64)
   return YS_OK;
 }
 
