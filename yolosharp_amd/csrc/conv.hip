@@ -1272,7 +1272,11 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
         const int tx = ys_cdiv(a.Wout, tw), ty = ys_cdiv(a.Hout, th);
         const long ntiles = (long)tx * ty * a.B;
         const double per_tile = (double)ph * pw * a.Cin + (wres ? 0.0 : 0.5 * bn * (double)taps * a.Cin) + 1.0 * npx * (a.Cin + bn) + tileconst;
-        const double cost = (double)tx * ty * per_tile;
+        // Round 6 (plan sweep on the MI355X, tools/dev/r06/p2_sweep.py): the byte model above prefers the largest tile, but a plan of the three-workgroups-per-CU class
+        // (6-unit patch, register tile of <= 8 MFMAs, <= 50 KB of LDS: conv_p2_kernel's TIGHT variants) beats a cheaper-looking two-per-CU plan by more than the
+        // bytes say -- 1x1 64 -> 64 at M = 409600: 4 x 4 tiles 37.0 us, 1 x 4 tiles 28.2 us; 3x3 s2 16 -> 32 at M = 1.6 M: 68.0 -> 59.0 us.  The class gets a discount.
+        const bool cls3 = !f8 && nt == 256 && mr * nr <= 8 && ph * pw * cu <= 6 * nt && lds <= (size_t)50 * 1024;
+        const double cost = (double)tx * ty * per_tile * (cls3 ? (double)YS_OPT_INT("P2_CLS3", 75) * 0.01 : 1.0);
         const bool full = !want_full || ntiles * gy >= 512;   // (a small member of a grouped launch does not have to fill the chip by itself: cheapest tiles)
         if ((full && !best_full) || (full == best_full && cost < best)) {
           best = cost; best_full = full;

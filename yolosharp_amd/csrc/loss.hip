@@ -151,15 +151,15 @@ __device__ inline AnchorInfo anchor_of(const LossArgs& a, int idx) {
 // step's critical path between forward and backward.  Now a workgroup adds its partial -- rounded to 2^-30 (target-score sum: |partial| <= 256) or 2^-20 (loss sums:
 // |partial| < 2^42) -- with ONE 64-bit integer atomic into shard (workgroup index mod LOSS_SHARDS): integer addition commutes, so the totals are bit-reproducible
 // whatever the arrival order.  (Unsharded -- 21 thousand workgroups of loss_cls_kernel adding to ONE address -- the atomics serialised in the L2: 51 -> 261 us.)
-// Consumers sum the shards: loss_cls / loss_box once per workgroup (loss_tss_block), loss_items all of them.  The words live behind the 64 float scalars:
+// Consumers sum the shards: loss_cls / loss_box per wave (loss_tss_wave), loss_items all of them.  The words live behind the 64 float scalars:
 // (u64*)(scalars + 64) [shard][8]: [0] tss, [1] cls, [2] iou, [3] dfl, [4] angle, [5] poison (a non-finite or out-of-range partial: the items become NaN, as the
 // reference's do on divergence).
 #define LOSS_SHARDS 64
 #define LOSS_ACC(a) ((unsigned long long*)((a).scalars + 64))
 #define LOSS_FIX_T 1073741824.0f      // 2^30
 #define LOSS_FIX_L 1048576.0f         // 2^20
-__device__ inline void loss_acc_add(unsigned long long* acc, int word, float t, float fix) {
-  unsigned long long* a = acc + (size_t)(blockIdx.x & (LOSS_SHARDS - 1)) * 8;
+__device__ inline void loss_acc_add(unsigned long long* acc, int word, float t, float fix, int shards = LOSS_SHARDS) {
+  unsigned long long* a = acc + (size_t)(blockIdx.x & (shards - 1)) * 8;
   if (!(fabsf(t) * fix < 9.0e18f)) { atomicOr(a + 5, 1ull); return; }       // NaN fails the comparison too
 #ifdef YS_EMU_BUILD
   const long long q = (long long)llrintf(t * fix);
@@ -176,18 +176,19 @@ __device__ inline float loss_acc_get(const unsigned long long* acc, int word, fl
   return (float)((double)t * (1.0 / (double)fix));
 }
 __device__ inline float loss_tss_of(float t) { return t > 1.0f ? t : (t != t ? t : 1.0f); }        // target_scores_sum = max(sum, 1) (Loss.cs:444); NaN stays NaN
-// a whole workgroup (>= 64 threads): lane l of wave 0 reads shard l, the wave adds them up, LDS hands the value to everybody.  Contains a barrier.
-__device__ inline float loss_tss_block(const LossArgs& a) {
-  __shared__ float s_tss;
-  if (threadIdx.x < 64) {
-    const unsigned long long* acc = LOSS_ACC(a) + (size_t)threadIdx.x * 8;
-    long long t = threadIdx.x < LOSS_SHARDS ? (long long)acc[0] : 0;
-    int bad = threadIdx.x < LOSS_SHARDS ? (acc[5] != 0ull) : 0;
-    for (int m = 32; m >= 1; m >>= 1) { t += __shfl_xor(t, m); bad |= __shfl_xor(bad, m); }
-    if (threadIdx.x == 0) s_tss = bad ? __builtin_nanf("") : loss_tss_of((float)((double)t * (1.0 / (double)LOSS_FIX_T)));
-  }
-  __syncthreads();
-  return s_tss;
+// The target-score sum is written by tal_targets_kernel only (2100 workgroups at the headline shape) into the first LOSS_TSS_SHARDS shards; its readers are
+// every wave of loss_cls / loss_box: lanes 0 .. 15 load one shard each (and its poison word), four shuffles add them, lane 0's total goes to everybody.  No LDS,
+// no barrier, and the loads go out together with the wave's own operand loads -- a workgroup-wide form behind a barrier put one more dependent L2 round trip in
+// front of every ~1 us workgroup of loss_cls_kernel (51 -> 92 us).
+#define LOSS_TSS_SHARDS 16
+__device__ inline float loss_tss_wave(const LossArgs& a) {
+  const int l = threadIdx.x & 63;
+  const unsigned long long* acc = LOSS_ACC(a) + (size_t)(l & (LOSS_TSS_SHARDS - 1)) * 8;
+  long long t = l < LOSS_TSS_SHARDS ? (long long)acc[0] : 0;
+  int bad = l < LOSS_TSS_SHARDS ? (int)(acc[5] != 0ull) : 0;
+  for (int m = LOSS_TSS_SHARDS / 2; m >= 1; m >>= 1) { t += __shfl_xor(t, m); bad |= __shfl_xor(bad, m); }
+  t = __shfl(t, 0); bad = __shfl(bad, 0);
+  return bad ? __builtin_nanf("") : loss_tss_of((float)((double)t * (1.0 / (double)LOSS_FIX_T)));
 }
 // workgroup sum of up to four values -> lane 0 of wave 0 (fixed order: wave butterflies, then the waves in index order)
 __device__ inline void block_sum4(float& v0, float& v1, float& v2, float& v3) {
@@ -617,7 +618,7 @@ tal_targets_kernel(LossArgs a) {
   }
   float z1 = 0.f, z2 = 0.f, z3 = 0.f;
   block_sum4(nrm, z1, z2, z3);
-  if (threadIdx.x == 0) loss_acc_add(LOSS_ACC(a), 0, nrm, LOSS_FIX_T);
+  if (threadIdx.x == 0) loss_acc_add(LOSS_ACC(a), 0, nrm, LOSS_FIX_T, LOSS_TSS_SHARDS);
 }
 
 // ------------------------------------------------------------------ K5: BCE cls loss + gradient (Loss.cs:447)
@@ -625,19 +626,26 @@ template <class T>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_cls_kernel(LossArgs a) {
   constexpr int EPL = Elem<T>::EPL;
-  const float tss_blk = loss_tss_block(a);
   const int vpr = a.ld_ps / EPL;  // 16-byte vectors per anchor row (row padded to EPL)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float lsum = 0.f;
-  if (i < (long)a.B * a.A * vpr) {
-    long row; int c0, b;
-    if ((long)a.B * a.A * vpr < (1L << 31)) {    // 32-bit index arithmetic (a 64-bit division is ~80 VALU instructions)
-      const unsigned iu = (unsigned)i, r = iu / (unsigned)vpr;
+  const long total = (long)a.B * a.A * vpr;
+  const bool inb = i < total;
+  long row; int c0, b;
+  {
+    const long ii = inb ? i : 0;
+    if (total < (1L << 31)) {    // 32-bit index arithmetic (a 64-bit division is ~80 VALU instructions)
+      const unsigned iu = (unsigned)ii, r = iu / (unsigned)vpr;
       row = r; c0 = (int)(iu - r * (unsigned)vpr) * EPL; b = (int)(r / (unsigned)a.A);
     } else {
-      row = i / vpr; c0 = (int)(i - row * vpr) * EPL; b = (int)(row / a.A);
+      row = ii / vpr; c0 = (int)(ii - row * vpr) * EPL; b = (int)(row / a.A);
     }
-    const int g = a.fg_gt[row];
+  }
+  // every request of the thread goes out before anything is waited for: the logits, the assignment, and (wave-wide, shuffles) the shards of the target-score sum
+  const uint4 xv16 = ys_ld16((const T*)a.ps + row * a.ld_ps + c0);
+  const int g = a.fg_gt[row];
+  const float tss_w = loss_tss_wave(a);
+  if (inb) {
     int tc = -1;
     float tv = 0.f;
     if (g >= 0) {
@@ -645,9 +653,9 @@ loss_cls_kernel(LossArgs a) {
       tc = tc < 0 ? 0 : tc;  // target_labels.clamp_(0) (Tal.cs:183)
       tv = a.tnorm[row];
     }
-    const float gs = a.hyp_cls * (float)a.B / tss_blk;
     float x[EPL], gr[EPL];
-    ys_unpack<T>(ys_ld16((const T*)a.ps + row * a.ld_ps + c0), x);
+    const float gs = a.hyp_cls * (float)a.B / tss_w;
+    ys_unpack<T>(xv16, x);
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
       const int c = c0 + e;
@@ -680,7 +688,6 @@ template <class T, int RR, bool ROT>
 __global__ void __launch_bounds__(LS_THREADS)
 loss_box_kernel(LossArgs a) {
   constexpr int EPL = Elem<T>::EPL;
-  const float tss_blk = loss_tss_block(a);
   constexpr int RM = RR ? RR : 32;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.A * 4;
@@ -717,6 +724,7 @@ loss_box_kernel(LossArgs a) {
   const int base = lane & ~3;
   const float d0 = __shfl(dist, base + 0), d1 = __shfl(dist, base + 1), d2 = __shfl(dist, base + 2), d3 = __shfl(dist, base + 3);
   float l_iou = 0.f, l_dfl = 0.f, l_ang = 0.f;
+  const float tss_blk = loss_tss_wave(a);      // wave-wide (shuffles): outside the foreground branch
   if (g >= 0) {
     const int b = (int)(row / a.A), ai = (int)(row - (long)b * a.A);
     const AnchorInfo an = anchor_of(a, ai);
