@@ -1276,7 +1276,7 @@ static P2Plan conv_p2_plan(const ConvArgs& a, int force_mr = 0, int force_npu = 
         // (6-unit patch, register tile of <= 8 MFMAs, <= 50 KB of LDS: conv_p2_kernel's TIGHT variants) beats a cheaper-looking two-per-CU plan by more than the
         // bytes say -- 1x1 64 -> 64 at M = 409600: 4 x 4 tiles 37.0 us, 1 x 4 tiles 28.2 us; 3x3 s2 16 -> 32 at M = 1.6 M: 68.0 -> 59.0 us.  The class gets a discount.
         const bool cls3 = !f8 && nt == 256 && mr * nr <= 8 && ph * pw * cu <= 6 * nt && lds <= (size_t)50 * 1024;
-        const double cost = (double)tx * ty * per_tile * (cls3 ? (double)YS_OPT_INT("P2_CLS3", 75) * 0.01 : 1.0);
+        const double cost = (double)tx * ty * per_tile * (cls3 ? 0.75 : 1.0);   // (0.85 / 0.75 / 0.65 / 0.55 measured alike end to end: conv_p2 time 2.16 -> 2.11 ms per config-2 step, config 3 1.44 -> 1.40, config 4 3.27 -> 3.16)
         const bool full = !want_full || ntiles * gy >= 512;   // (a small member of a grouped launch does not have to fill the chip by itself: cheapest tiles)
         if ((full && !best_full) || (full == best_full && cost < best)) {
           best = cost; best_full = full;

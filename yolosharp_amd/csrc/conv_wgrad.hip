@@ -397,6 +397,10 @@ static bool wgrad_view_bytes(const WgradArgs& a, unsigned& dyb, unsigned& xb) {
   dyb = (unsigned)d; xb = (unsigned)x;
   return true;
 }
+// plan sweep (tools/dev/r06/wg_sweep.py through ys_debug_wgrad_force): tile height / log2 width / workgroups per CU imposed on every plan of the process; 0 = the
+// cost model's own choice.  Triage only.
+static int g_wg_force_th = 0, g_wg_force_tws = 0, g_wg_force_percu = 0;
+extern "C" __attribute__((visibility("default"))) int ys_debug_wgrad_force(int th, int tws, int per_cu) { g_wg_force_th = th; g_wg_force_tws = tws; g_wg_force_percu = per_cu; return 0; }
 static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   WgPlan p{};
   { unsigned d0, x0; if (!wgrad_view_bytes(a, d0, x0)) return p; }
@@ -429,7 +433,9 @@ static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   for (int tws = 2; tws <= 5; tws++) {
     const int tw = 1 << tws;
     if (tw > a.Wout && tws > 2 && (tw >> 1) >= a.Wout) continue;
+    if (g_wg_force_tws && tws != g_wg_force_tws) continue;
     for (int th = 1; th <= a.Hout && th * tw <= tpmax; th++) {
+      if (g_wg_force_th && th != g_wg_force_th) continue;
       const int ph = (th - 1) * S + a.KH, pw = (tw - 1) * S + a.KW;
       if (ph * pw * xv > nxu) continue;
       const int nkb = (th * tw + 31) / 32;
@@ -447,6 +453,7 @@ static WgPlan wgrad_tr_plan(const WgradArgs& a) {
   int per_cu = (int)((150 * 1024) / p.lds);
   const int per_cu_max = k3 ? (p.mra * p.nrb <= YS_WG_TWO_MAX ? 2 : 1) : 4;   // 9-wave workgroups are register-limited to 1-2 per CU (launch bounds of conv_wgrad_tr_kernel)
   if (per_cu > per_cu_max) per_cu = per_cu_max;
+  if (g_wg_force_percu && g_wg_force_percu < per_cu) per_cu = g_wg_force_percu;
   if (per_cu < 1) per_cu = 1;
   long gx = ((long)ys_cu_count() * per_cu) / gy;          // (round 6: 1.5x / 2x / 3x the resident slots -- shorter-lived workgroups, so that the main stream's kernels find free slots sooner -- measured 8.78 -> 8.89 / 8.99 / 9.27 ms on config 2)   (round 5: half / quarter grids -- fewer partial slabs for the split reduction -- measured 8.69 -> 8.73 / 10.01 ms on config 2)
   gx = gx / 8 * 8;                                       // same-x workgroups (same pixels, other channel tiles) share an XCD

@@ -17,7 +17,7 @@ namespace {
 // The table is process-wide: a host that flips a gate from one thread while another thread's model is between its plan-only dry run and the launch re-routes that launch;
 // set options before creating models, or from the thread that drives them.
 const char* const kOptKeys[] = {"ATTN_MFMA", "BNRED", "BNRED_LOG", "BN_ATOMIC", "F8_MIN_CIN", "F8_MIN_TAPS", "GEMM_HALO", "GEMM_MIN_CIN", "GEMM_MIN_M", "GROUP", "HALO_MAX_GRID",
-                                "HALO_MIN_FILL", "HALO_MR4", "HEAD_FUSE", "OVERLAP", "STEM_DIRECT", "WGEMM_KT", "WGEMM_MIN_M", "P2_CLS3", "DBG", "GEMM_DBG"};
+                                "HALO_MIN_FILL", "HALO_MR4", "HEAD_FUSE", "OVERLAP", "STEM_DIRECT", "WGEMM_KT", "WGEMM_MIN_M", "DBG", "GEMM_DBG"};
 bool opt_known(const std::string& k) {
   for (const char* n : kOptKeys) if (k == n) return true;
   return false;

@@ -151,7 +151,7 @@ __device__ inline AnchorInfo anchor_of(const LossArgs& a, int idx) {
 // step's critical path between forward and backward.  Now a workgroup adds its partial -- rounded to 2^-30 (target-score sum: |partial| <= 256) or 2^-20 (loss sums:
 // |partial| < 2^42) -- with ONE 64-bit integer atomic into shard (workgroup index mod LOSS_SHARDS): integer addition commutes, so the totals are bit-reproducible
 // whatever the arrival order.  (Unsharded -- 21 thousand workgroups of loss_cls_kernel adding to ONE address -- the atomics serialised in the L2: 51 -> 261 us.)
-// Consumers sum the shards: loss_cls / loss_box per wave (loss_tss_wave), loss_items all of them.  The words live behind the 64 float scalars:
+// Consumers: loss_items sums the shards of every word; the target-score sum is folded into scalars[0] by tal_targets_kernel's last workgroup (below).  The words live behind the 64 float scalars:
 // (u64*)(scalars + 64) [shard][8]: [0] tss, [1] cls, [2] iou, [3] dfl, [4] angle, [5] poison (a non-finite or out-of-range partial: the items become NaN, as the
 // reference's do on divergence).
 #define LOSS_SHARDS 64
@@ -176,20 +176,13 @@ __device__ inline float loss_acc_get(const unsigned long long* acc, int word, fl
   return (float)((double)t * (1.0 / (double)fix));
 }
 __device__ inline float loss_tss_of(float t) { return t > 1.0f ? t : (t != t ? t : 1.0f); }        // target_scores_sum = max(sum, 1) (Loss.cs:444); NaN stays NaN
-// The target-score sum is written by tal_targets_kernel only (2100 workgroups at the headline shape) into the first LOSS_TSS_SHARDS shards; its readers are
-// every wave of loss_cls / loss_box: lanes 0 .. 15 load one shard each (and its poison word), four shuffles add them, lane 0's total goes to everybody.  No LDS,
-// no barrier, and the loads go out together with the wave's own operand loads -- a workgroup-wide form behind a barrier put one more dependent L2 round trip in
-// front of every ~1 us workgroup of loss_cls_kernel (51 -> 92 us).
+// The target-score sum has readers in every workgroup of loss_cls / loss_box, so it must be ONE float again by the time they start (reading and adding its
+// shards per wave -- 64-bit shuffles, an i64 -> f64 -> f32 conversion per lane -- cost loss_cls_kernel 51 -> 74 us; a workgroup-wide read behind a barrier 92 us).
+// tal_targets_kernel's LAST workgroup to arrive does it: a workgroup adds its partial with a RETURNING atomic, then takes a ticket with a second atomic that is only
+// issued once the first has returned (the empty asm makes the ticket's operand depend on the returned value); whoever draws the last ticket reads the shards back
+// with atomics (coherent at the point where device-scope atomics execute: no fence, no L2 write-back -- every datum involved is an atomic's) and stores
+// scalars[0] = max(sum, 1), which the following launches read as they did in rounds 1-5.  Ticket word: shard 0, word 6.
 #define LOSS_TSS_SHARDS 16
-__device__ inline float loss_tss_wave(const LossArgs& a) {
-  const int l = threadIdx.x & 63;
-  const unsigned long long* acc = LOSS_ACC(a) + (size_t)(l & (LOSS_TSS_SHARDS - 1)) * 8;
-  long long t = l < LOSS_TSS_SHARDS ? (long long)acc[0] : 0;
-  int bad = l < LOSS_TSS_SHARDS ? (int)(acc[5] != 0ull) : 0;
-  for (int m = LOSS_TSS_SHARDS / 2; m >= 1; m >>= 1) { t += __shfl_xor(t, m); bad |= __shfl_xor(bad, m); }
-  t = __shfl(t, 0); bad = __shfl(bad, 0);
-  return bad ? __builtin_nanf("") : loss_tss_of((float)((double)t * (1.0 / (double)LOSS_FIX_T)));
-}
 // workgroup sum of up to four values -> lane 0 of wave 0 (fixed order: wave butterflies, then the waves in index order)
 __device__ inline void block_sum4(float& v0, float& v1, float& v2, float& v3) {
   __shared__ float s[LS_THREADS / 64][4];
@@ -618,7 +611,36 @@ tal_targets_kernel(LossArgs a) {
   }
   float z1 = 0.f, z2 = 0.f, z3 = 0.f;
   block_sum4(nrm, z1, z2, z3);
-  if (threadIdx.x == 0) loss_acc_add(LOSS_ACC(a), 0, nrm, LOSS_FIX_T, LOSS_TSS_SHARDS);
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    unsigned long long* acc = LOSS_ACC(a);
+    unsigned long long* mine = acc + (size_t)(blockIdx.x & (LOSS_TSS_SHARDS - 1)) * 8;
+    unsigned long long got = 0ull;
+    if (!(fabsf(nrm) * LOSS_FIX_T < 9.0e18f)) got = atomicOr(mine + 5, 1ull);
+    else {
+#ifdef YS_EMU_BUILD
+      const long long q = (long long)llrintf(nrm * LOSS_FIX_T);
+#else
+      const long long q = __float2ll_rn(nrm * LOSS_FIX_T);
+#endif
+      got = atomicAdd(mine, (unsigned long long)q);           // returning form, also for q = 0: the ticket below must come after it
+    }
+    unsigned one = 1u;
+#ifndef YS_EMU_BUILD
+    asm volatile("" : "+v"(one) : "v"(got));                   // the ticket is not issued before the add has returned
+#else
+    (void)got;
+#endif
+    const unsigned ticket = atomicAdd((unsigned*)(acc + 6), one);
+    s_last = ticket == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    unsigned long long* acc = LOSS_ACC(a);
+    long long t = 0; unsigned long long bad = 0ull;
+    for (int sh = 0; sh < LOSS_TSS_SHARDS; sh++) { t += (long long)atomicAdd(acc + sh * 8, 0ull); bad |= atomicOr(acc + sh * 8 + 5, 0ull); }
+    a.scalars[0] = bad ? __builtin_nanf("") : loss_tss_of((float)((double)t * (1.0 / (double)LOSS_FIX_T)));
+  }
 }
 
 // ------------------------------------------------------------------ K5: BCE cls loss + gradient (Loss.cs:447)
@@ -641,10 +663,9 @@ loss_cls_kernel(LossArgs a) {
       row = ii / vpr; c0 = (int)(ii - row * vpr) * EPL; b = (int)(row / a.A);
     }
   }
-  // every request of the thread goes out before anything is waited for: the logits, the assignment, and (wave-wide, shuffles) the shards of the target-score sum
   const uint4 xv16 = ys_ld16((const T*)a.ps + row * a.ld_ps + c0);
   const int g = a.fg_gt[row];
-  const float tss_w = loss_tss_wave(a);
+  const float tss_w = a.scalars[0];            // written by tal_targets_kernel's last workgroup
   if (inb) {
     int tc = -1;
     float tv = 0.f;
@@ -724,7 +745,7 @@ loss_box_kernel(LossArgs a) {
   const int base = lane & ~3;
   const float d0 = __shfl(dist, base + 0), d1 = __shfl(dist, base + 1), d2 = __shfl(dist, base + 2), d3 = __shfl(dist, base + 3);
   float l_iou = 0.f, l_dfl = 0.f, l_ang = 0.f;
-  const float tss_blk = loss_tss_wave(a);      // wave-wide (shuffles): outside the foreground branch
+  const float tss_blk = a.scalars[0];          // written by tal_targets_kernel's last workgroup
   if (g >= 0) {
     const int b = (int)(row / a.A), ai = (int)(row - (long)b * a.A);
     const AnchorInfo an = anchor_of(a, ai);
@@ -822,8 +843,8 @@ __global__ void loss_items_kernel(LossArgs a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float* sc = a.scalars;
     const unsigned long long* acc = LOSS_ACC(a);
-    const float tss = loss_tss_of(loss_acc_get(acc, 0, LOSS_FIX_T));
-    sc[0] = tss; sc[5] = loss_acc_get(acc, 1, LOSS_FIX_L); sc[6] = loss_acc_get(acc, 2, LOSS_FIX_L); sc[7] = loss_acc_get(acc, 3, LOSS_FIX_L);
+    const float tss = sc[0];                   // folded by tal_targets_kernel's last workgroup: the value loss_cls / loss_box scaled their gradients with
+    sc[5] = loss_acc_get(acc, 1, LOSS_FIX_L); sc[6] = loss_acc_get(acc, 2, LOSS_FIX_L); sc[7] = loss_acc_get(acc, 3, LOSS_FIX_L);
     if (a.rot) sc[12] = loss_acc_get(acc, 4, LOSS_FIX_L);
     const float l_cls = sc[5] / tss, l_iou = sc[6] / tss, l_dfl = sc[7] / tss;
     sc[1] = l_iou * a.hyp_box;
