@@ -253,8 +253,12 @@ def test_stem_reads_fp32_planes_directly_bf16(backend, engine):
     """model.0 (Conv(3, c, 3, 2): Yolo.cs:43, Convs.cs:36-62) on the bf16 path reads the fp32 NCHW image itself (csrc/conv_stem.hip) --
     forward, batch statistics and weight gradient -- instead of a packed bf16 NHWC copy.  Checked (a) against the packed-copy path of the
     same engine (YS_STEM_DIRECT=0 at model creation; same operand rounding, different summation order) on a canvas whose stem output
-    (48 x 80) leaves ragged 8 x 32 tiles, and (b) against the fp32 oracle restricted to that layer with rounding-matched operands."""
-    B, H, W, nc = 2, 96, 160, 80
+    (64 x 80) leaves ragged 8 x 32 tiles, and (b) against the fp32 oracle restricted to that layer with rounding-matched operands.
+    (Round 6: B = 4, 128 x 160 instead of B = 2, 96 x 160.  The two paths round identically but add their BatchNorm partial sums in different orders; on the smaller
+    canvas the P5 BatchNorms normalise over 30 values per channel and ONE activation whose bf16 rounding flips at the stem moves model.0's weight gradient by tens of
+    per cent -- the rounding-matched and the plain ORACLE differ that much from each other there -- so the comparison said more about the tile plan of the day than
+    about the stem kernels: a plan change in conv_p2_kernel turned 3e-2 into 1.08 with both paths correct layer by layer.)"""
+    B, H, W, nc = 4, 128, 160, 80
     ref = make_ref(seed=3)
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(4))
     batch = O.synthetic_batch(B, H, W, nc, seed=5, kmax=5)

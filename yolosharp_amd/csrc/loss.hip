@@ -181,7 +181,7 @@ __device__ inline float loss_tss_of(float t) { return t > 1.0f ? t : (t != t ? t
 // tal_targets_kernel's LAST workgroup to arrive does it: a workgroup adds its partial with a RETURNING atomic, then takes a ticket with a second atomic that is only
 // issued once the first has returned (the empty asm makes the ticket's operand depend on the returned value); whoever draws the last ticket reads the shards back
 // with atomics (coherent at the point where device-scope atomics execute: no fence, no L2 write-back -- every datum involved is an atomic's) and stores
-// scalars[0] = max(sum, 1), which the following launches read as they did in rounds 1-5.  Ticket word: shard 0, word 6.
+// scalars[0] = max(sum, 1), which the following launches read as they did in rounds 1-5.  Ticket words: word 6 of every shard (first level), shard 0 word 7 (second).
 #define LOSS_TSS_SHARDS 16
 // workgroup sum of up to four values -> lane 0 of wave 0 (fixed order: wave butterflies, then the waves in index order)
 __device__ inline void block_sum4(float& v0, float& v1, float& v2, float& v3) {
@@ -631,8 +631,15 @@ tal_targets_kernel(LossArgs a) {
 #else
     (void)got;
 #endif
-    const unsigned ticket = atomicAdd((unsigned*)(acc + 6), one);
-    s_last = ticket == gridDim.x - 1 ? 1 : 0;
+    // two-level ticket: 2100 workgroups drawing from ONE counter serialise in the L2 like the unsharded sums did (tal_targets_kernel 12.6 -> 36 us); the last
+    // workgroup of a shard (its shard's total is complete: every add to it returned before its owner's ticket) draws from the second counter
+    const int sh = (int)(blockIdx.x & (LOSS_TSS_SHARDS - 1));
+    const unsigned n_sh = ((unsigned)gridDim.x - (unsigned)sh + (LOSS_TSS_SHARDS - 1)) / LOSS_TSS_SHARDS;
+    const unsigned n_act = gridDim.x < LOSS_TSS_SHARDS ? gridDim.x : LOSS_TSS_SHARDS;
+    const unsigned t1 = atomicAdd((unsigned*)(mine + 6), one);
+    int last = 0;
+    if (t1 == n_sh - 1) last = atomicAdd((unsigned*)(acc + 7), 1u) == n_act - 1 ? 1 : 0;
+    s_last = last;
   }
   __syncthreads();
   if (s_last && threadIdx.x == 0) {
