@@ -245,6 +245,10 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(dev))
         stream = torch.cuda.current_stream(dev).cuda_stream
     eng = Engine(local_rank, stream=stream, lib_path=args.lib or None)   # N>1: run on torch's stream so RCCL orders against our kernels
+    if os.environ.get("BENCH_WG_FORCE"):                 # TRIAGE ONLY (plan sweeps): "th,tws,per_cu" for every conv_wgrad_tr plan of the process; stamps the line
+        import ctypes as _C
+        eng.lib.ys_debug_wgrad_force.argtypes = [_C.c_int] * 3
+        eng.lib.ys_debug_wgrad_force(*[int(v) for v in os.environ["BENCH_WG_FORCE"].split(",")])
     if not eng.is_device_build:                      # the measured thing is the hipcc-built gfx950 library, never the test interpreter
         raise SystemExit("bench.py: libyolosharp_hip.so is not a device build")
     if c_dist:
@@ -429,6 +433,8 @@ def main():
             out["dist"] = dist_info
         if args.lib:
             out["triage_lib"] = args.lib          # not the product library: never a bench line of record
+        if os.environ.get("BENCH_WG_FORCE"):
+            out["triage_wg_force"] = os.environ["BENCH_WG_FORCE"]
         # ---- secondary metric: inference images/s = eval forward (BN folded into the conv epilogues) + Detect decode
         model.eval()
         for _ in range(0 if args.no_infer else 3):

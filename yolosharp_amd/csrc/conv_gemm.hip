@@ -409,6 +409,7 @@ static GemmPlan conv_gemm_plan(const ConvArgs& a) {
   // 166 KB of weights per 256-pixel tile there
   const int wide_cout = 128;
   const bool wide_out = k3 && a.SA == 1 && a.Cin >= 64 && a.Cout >= wide_cout && !f8;
+  // (round 6: 1x1 layers with 160 <= Cin <= 256 / 384 / 512 on the patch kernel instead -- config 2 8.58 -> 8.63 / 8.64 / 8.63 ms, config 3 9.37 -> 9.51 / 9.55 / 9.78, config 4 29.5 -> 29.8 / 29.8 / 31.2: the gate stays)
   if ((a.Cin < min_cin && !s2_narrow && !wide_out) || Ktot < min_k || a.Cout < 64 || a.M < min_m) return p;
   if (k3 && a.SA == 1 && !f8) { const GemmPlan hp = conv_halo_plan(a); if (hp.ok) return hp; }
   // output-channel tile: least padding first, then the widest (most reuse of the A tile)

@@ -1130,7 +1130,7 @@ int allocate(ys_model* m) {
     {
       int least = 0, greatest = 0;
       if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-        YS_CHECK_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, least));
+        YS_CHECK_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, least));     // (round 6: the HIGHEST priority instead: 8.61 / 8.61 / 8.63 -> 8.65 / 8.65 / 8.66 ms)
       else
         YS_CHECK_HIP(hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking));
     }
