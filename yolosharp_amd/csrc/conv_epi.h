@@ -470,13 +470,16 @@ __device__ inline void p2_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[MR][NR
     return;
   }
   // ---- forward / eval form
-  const bool do_stats = FMODE == 0 ? true : (a.stats != nullptr && !EPI_DBG(512));
-  const bool bn_eval = FMODE == 0 ? false : a.scale != nullptr;
-  const bool bias = FMODE == 0 ? false : (!a.scale && a.shift);
-  const char* rb = FMODE == 0 ? nullptr : (const char*)a.res;
-  const bool accum = FMODE == 0 ? false : a.accumulate != 0;
-  const bool shift_on = FMODE == 0 ? false : a.shift != nullptr;
-  const bool act_on = FMODE == 0 ? false : a.act != 0;
+  // FMODE 0: training forward of a BatchNorm unit (raw output + statistics); 1 (round 6): eval forward of a BatchNorm unit -- folded scale / shift, SiLU when a.act,
+  // nothing else (no statistics, bias, residual or accumulation) -- as compile-time facts; 2: every option tested at run time
+  constexpr bool TRAIN = FMODE == 0, EVAL = FMODE == 1;
+  const bool do_stats = TRAIN ? true : (EVAL ? false : (a.stats != nullptr && !EPI_DBG(512)));
+  const bool bn_eval = TRAIN ? false : (EVAL ? true : a.scale != nullptr);
+  const bool bias = (TRAIN || EVAL) ? false : (!a.scale && a.shift);
+  const char* rb = (TRAIN || EVAL) ? nullptr : (const char*)a.res;
+  const bool accum = (TRAIN || EVAL) ? false : a.accumulate != 0;
+  const bool shift_on = TRAIN ? false : (EVAL ? true : a.shift != nullptr);
+  const bool act_on = TRAIN ? false : a.act != 0;
   stamp();
 #pragma unroll
   for (int nf = 0; nf < NR; nf++) {

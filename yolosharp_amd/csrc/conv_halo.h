@@ -72,7 +72,7 @@ template <int MR> struct HaloSched {
   static constexpr int jp0(int tap) { return MR == 8 ? (tap <= 4 ? 2 * tap : tap + 5) : tap; }                      // ... the first of them
 };
 // HALF: Cin mod 64 in 1 .. 32 (the last chunk's K-step 1 is all padding).  RED = epilogue class, a compile-time fact of the launch: 0 = forward with every run-time
-// option; 2 = the training forward of a BatchNorm unit (raw output + statistics only); 4 .. 7 = dgrad: 4 + (accumulate) + 2 (fused BN-backward reduction)
+// option; 1 (round 6) = the EVAL forward of a BatchNorm unit (folded scale / shift + SiLU, nothing else); 2 = the training forward of a BatchNorm unit (raw output + statistics only); 4 .. 7 = dgrad: 4 + (accumulate) + 2 (fused BN-backward reduction)
 template <int NR, int RED = 0, int HALF = 0, int MR = 8>
 __global__ void __launch_bounds__(256, 1)
 conv_halo_kernel(ConvArgs a, HaloArgs g) {
@@ -343,7 +343,7 @@ conv_halo_kernel(ConvArgs a, HaloArgs g) {
         pv[mf] = (bool)((int)(oy < a.Hout) & (int)(ox < a.Wout));
         orow[mf] = pv[mf] ? tc_.b * (int)a.out_bstride + oy * a.Wout + ox : 0;
       }
-      p2_epilogue_direct<MR, NR, RED >= 4 ? 1 : 0, YsNoStamp, RED == 2 ? 0 : (RED >= 4 ? RED : 2)>(a, acc, orow, pv, n0 + wn * NR * 16, *reinterpret_cast<float (*)[4 * NR]>(&st1), *reinterpret_cast<float (*)[4 * NR]>(&st2));
+      p2_epilogue_direct<MR, NR, RED >= 4 ? 1 : 0, YsNoStamp, RED == 2 ? 0 : (RED == 1 ? 1 : (RED >= 4 ? RED : 2))>(a, acc, orow, pv, n0 + wn * NR * 16, *reinterpret_cast<float (*)[4 * NR]>(&st1), *reinterpret_cast<float (*)[4 * NR]>(&st2));
     } else {
       ys_barrier_lds();                       // every wave has read the last chunk's patch: its buffer (par was flipped past it) is the staging area
       char* stg = lb + (par ^ 1) * PATCH + wave * halo_wstg(NR);
@@ -427,7 +427,8 @@ static int conv_halo_launch_nr(hipStream_t st, const ConvArgs& a, const HaloLaun
   const bool half = (a.Cin & 63) != 0 && (a.Cin & 63) <= 32;
   // epilogue class (conv_halo_kernel's RED parameter)
   const bool plain = !a.stats && !a.scale && !a.shift && !a.res && !a.act;
-  const int ec = (a.nred > 0 || (plain && a.accumulate)) ? 4 + (a.accumulate ? 1 : 0) + (a.nred > 0 ? 2 : 0) : ((a.stats && !a.scale && !a.shift && !a.res && !a.accumulate && !a.act) ? 2 : (plain ? 4 : 0));
+  const bool eval_bn = a.scale && a.shift && !a.stats && !a.res && !a.accumulate && a.nred == 0;     // (round 6: the eval forward ran class 0 -- 195 us against 112 for the training forward of the same 64 -> 144 layer)
+  const int ec = (a.nred > 0 || (plain && a.accumulate)) ? 4 + (a.accumulate ? 1 : 0) + (a.nred > 0 ? 2 : 0) : ((a.stats && !a.scale && !a.shift && !a.res && !a.accumulate && !a.act) ? 2 : (plain ? 4 : (eval_bn ? 1 : 0)));
 #ifndef HALO_INSTANTIATE_MR
 #define HALO_INSTANTIATE_MR 8
 #endif
@@ -437,6 +438,7 @@ static int conv_halo_launch_nr(hipStream_t st, const ConvArgs& a, const HaloLaun
     if (ec == 6) return half ? conv_halo_launch_t<R_, 6, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 6, 0, M_>(st, a, p); \
     if (ec == 7) return half ? conv_halo_launch_t<R_, 7, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 7, 0, M_>(st, a, p); \
     if (ec == 2) return half ? conv_halo_launch_t<R_, 2, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 2, 0, M_>(st, a, p); \
+    if (ec == 1) return half ? conv_halo_launch_t<R_, 1, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 1, 0, M_>(st, a, p); \
     return half ? conv_halo_launch_t<R_, 0, 1, M_>(st, a, p) : conv_halo_launch_t<R_, 0, 0, M_>(st, a, p); }
   HL(HALO_INSTANTIATE_NR, HALO_INSTANTIATE_MR)
 #undef HL
