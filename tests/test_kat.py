@@ -297,3 +297,38 @@ def test_oracle_adamw_matches_torch_optimizer():
         O.adamw_step(params, grads, state, lrs, step=step)
         for n in names:
             assert torch.allclose(params[n], ref[n].detach(), rtol=1e-12, atol=1e-14), (step, n)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_non_finite_inputs_poison_the_integer_accumulators(backend, engine):
+    """Round 6: the criterion's sums and the forward BatchNorm statistics are fixed-point INTEGER accumulators; a NaN / Inf partial has no integer image (an
+    unguarded fptosi is a garbage finite number that would be folded into the loss / into run_mean and run_var).  Both raise a poison word instead and the consumers turn it
+    into NaN -- what the reference's float sums do on divergence.  (a) a NaN class logit -> NaN loss items; (b) an Inf activation in a training-mode Conv unit -> non-finite
+    running statistics for that layer, finite ones for a clean rerun."""
+    from yolosharp_amd.model import Yolov8, v8DetectionLoss
+    k = KAT
+    bx, sc, batch = _case()
+    m = Yolov8(engine, nc=k["nc"], size="n", height=k["H"], width=k["W"], max_batch=k["B"], dtype="f32")
+    sc2 = sc.copy(); sc2[0, 1, 3] = np.nan
+    m.set_preds({"boxes": bx, "scores": sc2})
+    _, items = v8DetectionLoss(m)(None, batch)
+    assert np.isnan(items[1]), items                       # the class item (and the total) carry the NaN; nothing is silently finite
+    m.set_preds({"boxes": bx, "scores": sc})
+    _, items = v8DetectionLoss(m)(None, batch)             # the accumulators are cleared per call: a clean step after a poisoned one is clean
+    assert np.allclose(items, k["items"], rtol=1e-3, atol=1e-5), items
+    m.close()
+    # (b) BatchNorm statistics of a whole model forward (BN_ATOMIC path): an Inf in the image
+    B, H, W = 2, 64, 64
+    m = Yolov8(engine, nc=80, size="n", height=H, width=W, max_batch=B, dtype="bf16")
+    m.init_weights(3); m.train()
+    x = np.random.default_rng(0).random((B, 3, H, W), dtype=np.float32)
+    xi = x.copy(); xi[0, 1, 5, 7] = np.inf
+    m.forward(xi, fetch=False)
+    sd = m.state_dict()
+    assert not np.isfinite(sd["model.0.bn.running_mean"]).all() or not np.isfinite(sd["model.0.bn.running_var"]).all()
+    m.close()
+    m = Yolov8(engine, nc=80, size="n", height=H, width=W, max_batch=B, dtype="bf16")
+    m.init_weights(3); m.train(); m.forward(x, fetch=False)
+    sd = m.state_dict()
+    assert all(np.isfinite(v).all() for kk, v in sd.items() if "running" in kk)
+    m.close()
