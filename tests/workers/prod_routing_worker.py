@@ -124,6 +124,17 @@ def main():
                 mod.attn.proj.bn.weight.data.mul_(damp); mod.ffn[1].bn.weight.data.mul_(damp)
     sd = {k: v.detach().numpy().copy() for k, v in ref.state_dict().items()}
     m.load_state_dict(sd)
+    res_eval = {}
+    if kw["dtype"] != "fp8":
+        # eval forward first (BatchNorm folded from the loaded running statistics: no batch statistics, i.e. no chaotic amplification -- a tight statement): the decoded
+        # predictions [B, 4 + nc (+ nm), A] against the oracle's eval forward, rounding-matched and plain
+        m.eval()
+        inf, _ = m.forward(x.numpy())
+        res_eval["inf"] = np.asarray(inf["boxes"]).copy()
+        ref.eval()
+        with torch.no_grad():
+            res_eval["r_inf"] = R.forward_bf16(ref, x)[0]["boxes"].numpy().copy()
+            res_eval["f_inf"] = ref(x)[0]["boxes"].numpy().copy()
     m.train()
     if kw["dtype"] == "fp8":           # pass 0: bf16 kernels, records the maxima; no optimizer step, the weights stay the oracle's.  BatchNorm running statistics move,
         m.forward(x.numpy(), fetch=False)   # which a train-mode forward does not read
@@ -139,6 +150,7 @@ def main():
     labels = [l for l in open(lp).read().splitlines()[1:]]
     os.remove(lp)
     res = {"items": np.asarray(items, np.float32), "labels": np.array(labels)}
+    res.update(res_eval)
     res.update(head_outputs(preds, seg))
     # ---- oracle, twice: rounding-matched (bf16 storage points) and plain fp32
     ref.train()
